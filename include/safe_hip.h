@@ -1,0 +1,202 @@
+/*
+ * safe_hip.h -- C ABI of libsafe_hip.so: the MI355X (gfx950) implementation of the
+ * SAFE hot path (neighborhood definition + enrichment p-values).
+ *
+ * The reference (baryshnikova-lab/safepy) is pure Python and has no FFI; this header
+ * is the boundary a maintainer binds with ctypes.  Every entry
+ * point cites the reference code it replaces (paths relative to the reference root).
+ *
+ * Conventions
+ *   - every function returns 0 on success, a negative SAFE_E_* code on failure;
+ *     safe_last_error() returns a thread-local message for the last failure.
+ *   - "host" pointers are ordinary process memory owned by the caller; "dev" pointers
+ *     are HIP device memory (from safe_dev_alloc or any other HIP allocator, e.g. a
+ *     torch tensor's data_ptr()).  Outputs are always pre-allocated by the caller.
+ *   - the library owns device memory only behind its opaque handles.
+ *   - work is enqueued on the context's stream (safe_ctx_set_stream; default: a
+ *     stream the context owns).  Functions with host outputs synchronise before
+ *     returning; functions with only dev outputs are asynchronous.
+ *   - one context per device; a context is not thread-safe.
+ *   - there is NO CPU fallback: without a HIP device every compute call fails.
+ */
+#ifndef SAFE_HIP_H
+#define SAFE_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SAFE_HIP_ABI_VERSION 1
+
+#define SAFE_OK 0
+#define SAFE_E_INVALID (-1)   /* bad argument */
+#define SAFE_E_HIP (-2)       /* HIP runtime error (message has the hipError string) */
+#define SAFE_E_NOMEM (-3)
+#define SAFE_E_UNSUPPORTED (-4)
+#define SAFE_E_VALUE (-5)     /* input data violates a contract (e.g. non-0/1 membership) */
+
+#define SAFE_DTYPE_F32 0
+#define SAFE_DTYPE_F64 1
+
+#define SAFE_SCORE_SUM 0      /* neighborhood_score_type == 'sum'     */
+#define SAFE_SCORE_ZSCORE 1   /* neighborhood_score_type == 'z-score' */
+
+#define SAFE_SIGN_HIGHEST 0   /* attribute_sign == 'highest' */
+#define SAFE_SIGN_LOWEST 1    /* attribute_sign == 'lowest'  */
+#define SAFE_SIGN_BOTH 2      /* attribute_sign == 'both'    */
+
+typedef struct safe_ctx safe_ctx;
+typedef struct safe_nbr safe_nbr;       /* neighborhood membership, device resident     */
+typedef struct safe_attr safe_attr;     /* node x attribute matrix, device resident     */
+typedef struct safe_perms safe_perms;   /* composed row-permutation tables, device res. */
+
+/* ------------------------------------------------------------------ context ---- */
+int safe_abi_version(void);
+const char *safe_last_error(void);
+int safe_device_count(int *count);
+int safe_ctx_create(int device, safe_ctx **out);
+int safe_ctx_destroy(safe_ctx *ctx);
+/* Use an existing hipStream_t (passed as void*) for all subsequent work; NULL restores
+ * the context's own stream. */
+int safe_ctx_set_stream(safe_ctx *ctx, void *hip_stream);
+int safe_ctx_sync(safe_ctx *ctx);
+int safe_ctx_info(safe_ctx *ctx, int *num_cu, int64_t *hbm_bytes, char *arch, size_t arch_len);
+int safe_dev_alloc(safe_ctx *ctx, size_t bytes, void **out_dev);
+int safe_dev_free(safe_ctx *ctx, void *dev);
+int safe_dev_memset(safe_ctx *ctx, void *dev, int value, size_t bytes);
+int safe_memcpy_h2d(safe_ctx *ctx, void *dev, const void *host, size_t bytes);   /* synchronous */
+int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes);   /* synchronous */
+/* Event pair on the context stream, for timing a region that runs on that stream. */
+int safe_timer_start(safe_ctx *ctx);
+int safe_timer_stop_ms(safe_ctx *ctx, double *elapsed_ms);   /* synchronises */
+
+/* ------------------------------------------------------------ neighborhoods ---- */
+/* Replaces SAFE.define_neighborhoods, 'euclidean' branch (safepy/safe.py:389-399):
+ * A[i,j] = (sqrt(dx*dx + dy*dy) < nr), each op rounded to f64 (scipy pdist), diagonal
+ * kept.  xy_host is [n,2] row-major; nr = radius * (max x - min x) is computed by the
+ * caller exactly as safe.py:390-391 does. */
+int safe_nbr_euclidean(safe_ctx *ctx, const double *xy_host, int64_t n, double nr, safe_nbr **out);
+
+/* Replaces the two shortest-path branches (safepy/safe.py:401-417; networkx
+ * all_pairs_dijkstra_path_length with cutoff): A[s,t] = 1 iff the shortest-path length
+ * from s to t is <= cutoff.  Undirected edges (edge_u[e], edge_v[e]) with weight
+ * edge_w[e] ('length' for shortpath_weighted_layout) or unit weight when edge_w is NULL
+ * ('shortpath').  keep_distances != 0 also keeps the dense f64 distance matrix
+ * (inf where unreached) for safe_nbr_distances (self.node_distances, safe.py:417). */
+int safe_nbr_shortpath(safe_ctx *ctx, int64_t n, int64_t n_edges, const int32_t *edge_u,
+                       const int32_t *edge_v, const double *edge_w, double cutoff,
+                       int keep_distances, safe_nbr **out);
+
+/* Membership supplied by the caller as the reference's own layout: self.neighborhoods,
+ * int64 [n,n] row-major with entries in {0,1} (safe.py:387,430).  Any other value is
+ * SAFE_E_VALUE. */
+int safe_nbr_from_dense_i64(safe_ctx *ctx, const int64_t *a_host, int64_t n, safe_nbr **out);
+int safe_nbr_destroy(safe_nbr *nbr);
+int safe_nbr_info(const safe_nbr *nbr, int64_t *n, int64_t *nnz, int64_t *max_row_count);
+/* self.neighborhoods in the reference layout: int64 [n,n] row-major (safe.py:430). */
+int safe_nbr_to_dense_i64(safe_nbr *nbr, int64_t *out_host);
+int safe_nbr_to_dense_i64_dev(safe_nbr *nbr, int64_t *out_dev);
+/* np.sum(neighborhoods, axis=1) (safe.py:423). */
+int safe_nbr_row_counts(safe_nbr *nbr, int64_t *out_host);
+/* CSR view (row_ptr [n+1], col [nnz], ascending columns). */
+int safe_nbr_csr(safe_nbr *nbr, int32_t *row_ptr_host, int32_t *col_host);
+/* Dense f64 [n,n] distances of a shortest-path handle built with keep_distances
+ * (inf where unreached).  SAFE_E_INVALID if distances were not kept. */
+int safe_nbr_distances(safe_nbr *nbr, double *out_host);
+
+/* The fused all-pairs kernel on its own (compute_node_distances for 'euclidean', and
+ * the K1 roofline bench): xy_dev [n,2]; mask_out_dev int64 [n,n] and/or dist_out_dev
+ * f64 [n,n]; either may be NULL.  Same arithmetic as safe_nbr_euclidean
+ * (safepy/safe.py:397-399). */
+int safe_euclidean_dense_dev(safe_ctx *ctx, const double *xy_dev, int64_t n, double nr,
+                             int64_t *mask_out_dev, double *dist_out_dev);
+/* Replaces calculate_edge_lengths (safepy/safe_io.py:311-333): length[e] =
+ * sqrt(dx*dx + dy*dy) of the edge's end points, without the N x N detour. */
+int safe_edge_lengths(safe_ctx *ctx, const double *xy_host, int64_t n, int64_t n_edges,
+                      const int32_t *edge_u, const int32_t *edge_v, double *out_host);
+
+/* --------------------------------------------------------------- attributes ---- */
+/* self.node2attribute (safepy/safe_io.py:410): [n,m], f32 or f64, NaN = missing, with
+ * element strides (row_stride, col_stride): (m,1) for C order, (1,n) for Fortran order.
+ * The _host form uploads a copy; the _dev form borrows the caller's device buffer, which
+ * must outlive the handle. */
+int safe_attr_create_host(safe_ctx *ctx, const void *b_host, int dtype, int64_t n, int64_t m,
+                          int64_t row_stride, int64_t col_stride, safe_attr **out);
+int safe_attr_create_dev(safe_ctx *ctx, const void *b_dev, int dtype, int64_t n, int64_t m,
+                         int64_t row_stride, int64_t col_stride, safe_attr **out);
+int safe_attr_destroy(safe_attr *attr);
+/* Whole-matrix facts compute_pvalues needs before dispatch (safepy/safe.py:453-463):
+ *   n_other   = #(non-NaN values not in {0,1})          -> 'auto' rule (safe.py:461)
+ *   max_nan_col = max over columns of the NaN count      -> >50% warning (safe.py:454-459)
+ *   n_rows_with_value = #rows with >= 1 non-NaN value    -> hypergeometric N (safe.py:574-578)
+ *   n_non_integer = #(non-NaN values that are not integers) */
+int safe_attr_stats(safe_attr *attr, int64_t *n_other, int64_t *max_nan_col,
+                    int64_t *n_rows_with_value, int64_t *n_non_integer);
+/* row_has_value[i] = 1 iff row i has >= 1 non-NaN value: indx_vals of
+ * safepy/safe_extras.py:51 and nodes_not_nan of safepy/safe.py:574. */
+int safe_attr_row_flags(safe_attr *attr, uint8_t *out_host);
+/* Override the row flags (attribute-sharded multi-GPU runs must use the flags of the
+ * FULL matrix, not of the local column shard). */
+int safe_attr_set_row_flags(safe_attr *attr, const uint8_t *flags_host);
+
+/* ------------------------------------------------------------ permutations ---- */
+/* The row-permutation stream of run_permutations (safepy/safe_extras.py:46-58):
+ * np.random.seed(seed) (legacy MT19937 init_genrand) followed by num_permutations calls
+ * of np.random.permutation(indx_vals) (masked-rejection Fisher-Yates), applied
+ * cumulatively; movable_host[i] != 0 marks indx_vals.  has_seed == 0 seeds from OS
+ * entropy (random_seed=None).  The result is the composed table cur[p][i] with
+ * permuted_matrix_p = B[cur[p]], resident on the device. */
+int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host,
+                      int64_t num_permutations, int has_seed, uint32_t seed, safe_perms **out);
+int safe_perms_destroy(safe_perms *perms);
+/* Copy table rows [p0,p1) to host as int32 [p1-p0, n] (tests). */
+int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host);
+/* Host-only: the raw stream, for pinning against numpy (no device needed).  Writes
+ * count permutations of values[0..n_items) back to back into out[count*n_items]. */
+int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_items,
+                               int64_t count, int64_t *out);
+
+/* -------------------------------------------------------------- enrichment ---- */
+/* Replaces compute_neighborhood_score (safepy/safe_extras.py:6-33).  Columns
+ * [col0,col1) of the attribute handle; out_dev is f64 [n, col1-col0] row-major. */
+int safe_score(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int score_type,
+               int64_t col0, int64_t col1, double *out_dev);
+
+/* Replaces run_permutations (safepy/safe_extras.py:36-70): counts_neg/counts_pos as
+ * f64 [n, col1-col0] (number of permutations with permuted score <= / >= observed);
+ * ns_dev (observed score) may be NULL. */
+int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms,
+                         int score_type, int64_t col0, int64_t col1, double *ns_dev,
+                         double *counts_neg_dev, double *counts_pos_dev);
+
+/* Replaces compute_pvalues_by_randomization + the binarisation of compute_pvalues
+ * (safepy/safe.py:496-554, 468-472; FDR branch excluded): all outputs f64
+ * [n, col1-col0] row-major on the device, num_enriched_dev f64 [col1-col0].
+ * nes_table_host: optional [P+1] table with nes_table[k] = -log10(k/P), k >= 1, and
+ * nes_table[0] = -log10(1/P) evaluated by the caller's libm (NumPy) so NES matches the
+ * caller's log10 bit for bit; NULL = use the library's log10. */
+int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms,
+                       int score_type, int sign_mode, double enrichment_threshold,
+                       const double *nes_table_host, int64_t col0, int64_t col1,
+                       double *ns_dev, double *pvalues_neg_dev, double *pvalues_pos_dev,
+                       double *nes_dev, double *nes_binary_dev, double *num_enriched_dev);
+
+/* Replaces compute_pvalues_by_hypergeom + the binarisation (safepy/safe.py:573-608,
+ * 468-472; FDR branch excluded).  n_rows_with_value is the population size of
+ * safe.py:578 (from safe_attr_stats of the FULL matrix). */
+int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichment_threshold,
+                   int64_t col0, int64_t col1, double *pvalues_pos_dev, double *nes_dev,
+                   double *nes_binary_dev, double *num_enriched_dev);
+
+/* Name and average duration (ms) of the dominant kernel of the last enrichment call,
+ * measured with HIP events on the context stream (bench.py's roofline object). */
+int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *avg_ms,
+                           int64_t *launches);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SAFE_HIP_H */

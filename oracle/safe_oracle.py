@@ -1,0 +1,301 @@
+"""CPU oracle for the SAFE hot path -- TEST INFRASTRUCTURE ONLY.
+
+This module is a NumPy/SciPy restatement of the reference algorithm for
+``define_neighborhoods`` / ``compute_pvalues`` (baryshnikova-lab/safepy).  It is
+the *checker* for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and
+``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under ``safepy_amd/``
+imports it, and the product path has no CPU fallback.
+
+Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real
+reference from ``/root/reference`` (in the build container only), runs it on
+seeded synthetic inputs and commits the input/output vectors under
+``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function
+here against those vectors (masks/counts exact, scores <= 1e-12 relative).
+
+Each function cites the reference file:line it follows.  Arithmetic that the
+reference delegates to third-party libraries is delegated to the same library
+call here (scipy ``pdist``/``squareform``, ``np.dot``, ``scipy.stats.hypergeom.sf``,
+legacy ``np.random.seed`` + ``np.random.permutation``) so that the oracle *is*
+the reference arithmetic; the bounded Dijkstra (networkx 3.4.2 in the reference)
+is restated with ``heapq`` because networkx is not guaranteed on the GPU host.
+"""
+import heapq
+
+import numpy as np
+from scipy.spatial.distance import pdist, squareform
+from scipy.stats import hypergeom
+
+
+# ---------------------------------------------------------------------------
+# Neighborhoods (reference: safepy/safe.py:369-430)
+# ---------------------------------------------------------------------------
+
+def layout_radius(x, neighborhood_radius):
+    """nr = radius * (max x - min x): x-range only (safe.py:390-391, 404-405)."""
+    x = np.asarray(x, dtype=np.float64)
+    return neighborhood_radius * (np.max(x) - np.min(x))
+
+
+def euclidean_distances(xy):
+    """Dense symmetric distance matrix (safe.py:397; scipy pdist + squareform)."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    return squareform(pdist(xy, 'euclidean'))
+
+
+def neighborhoods_euclidean(xy, neighborhood_radius):
+    """A[i,j] = 1 iff D[i,j] < nr, int64, diagonal kept (safe.py:387-399, 419-420)."""
+    xy = np.ascontiguousarray(xy, dtype=np.float64)
+    n = xy.shape[0]
+    nr = layout_radius(xy[:, 0], neighborhood_radius)
+    out = np.zeros((n, n), dtype=np.int64)
+    out[euclidean_distances(xy) < nr] = 1
+    return out
+
+
+def _adjacency_lists(n, edge_u, edge_v, edge_w):
+    adj = [[] for _ in range(n)]
+    for u, v, w in zip(edge_u, edge_v, edge_w):
+        u = int(u)
+        v = int(v)
+        adj[u].append((v, w))
+        if u != v:
+            adj[v].append((u, w))
+    return adj
+
+
+def bounded_dijkstra(adj, source, cutoff):
+    """Single-source Dijkstra with cutoff, networkx semantics
+    (networkx 3.4.2 algorithms/shortest_paths/weighted.py:784-880 as called from
+    safe.py:406-410): a candidate distance is dropped iff it is > cutoff, so
+    targets at exactly ``cutoff`` are kept; dist(source) = 0."""
+    dist = {}
+    seen = {source: 0}
+    heap = [(0, 0, source)]
+    tick = 1
+    while heap:
+        d, _, v = heapq.heappop(heap)
+        if v in dist:
+            continue
+        dist[v] = d
+        for u, w in adj[v]:
+            cand = d + w
+            if cand > cutoff:
+                continue
+            if u in dist:
+                continue
+            if u not in seen or cand < seen[u]:
+                seen[u] = cand
+                heapq.heappush(heap, (cand, tick, u))
+                tick += 1
+    return dist
+
+
+def neighborhoods_shortpath(n, edge_u, edge_v, edge_w, cutoff):
+    """All-pairs bounded shortest paths -> (A int64 [N,N], D f64 [N,N] with inf
+    where unreached) (safe.py:403-417).  ``edge_w`` = edge 'length' for
+    'shortpath_weighted_layout' (cutoff = radius * x-range), or all ones for
+    'shortpath' (cutoff = radius)."""
+    adj = _adjacency_lists(n, edge_u, edge_v, edge_w)
+    out = np.zeros((n, n), dtype=np.int64)
+    dmat = np.full((n, n), np.inf, dtype=np.float64)
+    for s in range(n):
+        for t, d in bounded_dijkstra(adj, s, cutoff).items():
+            out[s, t] = 1
+            dmat[s, t] = d
+    return out, dmat
+
+
+def edge_lengths(xy, edge_u, edge_v):
+    """Euclidean length of every edge (safe_io.py:311-333 picks entries of the
+    pdist matrix; entry-wise that is sqrt(dx*dx + dy*dy) with each op rounded)."""
+    d = euclidean_distances(xy)
+    return d[np.asarray(edge_u, dtype=np.int64), np.asarray(edge_v, dtype=np.int64)]
+
+
+# ---------------------------------------------------------------------------
+# Neighborhood score (reference: safepy/safe_extras.py:6-33)
+# ---------------------------------------------------------------------------
+
+def compute_neighborhood_score(neighborhood2node, node2attribute, neighborhood_score_type):
+    with np.errstate(invalid='ignore', divide='ignore'):
+        notnan = ~np.isnan(node2attribute)
+        b0 = np.where(notnan, node2attribute, 0)        # safe_extras.py:10
+        score = np.dot(neighborhood2node, b0)           # safe_extras.py:15
+        if neighborhood_score_type == 'z-score':        # safe_extras.py:19-31
+            cnt = np.dot(neighborhood2node, np.where(notnan, 1, 0))
+            mean = np.divide(score, cnt)
+            exx = np.divide(np.dot(neighborhood2node, np.power(b0, 2)), cnt)
+            std = np.sqrt(exx - np.power(mean, 2))
+            score = np.divide(mean, std)
+            score[std == 0] = np.nan
+            score[cnt < 3] = np.nan
+    return score
+
+
+# ---------------------------------------------------------------------------
+# Permutation test (reference: safepy/safe_extras.py:36-70)
+# ---------------------------------------------------------------------------
+
+def run_permutations(neighborhood2node, node2attribute, neighborhood_score_type,
+                     num_permutations, random_seed):
+    """Returns (counts_neg, counts_pos) as float64 [N,M].  Reseeds the global
+    legacy RNG (safe_extras.py:46); rows are permuted cumulatively in place and
+    only rows with >= 1 non-NaN value move (safe_extras.py:50-58)."""
+    np.random.seed(random_seed)
+    observed = compute_neighborhood_score(neighborhood2node, node2attribute, neighborhood_score_type)
+    work = np.copy(node2attribute)
+    movable = np.nonzero(np.sum(~np.isnan(work), axis=1))[0]
+    counts_neg = np.zeros(observed.shape)
+    counts_pos = np.zeros(observed.shape)
+    for _ in range(int(num_permutations)):
+        work[movable, :] = work[np.random.permutation(movable), :]
+        perm_score = compute_neighborhood_score(neighborhood2node, work, neighborhood_score_type)
+        with np.errstate(invalid='ignore', divide='ignore'):
+            counts_neg = counts_neg + (perm_score <= observed)   # safe_extras.py:65
+            counts_pos = counts_pos + (perm_score >= observed)   # safe_extras.py:66
+    return counts_neg, counts_pos
+
+
+def permutation_index_table(node2attribute, num_permutations, random_seed):
+    """Composed row-index table [P,N]: permuted matrix at iteration k equals
+    node2attribute[table[k]] (follows safe_extras.py:46-58).
+    Consumes the legacy global RNG exactly as run_permutations does."""
+    np.random.seed(random_seed)
+    n = node2attribute.shape[0]
+    movable = np.nonzero(np.sum(~np.isnan(node2attribute), axis=1))[0]
+    cur = np.arange(n, dtype=np.int64)
+    table = np.empty((int(num_permutations), n), dtype=np.int64)
+    for k in range(int(num_permutations)):
+        cur[movable] = cur[np.random.permutation(movable)]
+        table[k] = cur
+    return table
+
+
+# ---------------------------------------------------------------------------
+# compute_pvalues and its two branches (reference: safepy/safe.py:432-608)
+# ---------------------------------------------------------------------------
+
+def wants_hypergeometric(node2attribute, enrichment_type):
+    """Dispatch rule of safe.py:461-463."""
+    other = np.sum(~np.isnan(node2attribute) & ~np.isin(node2attribute, [0, 1]))
+    return (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and other == 0)
+
+
+def pvalues_by_hypergeom(neighborhoods, node2attribute):
+    """safe.py:573-608 without the FDR branch.  Returns dict(pvalues_pos, nes)."""
+    n_nodes, n_attr = node2attribute.shape
+    nodes_not_nan = np.any(~np.isnan(node2attribute), axis=1)
+    total = np.sum(nodes_not_nan)
+    pop = np.zeros([n_nodes, n_attr]) + total
+    in_group = np.tile(np.nansum(node2attribute, axis=0), (n_nodes, 1))
+    nb_size = np.dot(neighborhoods, nodes_not_nan.astype(int))[:, np.newaxis]
+    in_nb = np.tile(nb_size, (1, n_attr))
+    hits = np.dot(neighborhoods, np.where(~np.isnan(node2attribute), node2attribute, 0))
+    with np.errstate(invalid='ignore', divide='ignore'):
+        pvalues_pos = hypergeom.sf(hits - 1, pop, in_group, in_nb)
+        nes = -np.log10(pvalues_pos)
+    return {'pvalues_pos': pvalues_pos, 'nes': nes}
+
+
+def pvalues_by_randomization(neighborhoods, node2attribute, neighborhood_score_type,
+                             num_permutations, random_seed, attribute_sign):
+    """safe.py:496-554 without the sleep, the (broken) multiprocessing split and FDR."""
+    ns = compute_neighborhood_score(neighborhoods, node2attribute, neighborhood_score_type)
+    counts_neg, counts_pos = run_permutations(neighborhoods, node2attribute,
+                                              neighborhood_score_type, num_permutations, random_seed)
+    idx = np.isnan(ns)
+    counts_neg[idx] = np.nan
+    counts_pos[idx] = np.nan
+    pvalues_neg = counts_neg / num_permutations
+    pvalues_pos = counts_pos / num_permutations
+    with np.errstate(invalid='ignore', divide='ignore'):
+        nes_pos = -np.log10(np.where(pvalues_pos == 0, 1 / num_permutations, pvalues_pos))
+        nes_neg = -np.log10(np.where(pvalues_neg == 0, 1 / num_permutations, pvalues_neg))
+    if attribute_sign == 'highest':
+        nes = nes_pos
+    elif attribute_sign == 'lowest':
+        nes = nes_neg
+    else:
+        nes = nes_pos - nes_neg
+    return {'ns': ns, 'pvalues_neg': pvalues_neg, 'pvalues_pos': pvalues_pos, 'nes': nes}
+
+
+def binarize(nes, enrichment_threshold):
+    """safe.py:468-472."""
+    idx = ~np.isnan(nes)
+    nes_binary = np.zeros(nes.shape)
+    nes_binary[idx] = np.abs(nes[idx]) > -np.log10(enrichment_threshold)
+    return nes_binary, np.sum(nes_binary, axis=0)
+
+
+def compute_pvalues(neighborhoods, node2attribute, enrichment_type='auto', neighborhood_score_type='sum',
+                    background='attribute_file', num_permutations=1000, random_seed=None,
+                    attribute_sign='both', enrichment_threshold=0.05):
+    """safe.py:432-472 (FDR off).  ``node2attribute`` is modified in place when
+    background == 'network' exactly as the reference does (safe.py:449-451)."""
+    if background == 'network':
+        node2attribute[np.isnan(node2attribute)] = 0
+    if wants_hypergeometric(node2attribute, enrichment_type):
+        out = pvalues_by_hypergeom(neighborhoods, node2attribute)
+    else:
+        out = pvalues_by_randomization(neighborhoods, node2attribute, neighborhood_score_type,
+                                       num_permutations, random_seed, attribute_sign)
+    out['nes_binary'], out['num_neighborhoods_enriched'] = binarize(out['nes'], enrichment_threshold)
+    return out
+
+
+# ---------------------------------------------------------------------------
+# Legacy MT19937 permutation stream, restated (numpy legacy RandomState;
+# SURVEY Appendix A.3).  Used to pin the product's host RNG against an
+# independent statement AND against numpy itself.
+# ---------------------------------------------------------------------------
+
+class LegacyMT19937:
+    def __init__(self, seed):
+        mt = np.empty(624, dtype=np.uint64)
+        s = int(seed) & 0xFFFFFFFF
+        for i in range(624):
+            mt[i] = s
+            s = (1812433253 * (s ^ (s >> 30)) + i + 1) & 0xFFFFFFFF
+        self.mt = [int(v) for v in mt]
+        self.pos = 624
+
+    def _refill(self):
+        mt = self.mt
+        for i in range(624):
+            y = (mt[i] & 0x80000000) | (mt[(i + 1) % 624] & 0x7FFFFFFF)
+            v = mt[(i + 397) % 624] ^ (y >> 1)
+            if y & 1:
+                v ^= 0x9908B0DF
+            mt[i] = v
+        self.pos = 0
+
+    def next_u32(self):
+        if self.pos == 624:
+            self._refill()
+        y = self.mt[self.pos]
+        self.pos += 1
+        y ^= y >> 11
+        y ^= (y << 7) & 0x9D2C5680
+        y ^= (y << 15) & 0xEFC60000
+        y ^= y >> 18
+        return y & 0xFFFFFFFF
+
+    def interval(self, top):
+        """Uniform integer in [0, top] by masked rejection (legacy random_interval)."""
+        if top == 0:
+            return 0
+        mask = top
+        for sh in (1, 2, 4, 8, 16):
+            mask |= mask >> sh
+        while True:
+            v = self.next_u32() & mask
+            if v <= top:
+                return v
+
+    def permutation(self, values):
+        a = list(values)
+        for i in range(len(a) - 1, 0, -1):
+            j = self.interval(i)
+            a[i], a[j] = a[j], a[i]
+        return a

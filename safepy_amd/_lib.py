@@ -1,0 +1,103 @@
+"""ctypes binding of libsafe_hip.so (the C ABI declared in include/safe_hip.h).
+
+There is no fallback: if the shared library is missing or cannot be loaded, importing
+this module raises, and every compute call raises ``SafeHipError`` when the library
+reports a failure (for example when no HIP device is present).
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libsafe_hip.so')
+
+ABI_VERSION = 1
+DTYPE_F32, DTYPE_F64 = 0, 1
+SCORE_SUM, SCORE_ZSCORE = 0, 1
+SIGN_HIGHEST, SIGN_LOWEST, SIGN_BOTH = 0, 1, 2
+E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_VALUE = -1, -2, -3, -4, -5
+
+
+class SafeHipError(RuntimeError):
+    def __init__(self, code, message):
+        super().__init__('libsafe_hip error %d: %s' % (code, message))
+        self.code = code
+
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        'safepy_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` or '
+        '`make -C safepy_amd/csrc` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
+
+lib = C.CDLL(LIB_PATH)
+
+_vp = C.c_void_p
+_i64 = C.c_int64
+_pp = C.POINTER(C.c_void_p)
+_pi64 = C.POINTER(C.c_int64)
+
+# name -> (restype, argtypes); every symbol include/safe_hip.h declares
+PROTOTYPES = {
+    'safe_abi_version': (C.c_int, []),
+    'safe_last_error': (C.c_char_p, []),
+    'safe_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'safe_ctx_create': (C.c_int, [C.c_int, _pp]),
+    'safe_ctx_destroy': (C.c_int, [_vp]),
+    'safe_ctx_set_stream': (C.c_int, [_vp, _vp]),
+    'safe_ctx_sync': (C.c_int, [_vp]),
+    'safe_ctx_info': (C.c_int, [_vp, C.POINTER(C.c_int), _pi64, C.c_char_p, C.c_size_t]),
+    'safe_dev_alloc': (C.c_int, [_vp, C.c_size_t, _pp]),
+    'safe_dev_free': (C.c_int, [_vp, _vp]),
+    'safe_dev_memset': (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
+    'safe_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'safe_memcpy_d2h': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'safe_timer_start': (C.c_int, [_vp]),
+    'safe_timer_stop_ms': (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    'safe_nbr_euclidean': (C.c_int, [_vp, _vp, _i64, C.c_double, _pp]),
+    'safe_nbr_shortpath': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, C.c_double, C.c_int, _pp]),
+    'safe_nbr_from_dense_i64': (C.c_int, [_vp, _vp, _i64, _pp]),
+    'safe_nbr_destroy': (C.c_int, [_vp]),
+    'safe_nbr_info': (C.c_int, [_vp, _pi64, _pi64, _pi64]),
+    'safe_nbr_to_dense_i64': (C.c_int, [_vp, _vp]),
+    'safe_nbr_to_dense_i64_dev': (C.c_int, [_vp, _vp]),
+    'safe_nbr_row_counts': (C.c_int, [_vp, _vp]),
+    'safe_nbr_csr': (C.c_int, [_vp, _vp, _vp]),
+    'safe_nbr_distances': (C.c_int, [_vp, _vp]),
+    'safe_euclidean_dense_dev': (C.c_int, [_vp, _vp, _i64, C.c_double, _vp, _vp]),
+    'safe_edge_lengths': (C.c_int, [_vp, _vp, _i64, _i64, _vp, _vp, _vp]),
+    'safe_attr_create_host': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _pp]),
+    'safe_attr_create_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _pp]),
+    'safe_attr_destroy': (C.c_int, [_vp]),
+    'safe_attr_stats': (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
+    'safe_attr_row_flags': (C.c_int, [_vp, _vp]),
+    'safe_attr_set_row_flags': (C.c_int, [_vp, _vp]),
+    'safe_perms_create': (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, C.c_uint32, _pp]),
+    'safe_perms_destroy': (C.c_int, [_vp]),
+    'safe_perms_read': (C.c_int, [_vp, _i64, _i64, _vp]),
+    'safe_rng_permutations_host': (C.c_int, [C.c_uint32, _vp, _i64, _i64, _vp]),
+    'safe_score': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _vp]),
+    'safe_permtest_counts': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, _i64, _i64, _vp, _vp, _vp]),
+    'safe_randomization': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp, _i64, _i64,
+                                     _vp, _vp, _vp, _vp, _vp, _vp]),
+    'safe_hypergeom': (C.c_int, [_vp, _vp, _vp, C.c_double, _i64, _i64, _vp, _vp, _vp, _vp]),
+    'safe_last_kernel_stats': (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), _pi64]),
+}
+
+for _name, (_res, _args) in PROTOTYPES.items():
+    _fn = getattr(lib, _name)      # AttributeError here = the library does not export the ABI
+    _fn.restype = _res
+    _fn.argtypes = _args
+
+if lib.safe_abi_version() != ABI_VERSION:
+    raise ImportError('safepy_amd: libsafe_hip.so ABI %d != expected %d; rebuild it'
+                      % (lib.safe_abi_version(), ABI_VERSION))
+
+
+def check(code):
+    if code != 0:
+        raise SafeHipError(code, lib.safe_last_error().decode('utf-8', 'replace'))
+
+
+def device_count():
+    c = C.c_int(0)
+    check(lib.safe_device_count(C.byref(c)))
+    return c.value

@@ -1,0 +1,350 @@
+"""Thin object layer over the C ABI: device context, device buffers and the three
+device-resident handles (membership, attribute matrix, permutation tables).
+
+Nothing here computes: every method forwards to libsafe_hip.so, and fails loudly if the
+library reports an error (no HIP device, bad arguments, ...).
+"""
+import ctypes as C
+
+import numpy as np
+
+from . import _lib
+from ._lib import lib, check
+
+_SCORE = {'sum': _lib.SCORE_SUM, 'z-score': _lib.SCORE_ZSCORE}
+_SIGN = {'highest': _lib.SIGN_HIGHEST, 'lowest': _lib.SIGN_LOWEST, 'both': _lib.SIGN_BOTH}
+
+
+def _ptr(a):
+    return C.c_void_p(a.ctypes.data) if a is not None else None
+
+
+class DeviceBuffer:
+    """A raw device allocation owned by the library allocator (f64/i64 element views)."""
+
+    def __init__(self, ctx, nbytes):
+        self.ctx = ctx
+        self.nbytes = int(nbytes)
+        p = C.c_void_p()
+        check(lib.safe_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p)))
+        self.ptr = p.value
+
+    def free(self):
+        if self.ptr:
+            check(lib.safe_dev_free(self.ctx.handle, C.c_void_p(self.ptr)))
+            self.ptr = None
+
+    def __del__(self):
+        try:
+            self.free()
+        except Exception:
+            pass
+
+    def upload(self, host):
+        host = np.ascontiguousarray(host)
+        assert host.nbytes <= self.nbytes
+        check(lib.safe_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), _ptr(host), host.nbytes))
+
+    def download(self, shape, dtype=np.float64):
+        out = np.empty(shape, dtype=dtype)
+        assert out.nbytes <= self.nbytes
+        check(lib.safe_memcpy_d2h(self.ctx.handle, _ptr(out), C.c_void_p(self.ptr), out.nbytes))
+        return out
+
+    def zero(self):
+        check(lib.safe_dev_memset(self.ctx.handle, C.c_void_p(self.ptr), 0, self.nbytes))
+
+
+class Context:
+    _default = {}
+
+    def __init__(self, device=0):
+        h = C.c_void_p()
+        check(lib.safe_ctx_create(int(device), C.byref(h)))
+        self.handle = h
+        self.device = int(device)
+        ncu = C.c_int()
+        hbm = C.c_int64()
+        arch = C.create_string_buffer(64)
+        check(lib.safe_ctx_info(h, C.byref(ncu), C.byref(hbm), arch, 64))
+        self.num_cu = ncu.value
+        self.hbm_bytes = hbm.value
+        self.arch = arch.value.decode()
+
+    @classmethod
+    def default(cls, device=0):
+        """Process-wide context per device (created on first use)."""
+        if device not in cls._default:
+            cls._default[device] = cls(device)
+        return cls._default[device]
+
+    def set_stream(self, stream_ptr):
+        check(lib.safe_ctx_set_stream(self.handle, C.c_void_p(stream_ptr) if stream_ptr else None))
+
+    def sync(self):
+        check(lib.safe_ctx_sync(self.handle))
+
+    def alloc(self, nbytes):
+        return DeviceBuffer(self, nbytes)
+
+    def alloc_f64(self, *shape):
+        return DeviceBuffer(self, int(np.prod(shape)) * 8)
+
+    def timer_start(self):
+        check(lib.safe_timer_start(self.handle))
+
+    def timer_stop_ms(self):
+        ms = C.c_double()
+        check(lib.safe_timer_stop_ms(self.handle, C.byref(ms)))
+        return ms.value
+
+    def last_kernel(self):
+        name = C.create_string_buffer(128)
+        ms = C.c_double()
+        cnt = C.c_int64()
+        check(lib.safe_last_kernel_stats(self.handle, name, 128, C.byref(ms), C.byref(cnt)))
+        return name.value.decode(), ms.value, cnt.value
+
+    def edge_lengths(self, xy, edge_u, edge_v):
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        eu = np.ascontiguousarray(edge_u, dtype=np.int32)
+        ev = np.ascontiguousarray(edge_v, dtype=np.int32)
+        out = np.empty(eu.shape[0], dtype=np.float64)
+        check(lib.safe_edge_lengths(self.handle, _ptr(xy), xy.shape[0], eu.shape[0], _ptr(eu), _ptr(ev), _ptr(out)))
+        return out
+
+    def euclidean_dense(self, xy_dev_ptr, n, nr, mask_dev_ptr=None, dist_dev_ptr=None):
+        check(lib.safe_euclidean_dense_dev(self.handle, C.c_void_p(xy_dev_ptr), int(n), float(nr),
+                                           C.c_void_p(mask_dev_ptr) if mask_dev_ptr else None,
+                                           C.c_void_p(dist_dev_ptr) if dist_dev_ptr else None))
+
+
+class Neighborhoods:
+    """Device-resident membership (bit matrix + CSR + SELL-64)."""
+
+    def __init__(self, ctx, handle):
+        self.ctx = ctx
+        self.handle = handle
+        n, nnz, mx = C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.safe_nbr_info(handle, C.byref(n), C.byref(nnz), C.byref(mx)))
+        self.n, self.nnz, self.max_row_count = n.value, nnz.value, mx.value
+
+    @classmethod
+    def euclidean(cls, ctx, xy, nr):
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        assert xy.ndim == 2 and xy.shape[1] == 2
+        h = C.c_void_p()
+        check(lib.safe_nbr_euclidean(ctx.handle, _ptr(xy), xy.shape[0], float(nr), C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def shortpath(cls, ctx, n, edge_u, edge_v, edge_w, cutoff, keep_distances=False):
+        eu = np.ascontiguousarray(edge_u, dtype=np.int32)
+        ev = np.ascontiguousarray(edge_v, dtype=np.int32)
+        ew = None if edge_w is None else np.ascontiguousarray(edge_w, dtype=np.float64)
+        h = C.c_void_p()
+        check(lib.safe_nbr_shortpath(ctx.handle, int(n), eu.shape[0], _ptr(eu), _ptr(ev), _ptr(ew), float(cutoff),
+                                     1 if keep_distances else 0, C.byref(h)))
+        return cls(ctx, h)
+
+    @classmethod
+    def from_dense(cls, ctx, a):
+        a = np.asarray(a)
+        if a.ndim != 2 or a.shape[0] != a.shape[1]:
+            raise ValueError('neighborhoods must be a square matrix, got shape %s' % (a.shape,))
+        a = np.ascontiguousarray(a, dtype=np.int64)
+        h = C.c_void_p()
+        check(lib.safe_nbr_from_dense_i64(ctx.handle, _ptr(a), a.shape[0], C.byref(h)))
+        return cls(ctx, h)
+
+    def to_dense(self):
+        out = np.empty((self.n, self.n), dtype=np.int64)
+        check(lib.safe_nbr_to_dense_i64(self.handle, _ptr(out)))
+        return out
+
+    def to_dense_dev(self, dev_ptr):
+        check(lib.safe_nbr_to_dense_i64_dev(self.handle, C.c_void_p(dev_ptr)))
+
+    def row_counts(self):
+        out = np.empty(self.n, dtype=np.int64)
+        check(lib.safe_nbr_row_counts(self.handle, _ptr(out)))
+        return out
+
+    def csr(self):
+        rp = np.empty(self.n + 1, dtype=np.int32)
+        col = np.empty(max(self.nnz, 1), dtype=np.int32)
+        check(lib.safe_nbr_csr(self.handle, _ptr(rp), _ptr(col)))
+        return rp, col[:self.nnz]
+
+    def distances(self):
+        out = np.empty((self.n, self.n), dtype=np.float64)
+        check(lib.safe_nbr_distances(self.handle, _ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            check(lib.safe_nbr_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Attributes:
+    """Device-resident node x attribute matrix (f32/f64, C or Fortran order, NaN = missing)."""
+
+    def __init__(self, ctx, handle, n, m, keepalive=None):
+        self.ctx = ctx
+        self.handle = handle
+        self.n, self.m = n, m
+        self._keepalive = keepalive
+
+    @staticmethod
+    def _layout(b):
+        if b.ndim != 2:
+            raise ValueError('node2attribute must be 2-D, got shape %s' % (b.shape,))
+        if b.dtype == np.float32:
+            dt = _lib.DTYPE_F32
+        elif b.dtype == np.float64:
+            dt = _lib.DTYPE_F64
+        else:
+            b = b.astype(np.float64)
+            dt = _lib.DTYPE_F64
+        if not (b.flags['C_CONTIGUOUS'] or b.flags['F_CONTIGUOUS']):
+            b = np.ascontiguousarray(b)
+        n, m = b.shape
+        if b.flags['C_CONTIGUOUS']:
+            rs, cs = m, 1
+        else:
+            rs, cs = 1, n
+        return b, dt, n, m, rs, cs
+
+    @classmethod
+    def from_host(cls, ctx, b):
+        b, dt, n, m, rs, cs = cls._layout(np.asarray(b))
+        h = C.c_void_p()
+        check(lib.safe_attr_create_host(ctx.handle, _ptr(b), dt, n, m, rs, cs, C.byref(h)))
+        return cls(ctx, h, n, m)
+
+    @classmethod
+    def from_device(cls, ctx, dev_ptr, dtype, n, m, order='C', keepalive=None):
+        dt = _lib.DTYPE_F32 if np.dtype(dtype) == np.float32 else _lib.DTYPE_F64
+        rs, cs = (m, 1) if order == 'C' else (1, n)
+        h = C.c_void_p()
+        check(lib.safe_attr_create_dev(ctx.handle, C.c_void_p(dev_ptr), dt, n, m, rs, cs, C.byref(h)))
+        return cls(ctx, h, n, m, keepalive=keepalive)
+
+    def stats(self):
+        a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
+        check(lib.safe_attr_stats(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))
+        return {'n_other': a.value, 'max_nan_col': b.value, 'n_rows_with_value': c.value, 'n_non_integer': d.value}
+
+    def row_flags(self):
+        out = np.empty(self.n, dtype=np.uint8)
+        check(lib.safe_attr_row_flags(self.handle, _ptr(out)))
+        return out
+
+    def set_row_flags(self, flags):
+        flags = np.ascontiguousarray(flags, dtype=np.uint8)
+        assert flags.shape == (self.n,)
+        check(lib.safe_attr_set_row_flags(self.handle, _ptr(flags)))
+
+    def close(self):
+        if self.handle:
+            check(lib.safe_attr_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class Permutations:
+    """Device-resident composed row-permutation tables (legacy NumPy MT19937 stream)."""
+
+    def __init__(self, ctx, n, movable, num_permutations, seed):
+        movable = np.ascontiguousarray(movable, dtype=np.uint8)
+        assert movable.shape == (n,)
+        if seed is not None:
+            seed = int(seed)
+            if seed < 0 or seed > 0xFFFFFFFF:
+                raise ValueError('Seed must be between 0 and 2**32 - 1')
+        self.ctx = ctx
+        self.n = int(n)
+        self.count = int(num_permutations)
+        h = C.c_void_p()
+        check(lib.safe_perms_create(ctx.handle, self.n, _ptr(movable), self.count, 0 if seed is None else 1,
+                                    0 if seed is None else seed, C.byref(h)))
+        self.handle = h
+
+    def read(self, p0=0, p1=None):
+        p1 = self.count if p1 is None else p1
+        out = np.empty((p1 - p0, self.n), dtype=np.int32)
+        check(lib.safe_perms_read(self.handle, p0, p1, _ptr(out)))
+        return out
+
+    def close(self):
+        if self.handle:
+            check(lib.safe_perms_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def rng_permutations_host(seed, values, count):
+    """Host-only: `count` successive np.random.permutation(values) draws after np.random.seed(seed)."""
+    values = np.ascontiguousarray(values, dtype=np.int64)
+    out = np.empty((count, values.shape[0]), dtype=np.int64)
+    check(lib.safe_rng_permutations_host(int(seed), _ptr(values), values.shape[0], int(count), _ptr(out)))
+    return out
+
+
+def nes_table(num_permutations):
+    """-log10 of every possible empirical p-value k/P (k=0 -> 1/P), evaluated with NumPy so
+    NES equals the reference's np.log10 bit for bit (safepy/safe.py:546-547)."""
+    p = np.arange(num_permutations + 1, dtype=np.float64) / num_permutations
+    with np.errstate(divide='ignore'):
+        return np.ascontiguousarray(-np.log10(np.where(p == 0, 1 / num_permutations, p)))
+
+
+# ---- enrichment entry points on device buffers -----------------------------------------
+
+def score(ctx, nbr, attr, score_type, out_ptr, col0=0, col1=None):
+    col1 = attr.m if col1 is None else col1
+    check(lib.safe_score(ctx.handle, nbr.handle, attr.handle, _SCORE[score_type], col0, col1, C.c_void_p(out_ptr)))
+
+
+def permtest_counts(ctx, nbr, attr, perms, score_type, ns_ptr, neg_ptr, pos_ptr, col0=0, col1=None):
+    col1 = attr.m if col1 is None else col1
+    check(lib.safe_permtest_counts(ctx.handle, nbr.handle, attr.handle, perms.handle, _SCORE[score_type], col0, col1,
+                                   C.c_void_p(ns_ptr) if ns_ptr else None, C.c_void_p(neg_ptr), C.c_void_p(pos_ptr)))
+
+
+def randomization(ctx, nbr, attr, perms, score_type, attribute_sign, enrichment_threshold, out_ptrs,
+                  col0=0, col1=None, table=None):
+    """out_ptrs = (ns, pvalues_neg, pvalues_pos, nes, nes_binary, num_enriched) device pointers."""
+    col1 = attr.m if col1 is None else col1
+    if table is None:
+        table = nes_table(perms.count)
+    ns, pn, pp, nes, nb, ne = out_ptrs
+    check(lib.safe_randomization(ctx.handle, nbr.handle, attr.handle, perms.handle, _SCORE[score_type],
+                                 _SIGN[attribute_sign], float(enrichment_threshold), _ptr(table), col0, col1,
+                                 C.c_void_p(ns) if ns else None, C.c_void_p(pn), C.c_void_p(pp), C.c_void_p(nes),
+                                 C.c_void_p(nb), C.c_void_p(ne)))
+
+
+def hypergeom(ctx, nbr, attr, enrichment_threshold, out_ptrs, col0=0, col1=None):
+    """out_ptrs = (pvalues_pos, nes, nes_binary, num_enriched) device pointers."""
+    col1 = attr.m if col1 is None else col1
+    pp, nes, nb, ne = out_ptrs
+    check(lib.safe_hypergeom(ctx.handle, nbr.handle, attr.handle, float(enrichment_threshold), col0, col1,
+                             C.c_void_p(pp), C.c_void_p(nes), C.c_void_p(nb), C.c_void_p(ne)))

@@ -1,0 +1,223 @@
+// Attribute matrix handle: upload / borrow self.node2attribute and derive the
+// whole-matrix facts compute_pvalues needs before it dispatches
+// (safepy/safe.py:453-463, 574-583; safepy/safe_extras.py:51).
+#include "common.h"
+
+template <typename T>
+__device__ __forceinline__ double load_attr(const void *raw, int64_t idx) {
+    return static_cast<double>(reinterpret_cast<const T *>(raw)[idx]);
+}
+
+// One block per column: NaN count, nansum (f64, row order), #values outside {0,1},
+// #non-integers, max |v|; and row flags by atomicOr into a byte map.
+template <typename T>
+__global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw, int64_t n, int64_t m,
+                                                    int64_t rs, int64_t cs, unsigned int *__restrict__ row_flags32,
+                                                    unsigned long long *__restrict__ acc /*[4]*/,
+                                                    double *__restrict__ col_sum, unsigned long long *__restrict__ max_abs_bits) {
+    const int64_t j = blockIdx.x;
+    __shared__ unsigned long long s_nan, s_other, s_nonint;
+    __shared__ double s_part[256];
+    __shared__ double s_max[256];
+    if (threadIdx.x == 0) {
+        s_nan = 0;
+        s_other = 0;
+        s_nonint = 0;
+    }
+    __syncthreads();
+    unsigned long long c_nan = 0, c_other = 0, c_nonint = 0;
+    double mx = 0.0;
+    // per-thread sums over a contiguous chunk keep the column sum in row order per chunk
+    const int64_t chunk = (n + 255) / 256;
+    const int64_t i0 = threadIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
+    double sum = 0.0;
+    for (int64_t i = i0; i < i1; ++i) {
+        const double v = load_attr<T>(raw, i * rs + j * cs);
+        if (v != v) {
+            ++c_nan;
+        } else {
+            sum += v;
+            if (v != 0.0 && v != 1.0) ++c_other;
+            if (v != floor(v)) ++c_nonint;
+            const double a = fabs(v);
+            if (a > mx) mx = a;
+            // row has a value: set its byte (4 rows share a 32-bit word)
+            const unsigned int bit = 1u << (8 * (i & 3));
+            if (!(row_flags32[i >> 2] & bit)) atomicOr(&row_flags32[i >> 2], bit);   // racy pre-check is benign
+        }
+    }
+    s_part[threadIdx.x] = sum;
+    s_max[threadIdx.x] = mx;
+    atomicAdd(&s_nan, c_nan);
+    atomicAdd(&s_other, c_other);
+    atomicAdd(&s_nonint, c_nonint);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double total = 0.0, tmx = 0.0;
+        for (int t = 0; t < 256; ++t) {
+            total += s_part[t];
+            if (s_max[t] > tmx) tmx = s_max[t];
+        }
+        col_sum[j] = total;
+        atomicAdd(&acc[0], s_other);
+        atomicMax(&acc[1], s_nan);
+        atomicAdd(&acc[2], s_nonint);
+        atomicMax(max_abs_bits, static_cast<unsigned long long>(__double_as_longlong(tmx)));
+    }
+}
+
+int safe_attr_prepare(safe_attr *attr) {
+    if (attr->stats_ready) return SAFE_OK;
+    safe_ctx *ctx = attr->ctx;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t n = attr->n, m = attr->m;
+    const size_t flag_bytes = static_cast<size_t>(ceil_div(n, 4)) * 4;
+    unsigned long long *d_acc = nullptr;
+    SAFE_TRY(dev_alloc(&d_acc, 4));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    uint8_t *flags = nullptr;
+    SAFE_TRY(dev_alloc(&flags, flag_bytes));
+    SAFE_HIP_CHECK(hipMemsetAsync(flags, 0, flag_bytes, ctx->stream));
+    if (!attr->col_sum) SAFE_TRY(dev_alloc(&attr->col_sum, m));
+    if (attr->dtype == SAFE_DTYPE_F32)
+        hipLaunchKernelGGL(k_attr_stats<float>, dim3(m), dim3(256), 0, ctx->stream, attr->raw, n, m, attr->row_stride,
+                           attr->col_stride, reinterpret_cast<unsigned int *>(flags), d_acc, attr->col_sum, d_acc + 3);
+    else
+        hipLaunchKernelGGL(k_attr_stats<double>, dim3(m), dim3(256), 0, ctx->stream, attr->raw, n, m, attr->row_stride,
+                           attr->col_stride, reinterpret_cast<unsigned int *>(flags), d_acc, attr->col_sum, d_acc + 3);
+    SAFE_HIP_CHECK(hipGetLastError());
+    unsigned long long h_acc[4];
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<uint8_t> h_flags(flag_bytes);
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_acc);
+    attr->n_other = static_cast<int64_t>(h_acc[0]);
+    attr->max_nan_col = static_cast<int64_t>(h_acc[1]);
+    attr->n_non_integer = static_cast<int64_t>(h_acc[2]);
+    double mx;
+    memcpy(&mx, &h_acc[3], sizeof(double));
+    attr->max_abs = mx;
+    if (!attr->flags_ready) {
+        if (attr->row_flags) (void)hipFree(attr->row_flags);
+        attr->row_flags = flags;
+        attr->flags_ready = true;
+        int64_t cnt = 0;
+        for (int64_t i = 0; i < n; ++i) cnt += h_flags[i] != 0;
+        attr->n_rows_with_value = cnt;
+    } else {
+        (void)hipFree(flags);    // caller supplied global flags (sharded run): keep them
+    }
+    attr->stats_ready = true;
+    return SAFE_OK;
+}
+
+static int attr_new(safe_ctx *ctx, int dtype, int64_t n, int64_t m, int64_t rs, int64_t cs, safe_attr **out) {
+    SAFE_REQUIRE(ctx && out, "safe_attr_create: NULL argument");
+    SAFE_REQUIRE(dtype == SAFE_DTYPE_F32 || dtype == SAFE_DTYPE_F64, "safe_attr_create: dtype must be f32 or f64");
+    SAFE_REQUIRE(n >= 1 && m >= 1, "safe_attr_create: empty matrix (%lld x %lld)", (long long)n, (long long)m);
+    SAFE_REQUIRE((rs == m && cs == 1) || (rs == 1 && cs == n) || (m == 1 && cs >= 1 && rs == 1) || (n == 1 && cs == 1),
+                 "safe_attr_create: matrix must be C- or Fortran-contiguous (strides %lld,%lld for %lld x %lld)",
+                 (long long)rs, (long long)cs, (long long)n, (long long)m);
+    safe_attr *a = new safe_attr();
+    a->ctx = ctx;
+    a->n = n;
+    a->m = m;
+    a->dtype = dtype;
+    a->row_stride = rs;
+    a->col_stride = cs;
+    *out = a;
+    return SAFE_OK;
+}
+
+extern "C" {
+
+int safe_attr_create_host(safe_ctx *ctx, const void *b_host, int dtype, int64_t n, int64_t m, int64_t row_stride,
+                          int64_t col_stride, safe_attr **out) {
+    SAFE_REQUIRE(b_host != nullptr, "safe_attr_create_host: b_host is NULL");
+    safe_attr *a = nullptr;
+    SAFE_TRY(attr_new(ctx, dtype, n, m, row_stride, col_stride, &a));
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(n) * m * (dtype == SAFE_DTYPE_F32 ? 4 : 8);
+    uint8_t *d = nullptr;
+    int rc = dev_alloc(&d, bytes);
+    if (rc != SAFE_OK) {
+        delete a;
+        return rc;
+    }
+    hipError_t e = hipMemcpyAsync(d, b_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        safe_set_error("safe_attr_create_host: %s", hipGetErrorString(e));
+        (void)hipFree(d);
+        delete a;
+        return SAFE_E_HIP;
+    }
+    a->raw = d;
+    a->owns_raw = true;
+    *out = a;
+    return SAFE_OK;
+}
+
+int safe_attr_create_dev(safe_ctx *ctx, const void *b_dev, int dtype, int64_t n, int64_t m, int64_t row_stride,
+                         int64_t col_stride, safe_attr **out) {
+    SAFE_REQUIRE(b_dev != nullptr, "safe_attr_create_dev: b_dev is NULL");
+    safe_attr *a = nullptr;
+    SAFE_TRY(attr_new(ctx, dtype, n, m, row_stride, col_stride, &a));
+    a->raw = b_dev;
+    a->owns_raw = false;
+    *out = a;
+    return SAFE_OK;
+}
+
+int safe_attr_destroy(safe_attr *attr) {
+    if (!attr) return SAFE_OK;
+    (void)hipSetDevice(attr->ctx->device);
+    (void)hipStreamSynchronize(attr->ctx->stream);
+    if (attr->owns_raw) (void)hipFree(const_cast<void *>(attr->raw));
+    (void)hipFree(attr->row_flags);
+    (void)hipFree(attr->col_sum);
+    delete attr;
+    return SAFE_OK;
+}
+
+int safe_attr_stats(safe_attr *attr, int64_t *n_other, int64_t *max_nan_col, int64_t *n_rows_with_value,
+                    int64_t *n_non_integer) {
+    SAFE_REQUIRE(attr != nullptr, "safe_attr_stats: attr is NULL");
+    SAFE_TRY(safe_attr_prepare(attr));
+    if (n_other) *n_other = attr->n_other;
+    if (max_nan_col) *max_nan_col = attr->max_nan_col;
+    if (n_rows_with_value) *n_rows_with_value = attr->n_rows_with_value;
+    if (n_non_integer) *n_non_integer = attr->n_non_integer;
+    return SAFE_OK;
+}
+
+int safe_attr_row_flags(safe_attr *attr, uint8_t *out_host) {
+    SAFE_REQUIRE(attr && out_host, "safe_attr_row_flags: NULL argument");
+    SAFE_TRY(safe_attr_prepare(attr));
+    safe_ctx *ctx = attr->ctx;
+    SAFE_HIP_CHECK(hipMemcpyAsync(out_host, attr->row_flags, attr->n, hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_attr_set_row_flags(safe_attr *attr, const uint8_t *flags_host) {
+    SAFE_REQUIRE(attr && flags_host, "safe_attr_set_row_flags: NULL argument");
+    safe_ctx *ctx = attr->ctx;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t flag_bytes = static_cast<size_t>(ceil_div(attr->n, 4)) * 4;
+    if (!attr->row_flags) SAFE_TRY(dev_alloc(&attr->row_flags, flag_bytes));
+    std::vector<uint8_t> tmp(flag_bytes, 0);
+    int64_t cnt = 0;
+    for (int64_t i = 0; i < attr->n; ++i) {
+        tmp[i] = flags_host[i] ? 1 : 0;
+        cnt += tmp[i];
+    }
+    SAFE_HIP_CHECK(hipMemcpyAsync(attr->row_flags, tmp.data(), flag_bytes, hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    attr->flags_ready = true;
+    attr->n_rows_with_value = cnt;
+    return SAFE_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,125 @@
+// Internal declarations shared by the translation units of libsafe_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <cstdarg>
+#include <cstdint>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "safe_hip.h"
+
+#define SAFE_WAVE 64
+#define SAFE_PAD_U16 0xFFFFu
+
+void safe_set_error(const char *fmt, ...);
+
+#define SAFE_HIP_CHECK(expr)                                                                   \
+    do {                                                                                       \
+        hipError_t _e = (expr);                                                                \
+        if (_e != hipSuccess) {                                                                \
+            safe_set_error("%s failed: %s (%s:%d)", #expr, hipGetErrorString(_e), __FILE__,    \
+                           __LINE__);                                                          \
+            return SAFE_E_HIP;                                                                 \
+        }                                                                                      \
+    } while (0)
+
+#define SAFE_REQUIRE(cond, ...)                                                                \
+    do {                                                                                       \
+        if (!(cond)) {                                                                         \
+            safe_set_error(__VA_ARGS__);                                                       \
+            return SAFE_E_INVALID;                                                             \
+        }                                                                                      \
+    } while (0)
+
+#define SAFE_TRY(expr)                                                                         \
+    do {                                                                                       \
+        int _rc = (expr);                                                                      \
+        if (_rc != SAFE_OK) return _rc;                                                        \
+    } while (0)
+
+struct KernelStat {
+    std::string name;
+    double total_ms = 0.0;
+    int64_t launches = 0;
+};
+
+struct safe_ctx {
+    int device = 0;
+    hipStream_t own_stream = nullptr;
+    hipStream_t stream = nullptr;
+    int num_cu = 0;
+    int64_t hbm_bytes = 0;
+    char arch[64] = {0};
+    hipEvent_t t0 = nullptr, t1 = nullptr;      // safe_timer_*
+    hipEvent_t k0 = nullptr, k1 = nullptr;      // dominant-kernel timing
+    KernelStat last_kernel;
+};
+
+// RAII-less device buffer helper: all frees go through the owning handle's destroy.
+template <typename T>
+static inline int dev_alloc(T **p, size_t count) {
+    *p = nullptr;
+    if (count == 0) count = 1;
+    hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
+    if (e != hipSuccess) {
+        safe_set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
+        return SAFE_E_NOMEM;
+    }
+    return SAFE_OK;
+}
+
+// Membership structure.  Canonical form: bit matrix; derived: CSR and SELL-64 (sliced
+// ELLPACK with rows sorted by descending count so each 64-row slice is nearly uniform).
+struct safe_nbr {
+    safe_ctx *ctx = nullptr;
+    int64_t n = 0;
+    int64_t nnz = 0;
+    int64_t max_count = 0;
+    int64_t words = 0;              // 64-bit words per bit-matrix row
+    uint64_t *bits = nullptr;       // [n][words]
+    int32_t *row_ptr = nullptr;     // [n+1]
+    int32_t *col = nullptr;         // [nnz]
+    // SELL-64
+    int64_t n_slices = 0;
+    int32_t *sell_row = nullptr;    // [n_slices*64] original row id, -1 = padding lane
+    int64_t *slice_off = nullptr;   // [n_slices+1] offset into sell_col (entries)
+    int32_t *slice_width = nullptr; // [n_slices]
+    int32_t *sell_col = nullptr;    // [slice_off[n_slices]] column id, n = padding (zero row)
+    int64_t sell_entries = 0;
+    std::vector<int32_t> h_slice_width;
+    std::vector<int64_t> h_slice_off;
+    std::vector<int32_t> h_row_count;   // host copy of per-row counts
+    double *dist = nullptr;         // optional [n][n]
+};
+
+struct safe_attr {
+    safe_ctx *ctx = nullptr;
+    int64_t n = 0, m = 0;
+    int dtype = SAFE_DTYPE_F64;
+    int64_t row_stride = 0, col_stride = 0;
+    const void *raw = nullptr;      // device
+    bool owns_raw = false;
+    uint8_t *row_flags = nullptr;   // [n] device, 1 = row has >= 1 non-NaN value
+    bool flags_ready = false;
+    bool stats_ready = false;
+    int64_t n_other = 0, max_nan_col = 0, n_rows_with_value = 0, n_non_integer = 0;
+    double *col_sum = nullptr;      // [m] nansum per column (device)
+    double max_abs = 0.0;           // max |value| over non-NaN entries
+};
+
+struct safe_perms {
+    safe_ctx *ctx = nullptr;
+    int64_t n = 0;
+    int64_t count = 0;
+    int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)
+};
+
+// launch-geometry helpers
+static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
+
+int safe_attr_prepare(safe_attr *attr);   // row flags + stats (attr.hip)
+int nbr_finalize_from_bits(safe_nbr *nbr);   // bits -> CSR + SELL (nbr.hip)

@@ -1,0 +1,161 @@
+// Context, error reporting and raw device-memory helpers of libsafe_hip.so.
+#include "common.h"
+
+static thread_local char g_error[1024] = "";
+
+void safe_set_error(const char *fmt, ...) {
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(g_error, sizeof(g_error), fmt, ap);
+    va_end(ap);
+}
+
+extern "C" {
+
+int safe_abi_version(void) { return SAFE_HIP_ABI_VERSION; }
+
+const char *safe_last_error(void) { return g_error; }
+
+int safe_device_count(int *count) {
+    SAFE_REQUIRE(count != nullptr, "safe_device_count: count is NULL");
+    int c = 0;
+    hipError_t e = hipGetDeviceCount(&c);
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
+        c = 0;
+    }
+    *count = c;
+    return SAFE_OK;
+}
+
+int safe_ctx_create(int device, safe_ctx **out) {
+    SAFE_REQUIRE(out != nullptr, "safe_ctx_create: out is NULL");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0) {
+        (void)hipGetLastError();
+        safe_set_error("safe_ctx_create: no HIP device available (%s); libsafe_hip has no CPU fallback",
+                       e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+        return SAFE_E_HIP;
+    }
+    SAFE_REQUIRE(device >= 0 && device < count, "safe_ctx_create: device %d out of range [0,%d)", device, count);
+    SAFE_HIP_CHECK(hipSetDevice(device));
+    safe_ctx *ctx = new safe_ctx();
+    ctx->device = device;
+    hipDeviceProp_t prop;
+    SAFE_HIP_CHECK(hipGetDeviceProperties(&prop, device));
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->hbm_bytes = static_cast<int64_t>(prop.totalGlobalMem);
+    snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
+    SAFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
+    ctx->stream = ctx->own_stream;
+    SAFE_HIP_CHECK(hipEventCreate(&ctx->t0));
+    SAFE_HIP_CHECK(hipEventCreate(&ctx->t1));
+    SAFE_HIP_CHECK(hipEventCreate(&ctx->k0));
+    SAFE_HIP_CHECK(hipEventCreate(&ctx->k1));
+    *out = ctx;
+    return SAFE_OK;
+}
+
+int safe_ctx_destroy(safe_ctx *ctx) {
+    if (!ctx) return SAFE_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    if (ctx->t0) (void)hipEventDestroy(ctx->t0);
+    if (ctx->t1) (void)hipEventDestroy(ctx->t1);
+    if (ctx->k0) (void)hipEventDestroy(ctx->k0);
+    if (ctx->k1) (void)hipEventDestroy(ctx->k1);
+    if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
+    delete ctx;
+    return SAFE_OK;
+}
+
+int safe_ctx_set_stream(safe_ctx *ctx, void *hip_stream) {
+    SAFE_REQUIRE(ctx != nullptr, "safe_ctx_set_stream: ctx is NULL");
+    ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
+    return SAFE_OK;
+}
+
+int safe_ctx_sync(safe_ctx *ctx) {
+    SAFE_REQUIRE(ctx != nullptr, "safe_ctx_sync: ctx is NULL");
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_ctx_info(safe_ctx *ctx, int *num_cu, int64_t *hbm_bytes, char *arch, size_t arch_len) {
+    SAFE_REQUIRE(ctx != nullptr, "safe_ctx_info: ctx is NULL");
+    if (num_cu) *num_cu = ctx->num_cu;
+    if (hbm_bytes) *hbm_bytes = ctx->hbm_bytes;
+    if (arch && arch_len) snprintf(arch, arch_len, "%s", ctx->arch);
+    return SAFE_OK;
+}
+
+int safe_dev_alloc(safe_ctx *ctx, size_t bytes, void **out_dev) {
+    SAFE_REQUIRE(ctx != nullptr && out_dev != nullptr, "safe_dev_alloc: NULL argument");
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    uint8_t *p = nullptr;
+    SAFE_TRY(dev_alloc(&p, bytes));
+    *out_dev = p;
+    return SAFE_OK;
+}
+
+int safe_dev_free(safe_ctx *ctx, void *dev) {
+    SAFE_REQUIRE(ctx != nullptr, "safe_dev_free: ctx is NULL");
+    if (!dev) return SAFE_OK;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(hipFree(dev));
+    return SAFE_OK;
+}
+
+int safe_dev_memset(safe_ctx *ctx, void *dev, int value, size_t bytes) {
+    SAFE_REQUIRE(ctx != nullptr && dev != nullptr, "safe_dev_memset: NULL argument");
+    SAFE_HIP_CHECK(hipMemsetAsync(dev, value, bytes, ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_memcpy_h2d(safe_ctx *ctx, void *dev, const void *host, size_t bytes) {
+    SAFE_REQUIRE(ctx != nullptr && (bytes == 0 || (dev && host)), "safe_memcpy_h2d: NULL argument");
+    if (bytes == 0) return SAFE_OK;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes) {
+    SAFE_REQUIRE(ctx != nullptr && (bytes == 0 || (dev && host)), "safe_memcpy_d2h: NULL argument");
+    if (bytes == 0) return SAFE_OK;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_timer_start(safe_ctx *ctx) {
+    SAFE_REQUIRE(ctx != nullptr, "safe_timer_start: ctx is NULL");
+    SAFE_HIP_CHECK(hipEventRecord(ctx->t0, ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_timer_stop_ms(safe_ctx *ctx, double *elapsed_ms) {
+    SAFE_REQUIRE(ctx != nullptr && elapsed_ms != nullptr, "safe_timer_stop_ms: NULL argument");
+    SAFE_HIP_CHECK(hipEventRecord(ctx->t1, ctx->stream));
+    SAFE_HIP_CHECK(hipEventSynchronize(ctx->t1));
+    float ms = 0.f;
+    SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
+    *elapsed_ms = ms;
+    return SAFE_OK;
+}
+
+int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *avg_ms, int64_t *launches) {
+    SAFE_REQUIRE(ctx != nullptr, "safe_last_kernel_stats: ctx is NULL");
+    if (name && name_len) snprintf(name, name_len, "%s", ctx->last_kernel.name.c_str());
+    if (avg_ms) *avg_ms = ctx->last_kernel.launches ? ctx->last_kernel.total_ms / ctx->last_kernel.launches : 0.0;
+    if (launches) *launches = ctx->last_kernel.launches;
+    return SAFE_OK;
+}
+
+}  // extern "C"

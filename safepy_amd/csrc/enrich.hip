@@ -1,0 +1,541 @@
+// Enrichment on gfx950: neighborhood score, permutation test and hypergeometric test.
+//
+// Replaces compute_neighborhood_score / run_permutations (safepy/safe_extras.py:6-70) and
+// compute_pvalues_by_randomization / compute_pvalues_by_hypergeom + the binarisation of
+// compute_pvalues (safepy/safe.py:468-608, FDR branch excluded).
+//
+// Formulation.  The reference evaluates every permutation as a dense product
+// A[N,N] . B[perm][N,M] (np.dot -> dgemm, 2*N^2*M flop) although A is ~1-3 % dense.  Here
+// the membership is held as SELL-64 (64-row slices, column-major inside a slice, rows
+// sorted by count) and a permuted score is a gather-sum
+//     S_p[i, j] = sum_{k in nbr(i)} B0[cur_p[k], j]
+// over a column tile of B0 that stays resident on chip for all P permutations; the
+// <= / >= comparisons against the observed score and the counters stay in registers, and
+// p-values / NES / binarisation are produced in the kernel epilogue -- S_p never exists in
+// HBM.  All arithmetic is f64 like the reference's dgemm (the comparison counts are only
+// reproducible at f64); compiled with -ffp-contract=off so the z-score's EXX - M*M is not
+// contracted.
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+// --------------------------------------------------------------------------------------
+// Column tiles of the attribute matrix: Bt[tile][row 0..n][plane][BN] f64, NaN -> 0; row n
+// is the all-zero padding row the SELL padding entries point at.  Planes: 0 = B0;
+// z-score adds 1 = B0^2 (squared in B's own dtype like np.power(B, 2),
+// safe_extras.py:24) and 2 = not-NaN indicator (safe_extras.py:13).
+// --------------------------------------------------------------------------------------
+template <typename T, int BN, int PLANES>
+__global__ __launch_bounds__(256) void k_tile_prep(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                   int64_t col0, int64_t mloc, int64_t n_tiles,
+                                                   double *__restrict__ bt) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t total = n_tiles * (n + 1) * BN;
+    if (idx >= total) return;
+    const int c = static_cast<int>(idx % BN);
+    const int64_t row = (idx / BN) % (n + 1);
+    const int64_t tile = idx / (static_cast<int64_t>(BN) * (n + 1));
+    const int64_t j = tile * BN + c;
+    double v = 0.0, v2 = 0.0, nn = 0.0;
+    if (row < n && j < mloc) {
+        const T x = reinterpret_cast<const T *>(raw)[row * rs + (col0 + j) * cs];
+        if (x == x) {
+            v = static_cast<double>(x);
+            v2 = static_cast<double>(static_cast<T>(x * x));
+            nn = 1.0;
+        }
+    }
+    double *dst = bt + ((tile * (n + 1) + row) * PLANES) * BN + c;
+    dst[0] = v;
+    if (PLANES == 3) {
+        dst[BN] = v2;
+        dst[2 * BN] = nn;
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// score from the accumulated planes (safe_extras.py:15-31)
+// --------------------------------------------------------------------------------------
+template <int BN, bool Z>
+__device__ __forceinline__ void finish_score(const double (&acc)[Z ? 3 : 1][BN], double (&score)[BN]) {
+#pragma unroll
+    for (int c = 0; c < BN; ++c) {
+        if (!Z) {
+            score[c] = acc[0][c];
+        } else {
+            const double cnt = acc[2][c];
+            const double mean = acc[0][c] / cnt;
+            const double exx = acc[1][c] / cnt;
+            const double sd = sqrt(exx - mean * mean);
+            double s = mean / sd;
+            if (sd == 0.0) s = __longlong_as_double(0x7FF8000000000000ll);
+            if (cnt < 3.0) s = __longlong_as_double(0x7FF8000000000000ll);
+            score[c] = s;
+        }
+    }
+}
+
+struct PermOut {
+    double *ns;            // [n][mloc] or NULL
+    double *counts_neg;    // raw-count mode
+    double *counts_pos;
+    double *pvalues_neg;   // full mode
+    double *pvalues_pos;
+    double *nes;
+    double *nes_binary;
+    unsigned int *enriched;   // [mloc] u32 column counters
+    const double *nes_table;  // [P+1]
+    double nes_threshold;     // -log10(enrichment_threshold)
+    int sign_mode;
+    int mode;                 // 0 = score only, 1 = raw counts, 2 = full post-processing
+};
+
+// --------------------------------------------------------------------------------------
+// K5 (general f64 form): one workgroup = (column tile, slice group); its 4 waves walk
+// 64-row slices; inside a slice every lane owns one neighborhood (row) and BN columns.
+// Workgroups of one tile are placed on one XCD (blockIdx % 8) so the tile is fetched into
+// a single L2.
+// --------------------------------------------------------------------------------------
+template <int BN, bool Z>
+__global__ __launch_bounds__(256) void k_permtest_gather(
+    const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
+    const int32_t *__restrict__ slice_width, const int32_t *__restrict__ sell_col, int64_t n_slices, int64_t n,
+    const double *__restrict__ bt, int64_t n_tiles, int n_groups, const int32_t *__restrict__ table, int64_t n_perm,
+    int64_t mloc, PermOut out) {
+    constexpr int PLANES = Z ? 3 : 1;
+    constexpr int ROWLEN = PLANES * BN;
+    const int64_t b = blockIdx.x;
+    const int64_t xcd = b & 7, q = b >> 3;
+    const int64_t tile = (q / n_groups) * 8 + xcd;
+    const int group = static_cast<int>(q % n_groups);
+    if (tile >= n_tiles) return;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const double *tb = bt + tile * (n + 1) * ROWLEN;
+    const int64_t stride = n + 1;
+    const int64_t jbase = tile * BN;
+
+    for (int64_t s = group + static_cast<int64_t>(n_groups) * wave; s < n_slices; s += static_cast<int64_t>(n_groups) * 4) {
+        const int32_t row = sell_row[s * 64 + lane];
+        const int32_t *cols = sell_col + slice_off[s] + lane;
+        const int wdt = slice_width[s];
+
+        double acc[PLANES][BN];
+        double obs[BN];
+#pragma unroll
+        for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+            for (int c = 0; c < BN; ++c) acc[pl][c] = 0.0;
+        for (int t = 0; t < wdt; ++t) {
+            const double *r = tb + static_cast<int64_t>(cols[t * 64]) * ROWLEN;
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                for (int c = 0; c < BN; ++c) acc[pl][c] += r[pl * BN + c];
+        }
+        finish_score<BN, Z>(acc, obs);
+
+        unsigned int cneg[BN], cpos[BN];
+#pragma unroll
+        for (int c = 0; c < BN; ++c) cneg[c] = cpos[c] = 0;
+
+        for (int64_t p = 0; p < n_perm; ++p) {
+            const int32_t *cur = table + p * stride;
+#pragma unroll
+            for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                for (int c = 0; c < BN; ++c) acc[pl][c] = 0.0;
+#pragma unroll 2
+            for (int t = 0; t < wdt; ++t) {
+                const double *r = tb + static_cast<int64_t>(cur[cols[t * 64]]) * ROWLEN;
+#pragma unroll
+                for (int pl = 0; pl < PLANES; ++pl)
+#pragma unroll
+                    for (int c = 0; c < BN; ++c) acc[pl][c] += r[pl * BN + c];
+            }
+            double sc[BN];
+            finish_score<BN, Z>(acc, sc);
+#pragma unroll
+            for (int c = 0; c < BN; ++c) {
+                cneg[c] += sc[c] <= obs[c];      // safe_extras.py:65
+                cpos[c] += sc[c] >= obs[c];      // safe_extras.py:66
+            }
+        }
+
+        // ---- epilogue: everything compute_pvalues derives from the counters -------------
+        const bool live = row >= 0;
+        const int64_t o = static_cast<int64_t>(live ? row : 0) * mloc + jbase;
+#pragma unroll
+        for (int c = 0; c < BN; ++c) {
+            const bool ok = live && (jbase + c < mloc);
+            const bool obs_nan = obs[c] != obs[c];
+            if (ok && out.ns) out.ns[o + c] = obs[c];
+            if (out.mode == 1) {
+                // run_permutations returns plain counts (no NaN masking, safe_extras.py:70)
+                if (ok) {
+                    out.counts_neg[o + c] = static_cast<double>(cneg[c]);
+                    out.counts_pos[o + c] = static_cast<double>(cpos[c]);
+                }
+            } else if (out.mode == 2) {
+                const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+                // safe.py:528-533: counts[isnan(ns)] = nan; p = counts / P
+                const double pn = obs_nan ? qnan : static_cast<double>(cneg[c]) / static_cast<double>(n_perm);
+                const double pp = obs_nan ? qnan : static_cast<double>(cpos[c]) / static_cast<double>(n_perm);
+                // safe.py:546-554 via the caller's -log10 table (k/P has P+1 possible values)
+                const double en = obs_nan ? qnan : out.nes_table[cneg[c]];
+                const double ep = obs_nan ? qnan : out.nes_table[cpos[c]];
+                double nes = ep - en;
+                if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+                if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+                // safe.py:468-470
+                const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+                if (ok) {
+                    out.pvalues_neg[o + c] = pn;
+                    out.pvalues_pos[o + c] = pp;
+                    out.nes[o + c] = nes;
+                    out.nes_binary[o + c] = hit ? 1.0 : 0.0;
+                }
+                const unsigned long long bal = __ballot(ok && hit);
+                if (lane == 0 && bal) atomicAdd(&out.enriched[jbase + c], static_cast<unsigned int>(__popcll(bal)));
+            }
+        }
+    }
+}
+
+__global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) out[i] = static_cast<double>(in[i]);
+}
+
+// neighborhood_size = A . nodes_not_nan (safe.py:587-588)
+__global__ void k_nbr_size(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                           const uint8_t *__restrict__ row_flags, int64_t n, double *__restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    int c = 0;
+    for (int32_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) c += row_flags[col[e]] != 0;
+    out[i] = static_cast<double>(c);
+}
+
+// --------------------------------------------------------------------------------------
+// K4: hypergeometric upper tail P[H >= X] = sf(X - 1) with the semantics of
+// scipy.stats.hypergeom.sf as called at safe.py:596 (rv_discrete.sf wrapper: argument
+// check -> NaN, below support -> 1, at/after the top of the support -> 0, result clipped
+// to [0,1]).  pmf from a host-built log-factorial table, tail by the term recurrence,
+// summed on the side of the mode that keeps the sum short (complemented when needed).
+// --------------------------------------------------------------------------------------
+__device__ __forceinline__ double hyp_logpmf(const double *__restrict__ lf, int64_t t, int64_t pop, int64_t good,
+                                             int64_t draws) {
+    return (lf[good] - lf[t] - lf[good - t]) + (lf[pop - good] - lf[draws - t] - lf[pop - good - draws + t]) -
+           (lf[pop] - lf[draws] - lf[pop - draws]);
+}
+
+__device__ double hyp_sf(const double *__restrict__ lf, double x_hits, double pop_d, double good_d, double draws_d) {
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    // _argcheck of scipy's hypergeom: integers, 0 <= good <= pop, 0 <= draws <= pop
+    if (!(pop_d >= 0.0) || !(good_d >= 0.0) || !(draws_d >= 0.0) || good_d > pop_d || draws_d > pop_d ||
+        pop_d != floor(pop_d) || good_d != floor(good_d) || draws_d != floor(draws_d))
+        return qnan;
+    const double k_d = x_hits - 1.0;
+    if (k_d != k_d) return qnan;
+    const int64_t pop = static_cast<int64_t>(pop_d), good = static_cast<int64_t>(good_d),
+                  draws = static_cast<int64_t>(draws_d);
+    const int64_t lo = draws - (pop - good) > 0 ? draws - (pop - good) : 0;
+    const int64_t hi = good < draws ? good : draws;
+    if (k_d < static_cast<double>(lo)) return 1.0;
+    if (k_d >= static_cast<double>(hi)) return 0.0;
+    const int64_t k = static_cast<int64_t>(floor(k_d));
+    const double eps = 2.220446049250313e-16;
+    const double mode = floor(static_cast<double>(good + 1) * static_cast<double>(draws + 1) / static_cast<double>(pop + 2));
+    double result;
+    if (static_cast<double>(k) < mode) {
+        // lower tail cdf(k) downwards from k, then complement
+        int64_t t = k;
+        double term = exp(hyp_logpmf(lf, t, pop, good, draws));
+        double sum = term;
+        while (t > lo && term > eps) {
+            // pmf(t-1) / pmf(t)
+            term = term * (static_cast<double>(t) * static_cast<double>(pop - good - draws + t)) /
+                   (static_cast<double>(good - t + 1) * static_cast<double>(draws - t + 1));
+            sum += term;
+            --t;
+        }
+        result = 1.0 - sum;
+    } else {
+        int64_t t = k + 1;
+        double term = exp(hyp_logpmf(lf, t, pop, good, draws));
+        double sum = term;
+        while (t < hi && term > eps * sum) {
+            // pmf(t+1) / pmf(t)
+            term = term * (static_cast<double>(good - t) * static_cast<double>(draws - t)) /
+                   (static_cast<double>(t + 1) * static_cast<double>(pop - good - draws + t + 1));
+            sum += term;
+            ++t;
+        }
+        result = sum;
+    }
+    return result < 0.0 ? 0.0 : (result > 1.0 ? 1.0 : result);
+}
+
+__global__ __launch_bounds__(256) void k_hypergeom_tail(const double *__restrict__ hits, const double *__restrict__ nb_size,
+                                                        const double *__restrict__ col_sum, int64_t col0, int64_t n,
+                                                        int64_t mloc, double pop, const double *__restrict__ lf,
+                                                        double nes_threshold, double *__restrict__ pvalues_pos,
+                                                        double *__restrict__ nes_out, double *__restrict__ nes_binary,
+                                                        unsigned int *__restrict__ enriched) {
+    // 2-D: x over columns (coalesced), y over rows
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
+    if (i >= n) return;
+    bool hit = false;
+    if (c < mloc) {
+        const double p = hyp_sf(lf, hits[i * mloc + c], pop, col_sum[col0 + c], nb_size[i]);
+        const double nes = -log10(p);                       // safe.py:608
+        hit = (nes == nes) && (fabs(nes) > nes_threshold);  // safe.py:468-470
+        pvalues_pos[i * mloc + c] = p;
+        nes_out[i * mloc + c] = nes;
+        nes_binary[i * mloc + c] = hit ? 1.0 : 0.0;
+    }
+    if (hit) atomicAdd(&enriched[c], 1u);
+}
+
+// --------------------------------------------------------------------------------------
+// host side
+// --------------------------------------------------------------------------------------
+struct Tiles {
+    double *bt = nullptr;
+    int64_t n_tiles = 0;
+    int bn = 0;
+    int planes = 1;
+};
+
+static int build_tiles(safe_ctx *ctx, safe_attr *attr, int64_t col0, int64_t col1, bool z, Tiles *tiles) {
+    const int64_t n = attr->n, mloc = col1 - col0;
+    const int bn = z ? 8 : 16;
+    const int planes = z ? 3 : 1;
+    tiles->bn = bn;
+    tiles->planes = planes;
+    tiles->n_tiles = ceil_div(mloc, bn);
+    const int64_t total = tiles->n_tiles * (n + 1) * bn;
+    SAFE_TRY(dev_alloc(&tiles->bt, static_cast<size_t>(total) * planes));
+    const dim3 grid(ceil_div(total, 256)), block(256);
+    const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+#define LAUNCH_PREP(T, BN, PL)                                                                                   \
+    hipLaunchKernelGGL((k_tile_prep<T, BN, PL>), grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,   \
+                       attr->col_stride, col0, mloc, tiles->n_tiles, tiles->bt)
+    if (z) {
+        if (f32) LAUNCH_PREP(float, 8, 3);
+        else LAUNCH_PREP(double, 8, 3);
+    } else {
+        if (f32) LAUNCH_PREP(float, 16, 1);
+        else LAUNCH_PREP(double, 16, 1);
+    }
+#undef LAUNCH_PREP
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
+}
+
+static int check_cols(const safe_nbr *nbr, const safe_attr *attr, int64_t col0, int64_t col1, const char *who) {
+    SAFE_REQUIRE(nbr && attr, "%s: NULL handle", who);
+    SAFE_REQUIRE(nbr->n == attr->n, "%s: membership is %lld x %lld but the attribute matrix has %lld rows", who,
+                 (long long)nbr->n, (long long)nbr->n, (long long)attr->n);
+    SAFE_REQUIRE(0 <= col0 && col0 < col1 && col1 <= attr->m, "%s: column range [%lld,%lld) outside [0,%lld)", who,
+                 (long long)col0, (long long)col1, (long long)attr->m);
+    return SAFE_OK;
+}
+
+// launches the gather kernel; table == NULL / n_perm == 0 gives the observed score only
+static int launch_gather(safe_ctx *ctx, safe_nbr *nbr, const Tiles &tiles, const int32_t *table, int64_t n_perm,
+                         int64_t mloc, bool z, const PermOut &out) {
+    // slice groups: enough workgroups to fill the chip several times over
+    int n_groups = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nbr->n_slices, 4),
+                                                                           ceil_div(ctx->num_cu * 8, tiles.n_tiles))));
+    const int64_t blocks = ceil_div(tiles.n_tiles, 8) * 8 * n_groups;
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    if (z)
+        hipLaunchKernelGGL((k_permtest_gather<8, true>), dim3(blocks), dim3(256), 0, ctx->stream, nbr->sell_row,
+                           nbr->slice_off, nbr->slice_width, nbr->sell_col, nbr->n_slices, nbr->n, tiles.bt,
+                           tiles.n_tiles, n_groups, table, n_perm, mloc, out);
+    else
+        hipLaunchKernelGGL((k_permtest_gather<16, false>), dim3(blocks), dim3(256), 0, ctx->stream, nbr->sell_row,
+                           nbr->slice_off, nbr->slice_width, nbr->sell_col, nbr->n_slices, nbr->n, tiles.bt,
+                           tiles.n_tiles, n_groups, table, n_perm, mloc, out);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = z ? "k_permtest_gather<8,true>" : "k_permtest_gather<16,false>";
+    ctx->last_kernel.launches = -1;   // resolved lazily by safe_last_kernel_stats... see finish_kernel_timing
+    return SAFE_OK;
+}
+
+static int finish_kernel_timing(safe_ctx *ctx) {
+    SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
+    float ms = 0.f;
+    SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->k0, ctx->k1));
+    ctx->last_kernel.total_ms = ms;
+    ctx->last_kernel.launches = 1;
+    return SAFE_OK;
+}
+
+extern "C" {
+
+int safe_score(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int score_type, int64_t col0, int64_t col1,
+               double *out_dev) {
+    SAFE_REQUIRE(ctx && out_dev, "safe_score: NULL argument");
+    SAFE_TRY(check_cols(nbr, attr, col0, col1, "safe_score"));
+    SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_score: bad score_type %d", score_type);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool z = score_type == SAFE_SCORE_ZSCORE;
+    Tiles tiles;
+    SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
+    PermOut out{};
+    out.ns = out_dev;
+    out.mode = 0;
+    int rc = launch_gather(ctx, nbr, tiles, nullptr, 0, col1 - col0, z, out);
+    if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
+    (void)hipFree(tiles.bt);
+    return rc;
+}
+
+int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int score_type,
+                         int64_t col0, int64_t col1, double *ns_dev, double *counts_neg_dev, double *counts_pos_dev) {
+    SAFE_REQUIRE(ctx && perms && counts_neg_dev && counts_pos_dev, "safe_permtest_counts: NULL argument");
+    SAFE_TRY(check_cols(nbr, attr, col0, col1, "safe_permtest_counts"));
+    SAFE_REQUIRE(perms->n == nbr->n, "safe_permtest_counts: permutation tables are for %lld rows, membership has %lld",
+                 (long long)perms->n, (long long)nbr->n);
+    SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_permtest_counts: bad score_type %d", score_type);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool z = score_type == SAFE_SCORE_ZSCORE;
+    Tiles tiles;
+    SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
+    PermOut out{};
+    out.ns = ns_dev;
+    out.counts_neg = counts_neg_dev;
+    out.counts_pos = counts_pos_dev;
+    out.mode = 1;
+    int rc = launch_gather(ctx, nbr, tiles, perms->table, perms->count, col1 - col0, z, out);
+    if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
+    (void)hipFree(tiles.bt);
+    return rc;
+}
+
+int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int score_type, int sign_mode,
+                       double enrichment_threshold, const double *nes_table_host, int64_t col0, int64_t col1,
+                       double *ns_dev, double *pvalues_neg_dev, double *pvalues_pos_dev, double *nes_dev,
+                       double *nes_binary_dev, double *num_enriched_dev) {
+    SAFE_REQUIRE(ctx && perms && pvalues_neg_dev && pvalues_pos_dev && nes_dev && nes_binary_dev && num_enriched_dev,
+                 "safe_randomization: NULL argument");
+    SAFE_TRY(check_cols(nbr, attr, col0, col1, "safe_randomization"));
+    SAFE_REQUIRE(perms->n == nbr->n, "safe_randomization: permutation tables are for %lld rows, membership has %lld",
+                 (long long)perms->n, (long long)nbr->n);
+    SAFE_REQUIRE(perms->count >= 1, "safe_randomization: no permutations");
+    SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_randomization: bad score_type %d", score_type);
+    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_randomization: bad sign_mode %d", sign_mode);
+    SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_randomization: enrichment_threshold must be in (0,1)");
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const bool z = score_type == SAFE_SCORE_ZSCORE;
+    const int64_t mloc = col1 - col0, P = perms->count;
+    std::vector<double> tab(P + 1);
+    if (nes_table_host) {
+        std::copy(nes_table_host, nes_table_host + P + 1, tab.begin());
+    } else {
+        tab[0] = -std::log10(1.0 / static_cast<double>(P));
+        for (int64_t k = 1; k <= P; ++k) tab[k] = -std::log10(static_cast<double>(k) / static_cast<double>(P));
+    }
+    double *d_tab = nullptr;
+    unsigned int *d_enr = nullptr;
+    Tiles tiles;
+    int rc = dev_alloc(&d_tab, P + 1);
+    if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 16);
+    if (rc == SAFE_OK) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
+    if (rc == SAFE_OK) {
+        hipError_t e = hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 16) * sizeof(unsigned int), ctx->stream);
+        if (e != hipSuccess) {
+            safe_set_error("safe_randomization: %s", hipGetErrorString(e));
+            rc = SAFE_E_HIP;
+        }
+    }
+    if (rc == SAFE_OK) {
+        PermOut out{};
+        out.ns = ns_dev;
+        out.pvalues_neg = pvalues_neg_dev;
+        out.pvalues_pos = pvalues_pos_dev;
+        out.nes = nes_dev;
+        out.nes_binary = nes_binary_dev;
+        out.enriched = d_enr;
+        out.nes_table = d_tab;
+        out.nes_threshold = -std::log10(enrichment_threshold);
+        out.sign_mode = sign_mode;
+        out.mode = 2;
+        rc = launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out);
+    }
+    if (rc == SAFE_OK) {
+        hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);
+        if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
+    }
+    if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
+    if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab (host) + temporaries
+    (void)hipFree(d_tab);
+    (void)hipFree(d_enr);
+    (void)hipFree(tiles.bt);
+    return rc;
+}
+
+int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichment_threshold, int64_t col0,
+                   int64_t col1, double *pvalues_pos_dev, double *nes_dev, double *nes_binary_dev,
+                   double *num_enriched_dev) {
+    SAFE_REQUIRE(ctx && pvalues_pos_dev && nes_dev && nes_binary_dev && num_enriched_dev, "safe_hypergeom: NULL argument");
+    SAFE_TRY(check_cols(nbr, attr, col0, col1, "safe_hypergeom"));
+    SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_hypergeom: enrichment_threshold must be in (0,1)");
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_TRY(safe_attr_prepare(attr));
+    const int64_t n = nbr->n, mloc = col1 - col0;
+    const int64_t pop = attr->n_rows_with_value;
+    // log-factorial table lf[k] = log(k!) for k = 0..n
+    std::vector<double> lf(n + 2);
+    for (int64_t k = 0; k <= n + 1; ++k) lf[k] = std::lgamma(static_cast<double>(k) + 1.0);
+    double *d_lf = nullptr, *d_hits = nullptr, *d_size = nullptr;
+    unsigned int *d_enr = nullptr;
+    Tiles tiles;
+    int rc = dev_alloc(&d_lf, n + 2);
+    if (rc == SAFE_OK) rc = dev_alloc(&d_hits, n * mloc);
+    if (rc == SAFE_OK) rc = dev_alloc(&d_size, n);
+    if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 64);
+    if (rc == SAFE_OK) rc = build_tiles(ctx, attr, col0, col1, false, &tiles);
+    if (rc == SAFE_OK) {
+        hipError_t e = hipMemcpyAsync(d_lf, lf.data(), (n + 2) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 64) * sizeof(unsigned int), ctx->stream);
+        if (e != hipSuccess) {
+            safe_set_error("safe_hypergeom: %s", hipGetErrorString(e));
+            rc = SAFE_E_HIP;
+        }
+    }
+    if (rc == SAFE_OK) {
+        PermOut out{};
+        out.ns = d_hits;
+        out.mode = 0;
+        rc = launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
+    }
+    if (rc == SAFE_OK) {
+        hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col,
+                           attr->row_flags, n, d_size);
+        SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+        hipLaunchKernelGGL(k_hypergeom_tail, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_hits,
+                           d_size, attr->col_sum, col0, n, mloc, static_cast<double>(pop), d_lf,
+                           -std::log10(enrichment_threshold), pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr);
+        SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+        ctx->last_kernel.name = "k_hypergeom_tail";
+        hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);
+        if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
+    }
+    if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
+    if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;
+    (void)hipFree(d_lf);
+    (void)hipFree(d_hits);
+    (void)hipFree(d_size);
+    (void)hipFree(d_enr);
+    (void)hipFree(tiles.bt);
+    return rc;
+}
+
+}  // extern "C"

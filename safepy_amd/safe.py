@@ -1,0 +1,482 @@
+"""`SAFE` -- host-side mirror of the reference class for the hot path.
+
+Same constructor signature, attribute names, method names, kwargs, array layouts and
+error behaviour as `safepy.safe.SAFE` (safepy/safe.py:37-608) for
+`define_neighborhoods()` / `compute_pvalues()` (+ the additive `compute_node_distances()`);
+the arithmetic runs in libsafe_hip.so on an MI355X.  File loaders, layouts, plotting,
+domains and output writers of the reference are out of scope.
+"""
+import configparser
+import logging
+import os
+
+import numpy as np
+
+from . import backend as be
+
+_DEFAULTS = {
+    # safepy/safe_default.ini:1-24 (only the keys the hot path reads)
+    'annotationsign': 'both',
+    'randomSeed': '',
+    'background': 'attribute_file',
+    'nodeDistanceType': 'shortpath_weighted_layout',
+    'neighborhoodRadius': '0.1',
+    'neighborhoodRadiusType': 'diameter',
+}
+
+
+class LayoutGraph:
+    """Minimal stand-in for the networkx graph the reference keeps in `self.graph`: node
+    coordinates in node order plus an undirected edge list with optional per-edge
+    'length' / 'weight'.  `SAFE` accepts either this or a networkx.Graph."""
+
+    def __init__(self, xy, edge_u=None, edge_v=None, length=None, weight=None, keys=None, labels=None):
+        self.xy = np.ascontiguousarray(xy, dtype=np.float64)
+        if self.xy.ndim != 2 or self.xy.shape[1] != 2:
+            raise ValueError('xy must be [N,2]')
+        n = self.xy.shape[0]
+        self.edge_u = np.zeros(0, np.int64) if edge_u is None else np.asarray(edge_u, dtype=np.int64)
+        self.edge_v = np.zeros(0, np.int64) if edge_v is None else np.asarray(edge_v, dtype=np.int64)
+        self.length = None if length is None else np.asarray(length, dtype=np.float64)
+        self.weight = None if weight is None else np.asarray(weight, dtype=np.float64)
+        self.keys = list(range(n)) if keys is None else list(keys)
+        self.labels = [str(k) for k in self.keys] if labels is None else list(labels)
+
+    def number_of_nodes(self):
+        return self.xy.shape[0]
+
+
+def _graph_arrays(graph):
+    """(xy [N,2] in node order, edge_u, edge_v, length or None, weight or None) from a
+    LayoutGraph or a networkx graph.  Follows the reference's access pattern: x/y via
+    graph.nodes.data (safe.py:390-396), edges indexed by node id (safe.py:412-415)."""
+    if isinstance(graph, LayoutGraph):
+        return graph.xy, graph.edge_u, graph.edge_v, graph.length, graph.weight
+    if hasattr(graph, 'is_directed') and graph.is_directed():
+        raise NotImplementedError('directed graphs are not supported (the reference networks are undirected)')
+    n = graph.number_of_nodes()
+    x = np.array([v for _, v in graph.nodes.data('x')], dtype=np.float64)
+    y = np.array([v for _, v in graph.nodes.data('y')], dtype=np.float64)
+    xy = np.stack([x, y], axis=1) if n else np.zeros((0, 2))
+    eu, ev, el, ew = [], [], [], []
+    has_len = has_w = False
+    for u, v, data in graph.edges(data=True):
+        eu.append(u)
+        ev.append(v)
+        # networkx _weight_function: data.get(weight, 1) (weighted.py:78)
+        el.append(data.get('length', 1))
+        ew.append(data.get('weight', 1))
+        has_len = has_len or ('length' in data)
+        has_w = has_w or ('weight' in data)
+    eu = np.asarray(eu, dtype=np.int64) if eu else np.zeros(0, np.int64)
+    ev = np.asarray(ev, dtype=np.int64) if ev else np.zeros(0, np.int64)
+    length = np.asarray(el, dtype=np.float64) if has_len else None
+    weight = np.asarray(ew, dtype=np.float64) if has_w else None
+    return xy, eu, ev, length, weight
+
+
+class SAFE:
+    """Defines an instance of SAFE analysis (hot path only); see module docstring."""
+
+    def __init__(self, path_to_ini_file='', path_to_safe_data=None, verbose=True, device=0):
+        self.verbose = verbose
+        self.default_config = None
+        self.path_to_safe_data = path_to_safe_data
+        self.path_to_network_file = None
+        self.view_name = None
+        self.path_to_attribute_file = None
+
+        self.graph = None
+        self.graph_euclidean = None
+        self.node_key_attribute = 'label_orf'
+
+        self.attributes = None
+        self.nodes = None
+        self.node2attribute = None
+        self.num_nodes_per_attribute = None
+        self.attribute_sign = 'both'
+
+        self.node_distance_metric = 'shortpath_weighted_layout'
+        self.neighborhood_radius_type = None
+        self.neighborhood_radius = None
+
+        self.background = 'attribute_file'
+        self.num_permutations = 1000
+        self.multiple_testing = False
+        self.neighborhood_score_type = 'sum'
+        self.enrichment_type = 'auto'
+        self.enrichment_threshold = 0.05
+        self.enrichment_max_log10 = 16
+        self.attribute_enrichment_min_size = 10
+        self.random_seed = None
+
+        self.ns = None
+        self.pvalues_neg = None
+        self.pvalues_pos = None
+        self.nes = None
+        self.nes_threshold = None
+        self.nes_binary = None
+
+        self.attribute_unimodality_metric = 'connectivity'
+        self.attribute_distance_metric = 'jaccard'
+        self.attribute_distance_threshold = 0.75
+        self.domains = None
+        self.node2domain = None
+        self.output_dir = ''
+
+        # device state (never pickled)
+        self.device = device
+        self._nbr = None                 # backend.Neighborhoods matching _neighborhoods_host / lazily downloaded
+        self._neighborhoods_host = None
+        self._node_distances = None
+        self._pending_binary = None
+
+        self.read_config(path_to_ini_file, path_to_safe_data=self.path_to_safe_data)
+        self.validate_config()
+
+    # ------------------------------------------------------------------ config ----
+    def read_config(self, path_to_ini_file, path_to_safe_data=None):
+        """safepy/safe.py:116-188, restricted to the keys the hot path reads."""
+        defaults = configparser.ConfigParser(allow_no_value=True, comment_prefixes=('#', ';', '{'),
+                                             inline_comment_prefixes='#')
+        defaults.read_dict({'DEFAULT': _DEFAULTS})
+        self.default_config = defaults['DEFAULT']
+        config = configparser.ConfigParser(defaults=defaults['DEFAULT'], allow_no_value=True,
+                                           comment_prefixes=('#', ';', '{'), inline_comment_prefixes='#')
+        if path_to_ini_file:
+            config.read(path_to_ini_file)
+        for section in ('Input files', 'Analysis parameters'):
+            if section not in config:
+                config[section] = {}
+        self.path_to_safe_data = path_to_safe_data
+        self.attribute_sign = config.get('Input files', 'annotationsign')
+        self.background = config.get('Analysis parameters', 'background')
+        self.node_distance_metric = config.get('Analysis parameters', 'nodeDistanceType')
+        self.neighborhood_radius_type = config.get('Analysis parameters', 'neighborhoodRadiusType')
+        self.neighborhood_radius = float(config.get('Analysis parameters', 'neighborhoodRadius'))
+        seed = config.get('Analysis parameters', 'randomSeed')
+        try:
+            self.random_seed = int(seed)
+        except (ValueError, TypeError):
+            self.random_seed = None
+        self.output_dir = os.path.dirname(path_to_ini_file) if path_to_ini_file else ''
+
+    def validate_config(self):
+        """safepy/safe.py:190-235: invalid option -> restore the default, raise ValueError."""
+        if self.background not in ['attribute_file', 'network']:
+            bad, self.background = self.background, self.default_config.get('background')
+            raise ValueError('%s is not a valid setting for background. '
+                             'Valid options are: attribute_file, network.' % bad)
+        if self.node_distance_metric not in ['euclidean', 'shortpath', 'shortpath_weighted_layout']:
+            bad, self.node_distance_metric = self.node_distance_metric, self.default_config.get('nodeDistanceType')
+            raise ValueError('%s is not a valid setting for node_distance_metric. '
+                             'Valid options are: euclidean, shortpath, shortpath_weighted_layout' % bad)
+        if self.attribute_sign not in ['highest', 'lowest', 'both']:
+            bad, self.attribute_sign = self.attribute_sign, self.default_config.get('annotationsign')
+            raise ValueError('%s is not a valid setting for attribute_sign. '
+                             'Valid options are: highest, lowest, both' % bad)
+        if not isinstance(self.num_permutations, int) or (self.num_permutations < 10):
+            self.num_permutations = 1000
+            raise ValueError('num_permutations must be an integer equal or greater than 10.')
+        if not isinstance(self.enrichment_threshold, float) or (self.enrichment_threshold <= 0) \
+                or (self.enrichment_threshold >= 1):
+            self.enrichment_threshold = 0.05
+            raise ValueError('enrichment_threshold must be in the (0,1) range.')
+        if not isinstance(self.enrichment_max_log10, (int, float)):
+            self.enrichment_max_log10 = 16
+            raise ValueError('enrichment_max_log10 must be a number.')
+        if not isinstance(self.attribute_enrichment_min_size, int) or (self.attribute_enrichment_min_size < 2):
+            self.attribute_enrichment_min_size = 10
+            raise ValueError('attribute_enrichment_min_size must be an integer equal or greater than 2.')
+        if not isinstance(self.attribute_distance_threshold, float) or (self.attribute_distance_threshold <= 0) \
+                or (self.attribute_distance_threshold >= 1):
+            self.attribute_distance_threshold = 0.75
+            raise ValueError('attribute_enrichment_min_size must be a float number in the (0,1) range.')
+
+    # pickling drops device handles (the reference pickles the whole object, safe.py:237-242)
+    def __getstate__(self):
+        state = self.__dict__.copy()
+        if state.get('_neighborhoods_host') is None and state.get('_nbr') is not None:
+            state['_neighborhoods_host'] = self._nbr.to_dense()
+        state['_nbr'] = None
+        state['default_config'] = dict(self.default_config) if self.default_config is not None else None
+        return state
+
+    def __setstate__(self, state):
+        self.__dict__.update(state)
+        if isinstance(self.default_config, dict):
+            cp = configparser.ConfigParser()
+            cp.read_dict({'DEFAULT': self.default_config})
+            self.default_config = cp['DEFAULT']
+
+    # ------------------------------------------------------------------ inputs ----
+    def load_network(self, **kwargs):
+        """Accepts an in-memory graph only: `graph=` a networkx.Graph with node attributes
+        x, y (and edge attribute 'length' for the default metric) or a `LayoutGraph`.
+        The reference's file loaders (safe.py:244-324, safe_io.py:30-285) are out of scope."""
+        if 'node_key_attribute' in kwargs:
+            self.node_key_attribute = kwargs['node_key_attribute']
+        self.validate_config()
+        graph = kwargs.get('graph', kwargs.get('network_file'))
+        if graph is None or isinstance(graph, str):
+            raise NotImplementedError('safepy_amd.SAFE.load_network takes graph=<networkx.Graph | LayoutGraph>; '
+                                      'network file parsing is out of scope for the hot-path build')
+        self.graph = graph
+        self._invalidate_neighborhoods()
+
+    def load_attributes(self, **kwargs):
+        """`attribute_file=` a pandas DataFrame indexed by node key (the DataFrame branch of
+        read_attributes, safe_io.py:372-410) or a ready [N,M] ndarray in node order."""
+        import pandas as pd
+        self.validate_config()
+        src = kwargs.get('attribute_file')
+        if isinstance(src, np.ndarray):
+            self.node2attribute = src
+            self.attributes = pd.DataFrame({'id': np.arange(src.shape[1]),
+                                            'name': [str(j) for j in range(src.shape[1])]})
+            return
+        if not isinstance(src, pd.DataFrame):
+            raise NotImplementedError('safepy_amd.SAFE.load_attributes takes attribute_file=<DataFrame | ndarray>; '
+                                      'attribute file parsing is out of scope for the hot-path build')
+        table = src.apply(pd.to_numeric, errors='coerce')
+        attributes = pd.DataFrame({'id': np.arange(len(table.columns)), 'name': table.columns})
+        attributes['name'] = attributes['name'].astype(str)
+        if not table.index.is_unique:
+            table = table.groupby(table.index).mean()
+        table = table.reindex(index=self._node_keys(), fill_value=kwargs.get('fill_value', np.nan))
+        self.attributes = attributes
+        self.node2attribute = table.values
+
+    def _node_keys(self):
+        if isinstance(self.graph, LayoutGraph):
+            return list(self.graph.keys)
+        return [v for _, v in self.graph.nodes.data(self.node_key_attribute)]
+
+    # ------------------------------------------------------- neighborhoods state ----
+    @property
+    def neighborhoods(self):
+        """int64 [N,N] 0/1, C order (safe.py:387,430); downloaded from the device on first
+        access after define_neighborhoods()."""
+        if self._neighborhoods_host is None and self._nbr is not None:
+            self._neighborhoods_host = self._nbr.to_dense()
+        return self._neighborhoods_host
+
+    @neighborhoods.setter
+    def neighborhoods(self, value):
+        self._invalidate_neighborhoods()
+        self._neighborhoods_host = value
+
+    def _invalidate_neighborhoods(self):
+        if self._nbr is not None:
+            self._nbr.close()
+        self._nbr = None
+        self._neighborhoods_host = None
+
+    def _ctx(self):
+        return be.Context.default(self.device)
+
+    def _device_neighborhoods(self):
+        if self._nbr is None:
+            if self._neighborhoods_host is None:
+                raise RuntimeError('neighborhoods are not defined: call define_neighborhoods() first')
+            self._nbr = be.Neighborhoods.from_dense(self._ctx(), self._neighborhoods_host)
+        return self._nbr
+
+    @property
+    def node_distances(self):
+        """Shortest-path metrics: dict-of-dicts {source: {target: distance}} over reached
+        pairs (safe.py:417).  Euclidean (additive, via compute_node_distances): f64 [N,N]."""
+        nd = self._node_distances
+        if isinstance(nd, tuple) and nd[0] == 'dense-shortpath':
+            dmat = nd[1]
+            rows, cols = np.nonzero(np.isfinite(dmat))
+            out = {int(s): {} for s in range(dmat.shape[0])}
+            for s, t in zip(rows.tolist(), cols.tolist()):
+                out[s][t] = float(dmat[s, t])
+            self._node_distances = out
+        return self._node_distances
+
+    @node_distances.setter
+    def node_distances(self, value):
+        self._node_distances = value
+
+    def _radius(self, xy):
+        x = xy[:, 0]
+        return self.neighborhood_radius * (np.max(x) - np.min(x))      # safe.py:390-391, 404-405
+
+    def _override_neighborhood_settings(self, kwargs):
+        if 'node_distance_metric' in kwargs:
+            self.node_distance_metric = kwargs['node_distance_metric']
+        if 'neighborhood_radius_type' in kwargs:
+            self.neighborhood_radius_type = kwargs['neighborhood_radius_type']
+        if 'neighborhood_radius' in kwargs:
+            self.neighborhood_radius = kwargs['neighborhood_radius']
+        self.validate_config()
+
+    def _shortpath_inputs(self, xy, eu, ev, length, weight):
+        n = xy.shape[0]
+        if eu.size and (eu.min() < 0 or ev.min() < 0 or eu.max() >= n or ev.max() >= n):
+            raise ValueError('shortest-path metrics index the neighborhood matrix by node id: ids must be 0..N-1')
+        if self.node_distance_metric == 'shortpath_weighted_layout':
+            w = length                                  # weight='length', missing -> 1 (networkx)
+            cutoff = self._radius(xy)
+        else:
+            w = weight                                  # default weight attr 'weight', missing -> 1
+            cutoff = self.neighborhood_radius          # safe.py:409
+        return w, cutoff
+
+    def define_neighborhoods(self, **kwargs):
+        """safepy/safe.py:369-430.  kwargs: node_distance_metric, neighborhood_radius_type,
+        neighborhood_radius (persisted on self).  Sets self.neighborhoods (and, for the
+        shortest-path metrics, self.node_distances); returns None."""
+        self._override_neighborhood_settings(kwargs)
+        xy, eu, ev, length, weight = _graph_arrays(self.graph)
+        ctx = self._ctx()
+        self._invalidate_neighborhoods()
+        if self.node_distance_metric == 'euclidean':
+            self._nbr = be.Neighborhoods.euclidean(ctx, xy, self._radius(xy))
+        else:
+            w, cutoff = self._shortpath_inputs(xy, eu, ev, length, weight)
+            self._nbr = be.Neighborhoods.shortpath(ctx, xy.shape[0], eu, ev, w, cutoff, keep_distances=True)
+            self._node_distances = ('dense-shortpath', self._nbr.distances())
+        if self.verbose:
+            num_neighbors = self._nbr.row_counts()
+            logging.info('Node distance metric: %s' % self.node_distance_metric)
+            logging.info('Neighborhood definition: %.2f x %s' % (self.neighborhood_radius, self.neighborhood_radius_type))
+            logging.info('Number of nodes per neighborhood (mean +/- std): %.2f +/- %.2f'
+                         % (np.mean(num_neighbors), np.std(num_neighbors)))
+
+    def compute_node_distances(self, **kwargs):
+        """Additive (named by the north star; absent from the reference at this commit):
+        fills self.node_distances without touching self.neighborhoods.  Euclidean: dense
+        f64 [N,N] == squareform(pdist(xy)) (safe.py:397).  Shortest-path metrics: the same
+        dict-of-dicts define_neighborhoods stores (safe.py:417)."""
+        self._override_neighborhood_settings(kwargs)
+        xy, eu, ev, length, weight = _graph_arrays(self.graph)
+        ctx = self._ctx()
+        n = xy.shape[0]
+        if self.node_distance_metric == 'euclidean':
+            d_xy = ctx.alloc(xy.nbytes)
+            d_out = ctx.alloc_f64(n, n)
+            try:
+                d_xy.upload(xy)
+                ctx.euclidean_dense(d_xy.ptr, n, self._radius(xy), None, d_out.ptr)
+                self._node_distances = d_out.download((n, n))
+            finally:
+                d_xy.free()
+                d_out.free()
+        else:
+            w, cutoff = self._shortpath_inputs(xy, eu, ev, length, weight)
+            nbr = be.Neighborhoods.shortpath(ctx, n, eu, ev, w, cutoff, keep_distances=True)
+            self._node_distances = ('dense-shortpath', nbr.distances())
+            nbr.close()
+
+    # -------------------------------------------------------------- enrichment ----
+    def compute_pvalues(self, **kwargs):
+        """safepy/safe.py:432-472."""
+        if 'how' in kwargs:
+            self.enrichment_type = kwargs['how']
+        if 'neighborhood_score_type' in kwargs:
+            self.neighborhood_score_type = kwargs['neighborhood_score_type']
+        if 'multiple_testing' in kwargs:
+            self.multiple_testing = kwargs['multiple_testing']
+        if 'background' in kwargs:
+            self.background = kwargs['background']
+        self.validate_config()
+
+        if self.background == 'network':
+            logging.info('Setting all null attribute values to 0. Using the network as background for enrichment.')
+            self.node2attribute[np.isnan(self.node2attribute)] = 0         # in place, like safe.py:451
+
+        attr = be.Attributes.from_host(self._ctx(), self.node2attribute)
+        try:
+            stats = attr.stats()
+            if stats['max_nan_col'] / self.node2attribute.shape[0] > 0.5:
+                logging.warning("WARNING: more than 50% of nodes in the network are set to NaN and "
+                                "will be ignored for calculating enrichment.\n"
+                                "Consider setting sf.background = 'network'.")
+            self._pending_binary = None
+            if (self.enrichment_type == 'hypergeometric') or \
+                    ((self.enrichment_type == 'auto') and (stats['n_other'] == 0)):
+                self.compute_pvalues_by_hypergeom(_attr=attr, **kwargs)
+            else:
+                self.compute_pvalues_by_randomization(_attr=attr, **kwargs)
+        finally:
+            attr.close()
+
+        # safe.py:468-472 -- computed by the same kernels, from the same nes
+        self.nes_binary, enriched = self._pending_binary
+        self._pending_binary = None
+        if self.attributes is None:
+            import pandas as pd
+            self.attributes = pd.DataFrame({'id': np.arange(len(enriched)), 'name': [str(j) for j in range(len(enriched))]})
+        self.attributes['num_neighborhoods_enriched'] = enriched
+
+    def _reject_fdr(self):
+        if self.multiple_testing:
+            raise NotImplementedError('multiple_testing=True (FDR, safe.py:536-542/599-605) is outside the hot-path '
+                                      'scope of this build (SURVEY.md section 8f)')
+
+    def compute_pvalues_by_randomization(self, _attr=None, **kwargs):
+        """safepy/safe.py:474-554 (no 1 s sleep, no multiprocessing split: `processes` is
+        accepted and ignored -- the reference's own split is broken at this commit)."""
+        if kwargs:
+            logging.warning('Current settings (possibly overwriting global ones):')
+            for k in kwargs:
+                logging.warning('\t%s=%s' % (k, str(kwargs[k])))
+        logging.info('Using randomization to calculate enrichment...')
+        if 'num_permutations' in kwargs:
+            self.num_permutations = kwargs['num_permutations']
+        self.validate_config()
+        self._reject_fdr()
+        score_type = 'z-score' if self.neighborhood_score_type == 'z-score' else 'sum'
+
+        ctx = self._ctx()
+        nbr = self._device_neighborhoods()
+        attr = _attr if _attr is not None else be.Attributes.from_host(ctx, self.node2attribute)
+        n, m = attr.n, attr.m
+        perms = be.Permutations(ctx, n, attr.row_flags(), self.num_permutations, self.random_seed)
+        bufs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
+        try:
+            be.randomization(ctx, nbr, attr, perms, score_type, self.attribute_sign, self.enrichment_threshold,
+                             [b.ptr for b in bufs])
+            self.ns = bufs[0].download((n, m))
+            self.pvalues_neg = bufs[1].download((n, m))
+            self.pvalues_pos = bufs[2].download((n, m))
+            self.nes = bufs[3].download((n, m))
+            self._pending_binary = (bufs[4].download((n, m)), bufs[5].download((m,)))
+        finally:
+            for b in bufs:
+                b.free()
+            perms.close()
+            if _attr is None:
+                attr.close()
+
+    def compute_pvalues_by_hypergeom(self, _attr=None, **kwargs):
+        """safepy/safe.py:556-608.  Sets pvalues_pos and nes only (ns / pvalues_neg untouched)."""
+        if kwargs:
+            if 'verbose' in kwargs:
+                self.verbose = kwargs['verbose']
+            if self.verbose:
+                logging.warning('Overwriting global settings:')
+                for k in kwargs:
+                    logging.warning('\t%s=%s' % (k, str(kwargs[k])))
+        self.validate_config()
+        self._reject_fdr()
+        if self.verbose:
+            logging.info('Using the hypergeometric test to calculate enrichment...')
+        ctx = self._ctx()
+        nbr = self._device_neighborhoods()
+        attr = _attr if _attr is not None else be.Attributes.from_host(ctx, self.node2attribute)
+        n, m = attr.n, attr.m
+        bufs = [ctx.alloc_f64(n, m) for _ in range(3)] + [ctx.alloc_f64(m)]
+        try:
+            be.hypergeom(ctx, nbr, attr, self.enrichment_threshold, [b.ptr for b in bufs])
+            self.pvalues_pos = bufs[0].download((n, m))
+            self.nes = bufs[1].download((n, m))
+            self._pending_binary = (bufs[2].download((n, m)), bufs[3].download((m,)))
+        finally:
+            for b in bufs:
+                b.free()
+            if _attr is None:
+                attr.close()

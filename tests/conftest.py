@@ -1,0 +1,32 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+GOLDEN = os.path.join(ROOT, 'tests', 'golden')
+
+
+def pytest_configure(config):
+    config.addinivalue_line('markers', 'gpu: needs a real MI355X (run with -m gpu on the GPU box)')
+
+
+@pytest.fixture(scope='session')
+def golden_nbr():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, 'neighborhoods.npz')))
+
+
+@pytest.fixture(scope='session')
+def golden_enr():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, 'enrichment.npz')))
+
+
+@pytest.fixture(scope='session')
+def golden_rng():
+    import numpy as np
+    return dict(np.load(os.path.join(GOLDEN, 'rng_kat.npz')))

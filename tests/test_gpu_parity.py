@@ -1,0 +1,329 @@
+"""Parity of the HIP path (through the C ABI) against the golden vectors produced by the
+real reference and against the CPU oracle on seeded inputs.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import safe_oracle as orc            # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import safepy_amd
+    assert safepy_amd.device_count() >= 1, 'no HIP device: the GPU tests must run on the MI355X box'
+    return safepy_amd
+
+
+@pytest.fixture(scope='module')
+def ctx(amd):
+    return amd.Context.default(0)
+
+
+def _layout_graph(amd, g):
+    return amd.LayoutGraph(g['xy'], g['edge_u'], g['edge_v'], length=g['edge_length'])
+
+
+def _safe(amd, graph, **attrs):
+    sf = amd.SAFE(verbose=False)
+    sf.graph = graph
+    for k, v in attrs.items():
+        setattr(sf, k, v)
+    return sf
+
+
+# ------------------------------------------------------------------ neighborhoods ----
+
+@pytest.mark.parametrize('radius', [0.05, 0.15])
+def test_euclidean_mask_bit_exact_vs_reference(amd, golden_nbr, radius):
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=radius)
+    got = sf.neighborhoods
+    assert got.dtype == np.int64 and got.flags['C_CONTIGUOUS']
+    assert np.array_equal(got, golden_nbr['euclidean_r%g' % radius].astype(np.int64))
+
+
+@pytest.mark.parametrize('n', [1, 2, 63, 64, 65, 1000, 2049])
+def test_euclidean_mask_vs_oracle_sizes(amd, ctx, n):
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(-3, 7, size=(n, 2))
+    # duplicates and exact-threshold pairs
+    if n > 10:
+        xy[5] = xy[3]
+        xy[7] = xy[3] + np.array([0.1 * 10.0, 0.0])
+    want = orc.neighborhoods_euclidean(xy, 0.1)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    assert np.array_equal(nbr.to_dense(), want)
+    assert np.array_equal(nbr.row_counts(), want.sum(axis=1))
+    rp, col = nbr.csr()
+    assert rp[-1] == want.sum() and np.array_equal(np.nonzero(want)[1], col)
+    nbr.close()
+
+
+@pytest.mark.parametrize('n', [257, 1000, 1001])
+def test_fused_dense_kernel_mask_and_distances(amd, ctx, golden_nbr, n):
+    if n == 257:
+        xy = golden_nbr['xy']
+        want_d = golden_nbr['euclidean_dist']
+    else:
+        xy = np.random.default_rng(n).normal(size=(n, 2))
+        want_d = orc.euclidean_distances(xy)
+    nr = orc.layout_radius(xy[:, 0], 0.15)
+    d_xy = ctx.alloc(xy.nbytes)
+    d_xy.upload(xy)
+    d_mask = ctx.alloc(n * n * 8)
+    d_dist = ctx.alloc(n * n * 8)
+    ctx.euclidean_dense(d_xy.ptr, n, nr, d_mask.ptr, d_dist.ptr)
+    mask = d_mask.download((n, n), np.int64)
+    dist = d_dist.download((n, n), np.float64)
+    assert np.array_equal(dist, want_d)                       # bit-exact f64 (no FMA, IEEE sqrt)
+    assert np.array_equal(mask, (want_d < nr).astype(np.int64))
+
+
+def test_compute_node_distances_euclidean(amd, golden_nbr):
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.compute_node_distances(node_distance_metric='euclidean')
+    assert np.array_equal(sf.node_distances, golden_nbr['euclidean_dist'])
+    assert sf.neighborhoods is None
+
+
+def test_edge_lengths_bit_exact(amd, ctx, golden_nbr):
+    g = golden_nbr
+    assert np.array_equal(ctx.edge_lengths(g['xy'], g['edge_u'], g['edge_v']), g['edge_length'])
+
+
+@pytest.mark.parametrize('radius', [0.08, 0.2])
+def test_weighted_shortpath_vs_reference(amd, golden_nbr, radius):
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=radius)
+    assert np.array_equal(sf.neighborhoods, golden_nbr['swl_r%g' % radius].astype(np.int64))
+    want = golden_nbr['swl_dist_r%g' % radius]
+    nd = sf.node_distances
+    assert isinstance(nd, dict) and len(nd) == want.shape[0]
+    got = np.full(want.shape, np.inf)
+    for s, row in nd.items():
+        for t, d in row.items():
+            got[s, t] = d
+    assert np.array_equal(got, want)                          # bit-exact path lengths
+
+
+@pytest.mark.parametrize('radius', [1, 2, 3])
+def test_unweighted_shortpath_vs_reference(amd, golden_nbr, radius):
+    g = golden_nbr
+    sf = _safe(amd, amd.LayoutGraph(g['xy'], g['edge_u'], g['edge_v']))
+    sf.define_neighborhoods(node_distance_metric='shortpath', neighborhood_radius=radius)
+    assert np.array_equal(sf.neighborhoods, g['shortpath_r%d' % radius].astype(np.int64))
+
+
+def test_shortpath_with_networkx_graph(amd, golden_nbr):
+    nx = pytest.importorskip('networkx')
+    g = golden_nbr
+    graph = nx.Graph()
+    for i, (x, y) in enumerate(g['xy']):
+        graph.add_node(i, x=float(x), y=float(y), label='n%d' % i, label_orf='ORF%d' % i)
+    for u, v, w in zip(g['edge_u'], g['edge_v'], g['edge_length']):
+        graph.add_edge(int(u), int(v), length=float(w))
+    sf = _safe(amd, graph)
+    sf.define_neighborhoods(neighborhood_radius=0.2)          # default metric
+    assert sf.node_distance_metric == 'shortpath_weighted_layout'
+    assert np.array_equal(sf.neighborhoods, g['swl_r0.2'].astype(np.int64))
+
+
+def test_shortpath_disconnected_and_isolated(amd, ctx):
+    # two components + an isolated node + a self loop + a zero-length edge
+    eu = np.array([0, 1, 3, 4, 4, 2], dtype=np.int32)
+    ev = np.array([1, 2, 4, 5, 4, 0], dtype=np.int32)
+    ew = np.array([0.5, 0.25, 1.0, 0.0, 3.0, 0.875])
+    want, want_d = orc.neighborhoods_shortpath(7, eu, ev, ew, 0.75)
+    nbr = amd.Neighborhoods.shortpath(ctx, 7, eu, ev, ew, 0.75, keep_distances=True)
+    assert np.array_equal(nbr.to_dense(), want)
+    assert np.array_equal(nbr.distances(), want_d)
+
+
+def test_dense_roundtrip_and_validation(amd, ctx):
+    rng = np.random.default_rng(5)
+    a = (rng.uniform(size=(130, 130)) < 0.1).astype(np.int64)
+    nbr = amd.Neighborhoods.from_dense(ctx, a)
+    assert np.array_equal(nbr.to_dense(), a) and nbr.nnz == a.sum()
+    a[3, 4] = 2
+    with pytest.raises(amd.SafeHipError):
+        amd.Neighborhoods.from_dense(ctx, a)
+    with pytest.raises(ValueError):
+        amd.Neighborhoods.from_dense(ctx, np.zeros((3, 4)))
+
+
+# ---------------------------------------------------------------------- RNG stream ----
+
+def test_permutation_tables_vs_numpy_stream(amd, ctx, golden_enr):
+    b = golden_enr['b_q']
+    want = orc.permutation_index_table(b, 25, 29)
+    movable = (~np.isnan(b)).any(axis=1).astype(np.uint8)
+    perms = amd.Permutations(ctx, b.shape[0], movable, 25, 29)
+    assert np.array_equal(perms.read().astype(np.int64), want)
+    perms.close()
+
+
+# ------------------------------------------------------------------ module functions ----
+
+def test_compute_neighborhood_score_vs_reference(amd, golden_enr):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    for key, mat, kind in (('score_sum_q', g['b_q'], 'sum'), ('score_z_q', g['b_q'], 'z-score'),
+                           ('score_z_q32', g['b_q_f32'], 'z-score'),
+                           ('score_sum_binF', np.asfortranarray(g['b_bin'].astype(np.float32)), 'sum')):
+        before = mat.copy()
+        got = amd.compute_neighborhood_score(a, mat, kind)
+        assert got.dtype == np.float64
+        # f64 sums in a different order than OpenBLAS: 1e-6 is the north-star tolerance,
+        # the observed agreement is ~1e-13
+        np.testing.assert_allclose(got, g[key], rtol=1e-9, atol=1e-12, equal_nan=True)
+        assert np.array_equal(np.isnan(got), np.isnan(g[key]))
+        np.testing.assert_array_equal(mat, before)           # no mutation
+
+
+def test_run_permutations_counts_vs_reference(amd, golden_enr):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    cn, cp = amd.run_permutations((a, g['b_bin'], 'sum', 25, 31), verbose=False)
+    assert np.array_equal(cn, g['runperm_bin_neg']) and np.array_equal(cp, g['runperm_bin_pos'])
+    cn, cp = amd.run_permutations((a, g['b_q'], 'sum', 25, 29), verbose=False)
+    assert np.array_equal(cn, g['runperm_q_neg']) and np.array_equal(cp, g['runperm_q_pos'])
+
+
+# ------------------------------------------------------------------ compute_pvalues ----
+
+HYP = (('hyp_f64', 'b_bin', None, 'attribute_file'), ('hyp_f32F', 'b_bin', np.float32, 'attribute_file'),
+       ('hyp_net', 'b_bin', None, 'network'))
+
+
+@pytest.mark.parametrize('tag,src,dtype,bg', HYP)
+def test_compute_pvalues_hypergeometric_vs_reference(amd, golden_nbr, golden_enr, tag, src, dtype, bg):
+    g = golden_enr
+    b = g[src].copy()
+    if dtype is not None:
+        b = np.asfortranarray(b.astype(dtype))
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.neighborhoods = g['A'].astype(np.int64)
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues(background=bg)
+    assert sf.ns is None and sf.pvalues_neg is None           # hypergeometric path leaves them alone
+    np.testing.assert_allclose(sf.pvalues_pos, g[tag + '_pvalues_pos'], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(sf.nes, g[tag + '_nes'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(sf.nes_binary, g[tag + '_nes_binary'])
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, g[tag + '_num_enriched'])
+    if bg == 'network':
+        assert not np.isnan(sf.node2attribute).any()          # mutated in place like safe.py:451
+
+
+def test_hypergeometric_forced_on_non_binary_gives_nan(amd, golden_nbr, golden_enr):
+    g = golden_enr
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.neighborhoods = g['A'].astype(np.int64)
+    sf.load_attributes(attribute_file=g['b_int'].copy())
+    sf.compute_pvalues(how='hypergeometric')
+    np.testing.assert_array_equal(sf.pvalues_pos, g['hyp_int_pvalues_pos'])      # all NaN (K > population)
+    np.testing.assert_array_equal(sf.nes, g['hyp_int_nes'])
+
+
+RND = (('rnd_bin_sum', 'b_bin', np.float32, 'sum', 'both', 'attribute_file'),
+       ('rnd_q_sum', 'b_q', None, 'sum', 'both', 'attribute_file'),
+       ('rnd_q32_sum_hi', 'b_q_f32', None, 'sum', 'highest', 'attribute_file'),
+       ('rnd_q_sum_lo', 'b_q', None, 'sum', 'lowest', 'attribute_file'),
+       ('rnd_q_z', 'b_q', None, 'z-score', 'both', 'attribute_file'),
+       ('rnd_q32_z', 'b_q_f32', None, 'z-score', 'both', 'attribute_file'),
+       ('rnd_q_net', 'b_q', None, 'sum', 'both', 'network'),
+       ('rnd_int_sum', 'b_int', None, 'sum', 'both', 'attribute_file'))
+
+
+@pytest.mark.parametrize('tag,src,dtype,score,sign,bg', RND)
+def test_compute_pvalues_randomization_vs_reference(amd, golden_nbr, golden_enr, tag, src, dtype, score, sign, bg):
+    g = golden_enr
+    b = g[src].copy()
+    if dtype is not None:
+        b = np.asfortranarray(b.astype(dtype))
+    nperm, seed = (int(v) for v in g[tag + '_meta'])
+    sf = _safe(amd, _layout_graph(amd, golden_nbr), attribute_sign=sign, random_seed=seed)
+    sf.neighborhoods = g['A'].astype(np.int64)
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues(how='randomization', neighborhood_score_type=score, background=bg,
+                       num_permutations=nperm, verbose=False)
+    for arr in (sf.ns, sf.pvalues_neg, sf.pvalues_pos, sf.nes, sf.nes_binary):
+        assert arr.dtype == np.float64 and arr.shape == b.shape
+    np.testing.assert_allclose(sf.ns, g[tag + '_ns'], rtol=1e-9, atol=1e-12, equal_nan=True)
+    # empirical p-values are counts / P: any flipped comparison would show as >= 1/P
+    np.testing.assert_array_equal(sf.pvalues_neg, g[tag + '_pvalues_neg'])
+    np.testing.assert_array_equal(sf.pvalues_pos, g[tag + '_pvalues_pos'])
+    np.testing.assert_array_equal(sf.nes, g[tag + '_nes'])
+    np.testing.assert_array_equal(sf.nes_binary, g[tag + '_nes_binary'])
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, g[tag + '_num_enriched'])
+
+
+def test_define_then_compute_uses_device_resident_membership(amd, golden_nbr, golden_enr):
+    """The usual flow: define_neighborhoods() then compute_pvalues() without the host
+    ever materialising self.neighborhoods in between."""
+    g = golden_enr
+    sf = _safe(amd, _layout_graph(amd, golden_nbr), random_seed=11)
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.2)
+    assert sf._neighborhoods_host is None
+    sf.load_attributes(attribute_file=g['b_q'].copy())
+    sf.compute_pvalues(how='randomization', num_permutations=40, verbose=False)
+    np.testing.assert_array_equal(sf.pvalues_pos, g['rnd_q_sum_pvalues_pos'])
+    np.testing.assert_array_equal(sf.nes, g['rnd_q_sum_nes'])
+    assert np.array_equal(sf.neighborhoods, g['A'].astype(np.int64))
+
+
+def test_config_errors_match_reference_behaviour(amd, golden_nbr):
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    with pytest.raises(ValueError):
+        sf.define_neighborhoods(node_distance_metric='manhattan')
+    assert sf.node_distance_metric == 'shortpath_weighted_layout'      # default restored (safe.py:205-209)
+    sf.neighborhoods = np.eye(golden_nbr['xy'].shape[0], dtype=np.int64)
+    sf.load_attributes(attribute_file=np.zeros((golden_nbr['xy'].shape[0], 2)))
+    with pytest.raises(ValueError):
+        sf.compute_pvalues(how='randomization', num_permutations=5)
+    assert sf.num_permutations == 1000
+    with pytest.raises(NotImplementedError):
+        sf.compute_pvalues(multiple_testing=True)
+
+
+# ------------------------------------------------- mid-size seeded check vs the oracle ----
+
+def test_midsize_randomization_vs_oracle(amd, ctx):
+    rng = np.random.default_rng(77)
+    n, m, nperm = 1203, 150, 12
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.07)
+    b = (rng.uniform(size=(n, m)) < 0.03).astype(np.float32)
+    b[rng.choice(n, 60, replace=False)] = np.nan
+    b = np.asfortranarray(b)
+    want = orc.compute_pvalues(a, b.copy(order='F'), enrichment_type='randomization', num_permutations=nperm,
+                               random_seed=3)
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(xy)
+    sf.random_seed = 3
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.07)
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues(how='randomization', num_permutations=nperm, verbose=False)
+    for key in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        np.testing.assert_array_equal(getattr(sf, key), want[key])     # integer-valued data: exact
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values,
+                                  want['num_neighborhoods_enriched'])
+
+
+def test_midsize_hypergeometric_vs_oracle(amd, ctx):
+    rng = np.random.default_rng(78)
+    n, m = 1500, 300
+    xy = rng.uniform(size=(n, 2))
+    b = (rng.uniform(size=(n, m)) < rng.uniform(0.002, 0.3, size=m)).astype(np.float64)
+    b[rng.choice(n, 40, replace=False)] = np.nan
+    a = orc.neighborhoods_euclidean(xy, 0.12)
+    want = orc.compute_pvalues(a, b.copy())
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(xy)
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.12)
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues()
+    np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
+    mism = (sf.nes_binary != want['nes_binary']).sum()
+    assert mism == 0

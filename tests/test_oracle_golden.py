@@ -1,0 +1,139 @@
+"""Pin the CPU oracle against vectors produced by the real reference
+(tests/golden/make_golden.py).  CPU only."""
+import numpy as np
+import pytest
+
+from oracle import safe_oracle as orc
+
+RADII_E = (0.05, 0.15)
+RADII_W = (0.08, 0.2)
+
+
+def test_euclidean_masks_bit_exact(golden_nbr):
+    g = golden_nbr
+    for r in RADII_E:
+        got = orc.neighborhoods_euclidean(g['xy'], r)
+        assert got.dtype == np.int64
+        assert np.array_equal(got, g['euclidean_r%g' % r].astype(np.int64))
+        assert np.all(np.diag(got) == 1)
+    assert np.array_equal(orc.euclidean_distances(g['xy']), g['euclidean_dist'])
+
+
+def test_edge_lengths_match_reference(golden_nbr):
+    g = golden_nbr
+    assert np.array_equal(orc.edge_lengths(g['xy'], g['edge_u'], g['edge_v']), g['edge_length'])
+
+
+def test_weighted_shortpath_masks_and_distances(golden_nbr):
+    g = golden_nbr
+    n = g['xy'].shape[0]
+    for r in RADII_W:
+        cutoff = orc.layout_radius(g['xy'][:, 0], r)
+        a, d = orc.neighborhoods_shortpath(n, g['edge_u'], g['edge_v'], g['edge_length'], cutoff)
+        assert np.array_equal(a, g['swl_r%g' % r].astype(np.int64))
+        assert np.array_equal(d, g['swl_dist_r%g' % r])       # bit-exact f64 path lengths
+
+
+def test_unweighted_shortpath_masks(golden_nbr):
+    g = golden_nbr
+    n = g['xy'].shape[0]
+    ones = np.ones(g['edge_u'].shape[0])
+    for r in (1, 2, 3):
+        a, _ = orc.neighborhoods_shortpath(n, g['edge_u'], g['edge_v'], ones, r)
+        assert np.array_equal(a, g['shortpath_r%d' % r].astype(np.int64))
+
+
+def test_scores(golden_enr):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    for key, mat, kind in (('score_sum_q', g['b_q'], 'sum'), ('score_z_q', g['b_q'], 'z-score'),
+                           ('score_z_q32', g['b_q_f32'], 'z-score')):
+        np.testing.assert_allclose(orc.compute_neighborhood_score(a, mat, kind), g[key],
+                                   rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_run_permutations(golden_enr):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    cn, cp = orc.run_permutations(a, g['b_q'], 'sum', 25, 29)
+    assert np.array_equal(cn, g['runperm_q_neg']) and np.array_equal(cp, g['runperm_q_pos'])
+    cn, cp = orc.run_permutations(a, g['b_bin'], 'sum', 25, 31)
+    assert np.array_equal(cn, g['runperm_bin_neg']) and np.array_equal(cp, g['runperm_bin_pos'])
+
+
+def test_index_table_reproduces_row_permutation(golden_enr):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    b = g['b_q']
+    table = orc.permutation_index_table(b, 25, 29)
+    obs = orc.compute_neighborhood_score(a, b, 'sum')
+    cn = np.zeros(obs.shape)
+    cp = np.zeros(obs.shape)
+    for k in range(25):
+        s = orc.compute_neighborhood_score(a, b[table[k]], 'sum')
+        cn += s <= obs
+        cp += s >= obs
+    assert np.array_equal(cn, g['runperm_q_neg']) and np.array_equal(cp, g['runperm_q_pos'])
+
+
+HYP = (('hyp_f64', 'b_bin', None, 'attribute_file'), ('hyp_f32F', 'b_bin', np.float32, 'attribute_file'),
+       ('hyp_net', 'b_bin', None, 'network'))
+
+
+@pytest.mark.parametrize('tag,src,dtype,bg', HYP)
+def test_hypergeometric(golden_enr, tag, src, dtype, bg):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    b = g[src].copy()
+    if dtype is not None:
+        b = np.asfortranarray(b.astype(dtype))
+    out = orc.compute_pvalues(a, b, background=bg)
+    assert 'pvalues_neg' not in out and 'ns' not in out
+    np.testing.assert_array_equal(out['pvalues_pos'], g[tag + '_pvalues_pos'])
+    np.testing.assert_array_equal(out['nes'], g[tag + '_nes'])
+    np.testing.assert_array_equal(out['nes_binary'], g[tag + '_nes_binary'])
+    np.testing.assert_array_equal(out['num_neighborhoods_enriched'], g[tag + '_num_enriched'])
+
+
+def test_hypergeometric_forced_on_integers(golden_enr):
+    g = golden_enr
+    out = orc.compute_pvalues(g['A'].astype(np.int64), g['b_int'].copy(), enrichment_type='hypergeometric')
+    np.testing.assert_array_equal(out['pvalues_pos'], g['hyp_int_pvalues_pos'])
+    np.testing.assert_array_equal(out['nes'], g['hyp_int_nes'])
+
+
+RND = (('rnd_bin_sum', 'b_bin', np.float32, 'sum', 'both', 'attribute_file'),
+       ('rnd_q_sum', 'b_q', None, 'sum', 'both', 'attribute_file'),
+       ('rnd_q32_sum_hi', 'b_q_f32', None, 'sum', 'highest', 'attribute_file'),
+       ('rnd_q_sum_lo', 'b_q', None, 'sum', 'lowest', 'attribute_file'),
+       ('rnd_q_z', 'b_q', None, 'z-score', 'both', 'attribute_file'),
+       ('rnd_q32_z', 'b_q_f32', None, 'z-score', 'both', 'attribute_file'),
+       ('rnd_q_net', 'b_q', None, 'sum', 'both', 'network'),
+       ('rnd_int_sum', 'b_int', None, 'sum', 'both', 'attribute_file'))
+
+
+@pytest.mark.parametrize('tag,src,dtype,score,sign,bg', RND)
+def test_randomization(golden_enr, tag, src, dtype, score, sign, bg):
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    b = g[src].copy()
+    if dtype is not None:
+        b = np.asfortranarray(b.astype(dtype))
+    nperm, seed = (int(v) for v in g[tag + '_meta'])
+    out = orc.compute_pvalues(a, b, enrichment_type='randomization', neighborhood_score_type=score,
+                              background=bg, num_permutations=nperm, random_seed=seed, attribute_sign=sign)
+    np.testing.assert_allclose(out['ns'], g[tag + '_ns'], rtol=1e-12, atol=0, equal_nan=True)
+    for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        np.testing.assert_array_equal(out[key], g[tag + '_' + key])
+    np.testing.assert_array_equal(out['num_neighborhoods_enriched'], g[tag + '_num_enriched'])
+
+
+def test_restated_mt19937_matches_reference_stream(golden_rng):
+    g = golden_rng
+    for seed in (0, 42, 12345, 4294967295):
+        rng = orc.LegacyMT19937(seed)
+        for n_items in (1, 2, 10, 257, 3971):
+            base = [3 * i + 1 for i in range(n_items)]
+            for suffix in ('a', 'b'):
+                want = g['s%d_n%d_%s' % (seed, n_items, suffix)]
+                assert rng.permutation(base) == [int(v) for v in want]
