@@ -28,6 +28,31 @@ if not os.path.exists(LIB_PATH):
         'safepy_amd: %s not found. Build it with `python -c "import __graft_entry__ as g; g.build()"` or '
         '`make -C safepy_amd/csrc` (needs hipcc, --offload-arch=gfx950). There is no CPU fallback.' % LIB_PATH)
 
+
+
+def _preload_torch_hip_runtime():
+    """One HIP runtime per process.  PyTorch-ROCm wheels bundle their own libamdhip64.so
+    (same SONAME as /opt/rocm's).  If libsafe_hip.so were loaded first it would bind to
+    /opt/rocm's copy and a later `import torch` would bring a second runtime into the
+    process: device pointers, streams and torch.cuda.synchronize() would then belong to
+    different runtimes.  Loading torch's copy first (without importing torch) makes the
+    dynamic loader resolve libsafe_hip.so's NEEDED libamdhip64.so.7 to it, and torch
+    later finds the very same file.  Without torch installed, /opt/rocm's runtime is used."""
+    import importlib.util
+    try:
+        spec = importlib.util.find_spec('torch')
+    except (ImportError, ValueError):
+        spec = None
+    if spec is None or not spec.submodule_search_locations:
+        return None
+    path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    if not os.path.exists(path):
+        return None
+    C.CDLL(path, mode=C.RTLD_GLOBAL)
+    return path
+
+
+HIP_RUNTIME_PRELOADED = _preload_torch_hip_runtime()
 lib = C.CDLL(LIB_PATH)
 
 _vp = C.c_void_p

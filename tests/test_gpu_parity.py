@@ -327,3 +327,23 @@ def test_midsize_hypergeometric_vs_oracle(amd, ctx):
     np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
     mism = (sf.nes_binary != want['nes_binary']).sum()
     assert mism == 0
+
+
+def test_torch_tensors_share_the_hip_runtime(amd, ctx):
+    """Device pointers of torch tensors are usable by the library (one HIP runtime per
+    process, see safepy_amd/_lib.py) and torch sees the library's results."""
+    torch = pytest.importorskip('torch')
+    assert torch.cuda.is_available()
+    rng = np.random.default_rng(9)
+    n = 700
+    xy = rng.uniform(size=(n, 2))
+    t_xy = torch.from_numpy(xy).to('cuda')
+    t_mask = torch.empty((n, n), dtype=torch.int64, device='cuda')
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+    try:
+        ctx.euclidean_dense(t_xy.data_ptr(), n, 0.1, t_mask.data_ptr(), None)
+        torch.cuda.synchronize()
+        got = t_mask.cpu().numpy()
+    finally:
+        ctx.set_stream(None)
+    assert np.array_equal(got, (orc.euclidean_distances(xy) < 0.1).astype(np.int64))
