@@ -66,6 +66,55 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     }
 }
 
+// one wave per column: rows holding a 1, ascending, by ballot compaction
+template <typename T>
+__global__ __launch_bounds__(256) void k_fill_support(const void *__restrict__ raw, int64_t n, int64_t m, int64_t rs,
+                                                      int64_t cs, const int32_t *__restrict__ sup_ptr,
+                                                      int32_t *__restrict__ sup_row) {
+    const int64_t j = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (j >= m) return;
+    int32_t pos = sup_ptr[j];
+    for (int64_t i0 = 0; i0 < n; i0 += 64) {
+        const int64_t i = i0 + lane;
+        const bool one = i < n && reinterpret_cast<const T *>(raw)[i * rs + j * cs] == static_cast<T>(1);
+        const unsigned long long bal = __ballot(one);
+        if (one) sup_row[pos + __popcll(bal & ((1ull << lane) - 1ull))] = static_cast<int32_t>(i);
+        pos += __popcll(bal);
+    }
+}
+
+int attr_build_support(safe_attr *attr) {
+    if (attr->sup_ptr) return SAFE_OK;
+    SAFE_TRY(safe_attr_prepare(attr));
+    SAFE_REQUIRE(attr->n_other == 0, "attr_build_support: matrix is not binary");
+    safe_ctx *ctx = attr->ctx;
+    const int64_t n = attr->n, m = attr->m;
+    std::vector<double> sums(m);
+    SAFE_HIP_CHECK(hipMemcpyAsync(sums.data(), attr->col_sum, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    attr->h_sup_ptr.assign(m + 1, 0);
+    int64_t total = 0;
+    for (int64_t j = 0; j < m; ++j) {
+        total += static_cast<int64_t>(sums[j]);
+        SAFE_REQUIRE(total < (1ll << 31), "attr_build_support: too many ones for int32 offsets");
+        attr->h_sup_ptr[j + 1] = static_cast<int32_t>(total);
+    }
+    attr->n_ones = total;
+    SAFE_TRY(dev_alloc(&attr->sup_ptr, m + 1));
+    SAFE_TRY(dev_alloc(&attr->sup_row, total));
+    SAFE_HIP_CHECK(hipMemcpyAsync(attr->sup_ptr, attr->h_sup_ptr.data(), (m + 1) * sizeof(int32_t), hipMemcpyHostToDevice,
+                                  ctx->stream));
+    if (attr->dtype == SAFE_DTYPE_F32)
+        hipLaunchKernelGGL(k_fill_support<float>, dim3(ceil_div(m * 64, 256)), dim3(256), 0, ctx->stream, attr->raw, n, m,
+                           attr->row_stride, attr->col_stride, attr->sup_ptr, attr->sup_row);
+    else
+        hipLaunchKernelGGL(k_fill_support<double>, dim3(ceil_div(m * 64, 256)), dim3(256), 0, ctx->stream, attr->raw, n, m,
+                           attr->row_stride, attr->col_stride, attr->sup_ptr, attr->sup_row);
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
+}
+
 int safe_attr_prepare(safe_attr *attr) {
     if (attr->stats_ready) return SAFE_OK;
     safe_ctx *ctx = attr->ctx;
@@ -177,6 +226,8 @@ int safe_attr_destroy(safe_attr *attr) {
     if (attr->owns_raw) (void)hipFree(const_cast<void *>(attr->raw));
     (void)hipFree(attr->row_flags);
     (void)hipFree(attr->col_sum);
+    (void)hipFree(attr->sup_ptr);
+    (void)hipFree(attr->sup_row);
     delete attr;
     return SAFE_OK;
 }

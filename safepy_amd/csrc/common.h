@@ -94,6 +94,9 @@ struct safe_nbr {
     std::vector<int64_t> h_slice_off;
     std::vector<int32_t> h_row_count;   // host copy of per-row counts
     double *dist = nullptr;         // optional [n][n]
+    // CSR of the transpose (column k -> rows i with A[i,k] = 1), built on first use
+    int32_t *at_ptr = nullptr;      // [n+1]
+    int32_t *at_col = nullptr;      // [nnz], unordered inside a column
 };
 
 struct safe_attr {
@@ -109,6 +112,11 @@ struct safe_attr {
     int64_t n_other = 0, max_nan_col = 0, n_rows_with_value = 0, n_non_integer = 0;
     double *col_sum = nullptr;      // [m] nansum per column (device)
     double max_abs = 0.0;           // max |value| over non-NaN entries
+    // binary matrices only: support lists (CSC of the ones), built on first use
+    int32_t *sup_ptr = nullptr;     // [m+1]
+    int32_t *sup_row = nullptr;     // [n_ones]
+    int64_t n_ones = 0;
+    std::vector<int32_t> h_sup_ptr; // host copy
 };
 
 struct safe_perms {
@@ -116,6 +124,7 @@ struct safe_perms {
     int64_t n = 0;
     int64_t count = 0;
     int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)
+    int32_t *inverse = nullptr;     // [count][n+1] inverse permutations, built on first use
 };
 
 // launch-geometry helpers
@@ -123,3 +132,6 @@ static inline int64_t ceil_div(int64_t a, int64_t b) { return (a + b - 1) / b; }
 
 int safe_attr_prepare(safe_attr *attr);   // row flags + stats (attr.hip)
 int nbr_finalize_from_bits(safe_nbr *nbr);   // bits -> CSR + SELL (nbr.hip)
+int nbr_build_transpose(safe_nbr *nbr);      // at_ptr / at_col (nbr.hip)
+int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary matrix (attr.hip)
+int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)

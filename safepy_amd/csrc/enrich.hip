@@ -202,6 +202,129 @@ __global__ __launch_bounds__(256) void k_permtest_gather(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// K5 (binary attributes, sparse form).  For 0/1 data the permuted neighborhood sum is a
+// set intersection,   S_p[i,j] = | nbr(i)  n  { inv_p[r] : B[r,j] = 1 } |,
+// so instead of gathering nbr(i) for every (i,j,p) -- nnz(A)*M adds per permutation, almost
+// all of them adding 0 at GO-like densities (~1 %) -- the kernel SCATTERS: for every 1 of
+// column j it adds 1 to the neighborhoods that contain its permuted position
+// (nnz(A)*nnz(B)/N increments per permutation), then compares only the touched
+// neighborhoods with the observed count.  Untouched entries have S_p = 0, whose
+// contribution is known:  S_p <= S_obs always,  S_p >= S_obs iff S_obs == 0.  Hence
+//     counts_neg = P - #{p : S_p > S_obs}          (only touched entries can be greater)
+//     counts_pos = S_obs == 0 ? P : #{p : touched and S_p >= S_obs}.
+// Integer arithmetic: bit-exact against the reference's f64 sums of 0/1 values.
+//
+// One workgroup owns one attribute at a time (dynamic queue, largest attribute first); its
+// per-node state lives in LDS:  AS[i] = acc<<16 | S_obs,  CT[i] = #greater<<16 | #touched>=.
+// Phase A adds into acc with LDS atomics; phase B swaps acc back to 0 (the first arrival
+// sees the total) and updates the two counters.  No S_p, no counter ever touches HBM.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_permtest_scatter(
+    int64_t n, int64_t n_perm, const int32_t *__restrict__ inv, const int32_t *__restrict__ at_ptr,
+    const int32_t *__restrict__ at_col, const int32_t *__restrict__ sup_ptr, const int32_t *__restrict__ sup_row,
+    int64_t col0, const int32_t *__restrict__ order, int64_t mloc, unsigned int *__restrict__ queue, PermOut out) {
+    extern __shared__ unsigned int lds[];
+    unsigned int *AS = lds;        // [n]
+    unsigned int *CT = lds + n;    // [n]
+    unsigned int *slot_box = lds + 2 * n;
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t stride = n + 1;
+
+    for (;;) {
+        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t slot = *slot_box;
+        __syncthreads();
+        if (slot >= mloc) break;
+        const int j = order[slot];                                   // local column index
+        const int32_t sbeg = sup_ptr[col0 + j];
+        const int nrows = sup_ptr[col0 + j + 1] - sbeg;
+
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            AS[i] = 0;
+            CT[i] = 0;
+        }
+        // this wave's share of the support rows: row q = base + wave + 4*lane
+        const int q0 = wave + 4 * lane;
+        const int32_t r0 = q0 < nrows ? sup_row[sbeg + q0] : 0;
+        __syncthreads();
+
+        // walks all (support row, member neighborhood) pairs of this wave's share
+        auto walk = [&](const int32_t *__restrict__ cur_inv, auto &&body) {
+            for (int base = 0; base < nrows; base += 256) {
+                const int q = base + q0;
+                int32_t beg = 0, end = 0;
+                if (q < nrows) {
+                    const int32_t r = base == 0 ? r0 : sup_row[sbeg + q];
+                    const int32_t k = cur_inv ? cur_inv[r] : r;
+                    beg = at_ptr[k];
+                    end = at_ptr[k + 1];
+                }
+                int cnt = (nrows - base - wave + 3) >> 2;            // rows of this wave in this round
+                cnt = cnt > 64 ? 64 : cnt;
+                for (int s = 0; s < cnt; ++s) {
+                    const int32_t b = __builtin_amdgcn_readlane(beg, s);
+                    const int32_t e = __builtin_amdgcn_readlane(end, s);
+                    for (int32_t t = b + lane; t < e; t += 64) body(at_col[t]);
+                }
+            }
+        };
+
+        // observed counts: identity permutation (safe.py:496-499)
+        walk(nullptr, [&](int32_t i) { atomicAdd(&AS[i], 0x10000u); });
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n; i += 256) AS[i] = AS[i] >> 16;
+        __syncthreads();
+
+        for (int64_t p = 0; p < n_perm; ++p) {
+            const int32_t *cur_inv = inv + p * stride;
+            walk(cur_inv, [&](int32_t i) { atomicAdd(&AS[i], 0x10000u); });
+            __syncthreads();
+            walk(cur_inv, [&](int32_t i) {
+                const unsigned int old = atomicAnd(&AS[i], 0xFFFFu);
+                const unsigned int v = old >> 16;
+                if (v) {
+                    const unsigned int so = old & 0xFFFFu;
+                    atomicAdd(&CT[i], (static_cast<unsigned int>(v > so) << 16) | static_cast<unsigned int>(v >= so));
+                }
+            });
+            __syncthreads();
+        }
+
+        // ---- epilogue (same outputs as the gather kernel) ---------------------------------
+        unsigned int hits = 0;
+        for (int64_t i = threadIdx.x; i < n; i += 256) {
+            const unsigned int so = AS[i] & 0xFFFFu;
+            const unsigned int ct = CT[i];
+            const unsigned int cneg = static_cast<unsigned int>(n_perm) - (ct >> 16);
+            const unsigned int cpos = so == 0 ? static_cast<unsigned int>(n_perm) : (ct & 0xFFFFu);
+            const int64_t o = i * mloc + j;
+            if (out.ns) out.ns[o] = static_cast<double>(so);
+            if (out.mode == 1) {
+                out.counts_neg[o] = static_cast<double>(cneg);
+                out.counts_pos[o] = static_cast<double>(cpos);
+            } else if (out.mode == 2) {
+                const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
+                double nes = ep - en;
+                if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+                if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+                const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+                out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(n_perm);
+                out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(n_perm);
+                out.nes[o] = nes;
+                out.nes_binary[o] = hit ? 1.0 : 0.0;
+                hits += hit;
+            }
+        }
+        if (out.mode == 2) {
+            for (int off = 32; off > 0; off >>= 1) hits += __shfl_down(hits, off);
+            if (lane == 0 && hits) atomicAdd(&out.enriched[j], hits);
+        }
+        __syncthreads();
+    }
+}
+
 __global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < count) out[i] = static_cast<double>(in[i]);
@@ -367,6 +490,57 @@ static int launch_gather(safe_ctx *ctx, safe_nbr *nbr, const Tiles &tiles, const
     return SAFE_OK;
 }
 
+// Chooses the sparse binary form when it is exact and profitable: 'sum' score, every
+// non-NaN value in {0,1}, sparse enough that scattering beats gathering, counters and sums
+// fit 16 bits, and the per-node LDS state fits one CU.
+static bool scatter_applicable(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr *attr, int64_t n_perm, bool z) {
+    if (z || n_perm < 1 || n_perm > 65535) return false;
+    if (safe_attr_prepare(attr) != SAFE_OK) return false;
+    if (attr->n_other != 0) return false;
+    if (nbr->max_count > 65535) return false;
+    if ((2 * nbr->n + 4) * sizeof(unsigned int) > 160 * 1024) return false;
+    const char *force = getenv("SAFE_HIP_FORCE_PATH");
+    if (force && !strcmp(force, "gather")) return false;
+    if (attr_build_support(attr) != SAFE_OK) return false;
+    const double density = static_cast<double>(attr->n_ones) / (static_cast<double>(attr->n) * attr->m);
+    if (force && !strcmp(force, "scatter")) return true;
+    return density <= 0.125;
+}
+
+static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0,
+                          int64_t col1, const PermOut &out) {
+    const int64_t n = nbr->n, mloc = col1 - col0;
+    SAFE_TRY(nbr_build_transpose(nbr));
+    SAFE_TRY(perms_build_inverse(perms));
+    // attributes in descending support size: dynamic queue = longest-processing-time-first
+    std::vector<int32_t> order(mloc);
+    for (int64_t j = 0; j < mloc; ++j) order[j] = static_cast<int32_t>(j);
+    const int32_t *sp = attr->h_sup_ptr.data() + col0;
+    std::stable_sort(order.begin(), order.end(), [&](int32_t a, int32_t b) { return sp[a + 1] - sp[a] > sp[b + 1] - sp[b]; });
+    int32_t *d_order = nullptr;
+    unsigned int *d_queue = nullptr;
+    SAFE_TRY(dev_alloc(&d_order, mloc));
+    SAFE_TRY(dev_alloc(&d_queue, 1));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_order, order.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), ctx->stream));
+    const size_t lds_bytes = (2 * n + 4) * sizeof(unsigned int);
+    const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
+    const int64_t blocks = std::min<int64_t>(mloc, static_cast<int64_t>(ctx->num_cu) * per_cu);
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_scatter),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(k_permtest_scatter, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, perms->count,
+                       perms->inverse, nbr->at_ptr, nbr->at_col, attr->sup_ptr, attr->sup_row, col0, d_order, mloc, d_queue,
+                       out);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = "k_permtest_scatter";
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // order (host vector) and temporaries
+    (void)hipFree(d_order);
+    (void)hipFree(d_queue);
+    return SAFE_OK;
+}
+
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
     float ms = 0.f;
@@ -405,13 +579,17 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
     SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_permtest_counts: bad score_type %d", score_type);
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const bool z = score_type == SAFE_SCORE_ZSCORE;
-    Tiles tiles;
-    SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
     PermOut out{};
     out.ns = ns_dev;
     out.counts_neg = counts_neg_dev;
     out.counts_pos = counts_pos_dev;
     out.mode = 1;
+    if (scatter_applicable(ctx, nbr, attr, perms->count, z)) {
+        SAFE_TRY(launch_scatter(ctx, nbr, attr, perms, col0, col1, out));
+        return finish_kernel_timing(ctx);
+    }
+    Tiles tiles;
+    SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
     int rc = launch_gather(ctx, nbr, tiles, perms->table, perms->count, col1 - col0, z, out);
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
     (void)hipFree(tiles.bt);
@@ -444,9 +622,10 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     double *d_tab = nullptr;
     unsigned int *d_enr = nullptr;
     Tiles tiles;
+    const bool scatter = scatter_applicable(ctx, nbr, attr, P, z);
     int rc = dev_alloc(&d_tab, P + 1);
     if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 16);
-    if (rc == SAFE_OK) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
+    if (rc == SAFE_OK && !scatter) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
     if (rc == SAFE_OK) {
         hipError_t e = hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 16) * sizeof(unsigned int), ctx->stream);
@@ -467,7 +646,8 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.nes_threshold = -std::log10(enrichment_threshold);
         out.sign_mode = sign_mode;
         out.mode = 2;
-        rc = launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out);
+        rc = scatter ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
+                     : launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out);
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);

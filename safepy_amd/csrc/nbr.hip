@@ -284,6 +284,24 @@ __global__ __launch_bounds__(64) void k_shortpath(int64_t n, const int32_t *__re
     }
 }
 
+__global__ void k_count_cols(const int32_t *__restrict__ col, int64_t nnz, int32_t *__restrict__ cnt) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (e < nnz) atomicAdd(&cnt[col[e]], 1);
+}
+
+__global__ void k_fill_transpose(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col, int64_t n,
+                                 const int32_t *__restrict__ at_ptr, int32_t *__restrict__ cursor,
+                                 int32_t *__restrict__ at_col) {
+    // one wave per row
+    const int64_t row = (static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x) >> 6;
+    const int lane = threadIdx.x & 63;
+    if (row >= n) return;
+    for (int32_t e = row_ptr[row] + lane; e < row_ptr[row + 1]; e += 64) {
+        const int32_t k = col[e];
+        at_col[at_ptr[k] + atomicAdd(&cursor[k], 1)] = static_cast<int32_t>(row);
+    }
+}
+
 __global__ void k_fill_u64(unsigned long long *p, unsigned long long v, int64_t count) {
     for (int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x; i < count;
          i += static_cast<int64_t>(gridDim.x) * blockDim.x)
@@ -303,6 +321,8 @@ static void nbr_free(safe_nbr *nbr) {
     (void)hipFree(nbr->slice_width);
     (void)hipFree(nbr->sell_col);
     (void)hipFree(nbr->dist);
+    (void)hipFree(nbr->at_ptr);
+    (void)hipFree(nbr->at_col);
     delete nbr;
 }
 
@@ -385,6 +405,30 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
                        nbr->sell_col);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host vectors above go out of scope
+    return SAFE_OK;
+}
+
+int nbr_build_transpose(safe_nbr *nbr) {
+    if (nbr->at_ptr) return SAFE_OK;
+    safe_ctx *ctx = nbr->ctx;
+    const int64_t n = nbr->n, nnz = nbr->nnz;
+    int32_t *d_cnt = nullptr;
+    SAFE_TRY(dev_alloc(&d_cnt, n));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, n * sizeof(int32_t), ctx->stream));
+    if (nnz) hipLaunchKernelGGL(k_count_cols, dim3(ceil_div(nnz, 256)), dim3(256), 0, ctx->stream, nbr->col, nnz, d_cnt);
+    std::vector<int32_t> cnt(n), ptr(n + 1, 0);
+    SAFE_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int64_t k = 0; k < n; ++k) ptr[k + 1] = ptr[k] + cnt[k];
+    SAFE_TRY(dev_alloc(&nbr->at_ptr, n + 1));
+    SAFE_TRY(dev_alloc(&nbr->at_col, nnz));
+    SAFE_HIP_CHECK(hipMemcpyAsync(nbr->at_ptr, ptr.data(), (n + 1) * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_cnt, 0, n * sizeof(int32_t), ctx->stream));
+    hipLaunchKernelGGL(k_fill_transpose, dim3(ceil_div(n * 64, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col, n,
+                       nbr->at_ptr, d_cnt, nbr->at_col);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_cnt);
     return SAFE_OK;
 }
 

@@ -3,6 +3,7 @@
 // Fisher-Yates from the top with masked-rejection bounded integers.
 // The stream is inherently sequential (the number of draws a shuffle consumes depends on
 // the rejections), so it runs on the host and the composed index tables are uploaded.
+#include <algorithm>
 #include <random>
 
 #include "common.h"
@@ -70,6 +71,26 @@ uint32_t entropy_seed() {
 }
 
 }  // namespace
+
+__global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride, int64_t total,
+                               int32_t *__restrict__ inverse) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= total) return;
+    const int64_t p = idx / stride, k = idx % stride;
+    inverse[p * stride + table[idx]] = static_cast<int32_t>(k);
+}
+
+int perms_build_inverse(safe_perms *perms) {
+    if (perms->inverse) return SAFE_OK;
+    safe_ctx *ctx = perms->ctx;
+    const int64_t stride = perms->n + 1, total = perms->count * stride;
+    SAFE_TRY(dev_alloc(&perms->inverse, static_cast<size_t>(std::max<int64_t>(total, 1))));
+    if (total)
+        hipLaunchKernelGGL(k_invert_perms, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, perms->table, stride,
+                           total, perms->inverse);
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
+}
 
 extern "C" {
 
@@ -160,6 +181,7 @@ int safe_perms_destroy(safe_perms *perms) {
     (void)hipSetDevice(perms->ctx->device);
     (void)hipStreamSynchronize(perms->ctx->stream);
     (void)hipFree(perms->table);
+    (void)hipFree(perms->inverse);
     delete perms;
     return SAFE_OK;
 }

@@ -347,3 +347,56 @@ def test_torch_tensors_share_the_hip_runtime(amd, ctx):
     finally:
         ctx.set_stream(None)
     assert np.array_equal(got, (orc.euclidean_distances(xy) < 0.1).astype(np.int64))
+
+
+# ------------------------------------------ both forms of the permutation kernel ----------
+
+@pytest.mark.parametrize('path', ['gather', 'scatter'])
+def test_binary_permutation_test_both_kernel_forms(amd, golden_enr, monkeypatch, path):
+    """Binary attributes can run through the general f64 gather kernel or the sparse integer
+    scatter kernel; both must reproduce the reference counts exactly."""
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    cn, cp = amd.run_permutations((a, g['b_bin'], 'sum', 25, 31), verbose=False)
+    assert np.array_equal(cn, g['runperm_bin_neg']) and np.array_equal(cp, g['runperm_bin_pos'])
+    ctx = amd.Context.default(0)
+    assert ctx.last_kernel()[0].startswith('k_permtest_' + path)
+
+
+@pytest.mark.parametrize('path', ['gather', 'scatter'])
+def test_binary_randomization_asymmetric_membership(amd, monkeypatch, path):
+    """User-supplied, non-symmetric membership (the scatter form walks the transpose)."""
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
+    rng = np.random.default_rng(21)
+    n, m, nperm = 333, 70, 15
+    a = (rng.uniform(size=(n, n)) < 0.04).astype(np.int64)
+    a[5, :] = 0                                              # an empty neighborhood
+    a[:, 9] = 0                                              # a node nobody contains
+    b = (rng.uniform(size=(n, m)) < 0.06).astype(np.float64)
+    b[:, 3] = 0                                              # attribute with no annotations
+    b[:, 4] = np.nan                                         # all-NaN attribute
+    b[rng.choice(n, 20, replace=False)] = np.nan
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=8,
+                               attribute_sign='highest')
+    sf = amd.SAFE(verbose=False)
+    sf.attribute_sign = 'highest'
+    sf.random_seed = 8
+    sf.neighborhoods = a
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues(how='randomization', num_permutations=nperm, verbose=False)
+    for key in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        np.testing.assert_array_equal(getattr(sf, key), want[key])
+
+
+def test_scatter_form_large_support_and_many_permutations(amd, monkeypatch):
+    """Support larger than one 256-row round per workgroup, > 255 permutations."""
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'scatter')
+    rng = np.random.default_rng(22)
+    n, m, nperm = 900, 12, 300
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.08)
+    b = (rng.uniform(size=(n, m)) < np.linspace(0.02, 0.6, m)).astype(np.float32)
+    cn_want, cp_want = orc.run_permutations(a, b, 'sum', nperm, 5)
+    cn, cp = amd.run_permutations((a, b, 'sum', nperm, 5), verbose=False)
+    assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
