@@ -124,7 +124,10 @@ struct safe_perms {
     int64_t n = 0;
     int64_t count = 0;
     int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)
-    int32_t *inverse = nullptr;     // [count][n+1] inverse permutations, built on first use
+    // transposed inverse permutations, built on first use (n < 65536 only):
+    // inverse_t[r * inv_stride + p] = position k with table[p][k] == r; inv_stride = padded count
+    uint16_t *inverse_t = nullptr;
+    int64_t inv_stride = 0;
 };
 
 // launch-geometry helpers

@@ -208,28 +208,98 @@ __global__ __launch_bounds__(256) void k_permtest_gather(
 // so instead of gathering nbr(i) for every (i,j,p) -- nnz(A)*M adds per permutation, almost
 // all of them adding 0 at GO-like densities (~1 %) -- the kernel SCATTERS: for every 1 of
 // column j it adds 1 to the neighborhoods that contain its permuted position
-// (nnz(A)*nnz(B)/N increments per permutation), then compares only the touched
-// neighborhoods with the observed count.  Untouched entries have S_p = 0, whose
-// contribution is known:  S_p <= S_obs always,  S_p >= S_obs iff S_obs == 0.  Hence
-//     counts_neg = P - #{p : S_p > S_obs}          (only touched entries can be greater)
-//     counts_pos = S_obs == 0 ? P : #{p : touched and S_p >= S_obs}.
+// (nnz(A)*nnz(B)/N increments per permutation) and only ever looks at touched
+// neighborhoods.  Untouched entries have S_p = 0, whose contribution is known
+// (S_p <= S_obs always; S_p >= S_obs iff S_obs == 0), and because a count only grows
+// inside one permutation each threshold is crossed at most once, at a known increment:
+//     counts_neg = P - #{p : S_p > S_obs}  = P - #{p : some increment made S_p == S_obs + 1}
+//     counts_pos = S_obs == 0 ? P : #{p : some increment made S_p == S_obs}.
 // Integer arithmetic: bit-exact against the reference's f64 sums of 0/1 values.
 //
 // One workgroup owns one attribute at a time (dynamic queue, largest attribute first); its
-// per-node state lives in LDS:  AS[i] = acc<<16 | S_obs,  CT[i] = #greater<<16 | #touched>=.
-// Phase A adds into acc with LDS atomics; phase B swaps acc back to 0 (the first arrival
-// sees the total) and updates the two counters.  No S_p, no counter ever touches HBM.
+// per-node state lives in LDS: EP[i] (epoch-tagged running count), SO[i] = S_obs (u16),
+// CT[i] = #greater<<16 | #reached.  The running count is a DOWN-counter updated with one
+// LDS atomicDec(addr, D_p): "old > D_p ? D_p : old - 1" -- D_p = D_0 - 4096*p, so a value
+// left over from an earlier permutation (> D_p) is lazily reset by the very increment that
+// first touches it.  One walk per permutation, no reset pass; no S_p, no counter ever
+// touches HBM.
 // --------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void k_permtest_scatter(
-    int64_t n, int64_t n_perm, const int32_t *__restrict__ inv, const int32_t *__restrict__ at_ptr,
-    const int32_t *__restrict__ at_col, const int32_t *__restrict__ sup_ptr, const int32_t *__restrict__ sup_row,
-    int64_t col0, const int32_t *__restrict__ order, int64_t mloc, unsigned int *__restrict__ queue, PermOut out) {
+#define SC_BATCH 16
+#define SC_D0 0xFFFF0000u
+#define SC_EPOCH 4096u
+#define SC_CHUNK 16          // permutations per prefetched chunk of the transposed inverse table
+
+// Enumerates up to SC_BATCH 64-wide segments of the transposed-membership rows held one per
+// lane (beg/end), level by level (segment 0 of every row, then segment 1 of the long rows,
+// ...), and issues the column loads.  All control is wave-uniform (scalar): no scan, no LDS.
+struct SegCursor {
+    unsigned long long mask;
+    int level;
+    bool done;
+};
+
+__device__ __forceinline__ SegCursor seg_begin(int nseg) {
+    SegCursor c;
+    c.level = 0;
+    c.mask = __ballot(nseg > 0);
+    c.done = c.mask == 0;
+    return c;
+}
+
+__device__ __forceinline__ void seg_issue(SegCursor &c, int32_t beg, int32_t end, int nseg, int lane,
+                                          const int32_t *__restrict__ at_col, int32_t (&node)[SC_BATCH]) {
+#pragma unroll
+    for (int u = 0; u < SC_BATCH; ++u) {
+        node[u] = -1;
+        if (!c.done && c.mask == 0) {
+            ++c.level;
+            c.mask = __ballot(nseg > c.level);
+            c.done = c.mask == 0;
+        }
+        if (!c.done) {
+            const int row = __ffsll(static_cast<unsigned long long>(c.mask)) - 1;
+            c.mask &= c.mask - 1;
+            const int32_t b = __builtin_amdgcn_readlane(beg, row);
+            const int32_t e = __builtin_amdgcn_readlane(end, row);
+            const int32_t t = b + (c.level << 6) + lane;
+            if (t < e) node[u] = at_col[t];
+        }
+    }
+    if (!c.done && c.mask == 0) {            // so that `done` is exact after a full batch
+        ++c.level;
+        c.mask = __ballot(nseg > c.level);
+        c.done = c.mask == 0;
+    }
+}
+
+template <int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void k_permtest_scatter(
+    int64_t n, int64_t n_perm, const uint16_t *__restrict__ inv_t, int64_t inv_stride,
+    const int32_t *__restrict__ at_ptr, const int32_t *__restrict__ at_col, const int32_t *__restrict__ sup_ptr,
+    const int32_t *__restrict__ sup_row, int64_t col0, const int32_t *__restrict__ order, int64_t mloc,
+    unsigned int *__restrict__ queue, PermOut out) {
     extern __shared__ unsigned int lds[];
-    unsigned int *AS = lds;        // [n]
-    unsigned int *CT = lds + n;    // [n]
-    unsigned int *slot_box = lds + 2 * n;
+    unsigned int *EP = lds;                                            // [n]
+    unsigned int *CT = lds + n;                                        // [n]
+    unsigned int *slot_box = lds + 2 * n;                              // [4]
+    unsigned short *SO = reinterpret_cast<unsigned short *>(lds + 2 * n + 4);   // [n]
+    constexpr int NT = 64 * WAVES;
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t stride = n + 1;
+
+    // LDS stage of one batch: SC_BATCH returning atomics in flight together
+    auto count_batch = [&](const int32_t (&node)[SC_BATCH], unsigned int dp) {
+        unsigned int so[SC_BATCH], old[SC_BATCH];
+#pragma unroll
+        for (int u = 0; u < SC_BATCH; ++u) so[u] = node[u] >= 0 ? SO[node[u]] : 0u;
+#pragma unroll
+        for (int u = 0; u < SC_BATCH; ++u) old[u] = node[u] >= 0 ? atomicDec(&EP[node[u]], dp) : 0u;
+#pragma unroll
+        for (int u = 0; u < SC_BATCH; ++u) {
+            const unsigned int v = old[u] > dp ? 1u : dp - old[u] + 2u;     // running count after this increment
+            const unsigned int inc = (static_cast<unsigned int>(v == so[u] + 1u) << 16) | static_cast<unsigned int>(v == so[u]);
+            if (node[u] >= 0 && inc) atomicAdd(&CT[node[u]], inc);
+        }
+    };
 
     for (;;) {
         if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
@@ -237,65 +307,148 @@ __global__ __launch_bounds__(256) void k_permtest_scatter(
         const int64_t slot = *slot_box;
         __syncthreads();
         if (slot >= mloc) break;
-        const int j = order[slot];                                   // local column index
+        const int j = order[slot];                                     // local column index
         const int32_t sbeg = sup_ptr[col0 + j];
         const int nrows = sup_ptr[col0 + j + 1] - sbeg;
 
-        for (int64_t i = threadIdx.x; i < n; i += 256) {
-            AS[i] = 0;
+        for (int64_t i = threadIdx.x; i < n; i += NT) {
+            EP[i] = 0xFFFFFFFFu;
             CT[i] = 0;
         }
-        // this wave's share of the support rows: row q = base + wave + 4*lane
-        const int q0 = wave + 4 * lane;
-        const int32_t r0 = q0 < nrows ? sup_row[sbeg + q0] : 0;
+        // this wave's share of the support rows: row q = round*NT + wave + WAVES*lane
+        const int q0 = wave + WAVES * lane;
+        const bool has0 = q0 < nrows;
+        const int32_t r0 = has0 ? sup_row[sbeg + q0] : 0;
         __syncthreads();
 
-        // walks all (support row, member neighborhood) pairs of this wave's share
-        auto walk = [&](const int32_t *__restrict__ cur_inv, auto &&body) {
-            for (int base = 0; base < nrows; base += 256) {
-                const int q = base + q0;
-                int32_t beg = 0, end = 0;
-                if (q < nrows) {
-                    const int32_t r = base == 0 ? r0 : sup_row[sbeg + q];
-                    const int32_t k = cur_inv ? cur_inv[r] : r;
-                    beg = at_ptr[k];
-                    end = at_ptr[k + 1];
-                }
-                int cnt = (nrows - base - wave + 3) >> 2;            // rows of this wave in this round
-                cnt = cnt > 64 ? 64 : cnt;
-                for (int s = 0; s < cnt; ++s) {
-                    const int32_t b = __builtin_amdgcn_readlane(beg, s);
-                    const int32_t e = __builtin_amdgcn_readlane(end, s);
-                    for (int32_t t = b + lane; t < e; t += 64) body(at_col[t]);
-                }
+        // ---- observed counts: identity permutation (safe.py:496-499) ----------------------
+        for (int base = 0; base < nrows; base += NT) {
+            const int q = base + q0;
+            int32_t beg = 0, end = 0;
+            if (q < nrows) {
+                const int32_t r = sup_row[sbeg + q];
+                beg = at_ptr[r];
+                end = at_ptr[r + 1];
             }
-        };
+            const int nseg = (end - beg + 63) >> 6;
+            SegCursor c = seg_begin(nseg);
+            while (!c.done) {
+                int32_t node[SC_BATCH];
+                seg_issue(c, beg, end, nseg, lane, at_col, node);
+#pragma unroll
+                for (int u = 0; u < SC_BATCH; ++u)
+                    if (node[u] >= 0) atomicAdd(&CT[node[u]], 1u);
+            }
+        }
+        __syncthreads();
+        for (int64_t i = threadIdx.x; i < n; i += NT) {
+            SO[i] = static_cast<unsigned short>(CT[i]);
+            CT[i] = 0;
+        }
+        __syncthreads();
 
-        // observed counts: identity permutation (safe.py:496-499)
-        walk(nullptr, [&](int32_t i) { atomicAdd(&AS[i], 0x10000u); });
-        __syncthreads();
-        for (int64_t i = threadIdx.x; i < n; i += 256) AS[i] = AS[i] >> 16;
-        __syncthreads();
+        // ---- permutations, software pipelined for the round-0 rows ------------------------
+        // kq: 32-entry queue of this lane's upcoming positions k = inv_p[r0] (16 bits each);
+        // refilled one chunk ahead from the transposed inverse table.
+        const uint16_t *my_inv = inv_t + static_cast<int64_t>(r0) * inv_stride;
+        unsigned int kq[16], kn[8];
+        {
+            const uint4 a0 = *reinterpret_cast<const uint4 *>(my_inv);
+            const uint4 a1 = *reinterpret_cast<const uint4 *>(my_inv + 8);
+            const uint4 a2 = *reinterpret_cast<const uint4 *>(my_inv + 16);
+            const uint4 a3 = *reinterpret_cast<const uint4 *>(my_inv + 24);
+            kq[0] = a0.x; kq[1] = a0.y; kq[2] = a0.z; kq[3] = a0.w; kq[4] = a1.x; kq[5] = a1.y; kq[6] = a1.z; kq[7] = a1.w;
+            kq[8] = a2.x; kq[9] = a2.y; kq[10] = a2.z; kq[11] = a2.w; kq[12] = a3.x; kq[13] = a3.y; kq[14] = a3.z; kq[15] = a3.w;
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) kn[i] = 0;
+
+        int32_t beg = 0, end = 0, begn = 0, endn = 0;
+        int32_t node[SC_BATCH];
+        SegCursor cur;
+        {   // prologue: p = 0 rows and first batch of column loads; p = 1 row pointers
+            if (has0) {
+                const int32_t k = kq[0] & 0xFFFFu;
+                beg = at_ptr[k];
+                end = at_ptr[k + 1];
+                const int32_t k1 = kq[0] >> 16;
+                begn = at_ptr[k1];
+                endn = at_ptr[k1 + 1];
+            }
+            cur = seg_begin((end - beg + 63) >> 6);
+            seg_issue(cur, beg, end, (end - beg + 63) >> 6, lane, at_col, node);
+        }
 
         for (int64_t p = 0; p < n_perm; ++p) {
-            const int32_t *cur_inv = inv + p * stride;
-            walk(cur_inv, [&](int32_t i) { atomicAdd(&AS[i], 0x10000u); });
-            __syncthreads();
-            walk(cur_inv, [&](int32_t i) {
-                const unsigned int old = atomicAnd(&AS[i], 0xFFFFu);
-                const unsigned int v = old >> 16;
-                if (v) {
-                    const unsigned int so = old & 0xFFFFu;
-                    atomicAdd(&CT[i], (static_cast<unsigned int>(v > so) << 16) | static_cast<unsigned int>(v >= so));
+            const unsigned int dp = SC_D0 - SC_EPOCH * static_cast<unsigned int>(p);
+            const int nseg = (end - beg + 63) >> 6;
+
+            // (a) row pointers for p+2 are not needed yet; issue those for... p+1 were issued one
+            //     iteration ago (begn/endn).  Advance the queue: element 0 becomes k_{p+1}.
+#pragma unroll
+            for (int i = 0; i < 15; ++i) kq[i] = __builtin_amdgcn_alignbit(kq[i + 1], kq[i], 16);
+            kq[15] >>= 16;
+            if (((p + 1) & (SC_CHUNK - 1)) == 0) {
+                // the upper half is now empty: move the prefetched chunk in, prefetch the next one
+#pragma unroll
+                for (int i = 0; i < 8; ++i) kq[8 + i] = kn[i];
+            }
+            if ((p & (SC_CHUNK - 1)) == 0) {
+                const int64_t c2 = (p / SC_CHUNK + 2) * SC_CHUNK;        // chunk that becomes the upper half next time
+                const uint4 a0 = *reinterpret_cast<const uint4 *>(my_inv + c2);
+                const uint4 a1 = *reinterpret_cast<const uint4 *>(my_inv + c2 + 8);
+                kn[0] = a0.x; kn[1] = a0.y; kn[2] = a0.z; kn[3] = a0.w; kn[4] = a1.x; kn[5] = a1.y; kn[6] = a1.z; kn[7] = a1.w;
+            }
+            // row pointers for p+2 (k_{p+2} is queue element 1 after the shift)
+            int32_t beg2 = 0, end2 = 0;
+            if (has0) {
+                const int32_t k2 = kq[0] >> 16;
+                beg2 = at_ptr[k2];
+                end2 = at_ptr[k2 + 1];
+            }
+
+            // (b) LDS stage of p: first batch was loaded during the previous iteration
+            count_batch(node, dp);
+            while (!cur.done) {                                          // long tails: not pipelined
+                seg_issue(cur, beg, end, nseg, lane, at_col, node);
+                count_batch(node, dp);
+            }
+            // rows beyond the first NT of very large attributes: plain path
+            for (int base = NT; base < nrows; base += NT) {
+                const int q = base + q0;
+                int32_t b2 = 0, e2 = 0;
+                if (q < nrows) {
+                    const int32_t r = sup_row[sbeg + q];
+                    const int32_t k = inv_t[static_cast<int64_t>(r) * inv_stride + p];
+                    b2 = at_ptr[k];
+                    e2 = at_ptr[k + 1];
                 }
-            });
-            __syncthreads();
+                const int ns2 = (e2 - b2 + 63) >> 6;
+                SegCursor c2 = seg_begin(ns2);
+                while (!c2.done) {
+                    seg_issue(c2, b2, e2, ns2, lane, at_col, node);
+                    count_batch(node, dp);
+                }
+            }
+
+            // (c) column loads of p+1's first batch (its row pointers arrived during (b))
+            beg = begn;
+            end = endn;
+            begn = beg2;
+            endn = end2;
+            if (p + 1 < n_perm) {
+                const int nsegn = (end - beg + 63) >> 6;
+                cur = seg_begin(nsegn);
+                seg_issue(cur, beg, end, nsegn, lane, at_col, node);
+            }
+            if (WAVES > 1) __syncthreads();     // all waves of a workgroup share the epoch
         }
+        __syncthreads();
 
         // ---- epilogue (same outputs as the gather kernel) ---------------------------------
         unsigned int hits = 0;
-        for (int64_t i = threadIdx.x; i < n; i += 256) {
-            const unsigned int so = AS[i] & 0xFFFFu;
+        for (int64_t i = threadIdx.x; i < n; i += NT) {
+            const unsigned int so = SO[i];
             const unsigned int ct = CT[i];
             const unsigned int cneg = static_cast<unsigned int>(n_perm) - (ct >> 16);
             const unsigned int cpos = so == 0 ? static_cast<unsigned int>(n_perm) : (ct & 0xFFFFu);
@@ -493,12 +646,16 @@ static int launch_gather(safe_ctx *ctx, safe_nbr *nbr, const Tiles &tiles, const
 // Chooses the sparse binary form when it is exact and profitable: 'sum' score, every
 // non-NaN value in {0,1}, sparse enough that scattering beats gathering, counters and sums
 // fit 16 bits, and the per-node LDS state fits one CU.
+static size_t scatter_lds_bytes(int64_t n) {
+    return (2 * static_cast<size_t>(n) + 4) * sizeof(unsigned int) + ((static_cast<size_t>(n) + 1) & ~size_t(1)) * sizeof(unsigned short);
+}
+
 static bool scatter_applicable(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr *attr, int64_t n_perm, bool z) {
     if (z || n_perm < 1 || n_perm > 65535) return false;
     if (safe_attr_prepare(attr) != SAFE_OK) return false;
     if (attr->n_other != 0) return false;
-    if (nbr->max_count > 65535) return false;
-    if ((2 * nbr->n + 4) * sizeof(unsigned int) > 160 * 1024) return false;
+    if (nbr->max_count >= SC_EPOCH) return false;           // running counts must fit one epoch
+    if (scatter_lds_bytes(nbr->n) > 160 * 1024) return false;
     const char *force = getenv("SAFE_HIP_FORCE_PATH");
     if (force && !strcmp(force, "gather")) return false;
     if (attr_build_support(attr) != SAFE_OK) return false;
@@ -523,15 +680,24 @@ static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     SAFE_TRY(dev_alloc(&d_queue, 1));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_order, order.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), ctx->stream));
-    const size_t lds_bytes = (2 * n + 4) * sizeof(unsigned int);
+    const size_t lds_bytes = scatter_lds_bytes(n);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t blocks = std::min<int64_t>(mloc, static_cast<int64_t>(ctx->num_cu) * per_cu);
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_scatter),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-    hipLaunchKernelGGL(k_permtest_scatter, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, perms->count,
-                       perms->inverse, nbr->at_ptr, nbr->at_col, attr->sup_ptr, attr->sup_row, col0, d_order, mloc, d_queue,
-                       out);
+    int waves = 4;
+    if (const char *w = getenv("SAFE_HIP_SCATTER_WAVES")) waves = atoi(w);
+#define LAUNCH_SCATTER(W)                                                                                          \
+    do {                                                                                                           \
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_scatter<W>),                  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))); \
+        SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                                                      \
+        hipLaunchKernelGGL(k_permtest_scatter<W>, dim3(blocks), dim3(64 * W), lds_bytes, ctx->stream, n, perms->count, \
+                           perms->inverse_t, perms->inv_stride, nbr->at_ptr, nbr->at_col, attr->sup_ptr, attr->sup_row, \
+                           col0, d_order, mloc, d_queue, out);                                                                          \
+    } while (0)
+    if (waves == 1) LAUNCH_SCATTER(1);
+    else if (waves == 4) LAUNCH_SCATTER(4);
+    else LAUNCH_SCATTER(2);
+#undef LAUNCH_SCATTER
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_permtest_scatter";

@@ -72,22 +72,26 @@ uint32_t entropy_seed() {
 
 }  // namespace
 
-__global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride, int64_t total,
-                               int32_t *__restrict__ inverse) {
+__global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride, int64_t total, int64_t inv_stride,
+                               uint16_t *__restrict__ inverse_t) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (idx >= total) return;
     const int64_t p = idx / stride, k = idx % stride;
-    inverse[p * stride + table[idx]] = static_cast<int32_t>(k);
+    inverse_t[static_cast<int64_t>(table[idx]) * inv_stride + p] = static_cast<uint16_t>(k);
 }
 
 int perms_build_inverse(safe_perms *perms) {
-    if (perms->inverse) return SAFE_OK;
+    if (perms->inverse_t) return SAFE_OK;
+    SAFE_REQUIRE(perms->n < 65535, "perms_build_inverse: n too large for 16-bit positions");
     safe_ctx *ctx = perms->ctx;
     const int64_t stride = perms->n + 1, total = perms->count * stride;
-    SAFE_TRY(dev_alloc(&perms->inverse, static_cast<size_t>(std::max<int64_t>(total, 1))));
+    perms->inv_stride = ((perms->count + 15) / 16) * 16 + 32;      // chunked prefetch may read two chunks ahead
+    const size_t elems = static_cast<size_t>(stride) * perms->inv_stride;
+    SAFE_TRY(dev_alloc(&perms->inverse_t, elems));
+    SAFE_HIP_CHECK(hipMemsetAsync(perms->inverse_t, 0, elems * sizeof(uint16_t), ctx->stream));
     if (total)
         hipLaunchKernelGGL(k_invert_perms, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, perms->table, stride,
-                           total, perms->inverse);
+                           total, perms->inv_stride, perms->inverse_t);
     SAFE_HIP_CHECK(hipGetLastError());
     return SAFE_OK;
 }
@@ -181,7 +185,7 @@ int safe_perms_destroy(safe_perms *perms) {
     (void)hipSetDevice(perms->ctx->device);
     (void)hipStreamSynchronize(perms->ctx->stream);
     (void)hipFree(perms->table);
-    (void)hipFree(perms->inverse);
+    (void)hipFree(perms->inverse_t);
     delete perms;
     return SAFE_OK;
 }
