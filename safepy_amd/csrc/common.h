@@ -128,6 +128,9 @@ struct safe_perms {
     // inverse_t[r * inv_stride + p] = position k with table[p][k] == r; inv_stride = padded count
     uint16_t *inverse_t = nullptr;
     int64_t inv_stride = 0;
+    // 16-bit copy of the table, rows padded to a multiple of 8 entries (n < 65535 only)
+    uint16_t *table16 = nullptr;
+    int64_t stride16 = 0;
 };
 
 // launch-geometry helpers
@@ -138,3 +141,4 @@ int nbr_finalize_from_bits(safe_nbr *nbr);   // bits -> CSR + SELL (nbr.hip)
 int nbr_build_transpose(safe_nbr *nbr);      // at_ptr / at_col (nbr.hip)
 int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary matrix (attr.hip)
 int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)
+int perms_build_table16(safe_perms *perms);  // 16-bit table copy (rng.cpp)

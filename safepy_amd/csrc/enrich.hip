@@ -61,7 +61,7 @@ template <int BN, bool Z>
 __device__ __forceinline__ void finish_score(const double (&acc)[Z ? 3 : 1][BN], double (&score)[BN]) {
 #pragma unroll
     for (int c = 0; c < BN; ++c) {
-        if (!Z) {
+        if constexpr (!Z) {
             score[c] = acc[0][c];
         } else {
             const double cnt = acc[2][c];
@@ -478,6 +478,256 @@ __global__ __launch_bounds__(64 * WAVES) void k_permtest_scatter(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// K5 (binary attributes, bit-sliced form).  64 attributes ride in one 64-bit word per node:
+// T[r] = bits of B[r, 64*wg .. 64*wg+63] (NaN -> 0).  A lane owns one neighborhood (SELL-64
+// slice row) and adds the words of its members with carry-save adders into VERTICAL
+// counters s[level] (bit b of s[l] = bit l of the sum for attribute b): ~4.4 bitwise ops per
+// member per 32 attributes instead of 32 adds.  The comparison with the observed sum and
+// the two permutation counters are bit-sliced too, so every instruction works on 32
+// attributes x 64 neighborhoods.  Exact integer arithmetic; no atomics; cost independent of
+// the attribute density.  A workgroup = 4 adjacent slices x one 64-attribute word group;
+// it keeps the word column T (8 B per node) and the current permutation (2 B per node,
+// double buffered) in LDS; one barrier per permutation.
+// --------------------------------------------------------------------------------------
+#define BT_LV 10               // levels of a neighborhood sum: max row count < 1024
+
+// 16-byte vector view of the u16 permutation rows: must be may_alias, the rows are read back
+// as unsigned short (without it TBAA lets the compiler move those reads across the refills)
+typedef uint4 __attribute__((may_alias)) uint4_alias;
+
+__device__ __forceinline__ void csa32(uint32_t &carry, uint32_t &sum, uint32_t a, uint32_t b, uint32_t c) {
+    const uint32_t u = a ^ b;
+    carry = (u & c) | (~u & a);            // majority(a,b,c) as one v_bfi_b32
+    sum = u ^ c;
+}
+
+// adds eight one-bit-per-attribute words into the vertical counter s[0..BT_LV)
+__device__ __forceinline__ void vadd8(uint32_t (&s)[BT_LV], const uint32_t (&x)[8]) {
+    uint32_t t2a, t2b, t4a, t4b, t8;
+    csa32(t2a, s[0], s[0], x[0], x[1]);
+    csa32(t2b, s[0], s[0], x[2], x[3]);
+    csa32(t4a, s[1], s[1], t2a, t2b);
+    csa32(t2a, s[0], s[0], x[4], x[5]);
+    csa32(t2b, s[0], s[0], x[6], x[7]);
+    csa32(t4b, s[1], s[1], t2a, t2b);
+    csa32(t8, s[2], s[2], t4a, t4b);
+#pragma unroll
+    for (int l = 3; l < BT_LV; ++l) {      // ripple the eights
+        const uint32_t c = s[l] & t8;
+        s[l] ^= t8;
+        t8 = c;
+    }
+}
+
+template <bool IDENT>
+__device__ __forceinline__ void bits_accumulate(const int32_t *__restrict__ cols, int wdt,
+                                                const unsigned short *__restrict__ cur, const uint2 *__restrict__ T,
+                                                uint32_t (&s0)[BT_LV], uint32_t (&s1)[BT_LV]) {
+#pragma unroll
+    for (int l = 0; l < BT_LV; ++l) s0[l] = s1[l] = 0;
+    for (int t0 = 0; t0 < wdt; t0 += 8) {
+        int32_t c[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = cols[(t0 + u) * 64];
+        uint32_t r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = IDENT ? static_cast<uint32_t>(c[u]) : static_cast<uint32_t>(cur[c[u]]);
+        uint32_t x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint2 w = T[r[u]];
+            x0[u] = w.x;
+            x1[u] = w.y;
+        }
+        vadd8(s0, x0);
+        vadd8(s1, x1);
+    }
+}
+
+// bit-sliced counter c[0..CL) += mask, with the carries out of the low three levels parked
+// in `pend` (a position wraps at most once per 8 increments) and rippled every 8th call
+template <int CL>
+__device__ __forceinline__ void vcount(uint32_t (&c)[CL], uint32_t &pend, uint32_t m) {
+#pragma unroll
+    for (int l = 0; l < 3; ++l) {
+        const uint32_t k = c[l] & m;
+        c[l] ^= m;
+        m = k;
+    }
+    pend |= m;
+}
+
+template <int CL>
+__device__ __forceinline__ void vflush(uint32_t (&c)[CL], uint32_t &pend) {
+    uint32_t m = pend;
+#pragma unroll
+    for (int l = 3; l < CL; ++l) {
+        const uint32_t k = c[l] & m;
+        c[l] ^= m;
+        m = k;
+    }
+    pend = 0;
+}
+
+template <int LEVELS>
+__device__ __forceinline__ unsigned int vextract(const uint32_t (&c)[LEVELS], int bit) {
+    unsigned int v = 0;
+#pragma unroll
+    for (int l = 0; l < LEVELS; ++l) v |= ((c[l] >> bit) & 1u) << l;
+    return v;
+}
+
+template <int CL>
+__global__ __launch_bounds__(256) void k_permtest_bits(
+    int64_t n, int64_t n_perm, const uint16_t *__restrict__ cur16, int64_t stride16,
+    const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
+    const int32_t *__restrict__ slice_width, const int32_t *__restrict__ sell_col, int64_t n_slices,
+    const uint2 *__restrict__ bbits, int64_t n_tasks, const int2 *__restrict__ tasks,
+    unsigned int *__restrict__ queue, int64_t mloc, PermOut out) {
+    extern __shared__ unsigned int lds[];
+    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
+    uint2 *T = reinterpret_cast<uint2 *>(lds);
+    unsigned short *CUR = reinterpret_cast<unsigned short *>(lds + t_words);     // [2][stride16]
+    unsigned int *slot_box = lds + t_words + stride16;                  // after the two u16 buffers
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int vec_per_row = static_cast<int>(stride16 / 8);              // uint4 (8 x u16) per table row
+
+    for (;;) {
+        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t slot = *slot_box;
+        __syncthreads();
+        if (slot >= n_tasks) break;
+        const int wg = tasks[slot].x, sg = tasks[slot].y;
+
+        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        if (n_perm > 0)
+            for (int v = threadIdx.x; v < vec_per_row; v += 256)
+                reinterpret_cast<uint4_alias *>(CUR)[v] = reinterpret_cast<const uint4_alias *>(cur16)[v];
+
+        const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
+        const bool active = s < n_slices;
+        const int32_t row = active ? sell_row[s * 64 + lane] : -1;
+        const int32_t *cols = sell_col + (active ? slice_off[s] : 0) + lane;
+        const int wdt = active ? slice_width[s] : 0;
+        __syncthreads();
+
+        uint32_t o0[BT_LV], o1[BT_LV];                                   // observed sums (safe.py:496-499)
+        bits_accumulate<true>(cols, wdt, nullptr, T, o0, o1);
+
+        uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
+        uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
+#pragma unroll
+        for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
+
+        for (int64_t p = 0; p < n_perm; ++p) {
+            const unsigned short *cur = CUR + (p & 1) * stride16;
+            // next permutation's row: global -> registers now, registers -> LDS after the compute
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            const bool fetch = (p + 1 < n_perm) && (static_cast<int>(threadIdx.x) < vec_per_row);
+            if (fetch) nxt = reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[threadIdx.x];
+
+            uint32_t s0[BT_LV], s1[BT_LV];
+            bits_accumulate<false>(cols, wdt, cur, T, s0, s1);
+
+            // bit-sliced compare as two borrow chains, least significant level first:
+            // lt = borrow out of (S - O), gt = borrow out of (O - S); per level
+            // borrow' = (s != o) ? subtrahend bit : borrow   -- one v_bfi_b32 each
+            uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
+#pragma unroll
+            for (int l = 0; l < BT_LV; ++l) {
+                const uint32_t d0 = s0[l] ^ o0[l], d1 = s1[l] ^ o1[l];
+                lt0 = (d0 & o0[l]) | (~d0 & lt0);
+                gt0 = (d0 & s0[l]) | (~d0 & gt0);
+                lt1 = (d1 & o1[l]) | (~d1 & lt1);
+                gt1 = (d1 & s1[l]) | (~d1 & gt1);
+            }
+            vcount<CL>(g0, gp0, gt0);
+            vcount<CL>(g1, gp1, gt1);
+            vcount<CL>(l0, lp0, lt0);
+            vcount<CL>(l1, lp1, lt1);
+            if ((p & 7) == 7) {
+                vflush<CL>(g0, gp0);
+                vflush<CL>(g1, gp1);
+                vflush<CL>(l0, lp0);
+                vflush<CL>(l1, lp1);
+            }
+
+            if (vec_per_row > 256) {                                     // rows longer than 256 vectors: strided copy
+                for (int v = threadIdx.x + 256; v < vec_per_row; v += 256)
+                    if (p + 1 < n_perm)
+                        reinterpret_cast<uint4_alias *>(CUR + ((p + 1) & 1) * stride16)[v] =
+                            reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[v];
+            }
+            if (fetch) reinterpret_cast<uint4_alias *>(CUR + ((p + 1) & 1) * stride16)[threadIdx.x] = nxt;
+            __syncthreads();
+        }
+        vflush<CL>(g0, gp0);
+        vflush<CL>(g1, gp1);
+        vflush<CL>(l0, lp0);
+        vflush<CL>(l1, lp1);
+
+        // ---- epilogue: un-slice the counters, same outputs as the other kernels -------------
+        const bool live = row >= 0;
+        const int64_t obase = static_cast<int64_t>(live ? row : 0) * mloc;
+        const unsigned int P = static_cast<unsigned int>(n_perm);
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            for (int bit = 0; bit < 32; ++bit) {
+                const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                if (jc >= mloc) break;
+                const unsigned int so = half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit);
+                const unsigned int ng = half ? vextract<CL>(g1, bit) : vextract<CL>(g0, bit);
+                const unsigned int nl = half ? vextract<CL>(l1, bit) : vextract<CL>(l0, bit);
+                const unsigned int cneg = P - ng, cpos = P - nl;          // safe_extras.py:65-66
+                const int64_t o = obase + jc;
+                if (live && out.ns) out.ns[o] = static_cast<double>(so);
+                if (out.mode == 1) {
+                    if (live) {
+                        out.counts_neg[o] = static_cast<double>(cneg);
+                        out.counts_pos[o] = static_cast<double>(cpos);
+                    }
+                } else if (out.mode == 2) {
+                    const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
+                    double nes = ep - en;
+                    if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+                    if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+                    const bool hit = live && (nes == nes) && (fabs(nes) > out.nes_threshold);
+                    if (live) {
+                        out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(P);
+                        out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(P);
+                        out.nes[o] = nes;
+                        out.nes_binary[o] = hit ? 1.0 : 0.0;
+                    }
+                    const unsigned long long bal = __ballot(hit);
+                    if (lane == 0 && bal) atomicAdd(&out.enriched[jc], static_cast<unsigned int>(__popcll(bal)));
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// bbits[wg][r] = 64 attribute bits of row r for word group wg (row n = 0: SELL padding)
+template <typename T>
+__global__ __launch_bounds__(256) void k_bits_prep(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                   int64_t col0, int64_t mloc, int64_t n_wg, uint2 *__restrict__ bbits) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n_wg * (n + 1)) return;
+    const int64_t wg = idx / (n + 1), r = idx % (n + 1);
+    uint32_t w[2] = {0, 0};
+    if (r < n) {
+        for (int a = 0; a < 64; ++a) {
+            const int64_t j = wg * 64 + a;
+            if (j >= mloc) break;
+            const T x = reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs];
+            if (x == static_cast<T>(1)) w[a >> 5] |= 1u << (a & 31);
+        }
+    }
+    bbits[idx] = make_uint2(w[0], w[1]);
+}
+
 __global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < count) out[i] = static_cast<double>(in[i]);
@@ -643,25 +893,8 @@ static int launch_gather(safe_ctx *ctx, safe_nbr *nbr, const Tiles &tiles, const
     return SAFE_OK;
 }
 
-// Chooses the sparse binary form when it is exact and profitable: 'sum' score, every
-// non-NaN value in {0,1}, sparse enough that scattering beats gathering, counters and sums
-// fit 16 bits, and the per-node LDS state fits one CU.
 static size_t scatter_lds_bytes(int64_t n) {
     return (2 * static_cast<size_t>(n) + 4) * sizeof(unsigned int) + ((static_cast<size_t>(n) + 1) & ~size_t(1)) * sizeof(unsigned short);
-}
-
-static bool scatter_applicable(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr *attr, int64_t n_perm, bool z) {
-    if (z || n_perm < 1 || n_perm > 65535) return false;
-    if (safe_attr_prepare(attr) != SAFE_OK) return false;
-    if (attr->n_other != 0) return false;
-    if (nbr->max_count >= SC_EPOCH) return false;           // running counts must fit one epoch
-    if (scatter_lds_bytes(nbr->n) > 160 * 1024) return false;
-    const char *force = getenv("SAFE_HIP_FORCE_PATH");
-    if (force && !strcmp(force, "gather")) return false;
-    if (attr_build_support(attr) != SAFE_OK) return false;
-    const double density = static_cast<double>(attr->n_ones) / (static_cast<double>(attr->n) * attr->m);
-    if (force && !strcmp(force, "scatter")) return true;
-    return density <= 0.125;
 }
 
 static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0,
@@ -703,6 +936,89 @@ static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     ctx->last_kernel.name = "k_permtest_scatter";
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // order (host vector) and temporaries
     (void)hipFree(d_order);
+    (void)hipFree(d_queue);
+    return SAFE_OK;
+}
+
+static size_t bits_lds_bytes(int64_t n, int64_t stride16) {
+    const size_t t_words = 2 * ((static_cast<size_t>(n) + 2) & ~size_t(1));
+    return (t_words + static_cast<size_t>(stride16) + 4) * sizeof(unsigned int);
+}
+
+enum PermPath { PATH_GATHER = 0, PATH_SCATTER = 1, PATH_BITS = 2 };
+
+// Picks the kernel form.  The two integer forms need 'sum' scores of 0/1 data (exact in
+// integers); scatter additionally wants sparse attributes (its work is nnz(A)*nnz(B)/N per
+// permutation, the bit-sliced form's is nnz(A)*M/64 word-adds).
+static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr *attr, int64_t n_perm, bool z) {
+    const char *force = getenv("SAFE_HIP_FORCE_PATH");
+    if (force && !strcmp(force, "gather")) return PATH_GATHER;
+    if (z || n_perm < 1 || n_perm > 65535) return PATH_GATHER;
+    if (safe_attr_prepare(attr) != SAFE_OK || attr->n_other != 0) return PATH_GATHER;
+    if (nbr->n >= 65535) return PATH_GATHER;
+    const bool bits_ok = nbr->max_count < (1 << BT_LV) && bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024;
+    const bool scatter_ok = nbr->max_count < SC_EPOCH && scatter_lds_bytes(nbr->n) <= 160 * 1024;
+    if (force && !strcmp(force, "bits") && bits_ok) return PATH_BITS;
+    if (force && !strcmp(force, "scatter") && scatter_ok) return attr_build_support(attr) == SAFE_OK ? PATH_SCATTER : PATH_GATHER;
+    if (bits_ok) return PATH_BITS;
+    if (scatter_ok && attr_build_support(attr) == SAFE_OK) return PATH_SCATTER;
+    return PATH_GATHER;
+}
+
+static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
+                       const PermOut &out) {
+    const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64);
+    SAFE_TRY(perms_build_table16(perms));
+    uint2 *d_bits = nullptr;
+    SAFE_TRY(dev_alloc(&d_bits, static_cast<size_t>(n_wg) * (n + 1)));
+    {
+        const dim3 grid(ceil_div(n_wg * (n + 1), 256)), block(256);
+        if (attr->dtype == SAFE_DTYPE_F32)
+            hipLaunchKernelGGL(k_bits_prep<float>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, n_wg, d_bits);
+        else
+            hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, n_wg, d_bits);
+    }
+    // tasks = (word group, group of 4 adjacent slices), heaviest first for the dynamic queue
+    const int64_t n_sg = ceil_div(nbr->n_slices, 4);
+    std::vector<int64_t> sg_cost(n_sg, 0);
+    for (int64_t s = 0; s < nbr->n_slices; ++s) sg_cost[s / 4] = std::max<int64_t>(sg_cost[s / 4], nbr->h_slice_width[s]);
+    std::vector<int32_t> sg_order(n_sg);
+    for (int64_t g = 0; g < n_sg; ++g) sg_order[g] = static_cast<int32_t>(g);
+    std::stable_sort(sg_order.begin(), sg_order.end(), [&](int32_t a, int32_t b) { return sg_cost[a] > sg_cost[b]; });
+    std::vector<int2> tasks;
+    tasks.reserve(n_sg * n_wg);
+    for (int64_t g = 0; g < n_sg; ++g)
+        for (int64_t w = 0; w < n_wg; ++w) tasks.push_back(make_int2(static_cast<int>(w), sg_order[g]));
+    int2 *d_tasks = nullptr;
+    unsigned int *d_queue = nullptr;
+    SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
+    SAFE_TRY(dev_alloc(&d_queue, 1));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), ctx->stream));
+    const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
+    const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), static_cast<int64_t>(ctx->num_cu) * per_cu);
+    const int64_t n_tasks = static_cast<int64_t>(tasks.size());
+#define LAUNCH_BITS(CLV)                                                                                          \
+    do {                                                                                                          \
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_bits<CLV>),                  \
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))); \
+        SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                                                     \
+        hipLaunchKernelGGL(k_permtest_bits<CLV>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, perms->count, \
+                           perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,      \
+                           nbr->sell_col, nbr->n_slices, d_bits, n_tasks, d_tasks, d_queue, mloc, out);            \
+    } while (0)
+    if (perms->count < 1024) LAUNCH_BITS(10);
+    else LAUNCH_BITS(16);
+#undef LAUNCH_BITS
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = "k_permtest_bits";
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // tasks (host vector) and temporaries
+    (void)hipFree(d_bits);
+    (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
     return SAFE_OK;
 }
@@ -750,8 +1066,10 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
     out.counts_neg = counts_neg_dev;
     out.counts_pos = counts_pos_dev;
     out.mode = 1;
-    if (scatter_applicable(ctx, nbr, attr, perms->count, z)) {
-        SAFE_TRY(launch_scatter(ctx, nbr, attr, perms, col0, col1, out));
+    const PermPath path = choose_path(ctx, nbr, attr, perms->count, z);
+    if (path != PATH_GATHER) {
+        SAFE_TRY(path == PATH_BITS ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
+                                   : launch_scatter(ctx, nbr, attr, perms, col0, col1, out));
         return finish_kernel_timing(ctx);
     }
     Tiles tiles;
@@ -788,7 +1106,8 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     double *d_tab = nullptr;
     unsigned int *d_enr = nullptr;
     Tiles tiles;
-    const bool scatter = scatter_applicable(ctx, nbr, attr, P, z);
+    const PermPath path = choose_path(ctx, nbr, attr, P, z);
+    const bool scatter = path != PATH_GATHER;
     int rc = dev_alloc(&d_tab, P + 1);
     if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 16);
     if (rc == SAFE_OK && !scatter) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
@@ -812,8 +1131,9 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.nes_threshold = -std::log10(enrichment_threshold);
         out.sign_mode = sign_mode;
         out.mode = 2;
-        rc = scatter ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
-                     : launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out);
+        rc = path == PATH_BITS      ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
+             : path == PATH_SCATTER ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
+                                    : launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out);
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);

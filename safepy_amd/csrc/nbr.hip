@@ -378,7 +378,7 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
     nbr->h_slice_off.assign(nbr->n_slices + 1, 0);
     for (int64_t s = 0; s < nbr->n_slices; ++s) {
         int32_t wdt = nbr->h_row_count[order[s * 64]];              // first row of the slice is its largest
-        wdt = (wdt + 3) & ~3;                                       // unroll granule of the gather loops
+        wdt = (wdt + 7) & ~7;                                       // unroll granule of the gather loops (8-input carry-save blocks)
         nbr->h_slice_width[s] = wdt;
         nbr->h_slice_off[s + 1] = nbr->h_slice_off[s] + static_cast<int64_t>(wdt) * 64;
     }

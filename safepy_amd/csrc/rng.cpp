@@ -96,6 +96,29 @@ int perms_build_inverse(safe_perms *perms) {
     return SAFE_OK;
 }
 
+__global__ void k_table_u16(const int32_t *__restrict__ table, int64_t stride, int64_t count, int64_t stride16,
+                            uint16_t *__restrict__ out) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (idx >= count * stride16) return;
+    const int64_t p = idx / stride16, k = idx % stride16;
+    out[idx] = k < stride ? static_cast<uint16_t>(table[p * stride + k]) : static_cast<uint16_t>(stride - 1);
+}
+
+int perms_build_table16(safe_perms *perms) {
+    if (perms->table16) return SAFE_OK;
+    SAFE_REQUIRE(perms->n < 65535, "perms_build_table16: n too large for 16-bit rows");
+    safe_ctx *ctx = perms->ctx;
+    const int64_t stride = perms->n + 1;
+    perms->stride16 = (stride + 7) / 8 * 8;
+    const int64_t total = std::max<int64_t>(perms->count, 1) * perms->stride16;
+    SAFE_TRY(dev_alloc(&perms->table16, static_cast<size_t>(total)));
+    if (perms->count)
+        hipLaunchKernelGGL(k_table_u16, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, perms->table, stride,
+                           perms->count, perms->stride16, perms->table16);
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
+}
+
 extern "C" {
 
 int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_items, int64_t count, int64_t *out) {
@@ -186,6 +209,7 @@ int safe_perms_destroy(safe_perms *perms) {
     (void)hipStreamSynchronize(perms->ctx->stream);
     (void)hipFree(perms->table);
     (void)hipFree(perms->inverse_t);
+    (void)hipFree(perms->table16);
     delete perms;
     return SAFE_OK;
 }

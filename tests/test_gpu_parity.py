@@ -351,7 +351,7 @@ def test_torch_tensors_share_the_hip_runtime(amd, ctx):
 
 # ------------------------------------------ both forms of the permutation kernel ----------
 
-@pytest.mark.parametrize('path', ['gather', 'scatter'])
+@pytest.mark.parametrize('path', ['gather', 'scatter', 'bits'])
 def test_binary_permutation_test_both_kernel_forms(amd, golden_enr, monkeypatch, path):
     """Binary attributes can run through the general f64 gather kernel or the sparse integer
     scatter kernel; both must reproduce the reference counts exactly."""
@@ -364,7 +364,7 @@ def test_binary_permutation_test_both_kernel_forms(amd, golden_enr, monkeypatch,
     assert ctx.last_kernel()[0].startswith('k_permtest_' + path)
 
 
-@pytest.mark.parametrize('path', ['gather', 'scatter'])
+@pytest.mark.parametrize('path', ['gather', 'scatter', 'bits'])
 def test_binary_randomization_asymmetric_membership(amd, monkeypatch, path):
     """User-supplied, non-symmetric membership (the scatter form walks the transpose)."""
     monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
@@ -389,9 +389,11 @@ def test_binary_randomization_asymmetric_membership(amd, monkeypatch, path):
         np.testing.assert_array_equal(getattr(sf, key), want[key])
 
 
-def test_scatter_form_large_support_and_many_permutations(amd, monkeypatch):
-    """Support larger than one 256-row round per workgroup, > 255 permutations."""
-    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'scatter')
+@pytest.mark.parametrize('path', ['scatter', 'bits'])
+def test_integer_forms_large_support_and_many_permutations(amd, monkeypatch, path):
+    """Support larger than one 256-row round per workgroup, > 255 permutations (counter
+    carries beyond the low levels), dense and sparse columns."""
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
     rng = np.random.default_rng(22)
     n, m, nperm = 900, 12, 300
     xy = rng.uniform(size=(n, 2))
