@@ -583,8 +583,8 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
     int64_t n, int64_t n_perm, const uint16_t *__restrict__ cur16, int64_t stride16,
     const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
     const int32_t *__restrict__ slice_width, const int32_t *__restrict__ sell_col, int64_t n_slices,
-    const uint2 *__restrict__ bbits, int64_t n_tasks, const int2 *__restrict__ tasks,
-    unsigned int *__restrict__ queue, int64_t mloc, PermOut out) {
+    const uint2 *__restrict__ bbits, int64_t n_tasks, const int4 *__restrict__ tasks,
+    unsigned int *__restrict__ queue, int64_t mloc, unsigned long long *__restrict__ gl_counts, double *__restrict__ ns_out) {
     extern __shared__ unsigned int lds[];
     const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
     uint2 *T = reinterpret_cast<uint2 *>(lds);
@@ -599,12 +599,14 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         const int64_t slot = *slot_box;
         __syncthreads();
         if (slot >= n_tasks) break;
-        const int wg = tasks[slot].x, sg = tasks[slot].y;
+        const int4 task = tasks[slot];
+        const int wg = task.x, sg = task.y;
+        const int64_t p_begin = task.z, p_end = task.w;                  // this task's permutations
 
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
-        if (n_perm > 0)
+        if (p_end > p_begin)
             for (int v = threadIdx.x; v < vec_per_row; v += 256)
-                reinterpret_cast<uint4_alias *>(CUR)[v] = reinterpret_cast<const uint4_alias *>(cur16)[v];
+                reinterpret_cast<uint4_alias *>(CUR)[v] = reinterpret_cast<const uint4_alias *>(cur16 + p_begin * stride16)[v];
 
         const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
         const bool active = s < n_slices;
@@ -621,11 +623,12 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
 #pragma unroll
         for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
 
-        for (int64_t p = 0; p < n_perm; ++p) {
-            const unsigned short *cur = CUR + (p & 1) * stride16;
+        for (int64_t p = p_begin; p < p_end; ++p) {
+            const int64_t rel = p - p_begin;
+            const unsigned short *cur = CUR + (rel & 1) * stride16;
             // next permutation's row: global -> registers now, registers -> LDS after the compute
             uint4 nxt = make_uint4(0, 0, 0, 0);
-            const bool fetch = (p + 1 < n_perm) && (static_cast<int>(threadIdx.x) < vec_per_row);
+            const bool fetch = (p + 1 < p_end) && (static_cast<int>(threadIdx.x) < vec_per_row);
             if (fetch) nxt = reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[threadIdx.x];
 
             uint32_t s0[BT_LV], s1[BT_LV];
@@ -647,7 +650,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
             vcount<CL>(g1, gp1, gt1);
             vcount<CL>(l0, lp0, lt0);
             vcount<CL>(l1, lp1, lt1);
-            if ((p & 7) == 7) {
+            if ((rel & 7) == 7) {
                 vflush<CL>(g0, gp0);
                 vflush<CL>(g1, gp1);
                 vflush<CL>(l0, lp0);
@@ -656,11 +659,11 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
 
             if (vec_per_row > 256) {                                     // rows longer than 256 vectors: strided copy
                 for (int v = threadIdx.x + 256; v < vec_per_row; v += 256)
-                    if (p + 1 < n_perm)
-                        reinterpret_cast<uint4_alias *>(CUR + ((p + 1) & 1) * stride16)[v] =
+                    if (p + 1 < p_end)
+                        reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[v] =
                             reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[v];
             }
-            if (fetch) reinterpret_cast<uint4_alias *>(CUR + ((p + 1) & 1) * stride16)[threadIdx.x] = nxt;
+            if (fetch) reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[threadIdx.x] = nxt;
             __syncthreads();
         }
         vflush<CL>(g0, gp0);
@@ -668,44 +671,62 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         vflush<CL>(l0, lp0);
         vflush<CL>(l1, lp1);
 
-        // ---- epilogue: un-slice the counters, same outputs as the other kernels -------------
+        // ---- epilogue: un-slice the counters of this permutation range and add them to the
+        //      per-(neighborhood, attribute) totals (#greater << 32 | #less); most are zero
         const bool live = row >= 0;
         const int64_t obase = static_cast<int64_t>(live ? row : 0) * mloc;
-        const unsigned int P = static_cast<unsigned int>(n_perm);
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
             for (int bit = 0; bit < 32; ++bit) {
                 const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
                 if (jc >= mloc) break;
-                const unsigned int so = half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit);
-                const unsigned int ng = half ? vextract<CL>(g1, bit) : vextract<CL>(g0, bit);
-                const unsigned int nl = half ? vextract<CL>(l1, bit) : vextract<CL>(l0, bit);
-                const unsigned int cneg = P - ng, cpos = P - nl;          // safe_extras.py:65-66
-                const int64_t o = obase + jc;
-                if (live && out.ns) out.ns[o] = static_cast<double>(so);
-                if (out.mode == 1) {
-                    if (live) {
-                        out.counts_neg[o] = static_cast<double>(cneg);
-                        out.counts_pos[o] = static_cast<double>(cpos);
-                    }
-                } else if (out.mode == 2) {
-                    const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
-                    double nes = ep - en;
-                    if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
-                    if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
-                    const bool hit = live && (nes == nes) && (fabs(nes) > out.nes_threshold);
-                    if (live) {
-                        out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(P);
-                        out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(P);
-                        out.nes[o] = nes;
-                        out.nes_binary[o] = hit ? 1.0 : 0.0;
-                    }
-                    const unsigned long long bal = __ballot(hit);
-                    if (lane == 0 && bal) atomicAdd(&out.enriched[jc], static_cast<unsigned int>(__popcll(bal)));
-                }
+                const unsigned long long ng = half ? vextract<CL>(g1, bit) : vextract<CL>(g0, bit);
+                const unsigned long long nl = half ? vextract<CL>(l1, bit) : vextract<CL>(l0, bit);
+                if (live && (ng | nl)) atomicAdd(&gl_counts[obase + jc], (ng << 32) | nl);
+                if (live && ns_out && p_begin == 0)
+                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit));
             }
         }
         __syncthreads();
+    }
+}
+
+// counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472)
+__global__ __launch_bounds__(256) void k_counts_finalize(const unsigned long long *__restrict__ gl_counts, int64_t n,
+                                                         int64_t mloc, int64_t n_perm, PermOut out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
+    bool hit = false;
+    if (i < n && c < mloc) {
+        const int64_t o = i * mloc + c;
+        const unsigned long long gl = gl_counts[o];
+        const unsigned int P = static_cast<unsigned int>(n_perm);
+        const unsigned int cneg = P - static_cast<unsigned int>(gl >> 32);            // #(S_p <= S_obs)
+        const unsigned int cpos = P - static_cast<unsigned int>(gl & 0xFFFFFFFFull);  // #(S_p >= S_obs)
+        if (out.mode == 1) {
+            out.counts_neg[o] = static_cast<double>(cneg);
+            out.counts_pos[o] = static_cast<double>(cpos);
+        } else if (out.mode == 2) {
+            const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
+            double nes = ep - en;
+            if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+            if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+            hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+            out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(P);
+            out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(P);
+            out.nes[o] = nes;
+            out.nes_binary[o] = hit ? 1.0 : 0.0;
+        }
+    }
+    if (out.mode == 2) {
+        // column counts: reduce the 4 rows of this block first
+        __shared__ unsigned int part[64];
+        if (threadIdx.x < 64) part[threadIdx.x] = 0;
+        __syncthreads();
+        if (hit) atomicAdd(&part[threadIdx.x & 63], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64 && part[threadIdx.x] && blockIdx.x * 64 + threadIdx.x < mloc)
+            atomicAdd(&out.enriched[blockIdx.x * 64 + threadIdx.x], part[threadIdx.x]);
     }
 }
 
@@ -980,26 +1001,45 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_wg, d_bits);
     }
-    // tasks = (word group, group of 4 adjacent slices), heaviest first for the dynamic queue
-    const int64_t n_sg = ceil_div(nbr->n_slices, 4);
-    std::vector<int64_t> sg_cost(n_sg, 0);
-    for (int64_t s = 0; s < nbr->n_slices; ++s) sg_cost[s / 4] = std::max<int64_t>(sg_cost[s / 4], nbr->h_slice_width[s]);
-    std::vector<int32_t> sg_order(n_sg);
-    for (int64_t g = 0; g < n_sg; ++g) sg_order[g] = static_cast<int32_t>(g);
-    std::stable_sort(sg_order.begin(), sg_order.end(), [&](int32_t a, int32_t b) { return sg_cost[a] > sg_cost[b]; });
-    std::vector<int2> tasks;
-    tasks.reserve(n_sg * n_wg);
-    for (int64_t g = 0; g < n_sg; ++g)
-        for (int64_t w = 0; w < n_wg; ++w) tasks.push_back(make_int2(static_cast<int>(w), sg_order[g]));
-    int2 *d_tasks = nullptr;
-    unsigned int *d_queue = nullptr;
-    SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
-    SAFE_TRY(dev_alloc(&d_queue, 1));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), ctx->stream));
+    // tasks = (word group, group of 4 adjacent slices, permutation range), sized so that every
+    // task costs about the same and there are several per workgroup slot; heaviest first
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
-    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), static_cast<int64_t>(ctx->num_cu) * per_cu);
+    const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
+    const int64_t n_sg = ceil_div(nbr->n_slices, 4), P = perms->count;
+    std::vector<int64_t> sg_blocks(n_sg, 0);
+    int64_t blocks_per_perm = 0;
+    for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / 4] = std::max<int64_t>(sg_blocks[s / 4], nbr->h_slice_width[s] / 8);
+    for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
+    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(8 * slots, n_wg));
+    const int64_t target = std::max<int64_t>(256, blocks_per_perm * P / tasks_per_wg);    // block-permutations per task
+    struct TaskCost { int4 t; int64_t cost; };
+    std::vector<TaskCost> tc;
+    for (int64_t g = 0; g < n_sg; ++g) {
+        const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
+        int64_t ppt = std::min<int64_t>(P, std::max<int64_t>(16, target / bl));
+        const int64_t chunks = ceil_div(P, ppt);
+        ppt = ceil_div(P, chunks);
+        for (int64_t c = 0; c < chunks; ++c) {
+            const int64_t p0 = c * ppt, p1 = std::min<int64_t>(P, p0 + ppt);
+            for (int64_t w = 0; w < n_wg; ++w)
+                tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
+                              bl * (p1 - p0)});
+        }
+    }
+    std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
+    std::vector<int4> tasks(tc.size());
+    for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
+    int4 *d_tasks = nullptr;
+    unsigned int *d_queue = nullptr;
+    unsigned long long *d_gl = nullptr;
+    SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
+    SAFE_TRY(dev_alloc(&d_queue, 1));
+    SAFE_TRY(dev_alloc(&d_gl, static_cast<size_t>(n) * mloc));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n) * mloc * sizeof(unsigned long long), ctx->stream));
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
 #define LAUNCH_BITS(CLV)                                                                                          \
     do {                                                                                                          \
@@ -1008,7 +1048,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                                                     \
         hipLaunchKernelGGL(k_permtest_bits<CLV>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, perms->count, \
                            perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,      \
-                           nbr->sell_col, nbr->n_slices, d_bits, n_tasks, d_tasks, d_queue, mloc, out);            \
+                           nbr->sell_col, nbr->n_slices, d_bits, n_tasks, d_tasks, d_queue, mloc, d_gl, out.ns);   \
     } while (0)
     if (perms->count < 1024) LAUNCH_BITS(10);
     else LAUNCH_BITS(16);
@@ -1016,10 +1056,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_permtest_bits";
+    hipLaunchKernelGGL(k_counts_finalize, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_gl, n, mloc,
+                       perms->count, out);
+    SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // tasks (host vector) and temporaries
     (void)hipFree(d_bits);
     (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
+    (void)hipFree(d_gl);
     return SAFE_OK;
 }
 
