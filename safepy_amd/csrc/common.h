@@ -119,18 +119,30 @@ struct safe_attr {
     std::vector<int32_t> h_sup_ptr; // host copy
 };
 
+struct DrawStream;   // host MT19937 draw stream (rng.cpp)
+
 struct safe_perms {
     safe_ctx *ctx = nullptr;
     int64_t n = 0;
     int64_t count = 0;
+    int64_t k = 0;                  // number of movable rows (indx_vals)
+    std::vector<int32_t> h_movable;
+    DrawStream *stream = nullptr;
+    int64_t generated = 0;          // permutations whose table rows have been enqueued
+    uint32_t *h_targets[2] = {nullptr, nullptr};   // pinned staging of the swap targets
+    hipEvent_t staged[2] = {nullptr, nullptr};
+    uint32_t *d_targets = nullptr;  // [chunk][k]
+    int32_t *d_drawn = nullptr;     // [chunk][k] shuffled copies of indx_vals
+    int32_t *d_movable = nullptr;   // [k]
+    int32_t *d_cur = nullptr;       // [n+1] running composition
     int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)
-    // transposed inverse permutations, built on first use (n < 65536 only):
-    // inverse_t[r * inv_stride + p] = position k with table[p][k] == r; inv_stride = padded count
-    uint16_t *inverse_t = nullptr;
-    int64_t inv_stride = 0;
     // 16-bit copy of the table, rows padded to a multiple of 8 entries (n < 65535 only)
     uint16_t *table16 = nullptr;
     int64_t stride16 = 0;
+    // transposed inverse permutations, built on first use (n < 65535 only):
+    // inverse_t[r * inv_stride + p] = position k with table[p][k] == r; inv_stride = padded count
+    uint16_t *inverse_t = nullptr;
+    int64_t inv_stride = 0;
 };
 
 // launch-geometry helpers
@@ -141,4 +153,4 @@ int nbr_finalize_from_bits(safe_nbr *nbr);   // bits -> CSR + SELL (nbr.hip)
 int nbr_build_transpose(safe_nbr *nbr);      // at_ptr / at_col (nbr.hip)
 int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary matrix (attr.hip)
 int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)
-int perms_build_table16(safe_perms *perms);  // 16-bit table copy (rng.cpp)
+int perms_generate_until(safe_perms *perms, int64_t upto);   // enqueue table rows [generated, upto) (rng.cpp)

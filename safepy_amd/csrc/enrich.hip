@@ -583,7 +583,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
     int64_t n, int64_t n_perm, const uint16_t *__restrict__ cur16, int64_t stride16,
     const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
     const int32_t *__restrict__ slice_width, const int32_t *__restrict__ sell_col, int64_t n_slices,
-    const uint2 *__restrict__ bbits, int64_t n_tasks, const int4 *__restrict__ tasks,
+    const uint2 *__restrict__ bbits, int64_t n_tasks, const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit,
     unsigned int *__restrict__ queue, int64_t mloc, unsigned long long *__restrict__ gl_counts, double *__restrict__ ns_out) {
     extern __shared__ unsigned int lds[];
     const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
@@ -601,7 +601,9 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         if (slot >= n_tasks) break;
         const int4 task = tasks[slot];
         const int wg = task.x, sg = task.y;
-        const int64_t p_begin = task.z, p_end = task.w;                  // this task's permutations
+        // this task's permutations (task ranges are relative to the launch's chunk)
+        const int64_t p_begin = p_base + task.z;
+        const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
 
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
         if (p_end > p_begin)
@@ -894,6 +896,7 @@ static int check_cols(const safe_nbr *nbr, const safe_attr *attr, int64_t col0, 
 // launches the gather kernel; table == NULL / n_perm == 0 gives the observed score only
 static int launch_gather(safe_ctx *ctx, safe_nbr *nbr, const Tiles &tiles, const int32_t *table, int64_t n_perm,
                          int64_t mloc, bool z, const PermOut &out) {
+    ctx->last_kernel.name.clear();
     // slice groups: enough workgroups to fill the chip several times over
     int n_groups = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>(ceil_div(nbr->n_slices, 4),
                                                                            ceil_div(ctx->num_cu * 8, tiles.n_tiles))));
@@ -988,8 +991,7 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
 
 static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
                        const PermOut &out) {
-    const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64);
-    SAFE_TRY(perms_build_table16(perms));
+    const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64), P = perms->count;
     uint2 *d_bits = nullptr;
     SAFE_TRY(dev_alloc(&d_bits, static_cast<size_t>(n_wg) * (n + 1)));
     {
@@ -1001,27 +1003,32 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_wg, d_bits);
     }
-    // tasks = (word group, group of 4 adjacent slices, permutation range), sized so that every
-    // task costs about the same and there are several per workgroup slot; heaviest first
+    // The permutations are consumed in launches of `span` permutations so that the host's draw
+    // stream for the next span overlaps this span's kernel.  Inside a launch, tasks = (word
+    // group, group of 4 adjacent slices, permutation sub-range), sized to about equal cost
+    // with several per workgroup slot, heaviest first for the dynamic queue.
+    int64_t span = 256;
+    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
+    span = std::min<int64_t>(span, std::max<int64_t>(P, 1));
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
-    const int64_t n_sg = ceil_div(nbr->n_slices, 4), P = perms->count;
+    const int64_t n_sg = ceil_div(nbr->n_slices, 4);
     std::vector<int64_t> sg_blocks(n_sg, 0);
     int64_t blocks_per_perm = 0;
     for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / 4] = std::max<int64_t>(sg_blocks[s / 4], nbr->h_slice_width[s] / 8);
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
-    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(8 * slots, n_wg));
-    const int64_t target = std::max<int64_t>(256, blocks_per_perm * P / tasks_per_wg);    // block-permutations per task
+    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(6 * slots, n_wg));
+    const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_wg);    // block-permutations per task
     struct TaskCost { int4 t; int64_t cost; };
     std::vector<TaskCost> tc;
     for (int64_t g = 0; g < n_sg; ++g) {
         const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
-        int64_t ppt = std::min<int64_t>(P, std::max<int64_t>(16, target / bl));
-        const int64_t chunks = ceil_div(P, ppt);
-        ppt = ceil_div(P, chunks);
+        int64_t ppt = std::min<int64_t>(span, std::max<int64_t>(16, target / bl));
+        const int64_t chunks = ceil_div(span, ppt);
+        ppt = ceil_div(span, chunks);
         for (int64_t c = 0; c < chunks; ++c) {
-            const int64_t p0 = c * ppt, p1 = std::min<int64_t>(P, p0 + ppt);
+            const int64_t p0 = c * ppt, p1 = std::min<int64_t>(span, p0 + ppt);
             for (int64_t w = 0; w < n_wg; ++w)
                 tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
                               bl * (p1 - p0)});
@@ -1030,36 +1037,55 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
     std::vector<int4> tasks(tc.size());
     for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
+    const int64_t n_launch = ceil_div(std::max<int64_t>(P, 1), span);
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_gl = nullptr;
     SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
-    SAFE_TRY(dev_alloc(&d_queue, 1));
+    SAFE_TRY(dev_alloc(&d_queue, n_launch));
     SAFE_TRY(dev_alloc(&d_gl, static_cast<size_t>(n) * mloc));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, n_launch * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n) * mloc * sizeof(unsigned long long), ctx->stream));
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
-#define LAUNCH_BITS(CLV)                                                                                          \
-    do {                                                                                                          \
-        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_bits<CLV>),                  \
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes))); \
-        SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                                                     \
-        hipLaunchKernelGGL(k_permtest_bits<CLV>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, perms->count, \
-                           perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,      \
-                           nbr->sell_col, nbr->n_slices, d_bits, n_tasks, d_tasks, d_queue, mloc, d_gl, out.ns);   \
-    } while (0)
-    if (perms->count < 1024) LAUNCH_BITS(10);
-    else LAUNCH_BITS(16);
-#undef LAUNCH_BITS
-    SAFE_HIP_CHECK(hipGetLastError());
-    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    const bool wide = P >= 1024;
+    SAFE_HIP_CHECK(hipFuncSetAttribute(wide ? reinterpret_cast<const void *>(k_permtest_bits<16>)
+                                            : reinterpret_cast<const void *>(k_permtest_bits<10>),
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     ctx->last_kernel.name = "k_permtest_bits";
+    ctx->last_kernel.total_ms = 0.0;
+    ctx->last_kernel.launches = 0;
+    std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
+    for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
+    for (int64_t c = 0; c < n_launch; ++c) {
+        const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span);
+        SAFE_TRY(perms_generate_until(perms, p_limit));      // host draws + table kernels for this span
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ctx->stream));
+        if (wide)
+            hipLaunchKernelGGL(k_permtest_bits<16>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, P, perms->table16,
+                               perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col, nbr->n_slices,
+                               d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, out.ns);
+        else
+            hipLaunchKernelGGL(k_permtest_bits<10>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, P, perms->table16,
+                               perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col, nbr->n_slices,
+                               d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, out.ns);
+        SAFE_HIP_CHECK(hipGetLastError());
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ctx->stream));
+    }
     hipLaunchKernelGGL(k_counts_finalize, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_gl, n, mloc,
-                       perms->count, out);
+                       P, out);
     SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // tasks (host vector) and temporaries
+    for (int64_t c = 0; c < n_launch; ++c) {
+        float ms = 0.f;
+        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
+        ctx->last_kernel.total_ms += ms;
+        ctx->last_kernel.launches += 1;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
     (void)hipFree(d_bits);
     (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
@@ -1069,6 +1095,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
 
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
+    if (ctx->last_kernel.name == "k_permtest_bits") return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;
     SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->k0, ctx->k1));
     ctx->last_kernel.total_ms = ms;
@@ -1118,6 +1145,7 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
     }
     Tiles tiles;
     SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
+    SAFE_TRY(perms_generate_until(perms, perms->count));
     int rc = launch_gather(ctx, nbr, tiles, perms->table, perms->count, col1 - col0, z, out);
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
     (void)hipFree(tiles.bt);
@@ -1177,7 +1205,9 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.mode = 2;
         rc = path == PATH_BITS      ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
              : path == PATH_SCATTER ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
-                                    : launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out);
+                                    : (perms_generate_until(perms, P) == SAFE_OK
+                                           ? launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out)
+                                           : SAFE_E_HIP);
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);

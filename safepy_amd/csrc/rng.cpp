@@ -1,14 +1,22 @@
-// Host-side permutation stream of run_permutations (safepy/safe_extras.py:46-58):
-// legacy NumPy RandomState = MT19937 seeded by init_genrand, np.random.permutation =
-// Fisher-Yates from the top with masked-rejection bounded integers.
-// The stream is inherently sequential (the number of draws a shuffle consumes depends on
-// the rejections), so it runs on the host and the composed index tables are uploaded.
+// Row-permutation stream of run_permutations (safepy/safe_extras.py:46-58): legacy NumPy
+// RandomState = MT19937 seeded by init_genrand; np.random.permutation = Fisher-Yates from the
+// top with masked-rejection bounded integers; permutations applied
+// cumulatively to the rows that hold at least one value.
+//
+// Split of the work.  The only inherently sequential part is the draw stream: how many
+// 32-bit outputs a shuffle consumes depends on its rejections, so permutation q+1 cannot
+// start before q has finished drawing.  The host therefore produces just the accepted swap
+// targets j[q][i] (bulk MT19937 generation + a branch-light rejection loop, ~1.5 ns per
+// draw).  Everything else runs on the GPU, chunk by chunk, overlapping the host's next
+// chunk and the enrichment kernel of the previous one:
+//   k_apply_shuffles   one wave per permutation replays the swaps on a copy of indx_vals
+//                      held in LDS  (independent across permutations)
+//   k_compose_rows     cur[indx_vals] = cur[shuffled]  cumulatively, one workgroup walking
+//                      the chunk, emitting the composed table rows (int32 and 16-bit)
 #include <algorithm>
 #include <random>
 
 #include "common.h"
-
-namespace {
 
 struct MT19937 {
     uint32_t mt[624];
@@ -29,48 +37,147 @@ struct MT19937 {
         pos = 0;
     }
 
-    inline uint32_t next() {
-        if (pos == 624) refill();
-        uint32_t y = mt[pos++];
-        y ^= y >> 11;
-        y ^= (y << 7) & 0x9d2c5680u;
-        y ^= (y << 15) & 0xefc60000u;
-        y ^= y >> 18;
-        return y;
-    }
-
-    // uniform integer in [0, top], legacy random_interval
-    inline uint32_t interval(uint32_t top) {
-        if (top == 0) return 0;
-        uint32_t mask = top;
-        mask |= mask >> 1;
-        mask |= mask >> 2;
-        mask |= mask >> 4;
-        mask |= mask >> 8;
-        mask |= mask >> 16;
-        uint32_t v;
-        while ((v = next() & mask) > top) {
-        }
-        return v;
-    }
-
-    template <typename T>
-    inline void shuffle(T *a, int64_t n) {
-        for (int64_t i = n - 1; i > 0; --i) {
-            const uint32_t j = interval(static_cast<uint32_t>(i));
-            const T t = a[i];
-            a[i] = a[j];
-            a[j] = t;
+    // tempered outputs in bulk (the tempering loop vectorises)
+    void bulk(uint32_t *out, size_t count) {
+        size_t done = 0;
+        while (done < count) {
+            if (pos == 624) refill();
+            const size_t take = std::min<size_t>(624 - pos, count - done);
+            for (size_t i = 0; i < take; ++i) {
+                uint32_t y = mt[pos + i];
+                y ^= y >> 11;
+                y ^= (y << 7) & 0x9d2c5680u;
+                y ^= (y << 15) & 0xefc60000u;
+                y ^= y >> 18;
+                out[done + i] = y;
+            }
+            pos += static_cast<int>(take);
+            done += take;
         }
     }
 };
 
-uint32_t entropy_seed() {
+// The draw stream: raw outputs are buffered so that leftovers of one shuffle feed the next
+// (the legacy stream is continuous across np.random.permutation calls).
+struct DrawStream {
+    MT19937 rng;
+    std::vector<uint32_t> raw;
+    size_t rp = 0, avail = 0;
+
+    explicit DrawStream(uint32_t seed) : rng(seed), raw(1 << 14) {}
+
+    // accepted swap targets of one shuffle of k items: j[i] for i = k-1 .. 1  (j[0] unused)
+    void shuffle_targets(int64_t k, uint32_t *j) {
+        int64_t i = k - 1;
+        while (i > 0) {
+            uint32_t mask = static_cast<uint32_t>(i);
+            mask |= mask >> 1;
+            mask |= mask >> 2;
+            mask |= mask >> 4;
+            mask |= mask >> 8;
+            mask |= mask >> 16;
+            const int64_t lo = mask >> 1;          // the mask is unchanged while i is in (lo, mask]
+            while (i > lo) {
+                if (rp == avail) {
+                    rng.bulk(raw.data(), raw.size());
+                    avail = raw.size();
+                    rp = 0;
+                }
+                const uint32_t *r = raw.data() + rp;
+                const size_t n = avail - rp;
+                size_t t = 0;
+                while (t < n && i > lo) {
+                    const uint32_t v = r[t++] & mask;
+                    j[i] = v;                       // rejected draws are overwritten by the next one
+                    i -= (v <= static_cast<uint32_t>(i));
+                }
+                rp += t;
+            }
+        }
+    }
+};
+
+static uint32_t entropy_seed() {
     std::random_device rd;
     return rd();
 }
 
-}  // namespace
+// --------------------------------------------------------------------------------------
+// device side
+// --------------------------------------------------------------------------------------
+// One wave per permutation: a = copy of indx_vals in LDS; for i = k-1..1: swap(a[i], a[j[i]]).
+// Lane 0 replays the dependent swaps (LDS operations of one wave complete in order); the
+// other lanes stage the targets 64 at a time and copy in / out.
+__global__ __launch_bounds__(64) void k_apply_shuffles(const int32_t *__restrict__ movable, int64_t k,
+                                                       const uint32_t *__restrict__ targets, int32_t *__restrict__ drawn) {
+    extern __shared__ int32_t sh_a[];
+    const int lane = threadIdx.x;
+    const uint32_t *j = targets + static_cast<int64_t>(blockIdx.x) * k;
+    int32_t *out = drawn + static_cast<int64_t>(blockIdx.x) * k;
+    for (int64_t t = lane; t < k; t += 64) sh_a[t] = movable[t];
+    __syncthreads();
+    for (int64_t top = k - 1; top > 0; top -= 64) {
+        // lanes fetch j[top], j[top-1], ... (coalesced, descending)
+        const int64_t mine = top - lane;
+        const uint32_t jv = mine > 0 ? j[mine] : 0u;
+        const int cnt = top >= 64 ? 64 : static_cast<int>(top);
+        if (lane == 0) {
+            for (int s = 0; s < cnt; ++s) {
+                const int64_t i = top - s;
+                const uint32_t ji = __builtin_amdgcn_readlane(jv, s);
+                const int32_t vi = sh_a[i], vj = sh_a[ji];
+                sh_a[i] = vj;
+                sh_a[ji] = vi;
+            }
+        }
+    }
+    __syncthreads();
+    for (int64_t t = lane; t < k; t += 64) out[t] = sh_a[t];
+}
+
+// cur[movable[t]] = cur_old[drawn[q][t]] for q = 0..count-1 (cumulative), emitting row q of
+// the composed table after each step.  One workgroup; cur lives in LDS.
+__global__ __launch_bounds__(1024) void k_compose_rows(const int32_t *__restrict__ movable, int64_t k, int64_t n,
+                                                       const int32_t *__restrict__ drawn, int64_t count,
+                                                       int32_t *__restrict__ cur_state, int32_t *__restrict__ table,
+                                                       uint16_t *__restrict__ table16, int64_t stride16) {
+    extern __shared__ int32_t sh_cur[];      // [n+1]
+    const int tid = threadIdx.x;
+    const int64_t stride = n + 1;
+    for (int64_t i = tid; i < stride; i += 1024) sh_cur[i] = cur_state[i];
+    __syncthreads();
+    for (int64_t q = 0; q < count; ++q) {
+        const int32_t *d = drawn + q * k;
+        // gather first (cur_old), then scatter: the two index sets are the same set of rows
+        int32_t vals[40];                          // 40 x 1024 >= the 40959-row LDS limit
+#pragma unroll
+        for (int u = 0; u < 40; ++u) {
+            const int64_t t = tid + static_cast<int64_t>(u) * 1024;
+            vals[u] = t < k ? sh_cur[d[t]] : 0;
+        }
+        __syncthreads();
+#pragma unroll
+        for (int u = 0; u < 40; ++u) {
+            const int64_t t = tid + static_cast<int64_t>(u) * 1024;
+            if (t < k) sh_cur[movable[t]] = vals[u];
+        }
+        __syncthreads();
+        int32_t *row = table + q * stride;
+        for (int64_t i = tid; i < stride; i += 1024) row[i] = sh_cur[i];
+        if (table16) {
+            uint16_t *row16 = table16 + q * stride16;
+            for (int64_t i = tid; i < stride16; i += 1024)
+                row16[i] = static_cast<uint16_t>(i < stride ? sh_cur[i] : n);
+        }
+    }
+    __syncthreads();
+    for (int64_t i = tid; i < stride; i += 1024) cur_state[i] = sh_cur[i];
+}
+
+__global__ void k_iota(int32_t *p, int64_t count) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < count) p[i] = static_cast<int32_t>(i);
+}
 
 __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride, int64_t total, int64_t inv_stride,
                                uint16_t *__restrict__ inverse_t) {
@@ -80,9 +187,41 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
     inverse_t[static_cast<int64_t>(table[idx]) * inv_stride + p] = static_cast<uint16_t>(k);
 }
 
+// --------------------------------------------------------------------------------------
+// chunked generation
+// --------------------------------------------------------------------------------------
+static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
+
+int perms_generate_until(safe_perms *p, int64_t upto) {
+    safe_ctx *ctx = p->ctx;
+    upto = std::min<int64_t>(upto, p->count);
+    const int64_t k = p->k, n = p->n, stride = n + 1;
+    while (p->generated < upto) {
+        const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
+        const int b = static_cast<int>((q0 / kChunk) & 1);
+        // the pinned staging buffer of two chunks ago must have been uploaded
+        if (q0 >= 2 * kChunk) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
+        uint32_t *h = p->h_targets[b];
+        for (int64_t q = 0; q < cnt; ++q) p->stream->shuffle_targets(k, h + q * std::max<int64_t>(k, 1));
+        if (k > 0) {
+            SAFE_HIP_CHECK(hipMemcpyAsync(p->d_targets, h, cnt * k * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
+            SAFE_HIP_CHECK(hipEventRecord(p->staged[b], ctx->stream));
+            hipLaunchKernelGGL(k_apply_shuffles, dim3(cnt), dim3(64), static_cast<size_t>(k) * sizeof(int32_t), ctx->stream,
+                               p->d_movable, k, p->d_targets, p->d_drawn);
+        }
+        hipLaunchKernelGGL(k_compose_rows, dim3(1), dim3(1024), static_cast<size_t>(stride) * sizeof(int32_t), ctx->stream,
+                           p->d_movable, k, n, p->d_drawn, cnt, p->d_cur, p->table + q0 * stride,
+                           p->table16 ? p->table16 + q0 * p->stride16 : nullptr, p->stride16);
+        SAFE_HIP_CHECK(hipGetLastError());
+        p->generated = q1;
+    }
+    return SAFE_OK;
+}
+
 int perms_build_inverse(safe_perms *perms) {
     if (perms->inverse_t) return SAFE_OK;
     SAFE_REQUIRE(perms->n < 65535, "perms_build_inverse: n too large for 16-bit positions");
+    SAFE_TRY(perms_generate_until(perms, perms->count));
     safe_ctx *ctx = perms->ctx;
     const int64_t stride = perms->n + 1, total = perms->count * stride;
     perms->inv_stride = ((perms->count + 15) / 16) * 16 + 32;      // chunked prefetch may read two chunks ahead
@@ -96,27 +235,21 @@ int perms_build_inverse(safe_perms *perms) {
     return SAFE_OK;
 }
 
-__global__ void k_table_u16(const int32_t *__restrict__ table, int64_t stride, int64_t count, int64_t stride16,
-                            uint16_t *__restrict__ out) {
-    const int64_t idx = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (idx >= count * stride16) return;
-    const int64_t p = idx / stride16, k = idx % stride16;
-    out[idx] = k < stride ? static_cast<uint16_t>(table[p * stride + k]) : static_cast<uint16_t>(stride - 1);
-}
-
-int perms_build_table16(safe_perms *perms) {
-    if (perms->table16) return SAFE_OK;
-    SAFE_REQUIRE(perms->n < 65535, "perms_build_table16: n too large for 16-bit rows");
-    safe_ctx *ctx = perms->ctx;
-    const int64_t stride = perms->n + 1;
-    perms->stride16 = (stride + 7) / 8 * 8;
-    const int64_t total = std::max<int64_t>(perms->count, 1) * perms->stride16;
-    SAFE_TRY(dev_alloc(&perms->table16, static_cast<size_t>(total)));
-    if (perms->count)
-        hipLaunchKernelGGL(k_table_u16, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, perms->table, stride,
-                           perms->count, perms->stride16, perms->table16);
-    SAFE_HIP_CHECK(hipGetLastError());
-    return SAFE_OK;
+static void perms_free(safe_perms *p) {
+    if (!p) return;
+    for (int b = 0; b < 2; ++b) {
+        if (p->h_targets[b]) (void)hipHostFree(p->h_targets[b]);
+        if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
+    }
+    (void)hipFree(p->d_targets);
+    (void)hipFree(p->d_drawn);
+    (void)hipFree(p->d_movable);
+    (void)hipFree(p->d_cur);
+    (void)hipFree(p->table);
+    (void)hipFree(p->table16);
+    (void)hipFree(p->inverse_t);
+    delete p->stream;
+    delete p;
 }
 
 extern "C" {
@@ -125,11 +258,13 @@ int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_i
     SAFE_REQUIRE(n_items >= 0 && count >= 0, "safe_rng_permutations_host: negative size");
     SAFE_REQUIRE(n_items == 0 || count == 0 || (values && out), "safe_rng_permutations_host: NULL argument");
     SAFE_REQUIRE(n_items < (1ll << 32), "safe_rng_permutations_host: n_items too large");
-    MT19937 rng(seed);
+    DrawStream ds(seed);
+    std::vector<uint32_t> j(std::max<int64_t>(n_items, 1));
     for (int64_t c = 0; c < count; ++c) {
         int64_t *dst = out + c * n_items;
         memcpy(dst, values, n_items * sizeof(int64_t));
-        rng.shuffle(dst, n_items);
+        ds.shuffle_targets(n_items, j.data());
+        for (int64_t i = n_items - 1; i > 0; --i) std::swap(dst[i], dst[j[i]]);
     }
     return SAFE_OK;
 }
@@ -141,63 +276,59 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     SAFE_REQUIRE(num_permutations >= 0, "safe_perms_create: negative permutation count");
     *out = nullptr;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    std::vector<int32_t> movable;
-    movable.reserve(n);
-    for (int64_t i = 0; i < n; ++i)
-        if (movable_host[i]) movable.push_back(static_cast<int32_t>(i));
-    const int64_t k = static_cast<int64_t>(movable.size());
-    const int64_t stride = n + 1;
     safe_perms *p = new safe_perms();
     p->ctx = ctx;
     p->n = n;
     p->count = num_permutations;
-    int rc = dev_alloc(&p->table, static_cast<size_t>(std::max<int64_t>(num_permutations, 1)) * stride);
-    if (rc != SAFE_OK) {
-        delete p;
-        return rc;
-    }
-    // host staging in chunks so generation overlaps the uploads
-    const int64_t chunk = 64;
-    int32_t *h_buf[2] = {nullptr, nullptr};
-    hipEvent_t done[2] = {nullptr, nullptr};
-    hipError_t e = hipSuccess;
-    for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-        e = hipHostMalloc(reinterpret_cast<void **>(&h_buf[b]), chunk * stride * sizeof(int32_t), hipHostMallocDefault);
-        if (e == hipSuccess) e = hipEventCreateWithFlags(&done[b], hipEventDisableTiming);
-    }
-    if (e == hipSuccess) {
-        MT19937 rng(has_seed ? seed : entropy_seed());
-        std::vector<int32_t> cur(stride), draw(std::max<int64_t>(k, 1)), gathered(std::max<int64_t>(k, 1));
-        for (int64_t i = 0; i < stride; ++i) cur[i] = static_cast<int32_t>(i);
-        int64_t c = 0;
-        for (int64_t p0 = 0; p0 < num_permutations && e == hipSuccess; p0 += chunk, ++c) {
-            const int b = static_cast<int>(c & 1);
-            if (c >= 2) e = hipEventSynchronize(done[b]);
-            if (e != hipSuccess) break;
-            const int64_t p1 = std::min(num_permutations, p0 + chunk);
-            for (int64_t q = p0; q < p1; ++q) {
-                // n2a[indx_vals,:] = n2a[np.random.permutation(indx_vals),:]  (safe_extras.py:58)
-                memcpy(draw.data(), movable.data(), k * sizeof(int32_t));
-                rng.shuffle(draw.data(), k);
-                for (int64_t t = 0; t < k; ++t) gathered[t] = cur[draw[t]];
-                for (int64_t t = 0; t < k; ++t) cur[movable[t]] = gathered[t];
-                memcpy(h_buf[b] + (q - p0) * stride, cur.data(), stride * sizeof(int32_t));
-            }
-            e = hipMemcpyAsync(p->table + p0 * stride, h_buf[b], (p1 - p0) * stride * sizeof(int32_t),
-                               hipMemcpyHostToDevice, ctx->stream);
-            if (e == hipSuccess) e = hipEventRecord(done[b], ctx->stream);
+    for (int64_t i = 0; i < n; ++i)
+        if (movable_host[i]) p->h_movable.push_back(static_cast<int32_t>(i));
+    p->k = static_cast<int64_t>(p->h_movable.size());
+    p->stream = new DrawStream(has_seed ? seed : entropy_seed());
+    const int64_t k = p->k, stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
+    int rc = SAFE_OK;
+    do {
+        // the LDS-resident shuffle / composition need k and n+1 ints in one workgroup's LDS
+        if ((std::max<int64_t>(k, stride)) * sizeof(int32_t) > 160 * 1024) {
+            safe_set_error("safe_perms_create: %lld rows exceed the LDS-resident permutation builder (max 40959)", (long long)n);
+            rc = SAFE_E_UNSUPPORTED;
+            break;
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-    }
-    for (int b = 0; b < 2; ++b) {
-        if (h_buf[b]) (void)hipHostFree(h_buf[b]);
-        if (done[b]) (void)hipEventDestroy(done[b]);
-    }
-    if (e != hipSuccess) {
-        safe_set_error("safe_perms_create: %s", hipGetErrorString(e));
-        (void)hipFree(p->table);
-        delete p;
-        return SAFE_E_HIP;
+        if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
+        if (n < 65535) {
+            p->stride16 = (stride + 7) / 8 * 8;
+            if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
+        }
+        if ((rc = dev_alloc(&p->d_movable, k)) != SAFE_OK) break;
+        if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
+        if ((rc = dev_alloc(&p->d_targets, kChunk * std::max<int64_t>(k, 1))) != SAFE_OK) break;
+        if ((rc = dev_alloc(&p->d_drawn, kChunk * std::max<int64_t>(k, 1))) != SAFE_OK) break;
+        hipError_t e = hipSuccess;
+        for (int b = 0; b < 2 && e == hipSuccess; ++b) {
+            e = hipHostMalloc(reinterpret_cast<void **>(&p->h_targets[b]), kChunk * std::max<int64_t>(k, 1) * sizeof(uint32_t),
+                              hipHostMallocDefault);
+            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged[b], hipEventDisableTiming);
+        }
+        if (e == hipSuccess && k)
+            e = hipMemcpyAsync(p->d_movable, p->h_movable.data(), k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->stream, p->d_cur, stride);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess) {
+            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_apply_shuffles),
+                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e == hipSuccess)
+                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compose_rows),
+                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+        }
+        if (e != hipSuccess) {
+            safe_set_error("safe_perms_create: %s", hipGetErrorString(e));
+            rc = SAFE_E_HIP;
+        }
+    } while (0);
+    if (rc != SAFE_OK) {
+        perms_free(p);
+        return rc;
     }
     *out = p;
     return SAFE_OK;
@@ -207,10 +338,7 @@ int safe_perms_destroy(safe_perms *perms) {
     if (!perms) return SAFE_OK;
     (void)hipSetDevice(perms->ctx->device);
     (void)hipStreamSynchronize(perms->ctx->stream);
-    (void)hipFree(perms->table);
-    (void)hipFree(perms->inverse_t);
-    (void)hipFree(perms->table16);
-    delete perms;
+    perms_free(perms);
     return SAFE_OK;
 }
 
@@ -220,10 +348,12 @@ int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host
                  (long long)p0, (long long)p1, (long long)perms->count);
     safe_ctx *ctx = perms->ctx;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_TRY(perms_generate_until(perms, p1));
     const int64_t stride = perms->n + 1;
-    SAFE_HIP_CHECK(hipMemcpy2DAsync(out_host, perms->n * sizeof(int32_t), perms->table + p0 * stride,
-                                    stride * sizeof(int32_t), perms->n * sizeof(int32_t), p1 - p0,
-                                    hipMemcpyDeviceToHost, ctx->stream));
+    if (p1 > p0)
+        SAFE_HIP_CHECK(hipMemcpy2DAsync(out_host, perms->n * sizeof(int32_t), perms->table + p0 * stride,
+                                        stride * sizeof(int32_t), perms->n * sizeof(int32_t), p1 - p0,
+                                        hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SAFE_OK;
 }
