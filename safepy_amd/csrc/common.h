@@ -90,6 +90,7 @@ struct safe_nbr {
     int32_t *slice_width = nullptr; // [n_slices]
     int32_t *sell_col = nullptr;    // [slice_off[n_slices]] column id, n = padding (zero row)
     int64_t sell_entries = 0;
+    uint16_t *sell_col2 = nullptr;  // [sell_entries + 512] 2*column id as u16 (n < 32768 only): LDS byte offsets of a u16 table
     std::vector<int32_t> h_slice_width;
     std::vector<int64_t> h_slice_off;
     std::vector<int32_t> h_row_count;   // host copy of per-row counts

@@ -496,52 +496,82 @@ __global__ __launch_bounds__(64 * WAVES) void k_permtest_scatter(
 // as unsigned short (without it TBAA lets the compiler move those reads across the refills)
 typedef uint4 __attribute__((may_alias)) uint4_alias;
 
-__device__ __forceinline__ void csa32(uint32_t &carry, uint32_t &sum, uint32_t a, uint32_t b, uint32_t c) {
-    const uint32_t u = a ^ b;
-    carry = (u & c) | (~u & a);            // majority(a,b,c) as one v_bfi_b32
-    sum = u ^ c;
+// gfx950 has a three-input bitwise instruction (v_bitop3_b32, 8-bit truth table on
+// a = 0xF0, b = 0xCC, c = 0xAA): a full adder is two instructions.
+__device__ __forceinline__ uint32_t xor3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0x96); }
+__device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { return __builtin_amdgcn_bitop3_b32(a, b, c, 0xE8); }
+
+// adds eight one-bit-per-attribute words into the low three levels of the vertical counter
+// and returns the carry into level 3 (the "eights")
+__device__ __forceinline__ uint32_t vadd8(uint32_t (&s)[BT_LV], const uint32_t (&x)[8]) {
+    uint32_t t2a = maj3(s[0], x[0], x[1]);
+    s[0] = xor3(s[0], x[0], x[1]);
+    uint32_t t2b = maj3(s[0], x[2], x[3]);
+    s[0] = xor3(s[0], x[2], x[3]);
+    const uint32_t t4a = maj3(s[1], t2a, t2b);
+    s[1] = xor3(s[1], t2a, t2b);
+    t2a = maj3(s[0], x[4], x[5]);
+    s[0] = xor3(s[0], x[4], x[5]);
+    t2b = maj3(s[0], x[6], x[7]);
+    s[0] = xor3(s[0], x[6], x[7]);
+    const uint32_t t4b = maj3(s[1], t2a, t2b);
+    s[1] = xor3(s[1], t2a, t2b);
+    const uint32_t t8 = maj3(s[2], t4a, t4b);
+    s[2] = xor3(s[2], t4a, t4b);
+    return t8;
 }
 
-// adds eight one-bit-per-attribute words into the vertical counter s[0..BT_LV)
-__device__ __forceinline__ void vadd8(uint32_t (&s)[BT_LV], const uint32_t (&x)[8]) {
-    uint32_t t2a, t2b, t4a, t4b, t8;
-    csa32(t2a, s[0], s[0], x[0], x[1]);
-    csa32(t2b, s[0], s[0], x[2], x[3]);
-    csa32(t4a, s[1], s[1], t2a, t2b);
-    csa32(t2a, s[0], s[0], x[4], x[5]);
-    csa32(t2b, s[0], s[0], x[6], x[7]);
-    csa32(t4b, s[1], s[1], t2a, t2b);
-    csa32(t8, s[2], s[2], t4a, t4b);
+__device__ __forceinline__ void vripple(uint32_t (&s)[BT_LV], uint32_t t8) {
 #pragma unroll
-    for (int l = 3; l < BT_LV; ++l) {      // ripple the eights
+    for (int l = 3; l < BT_LV; ++l) {
         const uint32_t c = s[l] & t8;
         s[l] ^= t8;
         t8 = c;
     }
 }
 
-template <bool IDENT>
-__device__ __forceinline__ void bits_accumulate(const int32_t *__restrict__ cols, int wdt,
-                                                const unsigned short *__restrict__ cur, const uint2 *__restrict__ T,
-                                                uint32_t (&s0)[BT_LV], uint32_t (&s1)[BT_LV]) {
+// One pass over a lane's neighborhood: s = sum over members of T[cur[member]] (vertical).
+// cols2 holds 2*member id (the LDS byte offset into the u16 permutation row); with SCALED the
+// row itself holds 8*row id (the LDS byte offset into T, which starts at LDS address 0), so a
+// member costs two LDS reads and one address add.  `first` = the first block's ids (the same
+// for every permutation, loaded once per task); the ids of block b+1 are fetched as soon as
+// block b's look-ups have been issued.  The carry into the eights is rippled only when some
+// lane of the wave has one (sums rarely reach 8 on sparse annotations).
+template <bool IDENT, bool SCALED>
+__device__ __forceinline__ void bits_accumulate(const uint16_t *__restrict__ cols2, int wdt, const uint32_t (&first)[8],
+                                                uint32_t cur_base, uint32_t (&s0)[BT_LV], uint32_t (&s1)[BT_LV]) {
+    extern __shared__ unsigned int lds[];
+    const char *ldsb = reinterpret_cast<const char *>(lds);
 #pragma unroll
     for (int l = 0; l < BT_LV; ++l) s0[l] = s1[l] = 0;
-    for (int t0 = 0; t0 < wdt; t0 += 8) {
-        int32_t c[8];
+    uint32_t c[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = cols[(t0 + u) * 64];
+    for (int u = 0; u < 8; ++u) c[u] = first[u];
+    for (int t0 = 0; t0 < wdt; t0 += 8) {
         uint32_t r[8];
 #pragma unroll
-        for (int u = 0; u < 8; ++u) r[u] = IDENT ? static_cast<uint32_t>(c[u]) : static_cast<uint32_t>(cur[c[u]]);
+        for (int u = 0; u < 8; ++u) {
+            if (IDENT) r[u] = c[u] << 2;                                             // 2*id -> 8*id
+            else {
+                const uint32_t v = *reinterpret_cast<const unsigned short *>(ldsb + cur_base + c[u]);
+                r[u] = SCALED ? v : v << 3;
+            }
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = cols2[(t0 + 8 + u) * 64];                 // next block (array has a tail)
         uint32_t x0[8], x1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint2 w = T[r[u]];
+            const uint2 w = *reinterpret_cast<const uint2 *>(ldsb + r[u]);
             x0[u] = w.x;
             x1[u] = w.y;
         }
-        vadd8(s0, x0);
-        vadd8(s1, x1);
+        const uint32_t e0 = vadd8(s0, x0);
+        const uint32_t e1 = vadd8(s1, x1);
+        if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+            vripple(s0, e0);
+            vripple(s1, e1);
+        }
     }
 }
 
@@ -578,20 +608,33 @@ __device__ __forceinline__ unsigned int vextract(const uint32_t (&c)[LEVELS], in
     return v;
 }
 
-template <int CL>
+template <int CL, bool SCALED>
 __global__ __launch_bounds__(256) void k_permtest_bits(
     int64_t n, int64_t n_perm, const uint16_t *__restrict__ cur16, int64_t stride16,
     const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
-    const int32_t *__restrict__ slice_width, const int32_t *__restrict__ sell_col, int64_t n_slices,
+    const int32_t *__restrict__ slice_width, const uint16_t *__restrict__ sell_col2, int64_t n_slices,
     const uint2 *__restrict__ bbits, int64_t n_tasks, const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit,
     unsigned int *__restrict__ queue, int64_t mloc, unsigned long long *__restrict__ gl_counts, double *__restrict__ ns_out) {
     extern __shared__ unsigned int lds[];
-    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
+    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2 at LDS address 0, 16-B padded
     uint2 *T = reinterpret_cast<uint2 *>(lds);
     unsigned short *CUR = reinterpret_cast<unsigned short *>(lds + t_words);     // [2][stride16]
     unsigned int *slot_box = lds + t_words + stride16;                  // after the two u16 buffers
+    const uint32_t cur_bytes0 = static_cast<uint32_t>(t_words * 4);
+    const uint32_t cur_bytes1 = cur_bytes0 + static_cast<uint32_t>(stride16 * 2);
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int vec_per_row = static_cast<int>(stride16 / 8);              // uint4 (8 x u16) per table row
+
+    // a table row (8 x u16 per vector) scaled to T byte offsets
+    auto scale_row = [](uint4 v) {
+        if (SCALED) {
+            v.x = (v.x << 3) & 0xFFF8FFF8u;
+            v.y = (v.y << 3) & 0xFFF8FFF8u;
+            v.z = (v.z << 3) & 0xFFF8FFF8u;
+            v.w = (v.w << 3) & 0xFFF8FFF8u;
+        }
+        return v;
+    };
 
     for (;;) {
         if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
@@ -608,17 +651,21 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
         if (p_end > p_begin)
             for (int v = threadIdx.x; v < vec_per_row; v += 256)
-                reinterpret_cast<uint4_alias *>(CUR)[v] = reinterpret_cast<const uint4_alias *>(cur16 + p_begin * stride16)[v];
+                reinterpret_cast<uint4_alias *>(CUR)[v] =
+                    scale_row(reinterpret_cast<const uint4_alias *>(cur16 + p_begin * stride16)[v]);
 
         const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
         const bool active = s < n_slices;
         const int32_t row = active ? sell_row[s * 64 + lane] : -1;
-        const int32_t *cols = sell_col + (active ? slice_off[s] : 0) + lane;
+        const uint16_t *cols2 = sell_col2 + (active ? slice_off[s] : 0) + lane;
         const int wdt = active ? slice_width[s] : 0;
+        uint32_t first[8];                                               // 2 * member id of the first block
+#pragma unroll
+        for (int u = 0; u < 8; ++u) first[u] = cols2[u * 64];
         __syncthreads();
 
         uint32_t o0[BT_LV], o1[BT_LV];                                   // observed sums (safe.py:496-499)
-        bits_accumulate<true>(cols, wdt, nullptr, T, o0, o1);
+        bits_accumulate<true, SCALED>(cols2, wdt, first, 0u, o0, o1);
 
         uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
         uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
@@ -627,18 +674,18 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
 
         for (int64_t p = p_begin; p < p_end; ++p) {
             const int64_t rel = p - p_begin;
-            const unsigned short *cur = CUR + (rel & 1) * stride16;
+            const uint32_t cur_base = (rel & 1) ? cur_bytes1 : cur_bytes0;
             // next permutation's row: global -> registers now, registers -> LDS after the compute
             uint4 nxt = make_uint4(0, 0, 0, 0);
             const bool fetch = (p + 1 < p_end) && (static_cast<int>(threadIdx.x) < vec_per_row);
             if (fetch) nxt = reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[threadIdx.x];
 
             uint32_t s0[BT_LV], s1[BT_LV];
-            bits_accumulate<false>(cols, wdt, cur, T, s0, s1);
+            bits_accumulate<false, SCALED>(cols2, wdt, first, cur_base, s0, s1);
 
             // bit-sliced compare as two borrow chains, least significant level first:
             // lt = borrow out of (S - O), gt = borrow out of (O - S); per level
-            // borrow' = (s != o) ? subtrahend bit : borrow   -- one v_bfi_b32 each
+            // borrow' = (s != o) ? subtrahend bit : borrow   -- one v_bitop3_b32 each
             uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
 #pragma unroll
             for (int l = 0; l < BT_LV; ++l) {
@@ -663,9 +710,9 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
                 for (int v = threadIdx.x + 256; v < vec_per_row; v += 256)
                     if (p + 1 < p_end)
                         reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[v] =
-                            reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[v];
+                            scale_row(reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[v]);
             }
-            if (fetch) reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[threadIdx.x] = nxt;
+            if (fetch) reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[threadIdx.x] = scale_row(nxt);
             __syncthreads();
         }
         vflush<CL>(g0, gp0);
@@ -674,7 +721,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         vflush<CL>(l1, lp1);
 
         // ---- epilogue: un-slice the counters of this permutation range and add them to the
-        //      per-(neighborhood, attribute) totals (#greater << 32 | #less); most are zero
+        //      per-(neighborhood, attribute) totals (#greater << 32 | #less)
         const bool live = row >= 0;
         const int64_t obase = static_cast<int64_t>(live ? row : 0) * mloc;
 #pragma unroll
@@ -980,7 +1027,7 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
     if (z || n_perm < 1 || n_perm > 65535) return PATH_GATHER;
     if (safe_attr_prepare(attr) != SAFE_OK || attr->n_other != 0) return PATH_GATHER;
     if (nbr->n >= 65535) return PATH_GATHER;
-    const bool bits_ok = nbr->max_count < (1 << BT_LV) && bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024;
+    const bool bits_ok = nbr->sell_col2 != nullptr && nbr->max_count < (1 << BT_LV) && bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024;
     const bool scatter_ok = nbr->max_count < SC_EPOCH && scatter_lds_bytes(nbr->n) <= 160 * 1024;
     if (force && !strcmp(force, "bits") && bits_ok) return PATH_BITS;
     if (force && !strcmp(force, "scatter") && scatter_ok) return attr_build_support(attr) == SAFE_OK ? PATH_SCATTER : PATH_GATHER;
@@ -1050,9 +1097,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
     const bool wide = P >= 1024;
-    SAFE_HIP_CHECK(hipFuncSetAttribute(wide ? reinterpret_cast<const void *>(k_permtest_bits<16>)
-                                            : reinterpret_cast<const void *>(k_permtest_bits<10>),
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    const bool scaled = (n + 1) * 8 < 65536;
+    const void *kfn = wide ? (scaled ? reinterpret_cast<const void *>(k_permtest_bits<16, true>)
+                                     : reinterpret_cast<const void *>(k_permtest_bits<16, false>))
+                           : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
+                                     : reinterpret_cast<const void *>(k_permtest_bits<10, false>));
+    SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     ctx->last_kernel.name = "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
@@ -1062,14 +1112,16 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span);
         SAFE_TRY(perms_generate_until(perms, p_limit));      // host draws + table kernels for this span
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ctx->stream));
-        if (wide)
-            hipLaunchKernelGGL(k_permtest_bits<16>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, P, perms->table16,
-                               perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col, nbr->n_slices,
-                               d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, out.ns);
-        else
-            hipLaunchKernelGGL(k_permtest_bits<10>, dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, P, perms->table16,
-                               perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col, nbr->n_slices,
-                               d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, out.ns);
+#define LAUNCH_BITS(CLV, SC)                                                                                          \
+        hipLaunchKernelGGL((k_permtest_bits<CLV, SC>), dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, P,         \
+                           perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,          \
+                           nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, \
+                           d_gl, out.ns)
+        if (wide && scaled) LAUNCH_BITS(16, true);
+        else if (wide) LAUNCH_BITS(16, false);
+        else if (scaled) LAUNCH_BITS(10, true);
+        else LAUNCH_BITS(10, false);
+#undef LAUNCH_BITS
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ctx->stream));
     }

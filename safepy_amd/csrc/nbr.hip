@@ -199,6 +199,12 @@ __global__ void k_fill_sell(const int32_t *__restrict__ row_ptr, const int32_t *
     for (int32_t t = 0; t < wdt; ++t) sell_col[off + static_cast<int64_t>(t) * 64 + lane] = t < cnt ? col[beg + t] : pad;
 }
 
+__global__ void k_sell_scale16(const int32_t *__restrict__ sell_col, int64_t entries, int64_t total, uint32_t pad2,
+                               uint16_t *__restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < total) out[i] = i < entries ? static_cast<uint16_t>(2 * sell_col[i]) : static_cast<uint16_t>(pad2);
+}
+
 // --------------------------------------------------------------------------------------
 // K2: bounded all-pairs shortest paths.  One wave per source, label-correcting frontier
 // relaxation to a fixpoint over the CSR adjacency.  cand = dist[v] + w is an f64 add in
@@ -320,6 +326,7 @@ static void nbr_free(safe_nbr *nbr) {
     (void)hipFree(nbr->slice_off);
     (void)hipFree(nbr->slice_width);
     (void)hipFree(nbr->sell_col);
+    (void)hipFree(nbr->sell_col2);
     (void)hipFree(nbr->dist);
     (void)hipFree(nbr->at_ptr);
     (void)hipFree(nbr->at_col);
@@ -403,6 +410,12 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
     hipLaunchKernelGGL(k_fill_sell, dim3(nbr->n_slices), dim3(64), 0, ctx->stream, nbr->row_ptr, nbr->col,
                        nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->n_slices, static_cast<int32_t>(n),
                        nbr->sell_col);
+    if (n < 32768) {
+        const int64_t total = nbr->sell_entries + 512;          // tail: one block of 8 x 64 may be prefetched past the end
+        SAFE_TRY(dev_alloc(&nbr->sell_col2, total));
+        hipLaunchKernelGGL(k_sell_scale16, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, nbr->sell_col,
+                           nbr->sell_entries, total, static_cast<uint32_t>(2 * n), nbr->sell_col2);
+    }
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host vectors above go out of scope
     return SAFE_OK;
