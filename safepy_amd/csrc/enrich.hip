@@ -537,32 +537,38 @@ __device__ __forceinline__ void vripple(uint32_t (&s)[BT_LV], uint32_t t8) {
 // for every permutation, loaded once per task); the ids of block b+1 are fetched as soon as
 // block b's look-ups have been issued.  The carry into the eights is rippled only when some
 // lane of the wave has one (sums rarely reach 8 on sparse annotations).
+typedef const __attribute__((address_space(3))) unsigned short *lds_u16_ptr;
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) u32x2 *lds_u2_ptr;
+
 template <bool IDENT, bool SCALED>
 __device__ __forceinline__ void bits_accumulate(const uint16_t *__restrict__ cols2, int wdt, const uint32_t (&first)[8],
-                                                uint32_t cur_base, uint32_t (&s0)[BT_LV], uint32_t (&s1)[BT_LV]) {
-    extern __shared__ unsigned int lds[];
-    const char *ldsb = reinterpret_cast<const char *>(lds);
+                                                uint32_t cur_addr, uint32_t t_addr, uint32_t (&s0)[BT_LV],
+                                                uint32_t (&s1)[BT_LV]) {
+    // cur_addr / t_addr: absolute LDS byte addresses of the permutation row and of T; with
+    // SCALED the row entries already are absolute addresses of T rows
 #pragma unroll
     for (int l = 0; l < BT_LV; ++l) s0[l] = s1[l] = 0;
     uint32_t c[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) c[u] = first[u];
-    for (int t0 = 0; t0 < wdt; t0 += 8) {
+    const uint16_t *pc = cols2 + 8 * 64;                                              // next block's ids
+    for (int t0 = 0; t0 < wdt; t0 += 8, pc += 8 * 64) {
         uint32_t r[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            if (IDENT) r[u] = c[u] << 2;                                             // 2*id -> 8*id
+            if (IDENT) r[u] = (c[u] << 2) + t_addr;                                   // 2*id -> address of T[id]
             else {
-                const uint32_t v = *reinterpret_cast<const unsigned short *>(ldsb + cur_base + c[u]);
-                r[u] = SCALED ? v : v << 3;
+                const uint32_t v = *(lds_u16_ptr)(uintptr_t)(cur_addr + c[u]);
+                r[u] = SCALED ? v : (v << 3) + t_addr;
             }
         }
 #pragma unroll
-        for (int u = 0; u < 8; ++u) c[u] = cols2[(t0 + 8 + u) * 64];                 // next block (array has a tail)
+        for (int u = 0; u < 8; ++u) c[u] = pc[u * 64];                                // (the array has a tail)
         uint32_t x0[8], x1[8];
 #pragma unroll
         for (int u = 0; u < 8; ++u) {
-            const uint2 w = *reinterpret_cast<const uint2 *>(ldsb + r[u]);
+            const u32x2 w = *(lds_u2_ptr)(uintptr_t)(r[u]);
             x0[u] = w.x;
             x1[u] = w.y;
         }
@@ -620,18 +626,21 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
     uint2 *T = reinterpret_cast<uint2 *>(lds);
     unsigned short *CUR = reinterpret_cast<unsigned short *>(lds + t_words);     // [2][stride16]
     unsigned int *slot_box = lds + t_words + stride16;                  // after the two u16 buffers
-    const uint32_t cur_bytes0 = static_cast<uint32_t>(t_words * 4);
+    // absolute LDS byte addresses (the dynamic segment need not start at 0)
+    const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds);
+    const uint32_t cur_bytes0 = t_addr + static_cast<uint32_t>(t_words * 4);
     const uint32_t cur_bytes1 = cur_bytes0 + static_cast<uint32_t>(stride16 * 2);
+    const uint32_t t_addr2 = t_addr | (t_addr << 16);                    // both u16 halves
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int vec_per_row = static_cast<int>(stride16 / 8);              // uint4 (8 x u16) per table row
 
     // a table row (8 x u16 per vector) scaled to T byte offsets
-    auto scale_row = [](uint4 v) {
-        if (SCALED) {
-            v.x = (v.x << 3) & 0xFFF8FFF8u;
-            v.y = (v.y << 3) & 0xFFF8FFF8u;
-            v.z = (v.z << 3) & 0xFFF8FFF8u;
-            v.w = (v.w << 3) & 0xFFF8FFF8u;
+    auto scale_row = [=](uint4 v) {
+        if (SCALED) {                         // 8 * row + address of T, per u16 half (no carries: < 65536)
+            v.x = ((v.x << 3) & 0xFFF8FFF8u) + t_addr2;
+            v.y = ((v.y << 3) & 0xFFF8FFF8u) + t_addr2;
+            v.z = ((v.z << 3) & 0xFFF8FFF8u) + t_addr2;
+            v.w = ((v.w << 3) & 0xFFF8FFF8u) + t_addr2;
         }
         return v;
     };
@@ -665,7 +674,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         __syncthreads();
 
         uint32_t o0[BT_LV], o1[BT_LV];                                   // observed sums (safe.py:496-499)
-        bits_accumulate<true, SCALED>(cols2, wdt, first, 0u, o0, o1);
+        bits_accumulate<true, SCALED>(cols2, wdt, first, 0u, t_addr, o0, o1);
 
         uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
         uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
@@ -681,7 +690,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
             if (fetch) nxt = reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[threadIdx.x];
 
             uint32_t s0[BT_LV], s1[BT_LV];
-            bits_accumulate<false, SCALED>(cols2, wdt, first, cur_base, s0, s1);
+            bits_accumulate<false, SCALED>(cols2, wdt, first, cur_base, t_addr, s0, s1);
 
             // bit-sliced compare as two borrow chains, least significant level first:
             // lt = borrow out of (S - O), gt = borrow out of (O - S); per level
@@ -689,11 +698,11 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
             uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
 #pragma unroll
             for (int l = 0; l < BT_LV; ++l) {
-                const uint32_t d0 = s0[l] ^ o0[l], d1 = s1[l] ^ o1[l];
-                lt0 = (d0 & o0[l]) | (~d0 & lt0);
-                gt0 = (d0 & s0[l]) | (~d0 & gt0);
-                lt1 = (d1 & o1[l]) | (~d1 & lt1);
-                gt1 = (d1 & s1[l]) | (~d1 & gt1);
+                // f(s, o, b) = (s != o) ? o : b  -> 0x8E ;  (s != o) ? s : b -> 0xB2
+                lt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], lt0, 0x8E);
+                gt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], gt0, 0xB2);
+                lt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], lt1, 0x8E);
+                gt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], gt1, 0xB2);
             }
             vcount<CL>(g0, gp0, gt0);
             vcount<CL>(g1, gp1, gt1);
