@@ -16,6 +16,8 @@
 #define SAFE_PAD_U16 0xFFFFu
 
 void safe_set_error(const char *fmt, ...);
+// SAFE_HIP_TRACE=1: host-side time stamps (ms since the first call) on stderr
+void safe_trace(const char *what);
 
 #define SAFE_HIP_CHECK(expr)                                                                   \
     do {                                                                                       \
@@ -51,13 +53,22 @@ struct safe_ctx {
     int device = 0;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
+    hipStream_t aux_stream = nullptr;           // permutation-table generation (overlaps the enrichment kernels)
+    hipStream_t side_stream = nullptr;          // second enrichment stream: consecutive spans overlap their tails
     int num_cu = 0;
     int64_t hbm_bytes = 0;
     char arch[64] = {0};
     hipEvent_t t0 = nullptr, t1 = nullptr;      // safe_timer_*
     hipEvent_t k0 = nullptr, k1 = nullptr;      // dominant-kernel timing
     KernelStat last_kernel;
+    // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
+    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[4] = {0, 0, 0, 0};
 };
+
+// returns a device buffer of at least `bytes` from slot `slot`, valid until the next request
+// for the same slot; contents are undefined
+int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out);
 
 // RAII-less device buffer helper: all frees go through the owning handle's destroy.
 template <typename T>
@@ -130,6 +141,7 @@ struct safe_perms {
     std::vector<int32_t> h_movable;
     DrawStream *stream = nullptr;
     int64_t generated = 0;          // permutations whose table rows have been enqueued
+    std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each generated chunk
     uint32_t *h_targets[2] = {nullptr, nullptr};   // pinned staging of the swap targets
     hipEvent_t staged[2] = {nullptr, nullptr};
     uint32_t *d_targets = nullptr;  // [chunk][k]
@@ -154,4 +166,5 @@ int nbr_finalize_from_bits(safe_nbr *nbr);   // bits -> CSR + SELL (nbr.hip)
 int nbr_build_transpose(safe_nbr *nbr);      // at_ptr / at_col (nbr.hip)
 int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary matrix (attr.hip)
 int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)
-int perms_generate_until(safe_perms *perms, int64_t upto);   // enqueue table rows [generated, upto) (rng.cpp)
+int perms_generate_until(safe_perms *perms, int64_t upto);   // enqueue table rows [generated, upto) on aux_stream (rng.cpp)
+int perms_wait(safe_perms *perms, int64_t upto, hipStream_t s);   // make stream s wait until rows [0, upto) exist (rng.cpp)

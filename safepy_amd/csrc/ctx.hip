@@ -1,13 +1,45 @@
 // Context, error reporting and raw device-memory helpers of libsafe_hip.so.
 #include "common.h"
 
+#include <chrono>
+
 static thread_local char g_error[1024] = "";
+
+void safe_trace(const char *what) {
+    static const bool on = getenv("SAFE_HIP_TRACE") != nullptr;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[safe_hip %9.3f ms] %s\n",
+            std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
+}
 
 void safe_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);
     vsnprintf(g_error, sizeof(g_error), fmt, ap);
     va_end(ap);
+}
+
+int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out) {
+    if (bytes == 0) bytes = 1;
+    if (ctx->scratch_bytes[slot] < bytes) {
+        if (ctx->scratch[slot]) {
+            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->side_stream));
+            SAFE_HIP_CHECK(hipFree(ctx->scratch[slot]));
+            ctx->scratch[slot] = nullptr;
+            ctx->scratch_bytes[slot] = 0;
+        }
+        const size_t want = bytes + bytes / 8;
+        hipError_t e = hipMalloc(&ctx->scratch[slot], want);
+        if (e != hipSuccess) {
+            safe_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            return SAFE_E_NOMEM;
+        }
+        ctx->scratch_bytes[slot] = want;
+    }
+    *out = ctx->scratch[slot];
+    return SAFE_OK;
 }
 
 extern "C" {
@@ -50,6 +82,12 @@ int safe_ctx_create(int device, safe_ctx **out) {
     snprintf(ctx->arch, sizeof(ctx->arch), "%s", prop.gcnArchName);
     SAFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->own_stream, hipStreamNonBlocking));
     ctx->stream = ctx->own_stream;
+    {
+        int lo = 0, hi = 0;       // numerically lowest value = highest priority
+        SAFE_HIP_CHECK(hipDeviceGetStreamPriorityRange(&lo, &hi));
+        SAFE_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi));
+    }
+    SAFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
     SAFE_HIP_CHECK(hipEventCreate(&ctx->t0));
     SAFE_HIP_CHECK(hipEventCreate(&ctx->t1));
     SAFE_HIP_CHECK(hipEventCreate(&ctx->k0));
@@ -66,6 +104,10 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->k0) (void)hipEventDestroy(ctx->k0);
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
+    for (int i = 0; i < 4; ++i)
+        if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
+    if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SAFE_OK;

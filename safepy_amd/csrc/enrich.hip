@@ -1048,8 +1048,9 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
 static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
                        const PermOut &out) {
     const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64), P = perms->count;
+    safe_trace("launch_bits: enter");
     uint2 *d_bits = nullptr;
-    SAFE_TRY(dev_alloc(&d_bits, static_cast<size_t>(n_wg) * (n + 1)));
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
     {
         const dim3 grid(ceil_div(n_wg * (n + 1), 256)), block(256);
         if (attr->dtype == SAFE_DTYPE_F32)
@@ -1059,6 +1060,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_wg, d_bits);
     }
+    safe_trace("launch_bits: prep launched");
     // The permutations are consumed in launches of `span` permutations so that the host's draw
     // stream for the next span overlaps this span's kernel.  Inside a launch, tasks = (word
     // group, group of 4 adjacent slices, permutation sub-range), sized to about equal cost
@@ -1094,15 +1096,17 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     std::vector<int4> tasks(tc.size());
     for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
     const int64_t n_launch = ceil_div(std::max<int64_t>(P, 1), span);
+    safe_trace("launch_bits: tasks built");
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
     unsigned long long *d_gl = nullptr;
     SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
     SAFE_TRY(dev_alloc(&d_queue, n_launch));
-    SAFE_TRY(dev_alloc(&d_gl, static_cast<size_t>(n) * mloc));
+    SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n) * mloc * sizeof(unsigned long long), reinterpret_cast<void **>(&d_gl)));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, n_launch * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n) * mloc * sizeof(unsigned long long), ctx->stream));
+    safe_trace("launch_bits: buffers ready");
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
     const bool wide = P >= 1024;
@@ -1117,12 +1121,21 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     ctx->last_kernel.launches = 0;
     std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
     for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
+    // consecutive spans alternate between two streams so the tail of one launch (a few long
+    // tasks) overlaps the head of the next; both wait for the inputs prepared on ctx->stream
+    hipEvent_t ready = nullptr, side_done = nullptr;
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
         const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span);
-        SAFE_TRY(perms_generate_until(perms, p_limit));      // host draws + table kernels for this span
-        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ctx->stream));
+        hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
+        SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
+        safe_trace("launch_bits: span tables enqueued");
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
 #define LAUNCH_BITS(CLV, SC)                                                                                          \
-        hipLaunchKernelGGL((k_permtest_bits<CLV, SC>), dim3(blocks), dim3(256), lds_bytes, ctx->stream, n, P,         \
+        hipLaunchKernelGGL((k_permtest_bits<CLV, SC>), dim3(blocks), dim3(256), lds_bytes, ks, n, P,                  \
                            perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,          \
                            nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, \
                            d_gl, out.ns)
@@ -1132,14 +1145,18 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         else LAUNCH_BITS(10, false);
 #undef LAUNCH_BITS
         SAFE_HIP_CHECK(hipGetLastError());
-        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ctx->stream));
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
     }
+    SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
+    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
     hipLaunchKernelGGL(k_counts_finalize, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_gl, n, mloc,
                        P, out);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    safe_trace("launch_bits: all enqueued");
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // tasks (host vector) and temporaries
+    safe_trace("launch_bits: synced");
     for (int64_t c = 0; c < n_launch; ++c) {
         float ms = 0.f;
         SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
@@ -1147,10 +1164,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         ctx->last_kernel.launches += 1;
     }
     for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipFree(d_bits);
+    (void)hipEventDestroy(ready);
+    (void)hipEventDestroy(side_done);
     (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
-    (void)hipFree(d_gl);
     return SAFE_OK;
 }
 
@@ -1206,7 +1223,7 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
     }
     Tiles tiles;
     SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
-    SAFE_TRY(perms_generate_until(perms, perms->count));
+    SAFE_TRY(perms_wait(perms, perms->count, ctx->stream));
     int rc = launch_gather(ctx, nbr, tiles, perms->table, perms->count, col1 - col0, z, out);
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
     (void)hipFree(tiles.bt);
@@ -1266,7 +1283,7 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.mode = 2;
         rc = path == PATH_BITS      ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
              : path == PATH_SCATTER ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
-                                    : (perms_generate_until(perms, P) == SAFE_OK
+                                    : (perms_wait(perms, P, ctx->stream) == SAFE_OK
                                            ? launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out)
                                            : SAFE_E_HIP);
     }

@@ -194,35 +194,50 @@ static const int64_t kChunk = 128;      // permutations per host/GPU pipeline st
 
 int perms_generate_until(safe_perms *p, int64_t upto) {
     safe_ctx *ctx = p->ctx;
+    hipStream_t gs = ctx->aux_stream;
     upto = std::min<int64_t>(upto, p->count);
     const int64_t k = p->k, n = p->n, stride = n + 1;
     while (p->generated < upto) {
         const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
-        const int b = static_cast<int>((q0 / kChunk) & 1);
+        const int64_t ci = q0 / kChunk;
+        const int b = static_cast<int>(ci & 1);
         // the pinned staging buffer of two chunks ago must have been uploaded
         if (q0 >= 2 * kChunk) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
         uint32_t *h = p->h_targets[b];
         for (int64_t q = 0; q < cnt; ++q) p->stream->shuffle_targets(k, h + q * std::max<int64_t>(k, 1));
         if (k > 0) {
-            SAFE_HIP_CHECK(hipMemcpyAsync(p->d_targets, h, cnt * k * sizeof(uint32_t), hipMemcpyHostToDevice, ctx->stream));
-            SAFE_HIP_CHECK(hipEventRecord(p->staged[b], ctx->stream));
-            hipLaunchKernelGGL(k_apply_shuffles, dim3(cnt), dim3(64), static_cast<size_t>(k) * sizeof(int32_t), ctx->stream,
+            SAFE_HIP_CHECK(hipMemcpyAsync(p->d_targets, h, cnt * k * sizeof(uint32_t), hipMemcpyHostToDevice, gs));
+            SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
+            hipLaunchKernelGGL(k_apply_shuffles, dim3(cnt), dim3(64), static_cast<size_t>(k) * sizeof(int32_t), gs,
                                p->d_movable, k, p->d_targets, p->d_drawn);
         }
-        hipLaunchKernelGGL(k_compose_rows, dim3(1), dim3(1024), static_cast<size_t>(stride) * sizeof(int32_t), ctx->stream,
+        hipLaunchKernelGGL(k_compose_rows, dim3(1), dim3(1024), static_cast<size_t>(stride) * sizeof(int32_t), gs,
                            p->d_movable, k, n, p->d_drawn, cnt, p->d_cur, p->table + q0 * stride,
                            p->table16 ? p->table16 + q0 * p->stride16 : nullptr, p->stride16);
         SAFE_HIP_CHECK(hipGetLastError());
+        if (static_cast<int64_t>(p->chunk_done.size()) <= ci) p->chunk_done.resize(ci + 1, nullptr);
+        if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], hipEventDisableTiming));
+        SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[ci], gs));
         p->generated = q1;
     }
+    return SAFE_OK;
+}
+
+// stream s will not run past this point before table rows [0, upto) are complete
+int perms_wait(safe_perms *p, int64_t upto, hipStream_t s) {
+    SAFE_TRY(perms_generate_until(p, upto));
+    upto = std::min<int64_t>(upto, p->count);
+    if (upto <= 0) return SAFE_OK;
+    const int64_t ci = (upto - 1) / kChunk;
+    SAFE_HIP_CHECK(hipStreamWaitEvent(s, p->chunk_done[ci], 0));
     return SAFE_OK;
 }
 
 int perms_build_inverse(safe_perms *perms) {
     if (perms->inverse_t) return SAFE_OK;
     SAFE_REQUIRE(perms->n < 65535, "perms_build_inverse: n too large for 16-bit positions");
-    SAFE_TRY(perms_generate_until(perms, perms->count));
     safe_ctx *ctx = perms->ctx;
+    SAFE_TRY(perms_wait(perms, perms->count, ctx->stream));
     const int64_t stride = perms->n + 1, total = perms->count * stride;
     perms->inv_stride = ((perms->count + 15) / 16) * 16 + 32;      // chunked prefetch may read two chunks ahead
     const size_t elems = static_cast<size_t>(stride) * perms->inv_stride;
@@ -241,6 +256,8 @@ static void perms_free(safe_perms *p) {
         if (p->h_targets[b]) (void)hipHostFree(p->h_targets[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
     }
+    for (hipEvent_t e : p->chunk_done)
+        if (e) (void)hipEventDestroy(e);
     (void)hipFree(p->d_targets);
     (void)hipFree(p->d_drawn);
     (void)hipFree(p->d_movable);
@@ -276,6 +293,7 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     SAFE_REQUIRE(num_permutations >= 0, "safe_perms_create: negative permutation count");
     *out = nullptr;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    safe_trace("perms_create: enter");
     safe_perms *p = new safe_perms();
     p->ctx = ctx;
     p->n = n;
@@ -309,9 +327,9 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
             if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged[b], hipEventDisableTiming);
         }
         if (e == hipSuccess && k)
-            e = hipMemcpyAsync(p->d_movable, p->h_movable.data(), k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream);
+            e = hipMemcpyAsync(p->d_movable, p->h_movable.data(), k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux_stream);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->stream, p->d_cur, stride);
+            hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
             e = hipGetLastError();
         }
         if (e == hipSuccess) {
@@ -330,6 +348,7 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
         perms_free(p);
         return rc;
     }
+    safe_trace("perms_create: done");
     *out = p;
     return SAFE_OK;
 }
@@ -337,6 +356,8 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
 int safe_perms_destroy(safe_perms *perms) {
     if (!perms) return SAFE_OK;
     (void)hipSetDevice(perms->ctx->device);
+    (void)hipStreamSynchronize(perms->ctx->aux_stream);
+    (void)hipStreamSynchronize(perms->ctx->side_stream);
     (void)hipStreamSynchronize(perms->ctx->stream);
     perms_free(perms);
     return SAFE_OK;
@@ -348,7 +369,7 @@ int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host
                  (long long)p0, (long long)p1, (long long)perms->count);
     safe_ctx *ctx = perms->ctx;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    SAFE_TRY(perms_generate_until(perms, p1));
+    SAFE_TRY(perms_wait(perms, p1, ctx->stream));
     const int64_t stride = perms->n + 1;
     if (p1 > p0)
         SAFE_HIP_CHECK(hipMemcpy2DAsync(out_host, perms->n * sizeof(int32_t), perms->table + p0 * stride,
