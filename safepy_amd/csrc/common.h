@@ -8,6 +8,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "safe_hip.h"
@@ -140,14 +141,15 @@ struct safe_perms {
     int64_t k = 0;                  // number of movable rows (indx_vals)
     std::vector<int32_t> h_movable;
     DrawStream *stream = nullptr;
-    int64_t generated = 0;          // permutations whose table rows have been enqueued
-    std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each generated chunk
-    uint32_t *h_targets[2] = {nullptr, nullptr};   // pinned staging of the swap targets
+    // pipeline positions (in permutations): drawn >= handed to the swap workers >= enqueued on the GPU
+    int64_t generated = 0, swapping = 0, enqueued = 0;
+    std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each enqueued chunk
+    std::vector<uint32_t> h_targets[2];            // swap targets of a chunk (draw thread -> workers)
+    int32_t *h_maps[2] = {nullptr, nullptr};       // pinned: row maps of a chunk (workers -> GPU)
     hipEvent_t staged[2] = {nullptr, nullptr};
-    uint32_t *d_targets = nullptr;  // [chunk][k]
-    int32_t *d_drawn = nullptr;     // [chunk][k] shuffled copies of indx_vals
-    int32_t *d_movable = nullptr;   // [k]
-    int32_t *d_cur = nullptr;       // [n+1] running composition
+    std::vector<std::thread> workers;              // swap workers of the chunk in flight
+    int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] scan ping-pong
+    int32_t *d_cur = nullptr;       // [n+1] running composition (last emitted row)
     int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)
     // 16-bit copy of the table, rows padded to a multiple of 8 entries (n < 65535 only)
     uint16_t *table16 = nullptr;

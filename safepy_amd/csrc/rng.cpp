@@ -7,14 +7,17 @@
 // 32-bit outputs a shuffle consumes depends on its rejections, so permutation q+1 cannot
 // start before q has finished drawing.  The host therefore produces just the accepted swap
 // targets j[q][i] (bulk MT19937 generation + a branch-light rejection loop, ~1.5 ns per
-// draw).  Everything else runs on the GPU, chunk by chunk, overlapping the host's next
-// chunk and the enrichment kernel of the previous one:
-//   k_apply_shuffles   one wave per permutation replays the swaps on a copy of indx_vals
-//                      held in LDS  (independent across permutations)
-//   k_compose_rows     cur[indx_vals] = cur[shuffled]  cumulatively, one workgroup walking
-//                      the chunk, emitting the composed table rows (int32 and 16-bit)
+// draw) on one thread.  The rest is parallel and runs chunk by chunk, overlapping the draw
+// thread's next chunk and the enrichment kernel of the previous one:
+//   host workers       replay the swaps of each permutation on a copy of indx_vals (independent
+//                      across permutations: a few threads keep up with the draw thread) and
+//                      emit the row map M_q
+//   k_scan_round x log2(chunk), k_emit_rows
+//                      cur_q = cur_{q-1} o M_q is a prefix product under composition: a
+//                      log-depth parallel scan on the GPU, emitting the composed table rows
 #include <algorithm>
 #include <random>
+#include <thread>
 
 #include "common.h"
 
@@ -105,73 +108,33 @@ static uint32_t entropy_seed() {
 // --------------------------------------------------------------------------------------
 // device side
 // --------------------------------------------------------------------------------------
-// One wave per permutation: a = copy of indx_vals in LDS; for i = k-1..1: swap(a[i], a[j[i]]).
-// Lane 0 replays the dependent swaps (LDS operations of one wave complete in order); the
-// other lanes stage the targets 64 at a time and copy in / out.
-__global__ __launch_bounds__(64) void k_apply_shuffles(const int32_t *__restrict__ movable, int64_t k,
-                                                       const uint32_t *__restrict__ targets, int32_t *__restrict__ drawn) {
-    extern __shared__ int32_t sh_a[];
-    const int lane = threadIdx.x;
-    const uint32_t *j = targets + static_cast<int64_t>(blockIdx.x) * k;
-    int32_t *out = drawn + static_cast<int64_t>(blockIdx.x) * k;
-    for (int64_t t = lane; t < k; t += 64) sh_a[t] = movable[t];
-    __syncthreads();
-    for (int64_t top = k - 1; top > 0; top -= 64) {
-        // lanes fetch j[top], j[top-1], ... (coalesced, descending)
-        const int64_t mine = top - lane;
-        const uint32_t jv = mine > 0 ? j[mine] : 0u;
-        const int cnt = top >= 64 ? 64 : static_cast<int>(top);
-        if (lane == 0) {
-            for (int s = 0; s < cnt; ++s) {
-                const int64_t i = top - s;
-                const uint32_t ji = __builtin_amdgcn_readlane(jv, s);
-                const int32_t vi = sh_a[i], vj = sh_a[ji];
-                sh_a[i] = vj;
-                sh_a[ji] = vi;
-            }
-        }
-    }
-    __syncthreads();
-    for (int64_t t = lane; t < k; t += 64) out[t] = sh_a[t];
+// Composition of the chunk's row maps.  The host hands over, for every permutation q of the
+// chunk, the full-length map M_q (M_q[i] = i for rows that do not move, M_q[indx_vals[t]] =
+// shuffled[t]); the composed table is cur_q = cur_{q-1} o M_q, i.e. a prefix product under
+// composition.  Composition is associative, so the prefix is a log-depth scan
+// (Hillis-Steele): X_q <- X_{q-d} o X_q for d = 1, 2, 4, ...; every round is a fully parallel
+// gather, then cur_q = cur_base o X_q.
+__global__ __launch_bounds__(256) void k_scan_round(const int32_t *__restrict__ xin, int32_t *__restrict__ xout,
+                                                    int64_t cnt, int64_t stride, int64_t d) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y;
+    if (i >= stride) return;
+    const int32_t v = xin[q * stride + i];
+    xout[q * stride + i] = q >= d ? xin[(q - d) * stride + v] : v;
 }
 
-// cur[movable[t]] = cur_old[drawn[q][t]] for q = 0..count-1 (cumulative), emitting row q of
-// the composed table after each step.  One workgroup; cur lives in LDS.
-__global__ __launch_bounds__(1024) void k_compose_rows(const int32_t *__restrict__ movable, int64_t k, int64_t n,
-                                                       const int32_t *__restrict__ drawn, int64_t count,
-                                                       int32_t *__restrict__ cur_state, int32_t *__restrict__ table,
-                                                       uint16_t *__restrict__ table16, int64_t stride16) {
-    extern __shared__ int32_t sh_cur[];      // [n+1]
-    const int tid = threadIdx.x;
-    const int64_t stride = n + 1;
-    for (int64_t i = tid; i < stride; i += 1024) sh_cur[i] = cur_state[i];
-    __syncthreads();
-    for (int64_t q = 0; q < count; ++q) {
-        const int32_t *d = drawn + q * k;
-        // gather first (cur_old), then scatter: the two index sets are the same set of rows
-        int32_t vals[40];                          // 40 x 1024 >= the 40959-row LDS limit
-#pragma unroll
-        for (int u = 0; u < 40; ++u) {
-            const int64_t t = tid + static_cast<int64_t>(u) * 1024;
-            vals[u] = t < k ? sh_cur[d[t]] : 0;
-        }
-        __syncthreads();
-#pragma unroll
-        for (int u = 0; u < 40; ++u) {
-            const int64_t t = tid + static_cast<int64_t>(u) * 1024;
-            if (t < k) sh_cur[movable[t]] = vals[u];
-        }
-        __syncthreads();
-        int32_t *row = table + q * stride;
-        for (int64_t i = tid; i < stride; i += 1024) row[i] = sh_cur[i];
-        if (table16) {
-            uint16_t *row16 = table16 + q * stride16;
-            for (int64_t i = tid; i < stride16; i += 1024)
-                row16[i] = static_cast<uint16_t>(i < stride ? sh_cur[i] : n);
-        }
+__global__ __launch_bounds__(256) void k_emit_rows(const int32_t *__restrict__ x, const int32_t *__restrict__ cur_base,
+                                                   int64_t cnt, int64_t n, int32_t *__restrict__ table,
+                                                   uint16_t *__restrict__ table16, int64_t stride16) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y, stride = n + 1;
+    if (i < stride) {
+        const int32_t v = cur_base[x[q * stride + i]];
+        table[q * stride + i] = v;
+        if (table16) table16[q * stride16 + i] = static_cast<uint16_t>(v);
+    } else if (table16 && i < stride16) {
+        table16[q * stride16 + i] = static_cast<uint16_t>(n);
     }
-    __syncthreads();
-    for (int64_t i = tid; i < stride; i += 1024) cur_state[i] = sh_cur[i];
 }
 
 __global__ void k_iota(int32_t *p, int64_t count) {
@@ -192,33 +155,87 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 // --------------------------------------------------------------------------------------
 static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
 
-int perms_generate_until(safe_perms *p, int64_t upto) {
+// swaps of permutations [w, cnt) step W of one chunk -> row maps (host worker thread)
+static void swap_worker(const safe_perms *p, const uint32_t *targets, int32_t *maps, int64_t cnt, int w, int W) {
+    const int64_t k = p->k, stride = p->n + 1;
+    std::vector<int32_t> a(std::max<int64_t>(k, 1));
+    const int32_t *mov = p->h_movable.data();
+    for (int64_t q = w; q < cnt; q += W) {
+        const uint32_t *j = targets + q * std::max<int64_t>(k, 1);
+        memcpy(a.data(), mov, k * sizeof(int32_t));
+        for (int64_t i = k - 1; i > 0; --i) std::swap(a[i], a[j[i]]);     // safe_extras.py:58 / legacy shuffle
+        int32_t *m = maps + q * stride;
+        for (int64_t i = 0; i < stride; ++i) m[i] = static_cast<int32_t>(i);
+        for (int64_t t = 0; t < k; ++t) m[mov[t]] = a[t];
+    }
+}
+
+// enqueue the GPU part of a chunk whose row maps are ready in h_maps[b]
+static int enqueue_chunk(safe_perms *p, int64_t ci) {
     safe_ctx *ctx = p->ctx;
     hipStream_t gs = ctx->aux_stream;
+    const int64_t n = p->n, stride = n + 1;
+    const int64_t q0 = ci * kChunk, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
+    const int b = static_cast<int>(ci & 1);
+    for (std::thread &t : p->workers) t.join();
+    p->workers.clear();
+    int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
+    SAFE_HIP_CHECK(hipMemcpyAsync(xa, p->h_maps[b], cnt * stride * sizeof(int32_t), hipMemcpyHostToDevice, gs));
+    SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
+    const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), cnt), block(256);
+    for (int64_t d = 1; d < cnt; d <<= 1) {
+        hipLaunchKernelGGL(k_scan_round, grid, block, 0, gs, xa, xb, cnt, stride, d);
+        std::swap(xa, xb);
+    }
+    hipLaunchKernelGGL(k_emit_rows, grid, block, 0, gs, xa, p->d_cur, cnt, n, p->table + q0 * stride,
+                       p->table16 ? p->table16 + q0 * p->stride16 : nullptr, p->stride16);
+    SAFE_HIP_CHECK(hipGetLastError());
+    // the last row of the chunk is the base of the next one
+    SAFE_HIP_CHECK(hipMemcpyAsync(p->d_cur, p->table + (q1 - 1) * stride, stride * sizeof(int32_t),
+                                  hipMemcpyDeviceToDevice, gs));
+    if (static_cast<int64_t>(p->chunk_done.size()) <= ci) p->chunk_done.resize(ci + 1, nullptr);
+    if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[ci], gs));
+    p->enqueued = q1;
+    return SAFE_OK;
+}
+
+// Pipeline per chunk c:  draw thread: targets(c)  ||  workers: swaps(c-1)  ||  GPU: scan(c-2).
+// On return every row < upto has been enqueued on ctx->aux_stream.
+int perms_generate_until(safe_perms *p, int64_t upto) {
     upto = std::min<int64_t>(upto, p->count);
-    const int64_t k = p->k, n = p->n, stride = n + 1;
-    while (p->generated < upto) {
-        const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
-        const int64_t ci = q0 / kChunk;
-        const int b = static_cast<int>(ci & 1);
-        // the pinned staging buffer of two chunks ago must have been uploaded
-        if (q0 >= 2 * kChunk) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
-        uint32_t *h = p->h_targets[b];
-        for (int64_t q = 0; q < cnt; ++q) p->stream->shuffle_targets(k, h + q * std::max<int64_t>(k, 1));
-        if (k > 0) {
-            SAFE_HIP_CHECK(hipMemcpyAsync(p->d_targets, h, cnt * k * sizeof(uint32_t), hipMemcpyHostToDevice, gs));
-            SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
-            hipLaunchKernelGGL(k_apply_shuffles, dim3(cnt), dim3(64), static_cast<size_t>(k) * sizeof(int32_t), gs,
-                               p->d_movable, k, p->d_targets, p->d_drawn);
+    const int64_t k = p->k;
+    static const int W = [] {
+        const char *e = getenv("SAFE_HIP_SWAP_THREADS");
+        const int v = e ? atoi(e) : 4;
+        return v < 1 ? 1 : (v > 64 ? 64 : v);
+    }();
+    while (p->enqueued < upto) {
+        if (p->generated < p->count && p->generated < upto + kChunk && p->generated == p->swapping) {
+            // draw the next chunk (possibly one ahead of what was asked for: it overlaps the swaps)
+            const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
+            const int b = static_cast<int>((q0 / kChunk) & 1);
+            uint32_t *h = p->h_targets[b].data();
+            for (int64_t q = 0; q < cnt; ++q) p->stream->shuffle_targets(k, h + q * std::max<int64_t>(k, 1));
+            p->generated = q1;
         }
-        hipLaunchKernelGGL(k_compose_rows, dim3(1), dim3(1024), static_cast<size_t>(stride) * sizeof(int32_t), gs,
-                           p->d_movable, k, n, p->d_drawn, cnt, p->d_cur, p->table + q0 * stride,
-                           p->table16 ? p->table16 + q0 * p->stride16 : nullptr, p->stride16);
-        SAFE_HIP_CHECK(hipGetLastError());
-        if (static_cast<int64_t>(p->chunk_done.size()) <= ci) p->chunk_done.resize(ci + 1, nullptr);
-        if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], hipEventDisableTiming));
-        SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[ci], gs));
-        p->generated = q1;
+        if (p->swapping > p->enqueued) {
+            // swaps of the previous chunk ran while we were drawing: hand it to the GPU
+            SAFE_TRY(enqueue_chunk(p, p->enqueued / kChunk));
+        }
+        if (p->swapping < p->generated) {
+            const int64_t q0 = p->swapping, q1 = p->generated, cnt = q1 - q0;
+            const int b = static_cast<int>((q0 / kChunk) & 1);
+            // the pinned map buffer of two chunks ago must have been uploaded
+            if (q0 >= 2 * kChunk) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
+            for (int w = 0; w < W; ++w)
+                p->workers.emplace_back(swap_worker, p, p->h_targets[b].data(), p->h_maps[b], cnt, w, W);
+            p->swapping = q1;
+            if (p->generated >= std::min<int64_t>(p->count, upto + kChunk) || p->generated >= p->count) {
+                // nothing left to draw that could overlap: finish this chunk now
+                if (p->enqueued < upto) SAFE_TRY(enqueue_chunk(p, p->enqueued / kChunk));
+            }
+        }
     }
     return SAFE_OK;
 }
@@ -252,15 +269,15 @@ int perms_build_inverse(safe_perms *perms) {
 
 static void perms_free(safe_perms *p) {
     if (!p) return;
+    for (std::thread &t : p->workers) t.join();
+    p->workers.clear();
     for (int b = 0; b < 2; ++b) {
-        if (p->h_targets[b]) (void)hipHostFree(p->h_targets[b]);
+        if (p->h_maps[b]) (void)hipHostFree(p->h_maps[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
+        (void)hipFree(p->d_maps[b]);
     }
     for (hipEvent_t e : p->chunk_done)
         if (e) (void)hipEventDestroy(e);
-    (void)hipFree(p->d_targets);
-    (void)hipFree(p->d_drawn);
-    (void)hipFree(p->d_movable);
     (void)hipFree(p->d_cur);
     (void)hipFree(p->table);
     (void)hipFree(p->table16);
@@ -305,39 +322,23 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     const int64_t k = p->k, stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
     int rc = SAFE_OK;
     do {
-        // the LDS-resident shuffle / composition need k and n+1 ints in one workgroup's LDS
-        if ((std::max<int64_t>(k, stride)) * sizeof(int32_t) > 160 * 1024) {
-            safe_set_error("safe_perms_create: %lld rows exceed the LDS-resident permutation builder (max 40959)", (long long)n);
-            rc = SAFE_E_UNSUPPORTED;
-            break;
-        }
         if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
         if (n < 65535) {
             p->stride16 = (stride + 7) / 8 * 8;
             if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
         }
-        if ((rc = dev_alloc(&p->d_movable, k)) != SAFE_OK) break;
         if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
-        if ((rc = dev_alloc(&p->d_targets, kChunk * std::max<int64_t>(k, 1))) != SAFE_OK) break;
-        if ((rc = dev_alloc(&p->d_drawn, kChunk * std::max<int64_t>(k, 1))) != SAFE_OK) break;
+        if ((rc = dev_alloc(&p->d_maps[0], kChunk * stride)) != SAFE_OK) break;
+        if ((rc = dev_alloc(&p->d_maps[1], kChunk * stride)) != SAFE_OK) break;
         hipError_t e = hipSuccess;
         for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-            e = hipHostMalloc(reinterpret_cast<void **>(&p->h_targets[b]), kChunk * std::max<int64_t>(k, 1) * sizeof(uint32_t),
-                              hipHostMallocDefault);
+            p->h_targets[b].resize(kChunk * std::max<int64_t>(k, 1));
+            e = hipHostMalloc(reinterpret_cast<void **>(&p->h_maps[b]), kChunk * stride * sizeof(int32_t), hipHostMallocDefault);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged[b], hipEventDisableTiming);
         }
-        if (e == hipSuccess && k)
-            e = hipMemcpyAsync(p->d_movable, p->h_movable.data(), k * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux_stream);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
             e = hipGetLastError();
-        }
-        if (e == hipSuccess) {
-            e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_apply_shuffles),
-                                    hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-            if (e == hipSuccess)
-                e = hipFuncSetAttribute(reinterpret_cast<const void *>(k_compose_rows),
-                                        hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
         }
         if (e != hipSuccess) {
             safe_set_error("safe_perms_create: %s", hipGetErrorString(e));
