@@ -98,6 +98,7 @@ struct safe_nbr {
     // SELL-64
     int64_t n_slices = 0;
     int32_t *sell_row = nullptr;    // [n_slices*64] original row id, -1 = padding lane
+    int32_t *sell_pos = nullptr;    // [n] position of row i in sell_row (inverse map)
     int64_t *slice_off = nullptr;   // [n_slices+1] offset into sell_col (entries)
     int32_t *slice_width = nullptr; // [n_slices]
     int32_t *sell_col = nullptr;    // [slice_off[n_slices]] column id, n = padding (zero row)

@@ -614,13 +614,32 @@ __device__ __forceinline__ unsigned int vextract(const uint32_t (&c)[LEVELS], in
     return v;
 }
 
+// In-register transpose of a 32 x 32 bit matrix (rows = words): afterwards bit l of a[b] is
+// what bit b of a[l] was.  Used to turn vertical counters (one word per level) into one
+// value per attribute: 80 masked swaps instead of 32 x levels bit extractions.
+__device__ __forceinline__ void transpose32(uint32_t (&a)[32]) {
+#pragma unroll
+    for (int j = 16; j != 0; j >>= 1) {
+        const uint32_t m = j == 16 ? 0x0000FFFFu : j == 8 ? 0x00FF00FFu : j == 4 ? 0x0F0F0F0Fu : j == 2 ? 0x33333333u : 0x55555555u;
+#pragma unroll
+        for (int k = 0; k < 32; ++k) {
+            if ((k & j) == 0) {
+                const uint32_t t = ((a[k] >> j) ^ a[k + j]) & m;
+                a[k] ^= t << j;
+                a[k + j] ^= t;
+            }
+        }
+    }
+}
+
 template <int CL, bool SCALED>
 __global__ __launch_bounds__(256) void k_permtest_bits(
     int64_t n, int64_t n_perm, const uint16_t *__restrict__ cur16, int64_t stride16,
     const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
     const int32_t *__restrict__ slice_width, const uint16_t *__restrict__ sell_col2, int64_t n_slices,
     const uint2 *__restrict__ bbits, int64_t n_tasks, const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit,
-    unsigned int *__restrict__ queue, int64_t mloc, unsigned long long *__restrict__ gl_counts, double *__restrict__ ns_out) {
+    unsigned int *__restrict__ queue, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_pad,
+    double *__restrict__ ns_out) {
     extern __shared__ unsigned int lds[];
     const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2 at LDS address 0, 16-B padded
     uint2 *T = reinterpret_cast<uint2 *>(lds);
@@ -729,38 +748,54 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         vflush<CL>(l0, lp0);
         vflush<CL>(l1, lp1);
 
-        // ---- epilogue: un-slice the counters of this permutation range and add them to the
-        //      per-(neighborhood, attribute) totals (#greater << 32 | #less)
+        // ---- epilogue: un-slice the counters of this permutation range (bit-matrix transpose:
+        //      rows 0..15 = #greater levels, rows 16..31 = #less levels -> word b = less<<16 | greater
+        //      of attribute b) and add them to the totals, laid out [attribute][SELL position] so
+        //      that the 64 lanes of a wave update one contiguous 256-byte run
         const bool live = row >= 0;
-        const int64_t obase = static_cast<int64_t>(live ? row : 0) * mloc;
+        const int64_t spos = s * 64 + lane;
 #pragma unroll
         for (int half = 0; half < 2; ++half) {
+            uint32_t m[32];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                m[l] = l < CL ? (half ? g1[l < CL ? l : 0] : g0[l < CL ? l : 0]) : 0u;
+                m[16 + l] = l < CL ? (half ? l1[l < CL ? l : 0] : l0[l < CL ? l : 0]) : 0u;
+            }
+            transpose32(m);
+#pragma unroll
             for (int bit = 0; bit < 32; ++bit) {
                 const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
-                if (jc >= mloc) break;
-                const unsigned long long ng = half ? vextract<CL>(g1, bit) : vextract<CL>(g0, bit);
-                const unsigned long long nl = half ? vextract<CL>(l1, bit) : vextract<CL>(l0, bit);
-                if (live && (ng | nl)) atomicAdd(&gl_counts[obase + jc], (ng << 32) | nl);
-                if (live && ns_out && p_begin == 0)
-                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit));
+                if (jc < mloc && active && m[bit]) atomicAdd(&gl_counts[jc * n_pad + spos], m[bit]);
             }
+        }
+        if (ns_out && p_begin == 0 && live) {
+            const int64_t obase = static_cast<int64_t>(row) * mloc;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+                for (int bit = 0; bit < 32; ++bit) {
+                    const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                    if (jc >= mloc) break;
+                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit));
+                }
         }
         __syncthreads();
     }
 }
 
 // counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472)
-__global__ __launch_bounds__(256) void k_counts_finalize(const unsigned long long *__restrict__ gl_counts, int64_t n,
+__global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ gl_counts, int64_t n_pad,
+                                                         const int32_t *__restrict__ sell_pos, int64_t n,
                                                          int64_t mloc, int64_t n_perm, PermOut out) {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
     const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
     bool hit = false;
     if (i < n && c < mloc) {
         const int64_t o = i * mloc + c;
-        const unsigned long long gl = gl_counts[o];
+        const unsigned int gl = gl_counts[c * n_pad + sell_pos[i]];   // #less << 16 | #greater
         const unsigned int P = static_cast<unsigned int>(n_perm);
-        const unsigned int cneg = P - static_cast<unsigned int>(gl >> 32);            // #(S_p <= S_obs)
-        const unsigned int cpos = P - static_cast<unsigned int>(gl & 0xFFFFFFFFull);  // #(S_p >= S_obs)
+        const unsigned int cneg = P - (gl & 0xFFFFu);                 // #(S_p <= S_obs)
+        const unsigned int cpos = P - (gl >> 16);                     // #(S_p >= S_obs)
         if (out.mode == 1) {
             out.counts_neg[o] = static_cast<double>(cneg);
             out.counts_pos[o] = static_cast<double>(cpos);
@@ -1099,13 +1134,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     safe_trace("launch_bits: tasks built");
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
-    unsigned long long *d_gl = nullptr;
+    unsigned int *d_gl = nullptr;
     SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
     SAFE_TRY(dev_alloc(&d_queue, n_launch));
-    SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n) * mloc * sizeof(unsigned long long), reinterpret_cast<void **>(&d_gl)));
+    const int64_t n_pad = nbr->n_slices * 64;
+    SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), reinterpret_cast<void **>(&d_gl)));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, n_launch * sizeof(unsigned int), ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n) * mloc * sizeof(unsigned long long), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), ctx->stream));
     safe_trace("launch_bits: buffers ready");
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
@@ -1138,7 +1174,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         hipLaunchKernelGGL((k_permtest_bits<CLV, SC>), dim3(blocks), dim3(256), lds_bytes, ks, n, P,                  \
                            perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,          \
                            nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, \
-                           d_gl, out.ns)
+                           d_gl, n_pad, out.ns)
         if (wide && scaled) LAUNCH_BITS(16, true);
         else if (wide) LAUNCH_BITS(16, false);
         else if (scaled) LAUNCH_BITS(10, true);
@@ -1149,8 +1185,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    hipLaunchKernelGGL(k_counts_finalize, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_gl, n, mloc,
-                       P, out);
+    hipLaunchKernelGGL(k_counts_finalize, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_gl, n_pad,
+                       nbr->sell_pos, n, mloc, P, out);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));

@@ -323,6 +323,7 @@ static void nbr_free(safe_nbr *nbr) {
     (void)hipFree(nbr->row_ptr);
     (void)hipFree(nbr->col);
     (void)hipFree(nbr->sell_row);
+    (void)hipFree(nbr->sell_pos);
     (void)hipFree(nbr->slice_off);
     (void)hipFree(nbr->slice_width);
     (void)hipFree(nbr->sell_col);
@@ -381,6 +382,8 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
     nbr->n_slices = ceil_div(n, 64);
     std::vector<int32_t> sell_row(nbr->n_slices * 64, -1);
     std::copy(order.begin(), order.end(), sell_row.begin());
+    std::vector<int32_t> sell_pos(n);
+    for (int64_t t = 0; t < n; ++t) sell_pos[order[t]] = static_cast<int32_t>(t);
     nbr->h_slice_width.assign(nbr->n_slices, 0);
     nbr->h_slice_off.assign(nbr->n_slices + 1, 0);
     for (int64_t s = 0; s < nbr->n_slices; ++s) {
@@ -394,6 +397,8 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
     SAFE_TRY(dev_alloc(&nbr->row_ptr, n + 1));
     SAFE_TRY(dev_alloc(&nbr->col, nnz));
     SAFE_TRY(dev_alloc(&nbr->sell_row, nbr->n_slices * 64));
+    SAFE_TRY(dev_alloc(&nbr->sell_pos, n));
+    SAFE_HIP_CHECK(hipMemcpyAsync(nbr->sell_pos, sell_pos.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SAFE_TRY(dev_alloc(&nbr->slice_off, nbr->n_slices + 1));
     SAFE_TRY(dev_alloc(&nbr->slice_width, nbr->n_slices));
     SAFE_TRY(dev_alloc(&nbr->sell_col, nbr->sell_entries));
