@@ -148,7 +148,6 @@ struct safe_perms {
     std::vector<uint32_t> h_targets[2];            // swap targets of a chunk (draw thread -> workers)
     int32_t *h_maps[2] = {nullptr, nullptr};       // pinned: row maps of a chunk (workers -> GPU)
     hipEvent_t staged[2] = {nullptr, nullptr};
-    std::vector<std::thread> workers;              // swap workers of the chunk in flight
     int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] scan ping-pong
     int32_t *d_cur = nullptr;       // [n+1] running composition (last emitted row)
     int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)

@@ -1,0 +1,9 @@
+// Host draw stream of the legacy NumPy permutation (draws.cpp).
+#pragma once
+#include <cstdint>
+
+struct DrawStream;
+DrawStream *draw_stream_new(uint32_t seed);
+void draw_stream_free(DrawStream *s);
+// accepted swap targets of one shuffle of k items in step order: steps[s] = j for i = k-1-s
+void draw_stream_targets(DrawStream *s, int64_t k, uint32_t *steps);

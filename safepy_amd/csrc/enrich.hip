@@ -1100,7 +1100,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // stream for the next span overlaps this span's kernel.  Inside a launch, tasks = (word
     // group, group of 4 adjacent slices, permutation sub-range), sized to about equal cost
     // with several per workgroup slot, heaviest first for the dynamic queue.
-    int64_t span = 256;
+    int64_t span = 128;
     if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
     span = std::min<int64_t>(span, std::max<int64_t>(P, 1));
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);

@@ -6,8 +6,8 @@
 // Split of the work.  The only inherently sequential part is the draw stream: how many
 // 32-bit outputs a shuffle consumes depends on its rejections, so permutation q+1 cannot
 // start before q has finished drawing.  The host therefore produces just the accepted swap
-// targets j[q][i] (bulk MT19937 generation + a branch-light rejection loop, ~1.5 ns per
-// draw) on one thread.  The rest is parallel and runs chunk by chunk, overlapping the draw
+// targets j[q][i] (draws.cpp: bulk MT19937 generation + batch-resolved rejection, well under
+// 1 ns per draw) on one thread.  The rest is parallel and runs chunk by chunk, overlapping the draw
 // thread's next chunk and the enrichment kernel of the previous one:
 //   host workers       replay the swaps of each permutation on a copy of indx_vals (independent
 //                      across permutations: a few threads keep up with the draw thread) and
@@ -17,88 +17,13 @@
 //                      log-depth parallel scan on the GPU, emitting the composed table rows
 #include <algorithm>
 #include <random>
+#include <condition_variable>
+#include <functional>
+#include <mutex>
 #include <thread>
 
 #include "common.h"
-
-struct MT19937 {
-    uint32_t mt[624];
-    int pos;
-
-    explicit MT19937(uint32_t seed) {
-        mt[0] = seed;
-        for (int i = 1; i < 624; ++i) mt[i] = 1812433253u * (mt[i - 1] ^ (mt[i - 1] >> 30)) + static_cast<uint32_t>(i);
-        pos = 624;
-    }
-
-    void refill() {
-        auto twist = [](uint32_t u, uint32_t v) { return (((u & 0x80000000u) | (v & 0x7fffffffu)) >> 1) ^ ((v & 1u) ? 0x9908b0dfu : 0u); };
-        int i = 0;
-        for (; i < 624 - 397; ++i) mt[i] = mt[i + 397] ^ twist(mt[i], mt[i + 1]);
-        for (; i < 623; ++i) mt[i] = mt[i + 397 - 624] ^ twist(mt[i], mt[i + 1]);
-        mt[623] = mt[396] ^ twist(mt[623], mt[0]);
-        pos = 0;
-    }
-
-    // tempered outputs in bulk (the tempering loop vectorises)
-    void bulk(uint32_t *out, size_t count) {
-        size_t done = 0;
-        while (done < count) {
-            if (pos == 624) refill();
-            const size_t take = std::min<size_t>(624 - pos, count - done);
-            for (size_t i = 0; i < take; ++i) {
-                uint32_t y = mt[pos + i];
-                y ^= y >> 11;
-                y ^= (y << 7) & 0x9d2c5680u;
-                y ^= (y << 15) & 0xefc60000u;
-                y ^= y >> 18;
-                out[done + i] = y;
-            }
-            pos += static_cast<int>(take);
-            done += take;
-        }
-    }
-};
-
-// The draw stream: raw outputs are buffered so that leftovers of one shuffle feed the next
-// (the legacy stream is continuous across np.random.permutation calls).
-struct DrawStream {
-    MT19937 rng;
-    std::vector<uint32_t> raw;
-    size_t rp = 0, avail = 0;
-
-    explicit DrawStream(uint32_t seed) : rng(seed), raw(1 << 14) {}
-
-    // accepted swap targets of one shuffle of k items: j[i] for i = k-1 .. 1  (j[0] unused)
-    void shuffle_targets(int64_t k, uint32_t *j) {
-        int64_t i = k - 1;
-        while (i > 0) {
-            uint32_t mask = static_cast<uint32_t>(i);
-            mask |= mask >> 1;
-            mask |= mask >> 2;
-            mask |= mask >> 4;
-            mask |= mask >> 8;
-            mask |= mask >> 16;
-            const int64_t lo = mask >> 1;          // the mask is unchanged while i is in (lo, mask]
-            while (i > lo) {
-                if (rp == avail) {
-                    rng.bulk(raw.data(), raw.size());
-                    avail = raw.size();
-                    rp = 0;
-                }
-                const uint32_t *r = raw.data() + rp;
-                const size_t n = avail - rp;
-                size_t t = 0;
-                while (t < n && i > lo) {
-                    const uint32_t v = r[t++] & mask;
-                    j[i] = v;                       // rejected draws are overwritten by the next one
-                    i -= (v <= static_cast<uint32_t>(i));
-                }
-                rp += t;
-            }
-        }
-    }
-};
+#include "draws.h"
 
 static uint32_t entropy_seed() {
     std::random_device rd;
@@ -155,6 +80,70 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 // --------------------------------------------------------------------------------------
 static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
 
+// A small process-wide pool of swap workers (creating threads per chunk costs more than the
+// chunk's draws).  One job at a time: parallel-for over the permutations of a chunk.
+class SwapPool {
+public:
+    static SwapPool &get() {
+        static SwapPool pool;
+        return pool;
+    }
+    // runs fn(w, W) on every worker; returns immediately
+    void submit(std::function<void(int, int)> fn) {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+        fn_ = std::move(fn);
+        pending_ = static_cast<int>(threads_.size());
+        ++epoch_;
+        cv_work_.notify_all();
+    }
+    void wait() {
+        std::unique_lock<std::mutex> lk(mu_);
+        cv_done_.wait(lk, [&] { return pending_ == 0; });
+    }
+
+private:
+    SwapPool() {
+        const char *e = getenv("SAFE_HIP_SWAP_THREADS");
+        int W = e ? atoi(e) : 4;
+        W = W < 1 ? 1 : (W > 64 ? 64 : W);
+        for (int w = 0; w < W; ++w) threads_.emplace_back([this, w, W] { loop(w, W); });
+    }
+    ~SwapPool() {
+        {
+            std::unique_lock<std::mutex> lk(mu_);
+            stop_ = true;
+            cv_work_.notify_all();
+        }
+        for (std::thread &t : threads_) t.join();
+    }
+    void loop(int w, int W) {
+        uint64_t seen = 0;
+        for (;;) {
+            std::function<void(int, int)> fn;
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                cv_work_.wait(lk, [&] { return stop_ || epoch_ != seen; });
+                if (stop_) return;
+                seen = epoch_;
+                fn = fn_;
+            }
+            fn(w, W);
+            {
+                std::unique_lock<std::mutex> lk(mu_);
+                if (--pending_ == 0) cv_done_.notify_all();
+            }
+        }
+    }
+    std::mutex mu_;
+    std::condition_variable cv_work_, cv_done_;
+    std::vector<std::thread> threads_;
+    std::function<void(int, int)> fn_;
+    uint64_t epoch_ = 0;
+    int pending_ = 0;
+    bool stop_ = false;
+};
+
 // swaps of permutations [w, cnt) step W of one chunk -> row maps (host worker thread)
 static void swap_worker(const safe_perms *p, const uint32_t *targets, int32_t *maps, int64_t cnt, int w, int W) {
     const int64_t k = p->k, stride = p->n + 1;
@@ -163,7 +152,7 @@ static void swap_worker(const safe_perms *p, const uint32_t *targets, int32_t *m
     for (int64_t q = w; q < cnt; q += W) {
         const uint32_t *j = targets + q * std::max<int64_t>(k, 1);
         memcpy(a.data(), mov, k * sizeof(int32_t));
-        for (int64_t i = k - 1; i > 0; --i) std::swap(a[i], a[j[i]]);     // safe_extras.py:58 / legacy shuffle
+        for (int64_t i = k - 1, st = 0; i > 0; --i, ++st) std::swap(a[i], a[j[st]]);     // safe_extras.py:58 / legacy shuffle
         int32_t *m = maps + q * stride;
         for (int64_t i = 0; i < stride; ++i) m[i] = static_cast<int32_t>(i);
         for (int64_t t = 0; t < k; ++t) m[mov[t]] = a[t];
@@ -177,8 +166,8 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     const int64_t n = p->n, stride = n + 1;
     const int64_t q0 = ci * kChunk, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
-    for (std::thread &t : p->workers) t.join();
-    p->workers.clear();
+    SwapPool::get().wait();
+    safe_trace("  gen: workers joined");
     int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
     SAFE_HIP_CHECK(hipMemcpyAsync(xa, p->h_maps[b], cnt * stride * sizeof(int32_t), hipMemcpyHostToDevice, gs));
     SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
@@ -197,6 +186,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], hipEventDisableTiming));
     SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[ci], gs));
     p->enqueued = q1;
+    safe_trace("  gen: chunk enqueued");
     return SAFE_OK;
 }
 
@@ -205,19 +195,15 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
 int perms_generate_until(safe_perms *p, int64_t upto) {
     upto = std::min<int64_t>(upto, p->count);
     const int64_t k = p->k;
-    static const int W = [] {
-        const char *e = getenv("SAFE_HIP_SWAP_THREADS");
-        const int v = e ? atoi(e) : 4;
-        return v < 1 ? 1 : (v > 64 ? 64 : v);
-    }();
     while (p->enqueued < upto) {
         if (p->generated < p->count && p->generated < upto + kChunk && p->generated == p->swapping) {
             // draw the next chunk (possibly one ahead of what was asked for: it overlaps the swaps)
             const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
             const int b = static_cast<int>((q0 / kChunk) & 1);
             uint32_t *h = p->h_targets[b].data();
-            for (int64_t q = 0; q < cnt; ++q) p->stream->shuffle_targets(k, h + q * std::max<int64_t>(k, 1));
+            for (int64_t q = 0; q < cnt; ++q) draw_stream_targets(p->stream, k, h + q * std::max<int64_t>(k, 1));
             p->generated = q1;
+            safe_trace("  gen: chunk drawn");
         }
         if (p->swapping > p->enqueued) {
             // swaps of the previous chunk ran while we were drawing: hand it to the GPU
@@ -228,8 +214,12 @@ int perms_generate_until(safe_perms *p, int64_t upto) {
             const int b = static_cast<int>((q0 / kChunk) & 1);
             // the pinned map buffer of two chunks ago must have been uploaded
             if (q0 >= 2 * kChunk) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
-            for (int w = 0; w < W; ++w)
-                p->workers.emplace_back(swap_worker, p, p->h_targets[b].data(), p->h_maps[b], cnt, w, W);
+            safe_trace("  gen: staging buffer free");
+            {
+                const uint32_t *tg = p->h_targets[b].data();
+                int32_t *mp = p->h_maps[b];
+                SwapPool::get().submit([p, tg, mp, cnt](int w, int W) { swap_worker(p, tg, mp, cnt, w, W); });
+            }
             p->swapping = q1;
             if (p->generated >= std::min<int64_t>(p->count, upto + kChunk) || p->generated >= p->count) {
                 // nothing left to draw that could overlap: finish this chunk now
@@ -269,8 +259,7 @@ int perms_build_inverse(safe_perms *perms) {
 
 static void perms_free(safe_perms *p) {
     if (!p) return;
-    for (std::thread &t : p->workers) t.join();
-    p->workers.clear();
+    SwapPool::get().wait();
     for (int b = 0; b < 2; ++b) {
         if (p->h_maps[b]) (void)hipHostFree(p->h_maps[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
@@ -282,7 +271,7 @@ static void perms_free(safe_perms *p) {
     (void)hipFree(p->table);
     (void)hipFree(p->table16);
     (void)hipFree(p->inverse_t);
-    delete p->stream;
+    draw_stream_free(p->stream);
     delete p;
 }
 
@@ -292,14 +281,15 @@ int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_i
     SAFE_REQUIRE(n_items >= 0 && count >= 0, "safe_rng_permutations_host: negative size");
     SAFE_REQUIRE(n_items == 0 || count == 0 || (values && out), "safe_rng_permutations_host: NULL argument");
     SAFE_REQUIRE(n_items < (1ll << 32), "safe_rng_permutations_host: n_items too large");
-    DrawStream ds(seed);
+    DrawStream *ds = draw_stream_new(seed);
     std::vector<uint32_t> j(std::max<int64_t>(n_items, 1));
     for (int64_t c = 0; c < count; ++c) {
         int64_t *dst = out + c * n_items;
         memcpy(dst, values, n_items * sizeof(int64_t));
-        ds.shuffle_targets(n_items, j.data());
-        for (int64_t i = n_items - 1; i > 0; --i) std::swap(dst[i], dst[j[i]]);
+        draw_stream_targets(ds, n_items, j.data());
+        for (int64_t i = n_items - 1, st = 0; i > 0; --i, ++st) std::swap(dst[i], dst[j[st]]);
     }
+    draw_stream_free(ds);
     return SAFE_OK;
 }
 
@@ -318,7 +308,7 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     for (int64_t i = 0; i < n; ++i)
         if (movable_host[i]) p->h_movable.push_back(static_cast<int32_t>(i));
     p->k = static_cast<int64_t>(p->h_movable.size());
-    p->stream = new DrawStream(has_seed ? seed : entropy_seed());
+    p->stream = draw_stream_new(has_seed ? seed : entropy_seed());
     const int64_t k = p->k, stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
     int rc = SAFE_OK;
     do {
