@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--metric', default='shortpath_weighted_layout')
     ap.add_argument('--radius', type=float, default=0.1)
     ap.add_argument('--cpu-perms', type=int, default=8, help='permutations timed for the CPU baseline (0 = skip)')
+    ap.add_argument('--extras', type=int, default=1, help='also time the HBM-bound kernels (K1 distance, K4 hypergeometric)')
     return ap.parse_args()
 
 
@@ -68,6 +69,50 @@ def cpu_baseline(a_dense, b, sample_perms):
             'seconds_per_permutation': dt / sample_perms, 'blas': blas}
 
 
+def hbm_kernels(ctx, torch, np, be):
+    """The two HBM-bound kernels of the path at BASELINE.json configs[3] size, timed with HIP
+    events on the context stream: K1 fused all-pairs distance + threshold writing the reference's
+    int64 [N,N] layout (N = 20 000: 3.2 GB), and K4 hypergeometric tail + NES + binarisation
+    (N = 20 000 x M = 2 000 binary attributes: reads X, writes p / nes / nes_binary)."""
+    out = {}
+    n = 20000
+    rng = np.random.default_rng(4)
+    xy = rng.uniform(size=(n, 2))
+    t_xy = torch.from_numpy(xy).to('cuda')
+    t_mask = torch.empty((n, n), dtype=torch.int64, device='cuda')
+    nr = 0.1 * (xy[:, 0].max() - xy[:, 0].min())
+    for _ in range(2):
+        ctx.euclidean_dense(t_xy.data_ptr(), n, nr, t_mask.data_ptr(), None)
+    ctx.timer_start()
+    reps = 5
+    for _ in range(reps):
+        ctx.euclidean_dense(t_xy.data_ptr(), n, nr, t_mask.data_ptr(), None)
+    ms = ctx.timer_stop_ms() / reps
+    alg = 16 * n + 8 * n * n
+    out['k_euclid_dense'] = {'bound': 'hbm', 'workload': 'N=%d, int64 [N,N] membership (reference layout)' % n,
+                             'kernel_ms': ms, 'algorithmic_bytes': alg, 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS,
+                             'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS}
+    del t_mask
+    m = 2000
+    b = (rng.uniform(size=(n, m)) < 0.01).astype(np.float32)
+    nbr = be.Neighborhoods.euclidean(ctx, xy, nr)
+    attr = be.Attributes.from_host(ctx, b)
+    bufs = [torch.empty((n, m), dtype=torch.float64, device='cuda') for _ in range(3)] + \
+           [torch.empty((m,), dtype=torch.float64, device='cuda')]
+    ptrs = [t.data_ptr() for t in bufs]
+    be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
+    be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
+    name, ms, _ = ctx.last_kernel()
+    alg = n * m * 8 * 4                       # read X, write p, nes, nes_binary
+    out[name] = {'bound': 'hbm', 'workload': 'N=%d x M=%d binary attributes, %d members per neighborhood on average'
+                                             % (n, m, int(nbr.nnz / n)),
+                 'kernel_ms': ms, 'algorithmic_bytes': alg, 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS,
+                 'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS}
+    attr.close()
+    nbr.close()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -83,7 +128,7 @@ def main():
     import torch
     import safepy_amd
     from safepy_amd import backend as be
-    from safepy_amd import workloads
+    from safepy_amd import workloads, sharding
 
     torch.cuda.set_device(local_rank)
     dist = None
@@ -111,7 +156,7 @@ def main():
 
     out = [torch.empty((n, m), dtype=torch.float64, device='cuda') for _ in range(5)]
     enriched = torch.empty((m,), dtype=torch.float64, device='cuda')
-    gathered = [torch.empty((n, m), dtype=torch.float64, device='cuda') for _ in range(world)] if world > 1 else None
+    gathered = [None]
     table = be.nes_table(P)
     kernel_ms = []
 
@@ -120,16 +165,15 @@ def main():
         stats = attr.stats()                                  # dispatch rule + >50 % NaN check inputs
         flags = attr.row_flags()
         if world > 1:                                         # indx_vals must come from the FULL matrix
-            f = torch.from_numpy(flags).to('cuda')
-            dist.all_reduce(f, op=dist.ReduceOp.MAX)
-            flags = f.cpu().numpy()
+            flags = sharding.reduce_row_flags(flags)
+            stats = sharding.reduce_stats(stats)
             attr.set_row_flags(flags)
         perms = be.Permutations(ctx, n, flags, P, 0)          # seeded legacy stream (host) + upload
         be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05,
                          [t.data_ptr() for t in out] + [enriched.data_ptr()], table=table)
         kernel_ms.append(ctx.last_kernel()[1])
         if world > 1:
-            dist.all_gather(gathered, out[3])                 # NES slabs over RCCL / xGMI
+            gathered[0] = sharding.gather_columns(out[3], m * world)   # NES blocks over RCCL / xGMI
         perms.close()
         attr.close()
         return stats
@@ -158,17 +202,26 @@ def main():
         ms_per_step = 1e3 * elapsed / args.steps
         units = float(n) * m * P * world                      # node-attribute enrichments per step, all ranks
         value = units / (elapsed / args.steps)
-        kname = ctx.last_kernel()[0]
-        k_ms = float(np.mean(kernel_ms))
-        # algorithmic HBM bytes of one launch: read B once (f32), the index
-        # tables (int32 [P, n+1]), the SELL membership, write five f64 [n,m] outputs
-        alg_bytes = n * m * 4 + P * (n + 1) * 4 + int(nbr.nnz) * 4 + 5 * n * m * 8
+        kname, _, launches = ctx.last_kernel()
+        k_ms = float(np.mean(kernel_ms))                      # average duration of ONE launch (HIP events)
+        launches = max(int(launches), 1)
+        span = int(np.ceil(P / launches))                     # permutations per launch
+        # Algorithmic HBM bytes of ONE launch of the dominant kernel:
+        # SURVEY 8(d) compulsory traffic = one read of the attribute block, the permutation rows it
+        # consumes, the membership, and one read-modify-write of its per-(node, attribute) counters.
+        n_wg = -(-m // 64)
+        n_pad = -(-n // 64) * 64
+        if kname == 'k_permtest_bits':
+            alg_bytes = 8 * (n + 1) * n_wg + 2 * (n + 8) * span + 2 * int(nbr.nnz) + 2 * 4 * n_pad * m
+        else:
+            alg_bytes = n * m * 4 + P * (n + 1) * 4 + int(nbr.nnz) * 4 + 5 * n * m * 8
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
         line = {
             'metric': 'node-attribute enrichments/sec (nodes x attrs x perms), compute_pvalues permutation test',
             'value': value, 'unit': 'enrichments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
             'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'f64', 'data': 'synthetic',
+            'dtype': 'u1 (bit-sliced integer counts; f64 outputs)' if kname != 'k_permtest_gather' else 'f64',
+            'data': 'synthetic',
             'config': {'workload': 'configs[1]: Costanzo-2016-shaped surrogate, %d nodes x %d GO-BP-like binary attributes '
                                    'x %d permutations, metric %s r=%g, seed 0' % (n, m, P, args.metric, args.radius),
                        'nodes': n, 'attributes_per_gpu': m, 'permutations': P, 'membership_nnz': int(nbr.nnz),
@@ -176,16 +229,19 @@ def main():
                        'parallelism': 'attribute shards x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                          'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': k_ms,
+                         'launches_per_step': launches, 'permutations_per_launch': span,
                          'algorithmic_bytes': alg_bytes,
-                         'note': 'K5 is not HBM-bound (SURVEY 8d): its compulsory HBM traffic is ~0.7 GB; the binding '
-                                 'resource is the on-chip gather (L2/LDS) + f64 VALU. sparse-minimal adds = nnz*M*(P+1)',
-                         'gather_adds_per_s': float(nbr.nnz) * m * (P + 1) / (k_ms * 1e-3)},
-            'kernel_share_of_step': k_ms / ms_per_step,
+                         'binding_resource': 'VALU issue + LDS gather (not HBM, not MFMA): see DESIGN.md section 4 and '
+                                             'profiles/ for the PMC evidence',
+                         'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3)},
+            'kernel_share_of_step': k_ms * launches / ms_per_step,
         }
         if args.cpu_perms > 0:
             a_dense = sf.neighborhoods
             line['cpu_baseline'] = cpu_baseline(a_dense, b_host, args.cpu_perms)
             line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
+        if args.extras and world == 1:
+            line['hbm_bound_kernels'] = hbm_kernels(ctx, torch, np, be)
         print(json.dumps(line))
     if world > 1:
         dist.barrier()

@@ -1,0 +1,119 @@
+"""Attribute sharding of compute_pvalues across the GPUs of a node.
+
+The reference's only multi-process pattern (safepy/safe.py:1321-1361) splits the attribute
+columns with `np.array_split` over `cpu_count()` worker processes, runs the whole pipeline in
+each and concatenates the NES blocks (`np.concatenate(axis=1)`, safe.py:1355).  The same
+decomposition here: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm),
+rank r owns the column block `column_shards(m, world)[r]`; the membership and the seeded
+permutation stream are replicated (same seed => identical tables, no broadcast).  The path has
+exactly two exchange steps:
+
+  * whole-matrix facts that must NOT be computed per shard -- which rows carry a value
+    (`indx_vals`, safe_extras.py:51; hypergeometric population, safe.py:574-578) and the
+    dispatch / warning statistics (safe.py:453-463): an all-reduce (MAX / SUM) of a few bytes;
+  * the final all-gather of every rank's [N, M_r] result block (the `np.concatenate`).
+
+The collective helpers work on CPU tensors with the gloo backend as well, which is how the
+N > 1 plumbing is tested without GPUs (tests/test_sharding_gloo.py).
+"""
+import numpy as np
+
+
+def column_shards(m, world):
+    """[(c0, c1)] per rank, np.array_split semantics (safe.py:1339)."""
+    base, extra = divmod(int(m), int(world))
+    out, c0 = [], 0
+    for r in range(world):
+        c1 = c0 + base + (1 if r < extra else 0)
+        out.append((c0, c1))
+        c0 = c1
+    return out
+
+
+def _dist():
+    import torch.distributed as dist
+    return dist
+
+
+def _device_for(group=None):
+    import torch
+    dist = _dist()
+    backend = dist.get_backend(group)
+    return torch.device('cuda', torch.cuda.current_device()) if backend == 'nccl' else torch.device('cpu')
+
+
+def reduce_row_flags(local_flags, group=None):
+    """Rows holding at least one value in ANY rank's columns: element-wise MAX all-reduce of the
+    per-shard uint8 flags.  Returns a NumPy uint8 array (identical on every rank)."""
+    import torch
+    dist = _dist()
+    t = torch.from_numpy(np.array(local_flags, dtype=np.uint8, copy=True)).to(_device_for(group))   # never aliases the input
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    return t.cpu().numpy()
+
+
+def reduce_stats(local_stats, group=None):
+    """Whole-matrix statistics from per-shard ones: n_other / n_non_integer add up, the worst
+    NaN column is a maximum (safe.py:453-463).  `n_rows_with_value` must come from
+    reduce_row_flags, not from here."""
+    import torch
+    dist = _dist()
+    dev = _device_for(group)
+    sums = torch.tensor([local_stats['n_other'], local_stats['n_non_integer']], dtype=torch.int64, device=dev)
+    mx = torch.tensor([local_stats['max_nan_col']], dtype=torch.int64, device=dev)
+    dist.all_reduce(sums, op=dist.ReduceOp.SUM, group=group)
+    dist.all_reduce(mx, op=dist.ReduceOp.MAX, group=group)
+    return {'n_other': int(sums[0]), 'n_non_integer': int(sums[1]), 'max_nan_col': int(mx[0])}
+
+
+def gather_columns(local, m_total, group=None):
+    """All-gather of the per-rank [N, M_r] blocks into the full [N, M] matrix on every rank
+    (the reference's np.concatenate(axis=1), safe.py:1355).  `local` is a 2-D torch tensor on
+    the backend's device; blocks may differ by one column (array_split), so they travel padded
+    to the widest block."""
+    import torch
+    dist = _dist()
+    world = dist.get_world_size(group)
+    shards = column_shards(m_total, world)
+    widest = max(c1 - c0 for c0, c1 in shards)
+    n = local.shape[0]
+    if local.shape[1] != widest:
+        padded = torch.zeros((n, widest), dtype=local.dtype, device=local.device)
+        padded[:, :local.shape[1]] = local
+    else:
+        padded = local.contiguous()
+    parts = [torch.empty_like(padded) for _ in range(world)]
+    dist.all_gather(parts, padded, group=group)
+    return torch.cat([parts[r][:, :shards[r][1] - shards[r][0]] for r in range(world)], dim=1)
+
+
+def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
+                          neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05,
+                          group=None, gather=('nes',)):
+    """compute_pvalues_by_randomization for this rank's column block + the two exchange steps.
+    `local_attr_host`: this rank's [N, M_r] block of node2attribute (NumPy).  Returns a dict
+    with the local blocks (NumPy) and, for every name in `gather`, the all-gathered full matrix
+    under 'full_<name>'.  Needs a HIP device on every rank (no CPU fallback)."""
+    import torch
+    from . import backend as be
+    attr = be.Attributes.from_host(ctx, local_attr_host)
+    n, mloc = attr.n, attr.m
+    flags = reduce_row_flags(attr.row_flags(), group)          # global indx_vals
+    attr.set_row_flags(flags)
+    perms = be.Permutations(ctx, n, flags, int(num_permutations), random_seed)
+    names = ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')
+    dev = torch.device('cuda', ctx.device)
+    bufs = {k: torch.empty((n, mloc), dtype=torch.float64, device=dev) for k in names}
+    enriched = torch.empty((mloc,), dtype=torch.float64, device=dev)
+    try:
+        be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
+                         [bufs[k].data_ptr() for k in names] + [enriched.data_ptr()])
+        ctx.sync()
+        out = {k: v.cpu().numpy() for k, v in bufs.items()}
+        out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
+        for k in gather:
+            out['full_' + k] = gather_columns(bufs[k], m_total, group).cpu().numpy()
+        return out
+    finally:
+        perms.close()
+        attr.close()

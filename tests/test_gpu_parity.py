@@ -402,3 +402,57 @@ def test_integer_forms_large_support_and_many_permutations(amd, monkeypatch, pat
     cn_want, cp_want = orc.run_permutations(a, b, 'sum', nperm, 5)
     cn, cp = amd.run_permutations((a, b, 'sum', nperm, 5), verbose=False)
     assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
+
+
+# ------------------------------------------------------------ attribute sharding ----------
+
+def test_sharded_columns_equal_unsharded(amd, ctx, golden_enr):
+    """Column blocks computed separately (as ranks would) with the GLOBAL row flags reproduce the
+    unsharded result; with per-shard flags they would not (a row whose only value lives in
+    another shard must still move)."""
+    from safepy_amd import backend as be, sharding
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    b = g['b_q'].copy()
+    n, m = b.shape
+    b[11, :] = np.nan
+    b[11, m - 1] = 0.75                                       # row 11 has a value only in the last shard
+    nperm, seed = 20, 6
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=seed)
+    nbr = be.Neighborhoods.from_dense(ctx, a)
+    flags_global = (~np.isnan(b)).any(axis=1).astype(np.uint8)
+    got = {k: np.empty((n, m)) for k in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')}
+    for c0, c1 in sharding.column_shards(m, 3):
+        attr = be.Attributes.from_host(ctx, np.ascontiguousarray(b[:, c0:c1]))
+        attr.set_row_flags(flags_global)
+        perms = be.Permutations(ctx, n, flags_global, nperm, seed)
+        bufs = [ctx.alloc_f64(n, c1 - c0) for _ in range(5)] + [ctx.alloc_f64(c1 - c0)]
+        be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [x.ptr for x in bufs])
+        for k, buf in zip(('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'), bufs):
+            got[k][:, c0:c1] = buf.download((n, c1 - c0))
+        perms.close()
+        attr.close()
+    np.testing.assert_allclose(got['ns'], want['ns'], rtol=1e-9, atol=1e-12, equal_nan=True)
+    for k in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        np.testing.assert_array_equal(got[k], want[k])
+
+
+def test_column_range_arguments_of_the_c_abi(amd, ctx, golden_enr, monkeypatch):
+    """col0/col1 select a block of a resident matrix (all three kernel forms)."""
+    from safepy_amd import backend as be
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    nbr = be.Neighborhoods.from_dense(ctx, a)
+    for path, b in (('gather', g['b_q']), ('scatter', g['b_bin']), ('bits', g['b_bin'])):
+        monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
+        n, m = b.shape
+        cn_w, cp_w = orc.run_permutations(a, b, 'sum', 15, 2)
+        attr = be.Attributes.from_host(ctx, b)
+        perms = be.Permutations(ctx, n, attr.row_flags(), 15, 2)
+        c0, c1 = 5, 18
+        neg, pos = ctx.alloc_f64(n, c1 - c0), ctx.alloc_f64(n, c1 - c0)
+        be.permtest_counts(ctx, nbr, attr, perms, 'sum', None, neg.ptr, pos.ptr, col0=c0, col1=c1)
+        assert np.array_equal(neg.download((n, c1 - c0)), cn_w[:, c0:c1]), path
+        assert np.array_equal(pos.download((n, c1 - c0)), cp_w[:, c0:c1]), path
+        perms.close()
+        attr.close()

@@ -1,0 +1,96 @@
+"""N > 1 plumbing on CPU: world_size-2 gloo process group (no GPU).  Covers the two exchange
+steps of the attribute-sharded path (global row flags / statistics, final all-gather) and the
+shard arithmetic; the oracle plays the role of the per-rank compute so the assertion is
+'sharded == unsharded' on the same seeded inputs."""
+import os
+import socket
+
+import numpy as np
+import pytest
+
+torch = pytest.importorskip('torch')
+import torch.distributed as dist            # noqa: E402
+import torch.multiprocessing as mp          # noqa: E402
+
+from oracle import safe_oracle as orc       # noqa: E402  (checker only)
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, tmpdir):
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        from safepy_amd import sharding
+        rng = np.random.default_rng(5)                      # same data on every rank
+        n, m, nperm, seed = 120, 17, 12, 4
+        xy = rng.uniform(size=(n, 2))
+        a = orc.neighborhoods_euclidean(xy, 0.2)
+        b = rng.normal(size=(n, m))
+        b[rng.choice(n, 9, replace=False)] = np.nan
+        b[:, 3] = np.nan
+        # a row whose only values sit in the LAST rank's columns: per-shard flags differ
+        b[7, :] = np.nan
+        b[7, m - 1] = 1.5
+        shards = sharding.column_shards(m, world)
+        assert shards == [(0, 9), (9, 17)]
+        c0, c1 = shards[rank]
+        local = b[:, c0:c1]
+
+        # exchange step 1: whole-matrix row flags and statistics
+        local_flags = (~np.isnan(local)).any(axis=1).astype(np.uint8)
+        flags = sharding.reduce_row_flags(local_flags)
+        assert np.array_equal(flags, (~np.isnan(b)).any(axis=1).astype(np.uint8))
+        if rank == 0:
+            assert local_flags[7] == 0 and flags[7] == 1
+        st = sharding.reduce_stats({'n_other': int((~np.isnan(local) & ~np.isin(local, [0, 1])).sum()),
+                                    'n_non_integer': int((~np.isnan(local) & (local != np.floor(local))).sum()),
+                                    'max_nan_col': int(np.isnan(local).sum(axis=0).max())})
+        assert st['n_other'] == int((~np.isnan(b) & ~np.isin(b, [0, 1])).sum())
+        assert st['max_nan_col'] == n
+
+        # per-rank compute (oracle stand-in for the HIP kernels) with the GLOBAL permutation stream
+        table = orc.permutation_index_table(np.where(flags[:, None] > 0, 0.0, np.nan) * np.ones((n, 1)), nperm, seed)
+        obs = orc.compute_neighborhood_score(a, local, 'sum')
+        cn = np.zeros(obs.shape)
+        cp = np.zeros(obs.shape)
+        for k in range(nperm):
+            s = orc.compute_neighborhood_score(a, local[table[k]], 'sum')
+            cn += s <= obs
+            cp += s >= obs
+
+        # exchange step 2: all-gather of the result blocks
+        full_cn = sharding.gather_columns(torch.from_numpy(cn), m).numpy()
+        full_cp = sharding.gather_columns(torch.from_numpy(cp), m).numpy()
+        want_cn, want_cp = orc.run_permutations(a, b, 'sum', nperm, seed)
+        assert np.array_equal(full_cn, want_cn) and np.array_equal(full_cp, want_cp)
+        open(os.path.join(tmpdir, 'ok%d' % rank), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_sharded_equals_unsharded(tmp_path):
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    assert all((tmp_path / ('ok%d' % r)).exists() for r in range(world))
+
+
+def test_column_shards_match_array_split():
+    from safepy_amd import sharding
+    for m in (1, 7, 8, 4373, 50000):
+        for world in (1, 2, 3, 8):
+            want = [(int(c[0]), int(c[-1]) + 1) if len(c) else None for c in np.array_split(np.arange(m), world)]
+            got = sharding.column_shards(m, world)
+            for w, g in zip(want, got):
+                if w is None:
+                    assert g[0] == g[1]
+                else:
+                    assert w == g
+            assert got[0][0] == 0 and got[-1][1] == m
