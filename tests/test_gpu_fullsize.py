@@ -1,0 +1,129 @@
+"""Full BASELINE.json sizes on the GPU, checked through size-independent properties and against the
+oracle on a sample (the oracle needs ~0.4-1.4 s per permutation at this size)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import safe_oracle as orc            # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def cfg2():
+    import safepy_amd
+    from safepy_amd import workloads
+    assert safepy_amd.device_count() >= 1
+    data = workloads.costanzo_surrogate(seed=0)
+    sf = safepy_amd.SAFE(verbose=False)
+    sf.random_seed = 0
+    sf.graph = safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length'])
+    sf.define_neighborhoods()                    # default metric, r = 0.1
+    sf.load_attributes(attribute_file=data['attributes'])
+    return safepy_amd, sf, data
+
+
+def test_config2_neighborhood_statistics_and_symmetry(cfg2):
+    amd, sf, data = cfg2
+    a = sf.neighborhoods
+    assert a.shape == (3971, 3971) and a.dtype == np.int64
+    assert np.array_equal(a, a.T) and np.all(np.diag(a) == 1)
+    counts = a.sum(axis=1)
+    # surrogate tuned to the reference's known answer 37.5 +/- 56.7 (tests/test_neighborhoods.py:25-26)
+    assert abs(counts.mean() - 37.5) < 5 and abs(counts.std() - 56.7) < 8
+    # every member is within the weighted radius in the reference's own distance dict
+    nd = sf.node_distances
+    cutoff = 0.1 * (data['xy'][:, 0].max() - data['xy'][:, 0].min())
+    assert all(d <= cutoff for row in list(nd.values())[:50] for d in row.values())
+
+
+def test_config2_full_permutation_test_properties_and_sample(cfg2):
+    amd, sf, data = cfg2
+    b = data['attributes']
+    n, m = b.shape
+    nperm = 1000
+    sf.compute_pvalues(how='randomization', num_permutations=nperm, verbose=False)
+    assert sf.nes.shape == (n, m)
+    a = sf.neighborhoods
+    # (1) observed scores: exact integer neighbourhood counts (checked on a column sample with the oracle)
+    cols = np.r_[0:8, m - 8:m, 2000:2008]
+    want_ns = orc.compute_neighborhood_score(a, b[:, cols].astype(np.float64), 'sum')
+    assert np.array_equal(sf.ns[:, cols], want_ns)
+    # (2) p-values are multiples of 1/P in [0,1]; every permutation is <=, >= or both
+    cn, cp = sf.pvalues_neg * nperm, sf.pvalues_pos * nperm
+    assert np.array_equal(cn, np.round(cn)) and np.array_equal(cp, np.round(cp))
+    assert cn.min() >= 0 and cn.max() <= nperm and cp.min() >= 0 and cp.max() <= nperm
+    assert np.all(cn + cp >= nperm)                              # ties count on both sides (safe_extras.py:65-66)
+    # (3) an attribute nobody carries / an empty observed count can never be beaten from below
+    zero_obs = sf.ns == 0
+    assert np.all(cp[zero_obs] == nperm)
+    # (4) NES and binarisation follow from the p-values exactly as safe.py:546-554, 468-472
+    with np.errstate(divide='ignore'):
+        nes = -np.log10(np.where(sf.pvalues_pos == 0, 1 / nperm, sf.pvalues_pos)) + \
+            np.log10(np.where(sf.pvalues_neg == 0, 1 / nperm, sf.pvalues_neg))
+    assert np.array_equal(sf.nes, nes)
+    assert np.array_equal(sf.nes_binary, (np.abs(nes) > -np.log10(0.05)).astype(np.float64))
+    assert np.array_equal(sf.attributes['num_neighborhoods_enriched'].values, sf.nes_binary.sum(axis=0))
+    # (5) the first permutations, replayed by the oracle on the sampled columns, give the same counts
+    few = 12
+    sf2 = amd.SAFE(verbose=False)
+    sf2.random_seed = 0
+    sf2.neighborhoods = a
+    sf2.load_attributes(attribute_file=np.asfortranarray(b[:, cols]))
+    # same row set moves as in the full matrix: all-NaN rows are all-NaN in every column of the surrogate
+    sf2.compute_pvalues(how='randomization', num_permutations=few, verbose=False)
+    want = orc.compute_pvalues(a, b[:, cols].astype(np.float64), enrichment_type='randomization',
+                               num_permutations=few, random_seed=0)
+    assert np.array_equal(sf2.pvalues_neg, want['pvalues_neg']) and np.array_equal(sf2.pvalues_pos, want['pvalues_pos'])
+
+
+def test_config2_kernel_forms_agree_at_full_size(cfg2, monkeypatch):
+    """Bit-sliced, scatter and f64 gather forms on a 256-attribute block x 64 permutations."""
+    amd, sf, data = cfg2
+    from safepy_amd import backend as be
+    ctx = amd.Context.default(0)
+    b = np.asfortranarray(data['attributes'][:, 1000:1256])
+    n, m = b.shape
+    out = {}
+    for path in ('bits', 'scatter', 'gather'):
+        monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
+        attr = be.Attributes.from_host(ctx, b)
+        perms = be.Permutations(ctx, n, attr.row_flags(), 64, 9)
+        neg, pos = ctx.alloc_f64(n, m), ctx.alloc_f64(n, m)
+        be.permtest_counts(ctx, sf._device_neighborhoods(), attr, perms, 'sum', None, neg.ptr, pos.ptr)
+        assert ctx.last_kernel()[0].startswith('k_permtest_' + path)
+        out[path] = (neg.download((n, m)), pos.download((n, m)))
+        perms.close()
+        attr.close()
+    for path in ('scatter', 'gather'):
+        assert np.array_equal(out[path][0], out['bits'][0]) and np.array_equal(out[path][1], out['bits'][1])
+
+
+def test_config4_shape_hypergeometric_properties():
+    """20 000 nodes, euclidean r = 0.1, binary attributes (a 512-column block of config 4)."""
+    import safepy_amd
+    rng = np.random.default_rng(12)
+    n, m = 20000, 512
+    xy = rng.uniform(size=(n, 2))
+    b = (rng.uniform(size=(n, m)) < 0.01).astype(np.float32)
+    b[rng.choice(n, 1000, replace=False)] = np.nan
+    sf = safepy_amd.SAFE(verbose=False)
+    sf.graph = safepy_amd.LayoutGraph(xy)
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.1)
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues()                                        # 'auto' -> hypergeometric
+    assert sf.pvalues_neg is None
+    p = sf.pvalues_pos
+    assert p.shape == (n, m) and np.all((p >= 0) & (p <= 1))
+    # rows sampled against scipy through the oracle
+    rows = rng.choice(n, 40, replace=False)
+    a_rows = np.zeros((40, n), dtype=np.int64)
+    d = np.sqrt(((xy[rows, None, :] - xy[None, :, :]) ** 2).sum(-1))
+    nr = 0.1 * (xy[:, 0].max() - xy[:, 0].min())
+    a_rows[d < nr] = 1
+    notnan = ~np.isnan(b).all(axis=1)
+    from scipy.stats import hypergeom
+    hits = a_rows @ np.nan_to_num(b.astype(np.float64))
+    size = a_rows @ notnan.astype(np.int64)
+    want = hypergeom.sf(hits - 1, notnan.sum(), np.nansum(b, axis=0)[None, :], size[:, None])
+    np.testing.assert_allclose(p[rows], want, rtol=1e-6, atol=1e-300)
+    assert np.array_equal(sf.nes_binary[rows], (-np.log10(want) > -np.log10(0.05)).astype(np.float64))
