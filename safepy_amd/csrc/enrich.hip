@@ -842,6 +842,54 @@ __global__ __launch_bounds__(256) void k_bits_prep(const void *__restrict__ raw,
     bbits[idx] = make_uint2(w[0], w[1]);
 }
 
+// Observed neighborhood counts of binary attributes, bit-sliced (safe.py:593-594 for the
+// hypergeometric path; safe_extras.py:15 for 'sum' scores): one wave per (SELL slice, 64-attribute
+// word group), member words gathered from the L2-resident bit matrix, vertical carry-save sums,
+// bit-matrix transpose, 512 contiguous output bytes per lane.
+__global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ sell_row,
+                                                    const int64_t *__restrict__ slice_off,
+                                                    const int32_t *__restrict__ slice_width,
+                                                    const int32_t *__restrict__ sell_col, int64_t n,
+                                                    const uint2 *__restrict__ bbits, int64_t mloc,
+                                                    double *__restrict__ out) {
+    const int64_t s = blockIdx.x, wg = blockIdx.y;
+    const int lane = threadIdx.x;
+    const int32_t row = sell_row[s * 64 + lane];
+    const int32_t *cols = sell_col + slice_off[s] + lane;
+    const int wdt = slice_width[s];
+    const uint2 *T = bbits + wg * (n + 1);
+    uint32_t s0[BT_LV], s1[BT_LV];
+#pragma unroll
+    for (int l = 0; l < BT_LV; ++l) s0[l] = s1[l] = 0;
+    for (int t0 = 0; t0 < wdt; t0 += 8) {
+        uint32_t x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const uint2 w = T[cols[(t0 + u) * 64]];
+            x0[u] = w.x;
+            x1[u] = w.y;
+        }
+        const uint32_t e0 = vadd8(s0, x0);
+        const uint32_t e1 = vadd8(s1, x1);
+        if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+            vripple(s0, e0);
+            vripple(s1, e1);
+        }
+    }
+    if (row < 0) return;
+    double *o = out + static_cast<int64_t>(row) * mloc + wg * 64;
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t m[32];
+#pragma unroll
+        for (int l = 0; l < 32; ++l) m[l] = l < BT_LV ? (half ? s1[l < BT_LV ? l : 0] : s0[l < BT_LV ? l : 0]) : 0u;
+        transpose32(m);
+#pragma unroll
+        for (int bit = 0; bit < 32; ++bit)
+            if (wg * 64 + half * 32 + bit < mloc) o[half * 32 + bit] = static_cast<double>(m[bit]);
+    }
+}
+
 __global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < count) out[i] = static_cast<double>(in[i]);
@@ -1207,6 +1255,34 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     return SAFE_OK;
 }
 
+// X = A . B0 for a binary attribute block through the bit-sliced count kernel; false if the
+// block does not qualify (not binary, or neighborhoods of 1024+ members)
+static bool counts_bits_applicable(const safe_nbr *nbr, safe_attr *attr) {
+    const char *force = getenv("SAFE_HIP_FORCE_PATH");
+    if (force && !strcmp(force, "gather")) return false;
+    return safe_attr_prepare(attr) == SAFE_OK && attr->n_other == 0 && nbr->max_count < (1 << BT_LV);
+}
+
+static int launch_counts_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, double *out_dev) {
+    const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64);
+    uint2 *d_bits = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
+    const dim3 grid(ceil_div(n_wg * (n + 1), 256)), block(256);
+    if (attr->dtype == SAFE_DTYPE_F32)
+        hipLaunchKernelGGL(k_bits_prep<float>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                           attr->col_stride, col0, mloc, n_wg, d_bits);
+    else
+        hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                           attr->col_stride, col0, mloc, n_wg, d_bits);
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(k_counts_bits, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
+                       nbr->slice_width, nbr->sell_col, n, d_bits, mloc, out_dev);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = "k_counts_bits";
+    return SAFE_OK;
+}
+
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
     if (ctx->last_kernel.name == "k_permtest_bits") return SAFE_OK;   // per-launch events already summed
@@ -1226,6 +1302,10 @@ int safe_score(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int score_type, in
     SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_score: bad score_type %d", score_type);
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const bool z = score_type == SAFE_SCORE_ZSCORE;
+    if (!z && counts_bits_applicable(nbr, attr)) {
+        SAFE_TRY(launch_counts_bits(ctx, nbr, attr, col0, col1, out_dev));
+        return finish_kernel_timing(ctx);
+    }
     Tiles tiles;
     SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
     PermOut out{};
@@ -1351,11 +1431,12 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     double *d_lf = nullptr, *d_hits = nullptr, *d_size = nullptr;
     unsigned int *d_enr = nullptr;
     Tiles tiles;
+    const bool bits = counts_bits_applicable(nbr, attr);
     int rc = dev_alloc(&d_lf, n + 2);
-    if (rc == SAFE_OK) rc = dev_alloc(&d_hits, n * mloc);
+    if (rc == SAFE_OK) rc = ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&d_hits));
     if (rc == SAFE_OK) rc = dev_alloc(&d_size, n);
     if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 64);
-    if (rc == SAFE_OK) rc = build_tiles(ctx, attr, col0, col1, false, &tiles);
+    if (rc == SAFE_OK && !bits) rc = build_tiles(ctx, attr, col0, col1, false, &tiles);
     if (rc == SAFE_OK) {
         hipError_t e = hipMemcpyAsync(d_lf, lf.data(), (n + 2) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 64) * sizeof(unsigned int), ctx->stream);
@@ -1368,7 +1449,8 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
         PermOut out{};
         out.ns = d_hits;
         out.mode = 0;
-        rc = launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
+        rc = bits ? launch_counts_bits(ctx, nbr, attr, col0, col1, d_hits)
+                  : launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col,
@@ -1385,7 +1467,6 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
     if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;
     (void)hipFree(d_lf);
-    (void)hipFree(d_hits);
     (void)hipFree(d_size);
     (void)hipFree(d_enr);
     (void)hipFree(tiles.bt);
