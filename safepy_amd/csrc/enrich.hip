@@ -890,6 +890,219 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
     }
 }
 
+// --------------------------------------------------------------------------------------
+// K5 (general f64 form, LDS resident): quantitative attributes and z-scores on networks of up
+// to ~4500 nodes.  Same task structure as the bit-sliced kernel -- a workgroup owns 4 adjacent
+// SELL slices x one column tile x a permutation sub-range; LDS holds the tile as 32-byte rows
+// (sum: 4 attribute columns; z-score: B0, B0^2, not-NaN of ONE column) and the current
+// permutation row (u16, double buffered) -- but the arithmetic is the reference's f64: a lane
+// adds its members' rows in SELL order, compares with the observed score and keeps the two
+// counters in registers; they leave as packed (#>= << 16 | #<=) atomics, [column][SELL pos].
+// --------------------------------------------------------------------------------------
+typedef double f64x2 __attribute__((ext_vector_type(2)));
+typedef const __attribute__((address_space(3))) f64x2 *lds_d2_ptr;
+
+template <bool Z, int NW>
+__global__ __launch_bounds__(64 * NW) void k_permtest_lds(
+    int64_t n, const uint16_t *__restrict__ cur16, int64_t stride16, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint16_t *__restrict__ sell_col2, int64_t n_slices, const double *__restrict__ tiles, int64_t n_tasks,
+    const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
+    unsigned int *__restrict__ counts, int64_t n_pad, double *__restrict__ ns_out) {
+    extern __shared__ unsigned int lds[];
+    constexpr int BN = Z ? 1 : 4;
+    constexpr int NT = 64 * NW;                                          // NW waves = NW adjacent slices per workgroup
+    const int64_t t_words = 8 * (n + 1);                                 // tile: (n+1) rows x 32 B
+    double *T = reinterpret_cast<double *>(lds);
+    unsigned short *CUR = reinterpret_cast<unsigned short *>(lds + t_words);     // [2][stride16]
+    unsigned int *slot_box = lds + t_words + stride16;
+    const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds);
+    const uint32_t cur_bytes0 = t_addr + static_cast<uint32_t>(t_words * 4);
+    const uint32_t cur_bytes1 = cur_bytes0 + static_cast<uint32_t>(stride16 * 2);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int vec_per_row = static_cast<int>(stride16 / 8);
+
+    // one pass over the lane's neighborhood: acc = sum of the members' 32-byte rows
+    auto accumulate = [&](const uint16_t *cols2, int wdt, uint32_t cur_addr, bool ident, double (&acc)[4]) {
+        acc[0] = acc[1] = acc[2] = acc[3] = 0.0;
+        for (int t0 = 0; t0 < wdt; t0 += 8) {
+            uint32_t r[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const uint32_t c2 = cols2[(t0 + u) * 64];
+                r[u] = ident ? (c2 << 4) : (static_cast<uint32_t>(*(lds_u16_ptr)(uintptr_t)(cur_addr + c2)) << 5);
+            }
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+                const f64x2 a = *(lds_d2_ptr)(uintptr_t)(t_addr + r[u]);
+                const f64x2 b = *(lds_d2_ptr)(uintptr_t)(t_addr + r[u] + 16);
+                acc[0] += a.x;
+                acc[1] += a.y;
+                acc[2] += b.x;
+                if (!Z) acc[3] += b.y;
+            }
+        }
+    };
+    auto score_of = [](const double (&acc)[4], double (&sc)[BN]) {
+        if (!Z) {
+#pragma unroll
+            for (int c = 0; c < BN; ++c) sc[c] = acc[c];
+        } else {                                   // safe_extras.py:19-31
+            const double cnt = acc[2];
+            const double mean = acc[0] / cnt;
+            const double exx = acc[1] / cnt;
+            const double sd = sqrt(exx - mean * mean);
+            double v = mean / sd;
+            if (sd == 0.0) v = __longlong_as_double(0x7FF8000000000000ll);
+            if (cnt < 3.0) v = __longlong_as_double(0x7FF8000000000000ll);
+            sc[0] = v;
+        }
+    };
+
+    for (;;) {
+        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t slot = *slot_box;
+        __syncthreads();
+        if (slot >= n_tasks) break;
+        const int4 task = tasks[slot];
+        const int tile = task.x, sg = task.y;
+        const int64_t p_begin = p_base + task.z;
+        const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+
+        const double *src = tiles + static_cast<int64_t>(tile) * (n + 1) * 4;
+        for (int64_t i = threadIdx.x; i < (n + 1) * 4; i += NT) T[i] = src[i];
+        if (p_end > p_begin)
+            for (int v = threadIdx.x; v < vec_per_row; v += NT)
+                reinterpret_cast<uint4_alias *>(CUR)[v] = reinterpret_cast<const uint4_alias *>(cur16 + p_begin * stride16)[v];
+
+        const int64_t s = static_cast<int64_t>(sg) * NW + wave;
+        const bool active = s < n_slices;
+        const int32_t row = active ? sell_row[s * 64 + lane] : -1;
+        const uint16_t *cols2 = sell_col2 + (active ? slice_off[s] : 0) + lane;
+        const int wdt = active ? slice_width[s] : 0;
+        __syncthreads();
+
+        double acc[4], obs[BN];
+        accumulate(cols2, wdt, 0u, true, acc);
+        score_of(acc, obs);
+        unsigned int cneg[BN], cpos[BN];
+#pragma unroll
+        for (int c = 0; c < BN; ++c) cneg[c] = cpos[c] = 0;
+
+        for (int64_t p = p_begin; p < p_end; ++p) {
+            const int64_t rel = p - p_begin;
+            const uint32_t cur_base = (rel & 1) ? cur_bytes1 : cur_bytes0;
+            uint4 nxt = make_uint4(0, 0, 0, 0);
+            const bool fetch = (p + 1 < p_end) && (static_cast<int>(threadIdx.x) < vec_per_row);
+            if (fetch) nxt = reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[threadIdx.x];
+
+            accumulate(cols2, wdt, cur_base, false, acc);
+            double sc[BN];
+            score_of(acc, sc);
+#pragma unroll
+            for (int c = 0; c < BN; ++c) {
+                cneg[c] += sc[c] <= obs[c];                              // safe_extras.py:65
+                cpos[c] += sc[c] >= obs[c];                              // safe_extras.py:66
+            }
+            if (vec_per_row > NT)
+                for (int v = threadIdx.x + NT; v < vec_per_row; v += NT)
+                    if (p + 1 < p_end)
+                        reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[v] =
+                            reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[v];
+            if (fetch) reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[threadIdx.x] = nxt;
+            __syncthreads();
+        }
+
+        const int64_t spos = s * 64 + lane;
+#pragma unroll
+        for (int c = 0; c < BN; ++c) {
+            const int64_t jc = static_cast<int64_t>(tile) * BN + c;
+            if (active && jc < mloc) {
+                const unsigned int v = (cpos[c] << 16) | cneg[c];
+                if (v) atomicAdd(&counts[jc * n_pad + spos], v);
+                if (row >= 0 && p_begin == 0) ns_out[static_cast<int64_t>(row) * mloc + jc] = obs[c];
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// row-major tiles of 32 bytes per node for k_permtest_lds: sum -> 4 columns of B0; z-score ->
+// (B0, B0^2 squared in B's dtype, not-NaN, 0) of one column; row n = zeros (SELL padding)
+template <typename T, bool Z>
+__global__ __launch_bounds__(256) void k_tile32_prep(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                     int64_t col0, int64_t mloc, int64_t n_tiles, double *__restrict__ out) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= n_tiles * (n + 1)) return;
+    const int64_t tile = idx / (n + 1), r = idx % (n + 1);
+    double v[4] = {0.0, 0.0, 0.0, 0.0};
+    if (r < n) {
+        if (!Z) {
+            for (int c = 0; c < 4; ++c) {
+                const int64_t j = tile * 4 + c;
+                if (j < mloc) {
+                    const T x = reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs];
+                    if (x == x) v[c] = static_cast<double>(x);
+                }
+            }
+        } else if (tile < mloc) {
+            const T x = reinterpret_cast<const T *>(raw)[r * rs + (col0 + tile) * cs];
+            if (x == x) {
+                v[0] = static_cast<double>(x);
+                v[1] = static_cast<double>(static_cast<T>(x * x));
+                v[2] = 1.0;
+            }
+        }
+    }
+    double *o = out + idx * 4;
+    o[0] = v[0];
+    o[1] = v[1];
+    o[2] = v[2];
+    o[3] = v[3];
+}
+
+// packed counts (#>= << 16 | #<=) + observed score -> compute_pvalues outputs (safe.py:528-554, 468-472)
+__global__ __launch_bounds__(256) void k_counts_finalize_direct(const unsigned int *__restrict__ counts, int64_t n_pad,
+                                                                const int32_t *__restrict__ sell_pos,
+                                                                const double *__restrict__ ns, int64_t n, int64_t mloc,
+                                                                int64_t n_perm, PermOut out) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
+    bool hit = false;
+    if (i < n && c < mloc) {
+        const int64_t o = i * mloc + c;
+        const unsigned int v = counts[c * n_pad + sell_pos[i]];
+        const unsigned int cneg = v & 0xFFFFu, cpos = v >> 16;
+        const double obs = ns[o];
+        const bool obs_nan = obs != obs;
+        const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+        if (out.mode == 1) {
+            out.counts_neg[o] = static_cast<double>(cneg);
+            out.counts_pos[o] = static_cast<double>(cpos);
+        } else if (out.mode == 2) {
+            const double en = obs_nan ? qnan : out.nes_table[cneg], ep = obs_nan ? qnan : out.nes_table[cpos];
+            double nes = ep - en;
+            if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+            if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+            hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+            out.pvalues_neg[o] = obs_nan ? qnan : static_cast<double>(cneg) / static_cast<double>(n_perm);
+            out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / static_cast<double>(n_perm);
+            out.nes[o] = nes;
+            out.nes_binary[o] = hit ? 1.0 : 0.0;
+        }
+    }
+    if (out.mode == 2) {
+        __shared__ unsigned int part[64];
+        if (threadIdx.x < 64) part[threadIdx.x] = 0;
+        __syncthreads();
+        if (hit) atomicAdd(&part[threadIdx.x & 63], 1u);
+        __syncthreads();
+        if (threadIdx.x < 64 && part[threadIdx.x] && blockIdx.x * 64 + threadIdx.x < mloc)
+            atomicAdd(&out.enriched[blockIdx.x * 64 + threadIdx.x], part[threadIdx.x]);
+    }
+}
+
 __global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < count) out[i] = static_cast<double>(in[i]);
@@ -1283,9 +1496,143 @@ static int launch_counts_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int
     return SAFE_OK;
 }
 
+static size_t ldsf64_bytes(int64_t n, int64_t stride16) {
+    return (8 * static_cast<size_t>(n + 1) + static_cast<size_t>(stride16) + 4) * sizeof(unsigned int);
+}
+
+static bool lds_f64_applicable(const safe_nbr *nbr, const safe_perms *perms) {
+    const char *force = getenv("SAFE_HIP_FORCE_PATH");
+    if (force && !strcmp(force, "gather")) return false;
+    return nbr->sell_col2 != nullptr && perms->table16 != nullptr && perms->count >= 1 && perms->count <= 65535 &&
+           ldsf64_bytes(nbr->n, perms->stride16) <= 160 * 1024;
+}
+
+// general f64 permutation test with LDS-resident tiles (k_permtest_lds), pipelined over spans like launch_bits
+static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
+                          bool z, const PermOut &out_in) {
+    const int64_t n = nbr->n, mloc = col1 - col0, P = perms->count;
+    const int64_t n_tiles = z ? mloc : ceil_div(mloc, 4);
+    PermOut out = out_in;
+    double *d_tiles = nullptr, *d_ns = out.ns;
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_tiles) * (n + 1) * 4 * sizeof(double), reinterpret_cast<void **>(&d_tiles)));
+    if (!d_ns) SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&d_ns)));
+    {
+        const dim3 grid(ceil_div(n_tiles * (n + 1), 256)), block(256);
+        const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+#define PREP(T, ZZ) hipLaunchKernelGGL((k_tile32_prep<T, ZZ>), grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride, \
+                                        attr->col_stride, col0, mloc, n_tiles, d_tiles)
+        if (z) { if (f32) PREP(float, true); else PREP(double, true); }
+        else { if (f32) PREP(float, false); else PREP(double, false); }
+#undef PREP
+    }
+    int64_t span = 128;
+    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
+    span = std::min<int64_t>(span, P);
+    const size_t lds_bytes = ldsf64_bytes(n, perms->stride16);
+    const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
+    const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
+    int NW = 16;                                   // waves (= adjacent slices) per workgroup: LDS allows one workgroup per CU
+    if (const char *e = getenv("SAFE_HIP_LDS_WAVES")) NW = atoi(e);
+    NW = NW >= 16 ? 16 : (NW >= 8 ? 8 : 4);
+    const int64_t n_sg = ceil_div(nbr->n_slices, NW);
+    std::vector<int64_t> sg_blocks(n_sg, 0);
+    int64_t blocks_per_perm = 0;
+    for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / NW] = std::max<int64_t>(sg_blocks[s / NW], nbr->h_slice_width[s] / 8);
+    for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
+    const int64_t tasks_per_tile = std::max<int64_t>(1, ceil_div(6 * slots, n_tiles));
+    const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_tile);
+    struct TaskCost { int4 t; int64_t cost; };
+    std::vector<TaskCost> tc;
+    for (int64_t g = 0; g < n_sg; ++g) {
+        const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
+        int64_t ppt = std::min<int64_t>(span, std::max<int64_t>(16, target / bl));
+        const int64_t chunks = ceil_div(span, ppt);
+        ppt = ceil_div(span, chunks);
+        for (int64_t c = 0; c < chunks; ++c) {
+            const int64_t p0 = c * ppt, p1 = std::min<int64_t>(span, p0 + ppt);
+            for (int64_t w = 0; w < n_tiles; ++w)
+                tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
+                              bl * (p1 - p0)});
+        }
+    }
+    std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
+    std::vector<int4> tasks(tc.size());
+    for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
+    const int64_t n_launch = ceil_div(P, span), n_pad = nbr->n_slices * 64;
+    int4 *d_tasks = nullptr;
+    unsigned int *d_queue = nullptr, *d_counts = nullptr;
+    SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
+    SAFE_TRY(dev_alloc(&d_queue, n_launch));
+    SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), reinterpret_cast<void **>(&d_counts)));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, n_launch * sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), ctx->stream));
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
+    const int64_t n_tasks = static_cast<int64_t>(tasks.size());
+#define LDS_DISPATCH(ACTION)                                      \
+    do {                                                          \
+        if (z) {                                                  \
+            if (NW == 16) ACTION(true, 16);                       \
+            else if (NW == 8) ACTION(true, 8);                    \
+            else ACTION(true, 4);                                 \
+        } else {                                                  \
+            if (NW == 16) ACTION(false, 16);                      \
+            else if (NW == 8) ACTION(false, 8);                   \
+            else ACTION(false, 4);                                \
+        }                                                         \
+    } while (0)
+#define LDS_SETATTR(ZZ, W)                                                                                            \
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_lds<ZZ, W>),                         \
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)))
+    LDS_DISPATCH(LDS_SETATTR);
+    ctx->last_kernel.name = "k_permtest_lds";
+    ctx->last_kernel.total_ms = 0.0;
+    ctx->last_kernel.launches = 0;
+    std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
+    for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
+    hipEvent_t ready = nullptr, side_done = nullptr;
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
+    for (int64_t c = 0; c < n_launch; ++c) {
+        const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span);
+        hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
+        SAFE_TRY(perms_wait(perms, p_limit, ks));
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
+#define LDS_LAUNCH(ZZ, W)                                                                                              \
+    hipLaunchKernelGGL((k_permtest_lds<ZZ, W>), dim3(blocks), dim3(64 * W), lds_bytes, ks, n, perms->table16,          \
+                       perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, \
+                       d_tiles, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_counts, n_pad, d_ns)
+        LDS_DISPATCH(LDS_LAUNCH);
+        SAFE_HIP_CHECK(hipGetLastError());
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
+    }
+    SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
+    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
+    hipLaunchKernelGGL(k_counts_finalize_direct, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_counts,
+                       n_pad, nbr->sell_pos, d_ns, n, mloc, P, out);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int64_t c = 0; c < n_launch; ++c) {
+        float ms = 0.f;
+        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
+        ctx->last_kernel.total_ms += ms;
+        ctx->last_kernel.launches += 1;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ready);
+    (void)hipEventDestroy(side_done);
+    (void)hipFree(d_tasks);
+    (void)hipFree(d_queue);
+    return SAFE_OK;
+}
+
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
-    if (ctx->last_kernel.name == "k_permtest_bits") return SAFE_OK;   // per-launch events already summed
+    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_lds") return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;
     SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->k0, ctx->k1));
     ctx->last_kernel.total_ms = ms;
@@ -1337,6 +1684,10 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
                                    : launch_scatter(ctx, nbr, attr, perms, col0, col1, out));
         return finish_kernel_timing(ctx);
     }
+    if (lds_f64_applicable(nbr, perms)) {
+        SAFE_TRY(launch_lds_f64(ctx, nbr, attr, perms, col0, col1, z, out));
+        return finish_kernel_timing(ctx);
+    }
     Tiles tiles;
     SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
     SAFE_TRY(perms_wait(perms, perms->count, ctx->stream));
@@ -1373,7 +1724,8 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     unsigned int *d_enr = nullptr;
     Tiles tiles;
     const PermPath path = choose_path(ctx, nbr, attr, P, z);
-    const bool scatter = path != PATH_GATHER;
+    const bool lds64 = path == PATH_GATHER && lds_f64_applicable(nbr, perms);
+    const bool scatter = path != PATH_GATHER || lds64;
     int rc = dev_alloc(&d_tab, P + 1);
     if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 16);
     if (rc == SAFE_OK && !scatter) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
@@ -1397,7 +1749,8 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.nes_threshold = -std::log10(enrichment_threshold);
         out.sign_mode = sign_mode;
         out.mode = 2;
-        rc = path == PATH_BITS      ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
+        rc = lds64                  ? launch_lds_f64(ctx, nbr, attr, perms, col0, col1, z, out)
+             : path == PATH_BITS    ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
              : path == PATH_SCATTER ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
                                     : (perms_wait(perms, P, ctx->stream) == SAFE_OK
                                            ? launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out)

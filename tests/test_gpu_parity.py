@@ -456,3 +456,32 @@ def test_column_range_arguments_of_the_c_abi(amd, ctx, golden_enr, monkeypatch):
         assert np.array_equal(pos.download((n, c1 - c0)), cp_w[:, c0:c1]), path
         perms.close()
         attr.close()
+
+
+@pytest.mark.parametrize('score', ['sum', 'z-score'])
+def test_f64_kernel_forms_agree(amd, ctx, golden_enr, monkeypatch, score):
+    """Quantitative attributes: the LDS-resident f64 kernel (default for small networks) and the
+    global-tile gather kernel add the members in the same order, so even the observed scores
+    are bitwise identical."""
+    from safepy_amd import backend as be
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    b = g['b_q_f32']
+    n, m = b.shape
+    nbr = be.Neighborhoods.from_dense(ctx, a)
+    res = {}
+    for path in ('lds', 'gather'):
+        if path == 'gather':
+            monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'gather')
+        else:
+            monkeypatch.delenv('SAFE_HIP_FORCE_PATH', raising=False)
+        attr = be.Attributes.from_host(ctx, b)
+        perms = be.Permutations(ctx, n, attr.row_flags(), 33, 4)
+        ns, neg, pos = ctx.alloc_f64(n, m), ctx.alloc_f64(n, m), ctx.alloc_f64(n, m)
+        be.permtest_counts(ctx, nbr, attr, perms, score, ns.ptr, neg.ptr, pos.ptr)
+        assert ctx.last_kernel()[0].startswith('k_permtest_' + path)
+        res[path] = (ns.download((n, m)), neg.download((n, m)), pos.download((n, m)))
+        perms.close()
+        attr.close()
+    for x, y in zip(res['lds'], res['gather']):
+        np.testing.assert_array_equal(x, y)
