@@ -8,60 +8,62 @@ __device__ __forceinline__ double load_attr(const void *raw, int64_t idx) {
     return static_cast<double>(reinterpret_cast<const T *>(raw)[idx]);
 }
 
-// One block per column: NaN count, nansum (f64, row order), #values outside {0,1},
-// #non-integers, max |v|; and row flags by atomicOr into a byte map.
-template <typename T>
+// Whole-matrix facts in one pass: per column NaN count, nansum, #values outside {0,1},
+// #non-integers, max |v|; per row "has a value" flags.  One block per group of GC columns;
+// the thread grid is laid out along the contiguous axis of the matrix so loads coalesce:
+//   Fortran order (rs == 1): GC = 1,  256 threads walk the rows of one column
+//   C order       (cs == 1): GC = 64, 64 x 4 threads: x = column, y = row lane
+template <typename T, int GC>
 __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw, int64_t n, int64_t m,
                                                     int64_t rs, int64_t cs, unsigned int *__restrict__ row_flags32,
                                                     unsigned long long *__restrict__ acc /*[4]*/,
                                                     double *__restrict__ col_sum, unsigned long long *__restrict__ max_abs_bits) {
-    const int64_t j = blockIdx.x;
-    __shared__ unsigned long long s_nan, s_other, s_nonint;
-    __shared__ double s_part[256];
+    constexpr int RL = 256 / GC;                       // row lanes per column
+    const int cx = GC == 1 ? 0 : (threadIdx.x & (GC - 1));
+    const int ry = GC == 1 ? threadIdx.x : (threadIdx.x / GC);
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * GC + cx;
+    __shared__ double s_sum[256];
     __shared__ double s_max[256];
-    if (threadIdx.x == 0) {
-        s_nan = 0;
-        s_other = 0;
-        s_nonint = 0;
-    }
-    __syncthreads();
-    unsigned long long c_nan = 0, c_other = 0, c_nonint = 0;
-    double mx = 0.0;
-    // per-thread sums over a contiguous chunk keep the column sum in row order per chunk
-    const int64_t chunk = (n + 255) / 256;
-    const int64_t i0 = threadIdx.x * chunk, i1 = i0 + chunk < n ? i0 + chunk : n;
-    double sum = 0.0;
-    for (int64_t i = i0; i < i1; ++i) {
-        const double v = load_attr<T>(raw, i * rs + j * cs);
-        if (v != v) {
-            ++c_nan;
-        } else {
-            sum += v;
-            if (v != 0.0 && v != 1.0) ++c_other;
-            if (v != floor(v)) ++c_nonint;
-            const double a = fabs(v);
-            if (a > mx) mx = a;
-            // row has a value: set its byte (4 rows share a 32-bit word)
-            const unsigned int bit = 1u << (8 * (i & 3));
-            if (!(row_flags32[i >> 2] & bit)) atomicOr(&row_flags32[i >> 2], bit);   // racy pre-check is benign
+    __shared__ unsigned int s_nan[256], s_other[256], s_nonint[256];
+    unsigned int c_nan = 0, c_other = 0, c_nonint = 0;
+    double mx = 0.0, sum = 0.0;
+    if (j < m) {
+        for (int64_t i = ry; i < n; i += RL) {
+            const double v = load_attr<T>(raw, i * rs + j * cs);
+            if (v != v) {
+                ++c_nan;
+            } else {
+                sum += v;
+                if (v != 0.0 && v != 1.0) ++c_other;
+                if (v != floor(v)) ++c_nonint;
+                const double a = fabs(v);
+                if (a > mx) mx = a;
+                const unsigned int bit = 1u << (8 * (i & 3));       // 4 row flags share a 32-bit word
+                if (!(row_flags32[i >> 2] & bit)) atomicOr(&row_flags32[i >> 2], bit);   // racy pre-check is benign
+            }
         }
     }
-    s_part[threadIdx.x] = sum;
+    s_sum[threadIdx.x] = sum;
     s_max[threadIdx.x] = mx;
-    atomicAdd(&s_nan, c_nan);
-    atomicAdd(&s_other, c_other);
-    atomicAdd(&s_nonint, c_nonint);
+    s_nan[threadIdx.x] = c_nan;
+    s_other[threadIdx.x] = c_other;
+    s_nonint[threadIdx.x] = c_nonint;
     __syncthreads();
-    if (threadIdx.x == 0) {
+    if (ry == 0 && j < m) {
         double total = 0.0, tmx = 0.0;
-        for (int t = 0; t < 256; ++t) {
-            total += s_part[t];
+        unsigned long long t_nan = 0, t_other = 0, t_nonint = 0;
+        for (int r = 0; r < RL; ++r) {
+            const int t = GC == 1 ? r : r * GC + cx;
+            total += s_sum[t];
             if (s_max[t] > tmx) tmx = s_max[t];
+            t_nan += s_nan[t];
+            t_other += s_other[t];
+            t_nonint += s_nonint[t];
         }
         col_sum[j] = total;
-        atomicAdd(&acc[0], s_other);
-        atomicMax(&acc[1], s_nan);
-        atomicAdd(&acc[2], s_nonint);
+        if (t_other) atomicAdd(&acc[0], t_other);
+        atomicMax(&acc[1], t_nan);
+        if (t_nonint) atomicAdd(&acc[2], t_nonint);
         atomicMax(max_abs_bits, static_cast<unsigned long long>(__double_as_longlong(tmx)));
     }
 }
@@ -128,12 +130,20 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_TRY(dev_alloc(&flags, flag_bytes));
     SAFE_HIP_CHECK(hipMemsetAsync(flags, 0, flag_bytes, ctx->stream));
     if (!attr->col_sum) SAFE_TRY(dev_alloc(&attr->col_sum, m));
-    if (attr->dtype == SAFE_DTYPE_F32)
-        hipLaunchKernelGGL(k_attr_stats<float>, dim3(m), dim3(256), 0, ctx->stream, attr->raw, n, m, attr->row_stride,
-                           attr->col_stride, reinterpret_cast<unsigned int *>(flags), d_acc, attr->col_sum, d_acc + 3);
-    else
-        hipLaunchKernelGGL(k_attr_stats<double>, dim3(m), dim3(256), 0, ctx->stream, attr->raw, n, m, attr->row_stride,
-                           attr->col_stride, reinterpret_cast<unsigned int *>(flags), d_acc, attr->col_sum, d_acc + 3);
+    const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+    const bool c_order = attr->col_stride == 1 && m > 1;
+#define STATS(T, GC)                                                                                               \
+    hipLaunchKernelGGL((k_attr_stats<T, GC>), dim3(ceil_div(m, GC)), dim3(256), 0, ctx->stream, attr->raw, n, m,   \
+                       attr->row_stride, attr->col_stride, reinterpret_cast<unsigned int *>(flags), d_acc,         \
+                       attr->col_sum, d_acc + 3)
+    if (c_order) {
+        if (f32) STATS(float, 64);
+        else STATS(double, 64);
+    } else {
+        if (f32) STATS(float, 1);
+        else STATS(double, 1);
+    }
+#undef STATS
     SAFE_HIP_CHECK(hipGetLastError());
     unsigned long long h_acc[4];
     SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));

@@ -44,6 +44,8 @@ void safe_trace(const char *what);
         if (_rc != SAFE_OK) return _rc;                                                        \
     } while (0)
 
+struct safe_perms;
+
 struct KernelStat {
     std::string name;
     double total_ms = 0.0;
@@ -63,6 +65,7 @@ struct safe_ctx {
     hipEvent_t k0 = nullptr, k1 = nullptr;      // dominant-kernel timing
     KernelStat last_kernel;
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
+    struct safe_perms *perm_cache = nullptr;    // buffers of the last destroyed permutation handle, reused by the next
     void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[4] = {0, 0, 0, 0};
 };
@@ -70,6 +73,7 @@ struct safe_ctx {
 // returns a device buffer of at least `bytes` from slot `slot`, valid until the next request
 // for the same slot; contents are undefined
 int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out);
+void perms_cache_drop(safe_ctx *ctx);   // frees ctx->perm_cache (rng.cpp)
 
 // RAII-less device buffer helper: all frees go through the owning handle's destroy.
 template <typename T>

@@ -104,6 +104,7 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->k0) (void)hipEventDestroy(ctx->k0);
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
+    perms_cache_drop(ctx);
     for (int i = 0; i < 4; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);

@@ -1396,8 +1396,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
     unsigned int *d_gl = nullptr;
-    SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
-    SAFE_TRY(dev_alloc(&d_queue, n_launch));
+    {
+        void *ws = nullptr;       // tasks + queue words in one scratch buffer
+        SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int4) + (n_launch + 4) * sizeof(unsigned int), &ws));
+        d_tasks = static_cast<int4 *>(ws);
+        d_queue = reinterpret_cast<unsigned int *>(d_tasks + tasks.size());
+    }
     const int64_t n_pad = nbr->n_slices * 64;
     SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), reinterpret_cast<void **>(&d_gl)));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
@@ -1463,8 +1467,6 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     for (auto &e : ev) (void)hipEventDestroy(e);
     (void)hipEventDestroy(ready);
     (void)hipEventDestroy(side_done);
-    (void)hipFree(d_tasks);
-    (void)hipFree(d_queue);
     return SAFE_OK;
 }
 

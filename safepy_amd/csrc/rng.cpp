@@ -271,8 +271,15 @@ static void perms_free(safe_perms *p) {
     (void)hipFree(p->table);
     (void)hipFree(p->table16);
     (void)hipFree(p->inverse_t);
-    draw_stream_free(p->stream);
+    if (p->stream) draw_stream_free(p->stream);
     delete p;
+}
+
+void perms_cache_drop(safe_ctx *ctx) {
+    if (ctx->perm_cache) {
+        perms_free(ctx->perm_cache);
+        ctx->perm_cache = nullptr;
+    }
 }
 
 extern "C" {
@@ -301,7 +308,17 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     *out = nullptr;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     safe_trace("perms_create: enter");
-    safe_perms *p = new safe_perms();
+    safe_perms *p = nullptr;
+    bool reused = false;
+    if (ctx->perm_cache && ctx->perm_cache->n == n && ctx->perm_cache->count == num_permutations) {
+        p = ctx->perm_cache;               // same shape as the last destroyed handle: keep its buffers
+        ctx->perm_cache = nullptr;
+        reused = true;
+        p->h_movable.clear();
+    } else {
+        perms_cache_drop(ctx);
+        p = new safe_perms();
+    }
     p->ctx = ctx;
     p->n = n;
     p->count = num_permutations;
@@ -309,6 +326,16 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
         if (movable_host[i]) p->h_movable.push_back(static_cast<int32_t>(i));
     p->k = static_cast<int64_t>(p->h_movable.size());
     p->stream = draw_stream_new(has_seed ? seed : entropy_seed());
+    p->generated = p->swapping = p->enqueued = 0;
+    if (reused) {
+        const int64_t stride = n + 1;
+        for (int b = 0; b < 2; ++b) p->h_targets[b].resize(kChunk * std::max<int64_t>(p->k, 1));
+        hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
+        SAFE_HIP_CHECK(hipGetLastError());
+        safe_trace("perms_create: done (buffers reused)");
+        *out = p;
+        return SAFE_OK;
+    }
     const int64_t k = p->k, stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
     int rc = SAFE_OK;
     do {
@@ -347,10 +374,19 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
 int safe_perms_destroy(safe_perms *perms) {
     if (!perms) return SAFE_OK;
     (void)hipSetDevice(perms->ctx->device);
-    (void)hipStreamSynchronize(perms->ctx->aux_stream);
-    (void)hipStreamSynchronize(perms->ctx->side_stream);
-    (void)hipStreamSynchronize(perms->ctx->stream);
-    perms_free(perms);
+    safe_ctx *ctx = perms->ctx;
+    SwapPool::get().wait();
+    (void)hipStreamSynchronize(ctx->aux_stream);
+    (void)hipStreamSynchronize(ctx->side_stream);
+    (void)hipStreamSynchronize(ctx->stream);
+    // keep the allocations for the next handle of the same shape (hipMalloc / hipHostMalloc / hipFree of
+    // ~30 MB per call cost more than a millisecond)
+    perms_cache_drop(ctx);
+    draw_stream_free(perms->stream);
+    perms->stream = nullptr;
+    (void)hipFree(perms->inverse_t);
+    perms->inverse_t = nullptr;
+    ctx->perm_cache = perms;
     return SAFE_OK;
 }
 
