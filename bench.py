@@ -132,7 +132,8 @@ def main():
 
     torch.cuda.set_device(local_rank)
     dist = None
-    if world > 1:
+    force_dist = os.environ.get('SAFE_BENCH_FORCE_DIST') == '1'      # exercise the collectives with a single rank
+    if world > 1 or force_dist:
         import torch.distributed as dist
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
@@ -164,7 +165,7 @@ def main():
         attr = be.Attributes.from_device(ctx, b_dev.data_ptr(), np.float32, n, m, order='F')
         stats = attr.stats()                                  # dispatch rule + >50 % NaN check inputs
         flags = attr.row_flags()
-        if world > 1:                                         # indx_vals must come from the FULL matrix
+        if dist is not None:                                  # indx_vals must come from the FULL matrix
             flags = sharding.reduce_row_flags(flags)
             stats = sharding.reduce_stats(stats)
             attr.set_row_flags(flags)
@@ -172,7 +173,7 @@ def main():
         be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05,
                          [t.data_ptr() for t in out] + [enriched.data_ptr()], table=table)
         kernel_ms.append(ctx.last_kernel()[1])
-        if world > 1:
+        if dist is not None:
             gathered[0] = sharding.gather_columns(out[3], m * world)   # NES blocks over RCCL / xGMI
         perms.close()
         attr.close()
@@ -180,7 +181,7 @@ def main():
 
     def fence():
         torch.cuda.synchronize()
-        if world > 1:
+        if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -193,7 +194,7 @@ def main():
         step()
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
@@ -243,7 +244,7 @@ def main():
         if args.extras and world == 1:
             line['hbm_bound_kernels'] = hbm_kernels(ctx, torch, np, be)
         print(json.dumps(line))
-    if world > 1:
+    if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
 

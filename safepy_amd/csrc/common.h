@@ -150,6 +150,7 @@ struct safe_perms {
     int64_t generated = 0, swapping = 0, enqueued = 0;
     std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each enqueued chunk
     std::vector<uint32_t> h_targets[2];            // swap targets of a chunk (draw thread -> workers)
+    std::vector<uint32_t> h_local;                 // the draw thread's private chunk buffer
     int32_t *h_maps[2] = {nullptr, nullptr};       // pinned: row maps of a chunk (workers -> GPU)
     hipEvent_t staged[2] = {nullptr, nullptr};
     int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] scan ping-pong

@@ -164,6 +164,24 @@ struct DrawStream {
     }
 };
 
+// Streaming copy (no read-for-ownership of the destination lines): the draw thread hands a
+// chunk of targets to the swap workers on other cores; writing the shared buffer with ordinary
+// stores would first have to pull every line back from the workers' caches.
+void draws_nt_copy(void *dst, const void *src, size_t bytes) {
+#if defined(__x86_64__)
+    if ((reinterpret_cast<uintptr_t>(dst) & 15) == 0 && (reinterpret_cast<uintptr_t>(src) & 15) == 0) {
+        const size_t n16 = bytes / 16;
+        const __m128i *s = static_cast<const __m128i *>(src);
+        __m128i *d = static_cast<__m128i *>(dst);
+        for (size_t i = 0; i < n16; ++i) _mm_stream_si128(d + i, _mm_load_si128(s + i));
+        _mm_sfence();
+        memcpy(static_cast<char *>(dst) + n16 * 16, static_cast<const char *>(src) + n16 * 16, bytes - n16 * 16);
+        return;
+    }
+#endif
+    memcpy(dst, src, bytes);
+}
+
 DrawStream *draw_stream_new(uint32_t seed) { return new DrawStream(seed); }
 void draw_stream_free(DrawStream *s) { delete s; }
 void draw_stream_targets(DrawStream *s, int64_t k, uint32_t *steps) { s->shuffle_targets(k, steps); }

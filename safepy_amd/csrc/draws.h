@@ -1,5 +1,6 @@
 // Host draw stream of the legacy NumPy permutation (draws.cpp).
 #pragma once
+#include <cstddef>
 #include <cstdint>
 
 struct DrawStream;
@@ -7,3 +8,5 @@ DrawStream *draw_stream_new(uint32_t seed);
 void draw_stream_free(DrawStream *s);
 // accepted swap targets of one shuffle of k items in step order: steps[s] = j for i = k-1-s
 void draw_stream_targets(DrawStream *s, int64_t k, uint32_t *steps);
+// streaming (non-temporal) copy for hand-offs to other cores
+void draws_nt_copy(void *dst, const void *src, size_t bytes);

@@ -200,8 +200,10 @@ int perms_generate_until(safe_perms *p, int64_t upto) {
             // draw the next chunk (possibly one ahead of what was asked for: it overlaps the swaps)
             const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
             const int b = static_cast<int>((q0 / kChunk) & 1);
-            uint32_t *h = p->h_targets[b].data();
+            // draw into a buffer only this thread touches, then stream the chunk to the shared one
+            uint32_t *h = p->h_local.data();
             for (int64_t q = 0; q < cnt; ++q) draw_stream_targets(p->stream, k, h + q * std::max<int64_t>(k, 1));
+            draws_nt_copy(p->h_targets[b].data(), h, static_cast<size_t>(cnt) * std::max<int64_t>(k, 1) * sizeof(uint32_t));
             p->generated = q1;
             safe_trace("  gen: chunk drawn");
         }
@@ -329,7 +331,8 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     p->generated = p->swapping = p->enqueued = 0;
     if (reused) {
         const int64_t stride = n + 1;
-        for (int b = 0; b < 2; ++b) p->h_targets[b].resize(kChunk * std::max<int64_t>(p->k, 1));
+        for (int b = 0; b < 2; ++b) p->h_targets[b].resize(kChunk * std::max<int64_t>(p->k, 1) + 16);
+        p->h_local.resize(kChunk * std::max<int64_t>(p->k, 1) + 16);
         hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
         SAFE_HIP_CHECK(hipGetLastError());
         safe_trace("perms_create: done (buffers reused)");
@@ -349,7 +352,8 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
         if ((rc = dev_alloc(&p->d_maps[1], kChunk * stride)) != SAFE_OK) break;
         hipError_t e = hipSuccess;
         for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-            p->h_targets[b].resize(kChunk * std::max<int64_t>(k, 1));
+            p->h_targets[b].resize(kChunk * std::max<int64_t>(k, 1) + 16);
+            p->h_local.resize(kChunk * std::max<int64_t>(k, 1) + 16);
             e = hipHostMalloc(reinterpret_cast<void **>(&p->h_maps[b]), kChunk * stride * sizeof(int32_t), hipHostMallocDefault);
             if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged[b], hipEventDisableTiming);
         }
