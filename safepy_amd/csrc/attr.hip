@@ -9,38 +9,58 @@ __device__ __forceinline__ double load_attr(const void *raw, int64_t idx) {
 }
 
 // Whole-matrix facts in one pass: per column NaN count, nansum, #values outside {0,1},
-// #non-integers, max |v|; per row "has a value" flags.  One block per group of GC columns;
+// #non-integers, max |v|; per row "has a value" bits.  One block per group of GC columns;
 // the thread grid is laid out along the contiguous axis of the matrix so loads coalesce:
 //   Fortran order (rs == 1): GC = 1,  256 threads walk the rows of one column
 //   C order       (cs == 1): GC = 64, 64 x 4 threads: x = column, y = row lane
+// Row bits are collected per block in an LDS bitmap (wave ballots, no atomics on the hot
+// path) and OR-ed into the global bitmap once per block, skipping words already complete.
 template <typename T, int GC>
 __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw, int64_t n, int64_t m,
-                                                    int64_t rs, int64_t cs, unsigned int *__restrict__ row_flags32,
+                                                    int64_t rs, int64_t cs, unsigned int *__restrict__ row_bits,
                                                     unsigned long long *__restrict__ acc /*[4]*/,
                                                     double *__restrict__ col_sum, unsigned long long *__restrict__ max_abs_bits) {
+    extern __shared__ unsigned int s_bits[];           // [ceil(n/32)]
     constexpr int RL = 256 / GC;                       // row lanes per column
     const int cx = GC == 1 ? 0 : (threadIdx.x & (GC - 1));
     const int ry = GC == 1 ? threadIdx.x : (threadIdx.x / GC);
+    const int lane = threadIdx.x & 63;
     const int64_t j = static_cast<int64_t>(blockIdx.x) * GC + cx;
+    const int64_t n_words = (n + 31) / 32;
     __shared__ double s_sum[256];
     __shared__ double s_max[256];
     __shared__ unsigned int s_nan[256], s_other[256], s_nonint[256];
+    for (int64_t w = threadIdx.x; w < n_words; w += 256) s_bits[w] = 0;
+    __syncthreads();
     unsigned int c_nan = 0, c_other = 0, c_nonint = 0;
     double mx = 0.0, sum = 0.0;
-    if (j < m) {
-        for (int64_t i = ry; i < n; i += RL) {
+    const int64_t n_round = (n + RL - 1) / RL * RL;    // every thread runs the same trip count (ballots)
+    for (int64_t i = ry; i < n_round; i += RL) {
+        bool has = false;
+        if (i < n && j < m) {
             const double v = load_attr<T>(raw, i * rs + j * cs);
             if (v != v) {
                 ++c_nan;
             } else {
+                has = true;
                 sum += v;
                 if (v != 0.0 && v != 1.0) ++c_other;
                 if (v != floor(v)) ++c_nonint;
                 const double a = fabs(v);
                 if (a > mx) mx = a;
-                const unsigned int bit = 1u << (8 * (i & 3));       // 4 row flags share a 32-bit word
-                if (!(row_flags32[i >> 2] & bit)) atomicOr(&row_flags32[i >> 2], bit);   // racy pre-check is benign
             }
+        }
+        const unsigned long long bal = __ballot(has);
+        if (GC == 1) {
+            // the wave holds 64 consecutive rows starting at i - lane: two bitmap words, owned by this wave
+            const int64_t r0 = i - lane;
+            if (lane == 0 && bal) {
+                if (r0 < n) s_bits[r0 >> 5] |= static_cast<unsigned int>(bal);
+                if (r0 + 32 < n) s_bits[(r0 >> 5) + 1] |= static_cast<unsigned int>(bal >> 32);
+            }
+        } else {
+            // the wave holds ONE row (i) across 64 columns
+            if (lane == 0 && bal && i < n) atomicOr(&s_bits[i >> 5], 1u << (i & 31));
         }
     }
     s_sum[threadIdx.x] = sum;
@@ -49,6 +69,10 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     s_other[threadIdx.x] = c_other;
     s_nonint[threadIdx.x] = c_nonint;
     __syncthreads();
+    for (int64_t w = threadIdx.x; w < n_words; w += 256) {
+        const unsigned int mine = s_bits[w];
+        if (mine & ~row_bits[w]) atomicOr(&row_bits[w], mine);       // racy pre-check is benign
+    }
     if (ry == 0 && j < m) {
         double total = 0.0, tmx = 0.0;
         unsigned long long t_nan = 0, t_other = 0, t_nonint = 0;
@@ -66,6 +90,11 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
         if (t_nonint) atomicAdd(&acc[2], t_nonint);
         atomicMax(max_abs_bits, static_cast<unsigned long long>(__double_as_longlong(tmx)));
     }
+}
+
+__global__ void k_bits_to_bytes(const unsigned int *__restrict__ bits, int64_t n, uint8_t *__restrict__ bytes) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+    if (i < n) bytes[i] = (bits[i >> 5] >> (i & 31)) & 1u;
 }
 
 // one wave per column: rows holding a 1, ascending, by ballot compaction
@@ -128,14 +157,24 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_HIP_CHECK(hipMemsetAsync(d_acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
     uint8_t *flags = nullptr;
     SAFE_TRY(dev_alloc(&flags, flag_bytes));
-    SAFE_HIP_CHECK(hipMemsetAsync(flags, 0, flag_bytes, ctx->stream));
+    const int64_t n_words = (n + 31) / 32;
+    unsigned int *d_rowbits = nullptr;
+    SAFE_TRY(dev_alloc(&d_rowbits, n_words));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_rowbits, 0, n_words * sizeof(unsigned int), ctx->stream));
+    SAFE_REQUIRE(n_words * sizeof(unsigned int) <= 150 * 1024, "safe_attr_stats: too many rows for the LDS row bitmap");
     if (!attr->col_sum) SAFE_TRY(dev_alloc(&attr->col_sum, m));
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
     const bool c_order = attr->col_stride == 1 && m > 1;
 #define STATS(T, GC)                                                                                               \
-    hipLaunchKernelGGL((k_attr_stats<T, GC>), dim3(ceil_div(m, GC)), dim3(256), 0, ctx->stream, attr->raw, n, m,   \
-                       attr->row_stride, attr->col_stride, reinterpret_cast<unsigned int *>(flags), d_acc,         \
-                       attr->col_sum, d_acc + 3)
+    do {                                                                                                           \
+        if (n_words * sizeof(unsigned int) > 32 * 1024)                                                            \
+            SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attr_stats<T, GC>),                \
+                                               hipFuncAttributeMaxDynamicSharedMemorySize,                         \
+                                               static_cast<int>(n_words * sizeof(unsigned int))));                 \
+        hipLaunchKernelGGL((k_attr_stats<T, GC>), dim3(ceil_div(m, GC)), dim3(256), n_words * sizeof(unsigned int), \
+                           ctx->stream, attr->raw, n, m, attr->row_stride, attr->col_stride, d_rowbits, d_acc,     \
+                           attr->col_sum, d_acc + 3);                                                              \
+    } while (0)
     if (c_order) {
         if (f32) STATS(float, 64);
         else STATS(double, 64);
@@ -144,6 +183,7 @@ int safe_attr_prepare(safe_attr *attr) {
         else STATS(double, 1);
     }
 #undef STATS
+    hipLaunchKernelGGL(k_bits_to_bytes, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_rowbits, n, flags);
     SAFE_HIP_CHECK(hipGetLastError());
     unsigned long long h_acc[4];
     SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));
@@ -151,6 +191,7 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_acc);
+    (void)hipFree(d_rowbits);
     attr->n_other = static_cast<int64_t>(h_acc[0]);
     attr->max_nan_col = static_cast<int64_t>(h_acc[1]);
     attr->n_non_integer = static_cast<int64_t>(h_acc[2]);

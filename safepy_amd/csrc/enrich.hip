@@ -783,43 +783,69 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
     }
 }
 
-// counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472)
-__global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ gl_counts, int64_t n_pad,
-                                                         const int32_t *__restrict__ sell_pos, int64_t n,
-                                                         int64_t mloc, int64_t n_perm, PermOut out) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
-    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
-    bool hit = false;
-    if (i < n && c < mloc) {
-        const int64_t o = i * mloc + c;
-        const unsigned int gl = gl_counts[c * n_pad + sell_pos[i]];   // #less << 16 | #greater
-        const unsigned int P = static_cast<unsigned int>(n_perm);
-        const unsigned int cneg = P - (gl & 0xFFFFu);                 // #(S_p <= S_obs)
-        const unsigned int cpos = P - (gl >> 16);                     // #(S_p >= S_obs)
+// counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472).
+// The counters are [column][SELL position]; the outputs are [row][column].  A block takes a
+// 64 x 64 tile: coalesced reads along the SELL positions, transpose through LDS, coalesced
+// 512-byte writes along the columns of each row.
+// DIRECT = false: counters hold (#less << 16 | #greater)  (bit-sliced kernel)
+// DIRECT = true : counters hold (#>=   << 16 | #<=) and NaN observed scores matter (f64 kernel)
+template <bool DIRECT>
+__global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ counts, int64_t n_pad,
+                                                         const int32_t *__restrict__ sell_row,
+                                                         const double *__restrict__ ns, int64_t mloc, int64_t n_perm,
+                                                         PermOut out) {
+    __shared__ unsigned int tile[64][65];
+    __shared__ unsigned int part[4][64];
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+    const int64_t spos0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
+    for (int cc = wave; cc < 64; cc += 4) {
+        const int64_t c = c0 + cc;
+        tile[cc][lane] = c < mloc ? counts[c * n_pad + spos0 + lane] : 0u;
+    }
+    __syncthreads();
+    const int64_t c = c0 + lane;
+    const unsigned int P = static_cast<unsigned int>(n_perm);
+    unsigned int hits = 0;
+    for (int ss = wave; ss < 64; ss += 4) {
+        const int32_t row = sell_row[spos0 + ss];
+        if (row < 0 || c >= mloc) continue;
+        const unsigned int v = tile[lane][ss];
+        const int64_t o = static_cast<int64_t>(row) * mloc + c;
+        unsigned int cneg, cpos;
+        bool obs_nan = false;
+        if (DIRECT) {
+            cneg = v & 0xFFFFu;
+            cpos = v >> 16;
+            const double obs = ns[o];
+            obs_nan = obs != obs;
+        } else {
+            cneg = P - (v & 0xFFFFu);           // #(S_p <= S_obs) = P - #greater
+            cpos = P - (v >> 16);               // #(S_p >= S_obs) = P - #less
+        }
         if (out.mode == 1) {
             out.counts_neg[o] = static_cast<double>(cneg);
             out.counts_pos[o] = static_cast<double>(cpos);
         } else if (out.mode == 2) {
-            const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
+            const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+            const double en = obs_nan ? qnan : out.nes_table[cneg], ep = obs_nan ? qnan : out.nes_table[cpos];
             double nes = ep - en;
             if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
             if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
-            hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
-            out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(P);
-            out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(P);
+            const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+            out.pvalues_neg[o] = obs_nan ? qnan : static_cast<double>(cneg) / static_cast<double>(P);
+            out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / static_cast<double>(P);
             out.nes[o] = nes;
             out.nes_binary[o] = hit ? 1.0 : 0.0;
+            hits += hit;
         }
     }
     if (out.mode == 2) {
-        // column counts: reduce the 4 rows of this block first
-        __shared__ unsigned int part[64];
-        if (threadIdx.x < 64) part[threadIdx.x] = 0;
+        part[wave][lane] = hits;
         __syncthreads();
-        if (hit) atomicAdd(&part[threadIdx.x & 63], 1u);
-        __syncthreads();
-        if (threadIdx.x < 64 && part[threadIdx.x] && blockIdx.x * 64 + threadIdx.x < mloc)
-            atomicAdd(&out.enriched[blockIdx.x * 64 + threadIdx.x], part[threadIdx.x]);
+        if (wave == 0 && c < mloc) {
+            const unsigned int t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
+            if (t) atomicAdd(&out.enriched[c], t);
+        }
     }
 }
 
@@ -1060,47 +1086,6 @@ __global__ __launch_bounds__(256) void k_tile32_prep(const void *__restrict__ ra
     o[1] = v[1];
     o[2] = v[2];
     o[3] = v[3];
-}
-
-// packed counts (#>= << 16 | #<=) + observed score -> compute_pvalues outputs (safe.py:528-554, 468-472)
-__global__ __launch_bounds__(256) void k_counts_finalize_direct(const unsigned int *__restrict__ counts, int64_t n_pad,
-                                                                const int32_t *__restrict__ sell_pos,
-                                                                const double *__restrict__ ns, int64_t n, int64_t mloc,
-                                                                int64_t n_perm, PermOut out) {
-    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
-    const int64_t i = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
-    bool hit = false;
-    if (i < n && c < mloc) {
-        const int64_t o = i * mloc + c;
-        const unsigned int v = counts[c * n_pad + sell_pos[i]];
-        const unsigned int cneg = v & 0xFFFFu, cpos = v >> 16;
-        const double obs = ns[o];
-        const bool obs_nan = obs != obs;
-        const double qnan = __longlong_as_double(0x7FF8000000000000ll);
-        if (out.mode == 1) {
-            out.counts_neg[o] = static_cast<double>(cneg);
-            out.counts_pos[o] = static_cast<double>(cpos);
-        } else if (out.mode == 2) {
-            const double en = obs_nan ? qnan : out.nes_table[cneg], ep = obs_nan ? qnan : out.nes_table[cpos];
-            double nes = ep - en;
-            if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
-            if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
-            hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
-            out.pvalues_neg[o] = obs_nan ? qnan : static_cast<double>(cneg) / static_cast<double>(n_perm);
-            out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / static_cast<double>(n_perm);
-            out.nes[o] = nes;
-            out.nes_binary[o] = hit ? 1.0 : 0.0;
-        }
-    }
-    if (out.mode == 2) {
-        __shared__ unsigned int part[64];
-        if (threadIdx.x < 64) part[threadIdx.x] = 0;
-        __syncthreads();
-        if (hit) atomicAdd(&part[threadIdx.x & 63], 1u);
-        __syncthreads();
-        if (threadIdx.x < 64 && part[threadIdx.x] && blockIdx.x * 64 + threadIdx.x < mloc)
-            atomicAdd(&out.enriched[blockIdx.x * 64 + threadIdx.x], part[threadIdx.x]);
-    }
 }
 
 __global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
@@ -1450,8 +1435,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    hipLaunchKernelGGL(k_counts_finalize, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_gl, n_pad,
-                       nbr->sell_pos, n, mloc, P, out);
+    hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, d_gl, n_pad,
+                       nbr->sell_row, static_cast<const double *>(nullptr), mloc, P, out);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
@@ -1612,8 +1597,8 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    hipLaunchKernelGGL(k_counts_finalize_direct, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_counts,
-                       n_pad, nbr->sell_pos, d_ns, n, mloc, P, out);
+    hipLaunchKernelGGL(k_counts_finalize<true>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, d_counts,
+                       n_pad, nbr->sell_row, static_cast<const double *>(d_ns), mloc, P, out);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
