@@ -66,8 +66,8 @@ struct safe_ctx {
     KernelStat last_kernel;
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
     struct safe_perms *perm_cache = nullptr;    // buffers of the last destroyed permutation handle, reused by the next
-    void *scratch[4] = {nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[4] = {0, 0, 0, 0};
+    void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
+    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };
 
 // returns a device buffer of at least `bytes` from slot `slot`, valid until the next request

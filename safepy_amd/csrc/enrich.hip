@@ -783,6 +783,159 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// K5 bit-sliced form with PRE-PERMUTED member lists (the default when 8*(N+1) < 65536).
+// For every permutation p of a span a small kernel writes ids_p[e] = 8 * cur_p[member e]
+// for all SELL entries (u16: the LDS byte offset of the member's word pair).  The main
+// kernel then streams those lists from L2/MALL -- coalesced 128-byte loads, one block ahead
+// -- and needs a single LDS gather per member; the permutation row never enters LDS, so there
+// is no shared per-permutation state, no barrier inside a task, and half the LDS traffic.
+// --------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict__ cur16, int64_t stride16,
+                                                      const uint16_t *__restrict__ sell_col2, int64_t entries,
+                                                      int64_t entries_pad, int64_t p0, int64_t count, uint32_t pad_off,
+                                                      uint16_t *__restrict__ out) {
+    const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y;
+    if (e >= entries_pad || q >= count) return;
+    uint32_t v = pad_off;
+    if (e < entries) v = static_cast<uint32_t>(cur16[(p0 + q) * stride16 + (sell_col2[e] >> 1)]) << 3;
+    out[q * entries_pad + e] = static_cast<uint16_t>(v);
+}
+
+// ids: u16 LDS byte offsets (relative to T) of the members, SELL layout; SHIFT = 2 turns the
+// resident 2*id list into 8*id (observed pass), 0 takes pre-permuted offsets as they are
+template <int SHIFT>
+__device__ __forceinline__ void bits_accumulate_ids(const uint16_t *__restrict__ ids, int wdt, uint32_t t_addr,
+                                                    uint32_t (&s0)[BT_LV], uint32_t (&s1)[BT_LV]) {
+#pragma unroll
+    for (int l = 0; l < BT_LV; ++l) s0[l] = s1[l] = 0;
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = ids[u * 64];
+    const uint16_t *pc = ids + 8 * 64;
+    for (int t0 = 0; t0 < wdt; t0 += 8, pc += 8 * 64) {
+        uint32_t r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = (c[u] << SHIFT) + t_addr;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = pc[u * 64];                                // next block (lists have a tail)
+        uint32_t x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const u32x2 w = *(lds_u2_ptr)(uintptr_t)(r[u]);
+            x0[u] = w.x;
+            x1[u] = w.y;
+        }
+        const uint32_t e0 = vadd8(s0, x0);
+        const uint32_t e1 = vadd8(s1, x1);
+        if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+            vripple(s0, e0);
+            vripple(s1, e1);
+        }
+    }
+}
+
+template <int CL>
+__global__ __launch_bounds__(256) void k_permtest_bits_pre(
+    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint16_t *__restrict__ sell_col2, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
+    const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_pad, double *__restrict__ ns_out) {
+    extern __shared__ unsigned int lds[];
+    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
+    uint2 *T = reinterpret_cast<uint2 *>(lds);
+    unsigned int *slot_box = lds + t_words;
+    const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    for (;;) {
+        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t slot = *slot_box;
+        __syncthreads();
+        if (slot >= n_tasks) break;
+        const int4 task = tasks[slot];
+        const int wg = task.x, sg = task.y;
+        const int64_t p_begin = p_base + task.z;
+        const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+
+        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
+        const bool active = s < n_slices;
+        const int32_t row = active ? sell_row[s * 64 + lane] : -1;
+        const int64_t my_off = (active ? slice_off[s] : 0) + lane;
+        const int wdt = active ? slice_width[s] : 0;
+        __syncthreads();                                                  // T is complete; waves are independent from here
+
+        uint32_t o0[BT_LV], o1[BT_LV];                                   // observed sums (safe.py:496-499)
+        bits_accumulate_ids<2>(sell_col2 + my_off, wdt, t_addr, o0, o1);
+
+        uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
+        uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
+#pragma unroll
+        for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
+
+        for (int64_t p = p_begin; p < p_end; ++p) {
+            uint32_t s0[BT_LV], s1[BT_LV];
+            bits_accumulate_ids<0>(ids_p + (p - p_base) * entries_pad + my_off, wdt, t_addr, s0, s1);
+            uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
+#pragma unroll
+            for (int l = 0; l < BT_LV; ++l) {
+                // f(s, o, b) = (s != o) ? o : b  -> 0x8E ;  (s != o) ? s : b -> 0xB2
+                lt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], lt0, 0x8E);
+                gt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], gt0, 0xB2);
+                lt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], lt1, 0x8E);
+                gt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], gt1, 0xB2);
+            }
+            vcount<CL>(g0, gp0, gt0);
+            vcount<CL>(g1, gp1, gt1);
+            vcount<CL>(l0, lp0, lt0);
+            vcount<CL>(l1, lp1, lt1);
+            if (((p - p_begin) & 7) == 7) {
+                vflush<CL>(g0, gp0);
+                vflush<CL>(g1, gp1);
+                vflush<CL>(l0, lp0);
+                vflush<CL>(l1, lp1);
+            }
+        }
+        vflush<CL>(g0, gp0);
+        vflush<CL>(g1, gp1);
+        vflush<CL>(l0, lp0);
+        vflush<CL>(l1, lp1);
+
+        const bool live = row >= 0;
+        const int64_t spos = s * 64 + lane;
+#pragma unroll
+        for (int half = 0; half < 2; ++half) {
+            uint32_t m[32];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                m[l] = l < CL ? (half ? g1[l < CL ? l : 0] : g0[l < CL ? l : 0]) : 0u;
+                m[16 + l] = l < CL ? (half ? l1[l < CL ? l : 0] : l0[l < CL ? l : 0]) : 0u;
+            }
+            transpose32(m);
+#pragma unroll
+            for (int bit = 0; bit < 32; ++bit) {
+                const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                if (jc < mloc && active && m[bit]) atomicAdd(&gl_counts[jc * n_pad + spos], m[bit]);
+            }
+        }
+        if (ns_out && p_begin == 0 && live) {
+            const int64_t obase = static_cast<int64_t>(row) * mloc;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+                for (int bit = 0; bit < 32; ++bit) {
+                    const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                    if (jc >= mloc) break;
+                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit));
+                }
+        }
+        __syncthreads();                                                  // before T is overwritten by the next task
+    }
+}
+
 // counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472).
 // The counters are [column][SELL position]; the outputs are [row][column].  A block takes a
 // 64 x 64 tile: coalesced reads along the SELL positions, transpose through LDS, coalesced
@@ -1397,6 +1550,19 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
     const bool wide = P >= 1024;
     const bool scaled = (n + 1) * 8 < 65536;
+    const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
+    const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
+    const int64_t entries_pad = (nbr->sell_entries + 512 + 255) / 256 * 256;
+    uint16_t *d_ids[2] = {nullptr, nullptr};
+    if (pre)
+        for (int b = 0; b < 2; ++b)
+            SAFE_TRY(ctx_scratch(ctx, 4 + b, static_cast<size_t>(span) * entries_pad * sizeof(uint16_t),
+                                 reinterpret_cast<void **>(&d_ids[b])));
+    const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
+    if (pre)
+        SAFE_HIP_CHECK(hipFuncSetAttribute(wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
+                                                : reinterpret_cast<const void *>(k_permtest_bits_pre<10>),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
     const void *kfn = wide ? (scaled ? reinterpret_cast<const void *>(k_permtest_bits<16, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<16, false>))
                            : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
@@ -1419,6 +1585,25 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
         safe_trace("launch_bits: span tables enqueued");
+        if (pre) {
+            hipLaunchKernelGGL(k_permute_cols, dim3(entries_pad / 256, p_limit - p_base), dim3(256), 0, ks, perms->table16,
+                               perms->stride16, nbr->sell_col2, nbr->sell_entries, entries_pad, p_base, p_limit - p_base,
+                               static_cast<uint32_t>(8 * n), d_ids[c & 1]);
+            SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
+            const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(ctx->num_cu) *
+                                                         std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
+            if (wide)
+                hipLaunchKernelGGL(k_permtest_bits_pre<16>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
+                                   nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
+                                   n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
+            else
+                hipLaunchKernelGGL(k_permtest_bits_pre<10>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
+                                   nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
+                                   n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
+            SAFE_HIP_CHECK(hipGetLastError());
+            SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
+            continue;
+        }
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
 #define LAUNCH_BITS(CLV, SC)                                                                                          \
         hipLaunchKernelGGL((k_permtest_bits<CLV, SC>), dim3(blocks), dim3(256), lds_bytes, ks, n, P,                  \
