@@ -69,6 +69,20 @@ def cpu_baseline(a_dense, b, sample_perms):
             'seconds_per_permutation': dt / sample_perms, 'blas': blas}
 
 
+def pmc_traffic(kernel_name):
+    """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes
+    (profiles/pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
+    passes of this same bench command; tools/rocpd_counters.py).  PMC counters cannot be
+    collected from inside the timed process, so this is the offline measurement; None if the
+    profile has no entry for the kernel."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
+            entry = json.load(f).get(kernel_name)
+        return None if entry is None else entry['hbm_bytes_per_launch']
+    except (OSError, ValueError, KeyError):
+        return None
+
+
 def hbm_kernels(ctx, torch, np, be):
     """The two HBM-bound kernels of the path at BASELINE.json configs[3] size, timed with HIP
     events on the context stream: K1 fused all-pairs distance + threshold writing the reference's
@@ -212,11 +226,16 @@ def main():
         # consumes, the membership, and one read-modify-write of its per-(node, attribute) counters.
         n_wg = -(-m // 64)
         n_pad = -(-n // 64) * 64
-        if kname == 'k_permtest_bits':
+        if kname == 'k_permtest_bits_pre':
+            # attribute bit words + the span's pre-permuted member lists (2 B per membership entry and
+            # permutation) + the resident member list (observed pass) + counter read-modify-write
+            alg_bytes = 8 * (n + 1) * n_wg + 2 * int(nbr.nnz) * span + 2 * int(nbr.nnz) + 2 * 4 * n_pad * m
+        elif kname == 'k_permtest_bits':
             alg_bytes = 8 * (n + 1) * n_wg + 2 * (n + 8) * span + 2 * int(nbr.nnz) + 2 * 4 * n_pad * m
         else:
             alg_bytes = n * m * 4 + P * (n + 1) * 4 + int(nbr.nnz) * 4 + 5 * n * m * 8
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+        traffic = pmc_traffic(kname)
         line = {
             'metric': 'node-attribute enrichments/sec (nodes x attrs x perms), compute_pvalues permutation test',
             'value': value, 'unit': 'enrichments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -229,7 +248,7 @@ def main():
                        'neighbors_per_node_mean': float(counts.mean()), 'neighbors_per_node_std': float(counts.std()),
                        'parallelism': 'attribute shards x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': None, 'kernel_ms': k_ms,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel_ms': k_ms,
                          'launches_per_step': launches, 'permutations_per_launch': span,
                          'algorithmic_bytes': alg_bytes,
                          'binding_resource': 'VALU issue + LDS gather (not HBM, not MFMA): see DESIGN.md section 4 and '

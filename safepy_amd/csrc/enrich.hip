@@ -1568,7 +1568,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<10, false>));
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    ctx->last_kernel.name = "k_permtest_bits";
+    ctx->last_kernel.name = pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
     std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
@@ -1804,7 +1804,9 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
-    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_lds") return SAFE_OK;   // per-launch events already summed
+    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" ||
+        ctx->last_kernel.name == "k_permtest_lds")
+        return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;
     SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->k0, ctx->k1));
     ctx->last_kernel.total_ms = ms;
