@@ -94,6 +94,11 @@ int safe_nbr_shortpath(safe_ctx *ctx, int64_t n, int64_t n_edges, const int32_t 
  * int64 [n,n] row-major with entries in {0,1} (safe.py:387,430).  Any other value is
  * SAFE_E_VALUE. */
 int safe_nbr_from_dense_i64(safe_ctx *ctx, const int64_t *a_host, int64_t n, safe_nbr **out);
+/* Optional hint: the 2-D layout the membership was derived from ([n,2] row-major, the x/y node
+ * attributes read at safepy/safe.py:393-396).  Only used to renumber nodes along a
+ * space-filling curve for the block-sparse matrix-core kernel; results never depend on it.
+ * safe_nbr_euclidean records its own xy; without a layout the order is Cuthill-McKee. */
+int safe_nbr_set_layout(safe_nbr *nbr, const double *xy_host);
 int safe_nbr_destroy(safe_nbr *nbr);
 int safe_nbr_info(const safe_nbr *nbr, int64_t *n, int64_t *nnz, int64_t *max_row_count);
 /* self.neighborhoods in the reference layout: int64 [n,n] row-major (safe.py:430). */

@@ -157,6 +157,12 @@ class Neighborhoods:
         check(lib.safe_nbr_from_dense_i64(ctx.handle, _ptr(a), a.shape[0], C.byref(h)))
         return cls(ctx, h)
 
+    def set_layout(self, xy):
+        """Hint: the 2-D layout the membership came from (node order of the matrix-core kernel only)."""
+        xy = np.ascontiguousarray(xy, dtype=np.float64)
+        assert xy.shape == (self.n, 2)
+        check(lib.safe_nbr_set_layout(self.handle, _ptr(xy)))
+
     def to_dense(self):
         out = np.empty((self.n, self.n), dtype=np.int64)
         check(lib.safe_nbr_to_dense_i64(self.handle, _ptr(out)))

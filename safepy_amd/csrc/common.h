@@ -115,6 +115,37 @@ struct safe_nbr {
     // CSR of the transpose (column k -> rows i with A[i,k] = 1), built on first use
     int32_t *at_ptr = nullptr;      // [n+1]
     int32_t *at_col = nullptr;      // [nnz], unordered inside a column
+    // Block-sparse form for the MFMA permutation kernel (mfma.hip), built on first use:
+    // nodes in a locality-preserving order (Hilbert curve over the layout when one is known,
+    // Cuthill-McKee over the membership graph otherwise); 256-row groups x 32-column blocks,
+    // only blocks holding at least one member are stored, as 256 32-bit row words each.
+    std::vector<double> h_xy;       // [n][2] layout, if known (safe_nbr_euclidean / safe_nbr_set_layout)
+    bool blocks_ready = false;
+    int64_t bs_groups = 0;          // number of 256-row groups
+    int64_t bs_blocks = 0;          // stored blocks (every group padded to a multiple of 4)
+    int64_t bs_src = 0;             // length of a source-row map: (ceil(n/32)+1)*32, the last block is padding
+    int32_t *bs_order = nullptr;    // [bs_src] node at ordered position u (n = padding -> zero attribute row)
+    int32_t *bs_rowmap = nullptr;   // [bs_groups*256] node at ordered row u, -1 = padding
+    int32_t *bs_ptr = nullptr;      // [bs_groups+1] first block of a group
+    int32_t *bs_kb = nullptr;       // [bs_blocks] ordered column block of a stored block
+    uint32_t *bs_bits = nullptr;    // [bs_blocks][256] membership bits of the block's 256 rows
+    std::vector<int32_t> h_bs_ptr;
+};
+
+// outputs of the permutation-test kernels (enrich.hip, mfma.hip)
+struct PermOut {
+    double *ns;            // [n][mloc] or NULL
+    double *counts_neg;    // raw-count mode
+    double *counts_pos;
+    double *pvalues_neg;   // full mode
+    double *pvalues_pos;
+    double *nes;
+    double *nes_binary;
+    unsigned int *enriched;   // [mloc] u32 column counters
+    const double *nes_table;  // [P+1]
+    double nes_threshold;     // -log10(enrichment_threshold)
+    int sign_mode;
+    int mode;                 // 0 = score only, 1 = raw counts, 2 = full post-processing
 };
 
 struct safe_attr {
@@ -175,3 +206,11 @@ int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary ma
 int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)
 int perms_generate_until(safe_perms *perms, int64_t upto);   // enqueue table rows [generated, upto) on aux_stream (rng.cpp)
 int perms_wait(safe_perms *perms, int64_t upto, hipStream_t s);   // make stream s wait until rows [0, upto) exist (rng.cpp)
+// counters [column][position] (#less << 16 | #greater) -> outputs; rowmap[position] = row or -1 (enrich.hip)
+int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
+                           int64_t n_perm, const PermOut &out);
+// MFMA (i8, exact fixed point) form of the permutation test for quantitative attributes (mfma.hip)
+bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *attr, const safe_perms *perms, bool z);
+int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
+                const PermOut &out, bool *declined);
+void nbr_free_blocks(safe_nbr *nbr);

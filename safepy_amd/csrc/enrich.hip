@@ -76,20 +76,6 @@ __device__ __forceinline__ void finish_score(const double (&acc)[Z ? 3 : 1][BN],
     }
 }
 
-struct PermOut {
-    double *ns;            // [n][mloc] or NULL
-    double *counts_neg;    // raw-count mode
-    double *counts_pos;
-    double *pvalues_neg;   // full mode
-    double *pvalues_pos;
-    double *nes;
-    double *nes_binary;
-    unsigned int *enriched;   // [mloc] u32 column counters
-    const double *nes_table;  // [P+1]
-    double nes_threshold;     // -log10(enrichment_threshold)
-    int sign_mode;
-    int mode;                 // 0 = score only, 1 = raw counts, 2 = full post-processing
-};
 
 // --------------------------------------------------------------------------------------
 // K5 (general f64 form): one workgroup = (column tile, slice group); its 4 waves walk
@@ -1802,10 +1788,18 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     return SAFE_OK;
 }
 
+int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
+                           int64_t n_perm, const PermOut &out) {
+    hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, counts, n_pad,
+                       rowmap, static_cast<const double *>(nullptr), mloc, n_perm, out);
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
+}
+
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
     if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" ||
-        ctx->last_kernel.name == "k_permtest_lds")
+        ctx->last_kernel.name == "k_permtest_lds" || ctx->last_kernel.name == "k_permtest_mfma")
         return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;
     SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->k0, ctx->k1));
@@ -1858,6 +1852,11 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
                                    : launch_scatter(ctx, nbr, attr, perms, col0, col1, out));
         return finish_kernel_timing(ctx);
     }
+    if (mfma_applicable(ctx, nbr, attr, perms, z)) {
+        bool declined = false;
+        SAFE_TRY(launch_mfma(ctx, nbr, attr, perms, col0, col1, out, &declined));
+        if (!declined) return finish_kernel_timing(ctx);
+    }
     if (lds_f64_applicable(nbr, perms)) {
         SAFE_TRY(launch_lds_f64(ctx, nbr, attr, perms, col0, col1, z, out));
         return finish_kernel_timing(ctx);
@@ -1898,11 +1897,10 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     unsigned int *d_enr = nullptr;
     Tiles tiles;
     const PermPath path = choose_path(ctx, nbr, attr, P, z);
+    bool mfma = path == PATH_GATHER && mfma_applicable(ctx, nbr, attr, perms, z);
     const bool lds64 = path == PATH_GATHER && lds_f64_applicable(nbr, perms);
-    const bool scatter = path != PATH_GATHER || lds64;
     int rc = dev_alloc(&d_tab, P + 1);
     if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 16);
-    if (rc == SAFE_OK && !scatter) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
     if (rc == SAFE_OK) {
         hipError_t e = hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 16) * sizeof(unsigned int), ctx->stream);
@@ -1923,12 +1921,21 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.nes_threshold = -std::log10(enrichment_threshold);
         out.sign_mode = sign_mode;
         out.mode = 2;
-        rc = lds64                  ? launch_lds_f64(ctx, nbr, attr, perms, col0, col1, z, out)
-             : path == PATH_BITS    ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
-             : path == PATH_SCATTER ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
-                                    : (perms_wait(perms, P, ctx->stream) == SAFE_OK
-                                           ? launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out)
-                                           : SAFE_E_HIP);
+        if (mfma) {
+            bool declined = false;
+            rc = launch_mfma(ctx, nbr, attr, perms, col0, col1, out, &declined);
+            if (declined) mfma = false;
+        }
+        if (rc == SAFE_OK && !mfma) {
+            if (path == PATH_GATHER && !lds64) rc = build_tiles(ctx, attr, col0, col1, z, &tiles);
+            if (rc == SAFE_OK)
+                rc = lds64                  ? launch_lds_f64(ctx, nbr, attr, perms, col0, col1, z, out)
+                     : path == PATH_BITS    ? launch_bits(ctx, nbr, attr, perms, col0, col1, out)
+                     : path == PATH_SCATTER ? launch_scatter(ctx, nbr, attr, perms, col0, col1, out)
+                                            : (perms_wait(perms, P, ctx->stream) == SAFE_OK
+                                                   ? launch_gather(ctx, nbr, tiles, perms->table, P, mloc, z, out)
+                                                   : SAFE_E_HIP);
+        }
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);

@@ -1,0 +1,710 @@
+// K5, matrix-core form: the permutation test of run_permutations (safepy/safe_extras.py:36-70)
+// for quantitative attributes as an exact fixed-point block-sparse GEMM on the i8 MFMA pipe.
+//
+// The reference evaluates S_p = A . B0[perm_p] with dgemm.  Here
+//   * every attribute column is scaled by a power of two and rounded to a 47-bit integer,
+//     which is split into six balanced base-256 digits (i8 "slices", Ozaki-style splitting);
+//     A is 0/1, so each slice product accumulates EXACTLY in the i32 MFMA accumulators and
+//     the six partial sums recombine into the exact 64-bit integer sum.  Scores of different
+//     permutations are compared as integers: deterministic, independent of summation order,
+//     and at least as accurate as the reference's f64 dot products (quantisation 2^-46 of
+//     the column maximum, far below dgemm's own rounding of a ~k-term sum);
+//   * nodes are renumbered along a space-filling curve of the layout (the neighborhoods are
+//     balls of the layout, safe.py:389-417), which makes A block-sparse: a 256-row group only
+//     touches the 32-column blocks near it (fill 30-50 % at config-5 density), and only those
+//     blocks are multiplied;
+//   * the permuted operand B0[cur_p] is never materialised: the rows a block needs are
+//     gathered from the resident slice matrix straight into LDS (transposed on the way with
+//     v_perm so that every lane finds its 16 k-values contiguous), one 128-row super-step
+//     ahead of the MFMAs;
+//   * <= / >= counters, observed scores and accumulators live in registers for the whole
+//     (row group, 32-column tile, permutation span) task; tasks are queued per XCD by column
+//     tile so the slice rows a tile needs stay in that XCD's L2.
+#include <algorithm>
+#include <cmath>
+#include <numeric>
+
+#include "common.h"
+
+namespace {
+
+constexpr int MF_R = 256;             // rows per group = 8 waves x 32
+constexpr int MF_NS = 6;              // i8 slices per value
+constexpr int MF_SS = 1024 + 16;      // LDS bytes per (k-step, slice): [2 halves][32 lanes][16 B] + 16 B skew
+constexpr int MF_KS = MF_NS * MF_SS;  // LDS bytes per k-step (32 attribute rows)
+constexpr int MF_BUF = 4 * MF_KS;     // one buffer = one super-step = 4 k-steps
+constexpr int MF_MAXBLK = 4096;       // column blocks per row group the kernel can index from LDS
+constexpr int MF_SHIFT_BITS = 45;     // |q| < 2^46 after scaling: six balanced base-256 digits hold +-(2^47 - ...)
+
+typedef int v4i __attribute__((ext_vector_type(4)));
+typedef int v16i __attribute__((ext_vector_type(16)));
+
+// ---------------------------------------------------------------------------------------
+// column statistics: max |b|, sum b^2 and count over the non-NaN non-zero entries
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                       int64_t col0, int64_t mloc, int rows_per_block,
+                                                       unsigned long long *__restrict__ maxbits, double *__restrict__ sumsq,
+                                                       unsigned int *__restrict__ cnt) {
+    // 32 columns x 8 row lanes; the lane index runs along whichever axis is contiguous
+    __shared__ double s_max[8][33], s_sq[8][33];
+    __shared__ unsigned int s_cnt[8][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t c0 = static_cast<int64_t>(blockIdx.x) * 32, r0 = static_cast<int64_t>(blockIdx.y) * rows_per_block;
+    const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
+    const bool col_major = rs == 1;            // Fortran order: consecutive rows are adjacent
+    double mx = 0.0, sq = 0.0;
+    unsigned int ct = 0;
+    if (!col_major) {
+        const int64_t j = c0 + tx;
+        if (j < mloc)
+            for (int64_t r = r0 + ty; r < r1; r += 8) {
+                const double x = static_cast<double>(reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs]);
+                if (x == x && x != 0.0) {
+                    mx = fmax(mx, fabs(x));
+                    sq += x * x;
+                    ++ct;
+                }
+            }
+        s_max[ty][tx] = mx;
+        s_sq[ty][tx] = sq;
+        s_cnt[ty][tx] = ct;
+    } else {
+        // lanes along rows; column = c0 + ty + 8*i
+        for (int i = 0; i < 4; ++i) {
+            const int64_t j = c0 + ty + 8 * i;
+            mx = 0.0;
+            sq = 0.0;
+            ct = 0;
+            if (j < mloc)
+                for (int64_t r = r0 + tx; r < r1; r += 32) {
+                    const double x = static_cast<double>(reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs]);
+                    if (x == x && x != 0.0) {
+                        mx = fmax(mx, fabs(x));
+                        sq += x * x;
+                        ++ct;
+                    }
+                }
+            for (int o = 16; o > 0; o >>= 1) {
+                mx = fmax(mx, __shfl_xor(mx, o, 32));
+                sq += __shfl_xor(sq, o, 32);
+                ct += __shfl_xor(ct, o, 32);
+            }
+            if (tx == 0 && j < mloc && ct) {
+                atomicMax(&maxbits[j], static_cast<unsigned long long>(__double_as_longlong(mx)));
+                atomicAdd(&sumsq[j], sq);
+                atomicAdd(&cnt[j], ct);
+            }
+        }
+        return;
+    }
+    __syncthreads();
+    if (ty == 0) {
+        for (int k = 1; k < 8; ++k) {
+            mx = fmax(mx, s_max[k][tx]);
+            sq += s_sq[k][tx];
+            ct += s_cnt[k][tx];
+        }
+        const int64_t j = c0 + tx;
+        if (j < mloc && ct) {
+            atomicMax(&maxbits[j], static_cast<unsigned long long>(__double_as_longlong(mx)));
+            atomicAdd(&sumsq[j], sq);
+            atomicAdd(&cnt[j], ct);
+        }
+    }
+}
+
+// per column: the power-of-two scale that maps the column maximum just below 2^46
+__global__ void k_mfma_colfinish(const unsigned long long *__restrict__ maxbits, int64_t mloc, int *__restrict__ shift,
+                                 double *__restrict__ scale, int *__restrict__ bad) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= mloc) return;
+    const double mx = __longlong_as_double(static_cast<long long>(maxbits[j]));
+    int sh = 0;
+    if (mx > 0.0 && mx < __longlong_as_double(0x7FF0000000000000ll)) sh = MF_SHIFT_BITS - ilogb(mx);
+    else if (mx != 0.0) atomicOr(bad, 1);       // infinities are not representable at all
+    shift[j] = sh;
+    scale[j] = ldexp(1.0, -sh);
+}
+
+// ---------------------------------------------------------------------------------------
+// slices: bs[row][column tile][slice][32 columns] i8, row n = zeros.  q = rint(b * 2^shift)
+// as a 47-bit integer, digits d_t in [-128, 127] with q = sum d_t 256^t.
+// Also counts, per column, the values far below the column maximum (< 2^-6 max) and how many
+// of those had to be rounded: k_mfma_colcheck declines the path when such values are the bulk
+// of a column (an outlier would then set a grid too coarse for the typical sums).
+// ---------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                    int64_t col0, int64_t mloc, int64_t n_ct, const int *__restrict__ shift,
+                                                    const unsigned long long *__restrict__ maxbits,
+                                                    unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
+                                                    unsigned int *__restrict__ n_small_rounded) {
+    __shared__ double tile[32][33];
+    __shared__ unsigned int s_small[32], s_rounded[32];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t ct = blockIdx.x, r0 = static_cast<int64_t>(blockIdx.y) * 32;
+    const int64_t c0 = ct * 32;
+    const bool col_major = rs == 1;
+    if (threadIdx.x < 32) s_small[threadIdx.x] = s_rounded[threadIdx.x] = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int a = ty + 8 * i;                                  // the slow index of the read
+        const int64_t r = col_major ? r0 + tx : r0 + a, j = col_major ? c0 + a : c0 + tx;
+        double x = 0.0;
+        if (r < n && j < mloc) x = static_cast<double>(reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs]);
+        if (col_major) tile[tx][a] = x;
+        else tile[a][tx] = x;
+    }
+    __syncthreads();
+    const int64_t j = c0 + tx;
+    const int sh = j < mloc ? shift[j] : 0;
+    const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -6) : 0.0;
+    const int64_t row_bytes = n_ct * MF_NS * 32;
+    unsigned int k_small = 0, k_rounded = 0;
+    for (int i = 0; i < 4; ++i) {
+        const int rr = ty + 8 * i;
+        const int64_t r = r0 + rr;
+        if (r > n) continue;                                       // row n is the zero row
+        double x = tile[rr][tx];
+        if (!(x == x) || r == n) x = 0.0;                          // NaN -> 0 (safe_extras.py:10)
+        if (!(fabs(x) < __longlong_as_double(0x7FF0000000000000ll))) x = 0.0;   // +-inf: the path is declined anyway
+        const double scaled = ldexp(x, sh);
+        const double q = rint(scaled);
+        if (x != 0.0 && fabs(x) < small_below) {
+            ++k_small;
+            k_rounded += q != scaled;
+        }
+        const unsigned long long u = static_cast<unsigned long long>(static_cast<long long>(q) + 0x808080808080ll);
+        unsigned char *dst = bs + r * row_bytes + ct * (MF_NS * 32) + tx;
+#pragma unroll
+        for (int t = 0; t < MF_NS; ++t) dst[t * 32] = static_cast<unsigned char>(((u >> (8 * t)) & 0xFFu) ^ 0x80u);
+    }
+    if (k_small) atomicAdd(&s_small[tx], k_small);
+    if (k_rounded) atomicAdd(&s_rounded[tx], k_rounded);
+    __syncthreads();
+    if (threadIdx.x < 32 && c0 + threadIdx.x < mloc) {
+        if (s_small[threadIdx.x]) atomicAdd(&n_small[c0 + threadIdx.x], s_small[threadIdx.x]);
+        if (s_rounded[threadIdx.x]) atomicAdd(&n_small_rounded[c0 + threadIdx.x], s_rounded[threadIdx.x]);
+    }
+}
+
+__global__ void k_mfma_colcheck(const unsigned int *__restrict__ cnt, const unsigned int *__restrict__ n_small,
+                                const unsigned int *__restrict__ n_small_rounded, int64_t mloc, int *__restrict__ bad) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= mloc) return;
+    if (n_small_rounded[j] > 0 && 2ull * n_small[j] >= cnt[j]) atomicOr(bad, 1);
+}
+
+// source-row maps of a span: row 0 = identity (observed score), row 1 + q = permutation p_base + q
+__global__ __launch_bounds__(256) void k_mfma_src(const int32_t *__restrict__ order, int64_t n_src, int64_t n,
+                                                  const int32_t *__restrict__ table, int64_t p_base,
+                                                  int32_t *__restrict__ out) {
+    const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (u >= n_src) return;
+    const int64_t q = blockIdx.y;
+    const int32_t node = order[u];
+    out[q * n_src + u] = q == 0 ? node : table[(p_base + q - 1) * (n + 1) + node];
+}
+
+// ---------------------------------------------------------------------------------------
+// the kernel
+// ---------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t expand4(uint32_t nib) {       // 4 bits -> 4 bytes of 0/1
+    nib &= 0xFu;
+    return (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u;
+}
+
+// 4 x 4 byte transpose: in[r] = 4 columns of row r  ->  out[c] = 4 rows of column c
+__device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&out)[4]) {
+    const uint32_t lo01 = __builtin_amdgcn_perm(in[1], in[0], 0x05010400u);   // r0c0 r1c0 r0c1 r1c1
+    const uint32_t hi01 = __builtin_amdgcn_perm(in[1], in[0], 0x07030602u);   // r0c2 r1c2 r0c3 r1c3
+    const uint32_t lo23 = __builtin_amdgcn_perm(in[3], in[2], 0x05010400u);
+    const uint32_t hi23 = __builtin_amdgcn_perm(in[3], in[2], 0x07030602u);
+    out[0] = __builtin_amdgcn_perm(lo23, lo01, 0x05040100u);
+    out[1] = __builtin_amdgcn_perm(lo23, lo01, 0x07060302u);
+    out[2] = __builtin_amdgcn_perm(hi23, hi01, 0x05040100u);
+    out[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
+}
+
+__global__ __launch_bounds__(512) void k_permtest_mfma(
+    const unsigned char *__restrict__ bs, int64_t row_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
+    const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
+    const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
+    const double *__restrict__ col_scale, double *__restrict__ ns_out) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][MF_BUF] + kb list
+    __shared__ int slot_box;
+    int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * MF_BUF);
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lam = lane & 31, h = lane >> 5;
+    // gather role: thread -> (k-step of the super-step, row quad, 16-byte chunk of the row segment)
+    constexpr int CH = 2 * MF_NS, GT = 4 * 8 * CH;
+    const bool gth = tid < GT;
+    const int chunk = tid % CH, rq = (tid / CH) % 8, ks_g = tid / (8 * CH);
+    const int s_g = chunk >> 1, half_g = chunk & 1;
+    // this thread's LDS write base inside a buffer; column i of its 16 goes to lane slot
+    // (i & 3) + 4 * half + 8 * (i >> 2)
+    const uint32_t w_base = static_cast<uint32_t>(ks_g * MF_KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
+    const uint32_t r_base = static_cast<uint32_t>(h * 512 + lam * 16);        // MFMA B operand of this lane
+    const int col_in_tile = 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
+
+    const int home = blockIdx.x & 7;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int qx = (home + attempt) & 7;
+        const int q_begin = q_off[qx], q_len = q_off[qx + 1] - q_begin;
+        for (;;) {
+            if (tid == 0) slot_box = static_cast<int>(atomicAdd(&q_ctr[qx], 1u));
+            __syncthreads();
+            const int slot = slot_box;
+            __syncthreads();
+            if (slot >= q_len) break;
+            const int2 task = tasks[q_begin + slot];
+            const int g = task.x, ct = task.y;
+            const int b0 = blk_ptr[g], nb = blk_ptr[g + 1] - b0, S = nb >> 2;
+            if (S == 0) continue;
+            for (int i = tid; i < nb; i += 512) kb_list[i] = blk_kb[b0 + i];
+            __syncthreads();
+
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * (MF_NS * 32) + chunk * 16;
+            const uint32_t *bits_w = blk_bits + static_cast<int64_t>(b0) * MF_R + wave * 32 + lam;
+            const int total = n_q * S;
+
+            v16i acc[MF_NS];
+#pragma unroll
+            for (int s = 0; s < MF_NS; ++s)
+#pragma unroll
+                for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+            long long obs[16];
+            uint32_t cnt[16];
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                obs[r] = 0;
+                cnt[r] = 0;
+            }
+
+            auto load_src = [&](int q, int t) -> int4 {
+                const int kb = kb_list[4 * t + ks_g];
+                return *reinterpret_cast<const int4 *>(srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + 4 * rq);
+            };
+            auto load_rows = [&](const int4 &src, uint4 (&L)[4]) {
+                L[0] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.x) * row_bytes);
+                L[1] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.y) * row_bytes);
+                L[2] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.z) * row_bytes);
+                L[3] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.w) * row_bytes);
+            };
+            auto store_rows = [&](const uint4 (&L)[4], int buf) {
+                unsigned char *dst = lds + buf * MF_BUF + w_base;
+                const uint32_t w[4][4] = {{L[0].x, L[1].x, L[2].x, L[3].x},
+                                          {L[0].y, L[1].y, L[2].y, L[3].y},
+                                          {L[0].z, L[1].z, L[2].z, L[3].z},
+                                          {L[0].w, L[1].w, L[2].w, L[3].w}};
+#pragma unroll
+                for (int cw = 0; cw < 4; ++cw) {                   // columns 4cw .. 4cw+3 of this chunk
+                    uint32_t o[4];
+                    transpose4(w[cw], o);
+#pragma unroll
+                    for (int b = 0; b < 4; ++b)                     // column i = 4cw + b -> lane slot b + 8cw (+ 4 half)
+                        *reinterpret_cast<uint32_t *>(dst + (b + 8 * cw) * 16) = o[b];
+                }
+            };
+
+            // prologue: super-step 0 into buffer 0, source rows of super-step 1 in flight
+            int4 src_next = make_int4(0, 0, 0, 0);
+            uint4 L[4];
+            int q1 = 0, t1 = 0;                                      // (q, t) of iteration it + 1
+            if (gth) {
+                const int4 s0 = load_src(0, 0);
+                load_rows(s0, L);
+            }
+            t1 = 1;
+            if (t1 == S) {
+                t1 = 0;
+                q1 = 1;
+            }
+            if (gth && total > 1) src_next = load_src(q1, t1);
+            if (gth) store_rows(L, 0);
+            uint32_t aw[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) aw[k] = bits_w[static_cast<int64_t>(k) * MF_R];
+            __syncthreads();
+
+            int q = 0, t = 0;
+            for (int it = 0; it < total; ++it) {
+                const int buf = it & 1;
+                // (q2, t2) = iteration it + 2
+                int q2 = q1, t2 = t1 + 1;
+                if (t2 == S) {
+                    t2 = 0;
+                    q2 = q1 + 1;
+                }
+                const bool more1 = it + 1 < total, more2 = it + 2 < total;
+                if (gth && more1) load_rows(src_next, L);
+                if (gth && more2) src_next = load_src(q2, t2);
+                uint32_t aw_next[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) aw_next[k] = bits_w[static_cast<int64_t>(4 * t1 + k) * MF_R];
+
+                const unsigned char *bbuf = lds + buf * MF_BUF + r_base;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    const uint32_t x = aw[k] >> (16 * h);
+                    v4i a;
+                    a[0] = static_cast<int>(expand4(x));
+                    a[1] = static_cast<int>(expand4(x >> 4));
+                    a[2] = static_cast<int>(expand4(x >> 8));
+                    a[3] = static_cast<int>(expand4(x >> 12));
+#pragma unroll
+                    for (int s = 0; s < MF_NS; ++s) {
+                        const v4i b = *reinterpret_cast<const v4i *>(bbuf + k * MF_KS + s * MF_SS);
+                        acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[s], 0, 0, 0);
+                    }
+                }
+
+                if (t == S - 1) {                                    // a score is complete
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        long long v = static_cast<long long>(acc[MF_NS - 1][r]);
+#pragma unroll
+                        for (int s = MF_NS - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
+                        if (q == 0) obs[r] = v;
+                        else cnt[r] += (static_cast<uint32_t>(v < obs[r]) << 16) | static_cast<uint32_t>(v > obs[r]);
+#pragma unroll
+                        for (int s = 0; s < MF_NS; ++s) acc[s][r] = 0;
+                    }
+                }
+
+                if (gth && more1) store_rows(L, buf ^ 1);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) aw[k] = aw_next[k];
+                __syncthreads();
+                q = q1;
+                t = t1;
+                q1 = q2;
+                t1 = t2;
+            }
+
+            // ---- task epilogue: observed scores (first span only) and the counters
+            const int64_t col = static_cast<int64_t>(ct) * 32 + col_in_tile;
+            if (col < mloc) {
+                const double sc = ns_out ? col_scale[col] : 0.0;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (cnt[r]) atomicAdd(&gl_counts[col * n_padr + u], cnt[r]);
+                    if (ns_out) {
+                        const int32_t node = rowmap[u];
+                        if (node >= 0) ns_out[static_cast<int64_t>(node) * mloc + col] = static_cast<double>(obs[r]) * sc;
+                    }
+                }
+            }
+            __syncthreads();                                         // kb_list / buffers are reused by the next task
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
+// host: node order, block structure
+// ---------------------------------------------------------------------------------------
+uint64_t hilbert_index(uint32_t x, uint32_t y, int bits) {
+    uint64_t d = 0;
+    for (uint32_t s = 1u << (bits - 1); s > 0; s >>= 1) {
+        const uint32_t rx = (x & s) ? 1u : 0u, ry = (y & s) ? 1u : 0u;
+        d += static_cast<uint64_t>(s) * s * ((3u * rx) ^ ry);
+        if (ry == 0) {
+            if (rx == 1) {
+                x = s - 1 - (x & (s - 1));
+                y = s - 1 - (y & (s - 1));
+            }
+            std::swap(x, y);
+        }
+        x &= s - 1;
+        y &= s - 1;
+    }
+    return d;
+}
+
+void order_by_layout(const std::vector<double> &xy, int64_t n, std::vector<int32_t> *order) {
+    double x0 = xy[0], x1 = xy[0], y0 = xy[1], y1 = xy[1];
+    for (int64_t i = 0; i < n; ++i) {
+        x0 = std::min(x0, xy[2 * i]);
+        x1 = std::max(x1, xy[2 * i]);
+        y0 = std::min(y0, xy[2 * i + 1]);
+        y1 = std::max(y1, xy[2 * i + 1]);
+    }
+    const double span = std::max(std::max(x1 - x0, y1 - y0), 1e-300);
+    std::vector<uint64_t> key(n);
+    for (int64_t i = 0; i < n; ++i) {
+        const double fx = (xy[2 * i] - x0) / span, fy = (xy[2 * i + 1] - y0) / span;
+        const uint32_t ix = static_cast<uint32_t>(std::min(65535.0, std::max(0.0, fx * 65535.0)));
+        const uint32_t iy = static_cast<uint32_t>(std::min(65535.0, std::max(0.0, fy * 65535.0)));
+        key[i] = (fx == fx && fy == fy) ? hilbert_index(ix, iy, 16) : ~0ull;
+    }
+    order->resize(n);
+    std::iota(order->begin(), order->end(), 0);
+    std::stable_sort(order->begin(), order->end(), [&](int32_t a, int32_t b) { return key[a] < key[b]; });
+}
+
+// Cuthill-McKee (breadth first, neighbours by ascending degree) over the membership graph
+void order_by_graph(const std::vector<int32_t> &row_ptr, const std::vector<int32_t> &col, int64_t n,
+                    std::vector<int32_t> *order) {
+    order->clear();
+    order->reserve(n);
+    std::vector<char> seen(n, 0);
+    std::vector<int32_t> by_degree(n);
+    std::iota(by_degree.begin(), by_degree.end(), 0);
+    auto deg = [&](int32_t v) { return row_ptr[v + 1] - row_ptr[v]; };
+    std::stable_sort(by_degree.begin(), by_degree.end(), [&](int32_t a, int32_t b) { return deg(a) < deg(b); });
+    std::vector<int32_t> nb;
+    for (int32_t start : by_degree) {
+        if (seen[start]) continue;
+        seen[start] = 1;
+        size_t head = order->size();
+        order->push_back(start);
+        while (head < order->size()) {
+            const int32_t v = (*order)[head++];
+            nb.clear();
+            for (int32_t e = row_ptr[v]; e < row_ptr[v + 1]; ++e)
+                if (!seen[col[e]]) {
+                    seen[col[e]] = 1;
+                    nb.push_back(col[e]);
+                }
+            std::stable_sort(nb.begin(), nb.end(), [&](int32_t a, int32_t b) { return deg(a) < deg(b); });
+            order->insert(order->end(), nb.begin(), nb.end());
+        }
+    }
+}
+
+int build_blocks(safe_nbr *nbr) {
+    if (nbr->blocks_ready) return SAFE_OK;
+    safe_ctx *ctx = nbr->ctx;
+    const int64_t n = nbr->n, nnz = nbr->nnz;
+    std::vector<int32_t> row_ptr(n + 1), col(std::max<int64_t>(nnz, 1));
+    SAFE_HIP_CHECK(hipMemcpy(row_ptr.data(), nbr->row_ptr, (n + 1) * sizeof(int32_t), hipMemcpyDeviceToHost));
+    if (nnz) SAFE_HIP_CHECK(hipMemcpy(col.data(), nbr->col, nnz * sizeof(int32_t), hipMemcpyDeviceToHost));
+    std::vector<int32_t> order;
+    if (static_cast<int64_t>(nbr->h_xy.size()) == 2 * n) order_by_layout(nbr->h_xy, n, &order);
+    else order_by_graph(row_ptr, col, n, &order);
+    std::vector<int32_t> pos(n);
+    for (int64_t u = 0; u < n; ++u) pos[order[u]] = static_cast<int32_t>(u);
+
+    const int64_t n_groups = ceil_div(n, MF_R), n_kb = ceil_div(n, 32), n_src = (n_kb + 1) * 32;
+    std::vector<int32_t> h_order(n_src, static_cast<int32_t>(n)), h_rowmap(n_groups * MF_R, -1);
+    for (int64_t u = 0; u < n; ++u) {
+        h_order[u] = order[u];
+        h_rowmap[u] = order[u];
+    }
+    std::vector<int32_t> ptr(n_groups + 1, 0), kbs;
+    std::vector<uint32_t> bits;
+    std::vector<int32_t> slot(n_kb, -1), touched;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        touched.clear();
+        const int64_t u0 = g * MF_R, u1 = std::min<int64_t>(n, u0 + MF_R);
+        for (int64_t u = u0; u < u1; ++u) {
+            const int32_t node = order[u];
+            for (int32_t e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
+                const int32_t kb = pos[col[e]] >> 5;
+                if (slot[kb] < 0) {
+                    slot[kb] = 0;
+                    touched.push_back(kb);
+                }
+            }
+        }
+        std::sort(touched.begin(), touched.end());
+        const int64_t base = static_cast<int64_t>(kbs.size());
+        const int64_t count = ceil_div(static_cast<int64_t>(touched.size()), 4) * 4;
+        for (size_t i = 0; i < touched.size(); ++i) slot[touched[i]] = static_cast<int32_t>(i);
+        kbs.insert(kbs.end(), touched.begin(), touched.end());
+        kbs.resize(base + count, static_cast<int32_t>(n_kb));       // padding blocks: all-zero rows, no members
+        bits.resize((base + count) * MF_R, 0u);
+        for (int64_t u = u0; u < u1; ++u) {
+            const int32_t node = order[u];
+            for (int32_t e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
+                const int32_t p = pos[col[e]];
+                bits[(base + slot[p >> 5]) * MF_R + (u - u0)] |= 1u << (p & 31);
+            }
+        }
+        for (int32_t kb : touched) slot[kb] = -1;
+        ptr[g + 1] = static_cast<int32_t>(base + count);
+        SAFE_REQUIRE(count <= MF_MAXBLK, "membership row group touches %lld column blocks (limit %d)", (long long)count, MF_MAXBLK);
+    }
+    nbr->bs_groups = n_groups;
+    nbr->bs_blocks = static_cast<int64_t>(kbs.size());
+    nbr->bs_src = n_src;
+    nbr->h_bs_ptr = ptr;
+    SAFE_TRY(dev_alloc(&nbr->bs_order, n_src));
+    SAFE_TRY(dev_alloc(&nbr->bs_rowmap, n_groups * MF_R));
+    SAFE_TRY(dev_alloc(&nbr->bs_ptr, n_groups + 1));
+    SAFE_TRY(dev_alloc(&nbr->bs_kb, kbs.size()));
+    SAFE_TRY(dev_alloc(&nbr->bs_bits, bits.size()));
+    SAFE_HIP_CHECK(hipMemcpy(nbr->bs_order, h_order.data(), n_src * sizeof(int32_t), hipMemcpyHostToDevice));
+    SAFE_HIP_CHECK(hipMemcpy(nbr->bs_rowmap, h_rowmap.data(), h_rowmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    SAFE_HIP_CHECK(hipMemcpy(nbr->bs_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!kbs.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_kb, kbs.data(), kbs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!bits.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    nbr->blocks_ready = true;
+    (void)ctx;
+    return SAFE_OK;
+}
+
+}  // namespace
+
+void nbr_free_blocks(safe_nbr *nbr) {
+    (void)hipFree(nbr->bs_order);
+    (void)hipFree(nbr->bs_rowmap);
+    (void)hipFree(nbr->bs_ptr);
+    (void)hipFree(nbr->bs_kb);
+    (void)hipFree(nbr->bs_bits);
+    nbr->bs_order = nbr->bs_rowmap = nbr->bs_ptr = nbr->bs_kb = nullptr;
+    nbr->bs_bits = nullptr;
+    nbr->blocks_ready = false;
+}
+
+bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *attr, const safe_perms *perms, bool z) {
+    (void)ctx;
+    (void)attr;
+    const char *force = getenv("SAFE_HIP_FORCE_PATH");
+    if (force && (!strcmp(force, "gather") || !strcmp(force, "lds"))) return false;
+    if (z || perms->count < 1 || perms->count > 65535) return false;
+    if (nbr->n > (1ll << 30) / 32 || nbr->max_count >= (1 << 23)) return false;
+    if (force && !strcmp(force, "mfma")) return true;
+    return nbr->n >= 256;                       // below one row group the LDS-resident f64 kernel is the better fit
+}
+
+// Runs the permutation test of columns [col0, col1) on the MFMA path.  *declined = true (and
+// SAFE_OK) when the attribute values cannot be represented on the fixed-point grid without a
+// rounding that could matter; the caller then uses the f64 kernels.
+int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
+                const PermOut &out, bool *declined) {
+    *declined = false;
+    SAFE_TRY(build_blocks(nbr));
+    const int64_t n = nbr->n, mloc = col1 - col0, P = perms->count;
+    const int64_t n_ct = ceil_div(mloc, 32), row_bytes = n_ct * MF_NS * 32, n_src = nbr->bs_src;
+    const int64_t n_padr = nbr->bs_groups * MF_R;
+    const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+
+    // ---- column scales and slices
+    unsigned char *d_bs = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
+    void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale f64 | cnt, small, rounded u32 | shift i32 | bad i32
+    const size_t colbuf_bytes = static_cast<size_t>(mloc) * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 64;
+    SAFE_TRY(ctx_scratch(ctx, 6, colbuf_bytes, &d_colbuf));
+    unsigned long long *d_max = static_cast<unsigned long long *>(d_colbuf);
+    double *d_sumsq = reinterpret_cast<double *>(d_max + mloc);
+    double *d_scale = d_sumsq + mloc;
+    unsigned int *d_cnt = reinterpret_cast<unsigned int *>(d_scale + mloc);
+    unsigned int *d_small = d_cnt + mloc, *d_rounded = d_small + mloc;
+    int *d_shift = reinterpret_cast<int *>(d_rounded + mloc);
+    int *d_bad = d_shift + mloc;
+    SAFE_HIP_CHECK(hipMemsetAsync(d_colbuf, 0, colbuf_bytes, ctx->stream));
+    {
+        const int rows_per_block = 2048;
+        const dim3 grid(ceil_div(mloc, 32), ceil_div(n, rows_per_block));
+        if (f32)
+            hipLaunchKernelGGL(k_mfma_colstats<float>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, rows_per_block, d_max, d_sumsq, d_cnt);
+        else
+            hipLaunchKernelGGL(k_mfma_colstats<double>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, rows_per_block, d_max, d_sumsq, d_cnt);
+        hipLaunchKernelGGL(k_mfma_colfinish, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_max, mloc, d_shift, d_scale,
+                           d_bad);
+        const dim3 sgrid(n_ct, ceil_div(n + 1, 32));
+        if (f32)
+            hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_bs, d_small, d_rounded);
+        else
+            hipLaunchKernelGGL(k_mfma_slice<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_bs, d_small, d_rounded);
+        hipLaunchKernelGGL(k_mfma_colcheck, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_cnt, d_small, d_rounded, mloc,
+                           d_bad);
+        SAFE_HIP_CHECK(hipGetLastError());
+        int bad = 0;
+        SAFE_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        const char *force = getenv("SAFE_HIP_FORCE_PATH");
+        if (bad && !(force && !strcmp(force, "mfma"))) {
+            *declined = true;
+            return SAFE_OK;
+        }
+    }
+
+    // ---- tasks: (row group, column tile), one queue per XCD keyed by column tile so the slice
+    //      rows of a tile are pulled into one L2; inside a queue tile-major, heavy groups first
+    std::vector<int32_t> g_order(nbr->bs_groups);
+    std::iota(g_order.begin(), g_order.end(), 0);
+    const std::vector<int32_t> &bp = nbr->h_bs_ptr;
+    std::stable_sort(g_order.begin(), g_order.end(), [&](int32_t a, int32_t b) { return bp[a + 1] - bp[a] > bp[b + 1] - bp[b]; });
+    std::vector<int2> tasks;
+    tasks.reserve(nbr->bs_groups * n_ct);
+    int32_t q_off[9] = {0};
+    for (int qx = 0; qx < 8; ++qx) {
+        for (int64_t ct = qx; ct < n_ct; ct += 8)
+            for (int32_t g : g_order) tasks.push_back(make_int2(g, static_cast<int>(ct)));
+        q_off[qx + 1] = static_cast<int32_t>(tasks.size());
+    }
+    int64_t span = 128;
+    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
+    span = std::min<int64_t>(span, P);
+    const int64_t n_launch = ceil_div(P, span);
+    void *ws = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + (8 * n_launch + 8) * sizeof(unsigned int), &ws));
+    int2 *d_tasks = static_cast<int2 *>(ws);
+    int32_t *d_qoff = reinterpret_cast<int32_t *>(d_tasks + tasks.size());
+    unsigned int *d_qctr = reinterpret_cast<unsigned int *>(d_qoff + 16);
+    unsigned int *d_counts = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), reinterpret_cast<void **>(&d_counts)));
+    int32_t *d_src[2] = {nullptr, nullptr};
+    for (int b = 0; b < 2; ++b)
+        SAFE_TRY(ctx_scratch(ctx, 4 + b, static_cast<size_t>(span + 1) * n_src * sizeof(int32_t), reinterpret_cast<void **>(&d_src[b])));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_qoff, q_off, sizeof(q_off), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, (8 * n_launch + 8) * sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
+
+    const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t);
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes)));
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    ctx->last_kernel.name = "k_permtest_mfma";
+    ctx->last_kernel.total_ms = 0.0;
+    ctx->last_kernel.launches = 0;
+    std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
+    for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
+    hipEvent_t ready = nullptr, side_done = nullptr;
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
+    for (int64_t c = 0; c < n_launch; ++c) {
+        const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span), cnt = p_limit - p_base;
+        hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
+        SAFE_TRY(perms_wait(perms, p_limit, ks));
+        hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
+                           p_base, d_src[c & 1]);
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
+        hipLaunchKernelGGL(k_permtest_mfma, dim3(blocks), dim3(512), lds_bytes, ks, d_bs, row_bytes, d_src[c & 1], n_src,
+                           static_cast<int>(cnt + 1), nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr + 8 * c, mloc,
+                           d_counts, n_padr, nbr->bs_rowmap, d_scale, c == 0 ? out.ns : static_cast<double *>(nullptr));
+        SAFE_HIP_CHECK(hipGetLastError());
+        SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
+        if (c >= 1) {
+            // the source-map buffer of span c-1 is reused by span c+1: same stream, ordered
+        }
+    }
+    SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
+    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
+    SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_padr, nbr->bs_rowmap, mloc, P, out));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    for (int64_t c = 0; c < n_launch; ++c) {
+        float ms = 0.f;
+        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
+        ctx->last_kernel.total_ms += ms;
+        ctx->last_kernel.launches += 1;
+    }
+    for (auto &e : ev) (void)hipEventDestroy(e);
+    (void)hipEventDestroy(ready);
+    (void)hipEventDestroy(side_done);
+    return SAFE_OK;
+}

@@ -331,6 +331,7 @@ static void nbr_free(safe_nbr *nbr) {
     (void)hipFree(nbr->dist);
     (void)hipFree(nbr->at_ptr);
     (void)hipFree(nbr->at_col);
+    nbr_free_blocks(nbr);
     delete nbr;
 }
 
@@ -482,7 +483,15 @@ int safe_nbr_euclidean(safe_ctx *ctx, const double *xy_host, int64_t n, double n
         nbr_free(nbr);
         return rc;
     }
+    nbr->h_xy.assign(xy_host, xy_host + 2 * n);       // node order of the block-sparse form (mfma.hip)
     *out = nbr;
+    return SAFE_OK;
+}
+
+int safe_nbr_set_layout(safe_nbr *nbr, const double *xy_host) {
+    SAFE_REQUIRE(nbr && xy_host, "safe_nbr_set_layout: NULL argument");
+    nbr->h_xy.assign(xy_host, xy_host + 2 * nbr->n);
+    if (nbr->blocks_ready) nbr_free_blocks(nbr);      // rebuilt in the new order on next use
     return SAFE_OK;
 }
 

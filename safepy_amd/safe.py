@@ -280,6 +280,12 @@ class SAFE:
             if self._neighborhoods_host is None:
                 raise RuntimeError('neighborhoods are not defined: call define_neighborhoods() first')
             self._nbr = be.Neighborhoods.from_dense(self._ctx(), self._neighborhoods_host)
+            try:                          # a layout, when the graph has one, only orders the nodes on the device
+                xy = _graph_arrays(self.graph)[0]
+                if xy.shape == (self._nbr.n, 2) and np.isfinite(xy).all():
+                    self._nbr.set_layout(xy)
+            except Exception:
+                pass
         return self._nbr
 
     @property
@@ -338,6 +344,7 @@ class SAFE:
         else:
             w, cutoff = self._shortpath_inputs(xy, eu, ev, length, weight)
             self._nbr = be.Neighborhoods.shortpath(ctx, xy.shape[0], eu, ev, w, cutoff, keep_distances=True)
+            self._nbr.set_layout(xy)
             self._node_distances = ('dense-shortpath', self._nbr.distances())
         if self.verbose:
             num_neighbors = self._nbr.row_counts()

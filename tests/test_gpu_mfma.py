@@ -1,0 +1,180 @@
+"""Parity of the matrix-core (i8 MFMA, exact fixed point) permutation kernel against the CPU
+oracle: quantitative attributes, every layout of the inputs, every way a membership handle is
+made, ragged sizes, column shards, and the decline-and-fall-back rule.  Needs an MI355X."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+from oracle import safe_oracle as orc            # noqa: E402  (checker only)
+
+
+@pytest.fixture(scope='module')
+def amd():
+    import safepy_amd
+    assert safepy_amd.device_count() >= 1, 'no HIP device: the GPU tests must run on the MI355X box'
+    return safepy_amd
+
+
+@pytest.fixture(scope='module')
+def ctx(amd):
+    return amd.Context.default(0)
+
+
+def _quant(rng, n, m, dtype=np.float64, order='C', nan_rows=0, nan_frac=0.0):
+    b = rng.normal(size=(n, m)).astype(dtype)
+    if nan_frac:
+        b[rng.uniform(size=(n, m)) < nan_frac] = np.nan
+    if nan_rows:
+        b[rng.choice(n, nan_rows, replace=False)] = np.nan
+    return np.asfortranarray(b) if order == 'F' else np.ascontiguousarray(b)
+
+
+def _counts(amd, ctx, nbr, b, nperm, seed, col0=0, col1=None, flags=None):
+    from safepy_amd import backend as be
+    attr = be.Attributes.from_host(ctx, b)
+    if flags is not None:
+        attr.set_row_flags(flags)
+    n, m = b.shape
+    col1 = m if col1 is None else col1
+    perms = be.Permutations(ctx, n, attr.row_flags() if flags is None else flags, nperm, seed)
+    ns, neg, pos = (ctx.alloc_f64(n, col1 - col0) for _ in range(3))
+    be.permtest_counts(ctx, nbr, attr, perms, 'sum', ns.ptr, neg.ptr, pos.ptr, col0, col1)
+    name = ctx.last_kernel()[0]
+    out = (ns.download((n, col1 - col0)), neg.download((n, col1 - col0)), pos.download((n, col1 - col0)), name)
+    perms.close()
+    attr.close()
+    return out
+
+
+@pytest.mark.parametrize('n,m,dtype,order', [(600, 70, np.float64, 'C'), (1000, 33, np.float32, 'F'),
+                                             (257, 5, np.float64, 'F'), (1300, 64, np.float32, 'C')])
+def test_quantitative_counts_exact_vs_oracle(amd, ctx, n, m, dtype, order):
+    rng = np.random.default_rng(n + m)
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.09)
+    b = _quant(rng, n, m, dtype, order, nan_rows=n // 20, nan_frac=0.01)
+    nperm, seed = 40, 11
+    ns_w = orc.compute_neighborhood_score(a, b, 'sum')
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.09))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma'
+    np.testing.assert_allclose(ns, ns_w, rtol=1e-9, atol=1e-12)      # north-star tolerance: 1e-6 relative
+    np.testing.assert_array_equal(cn, cn_w)                            # every <= / >= decision identical
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_full_pipeline_quantitative_vs_oracle(amd):
+    """SAFE.compute_pvalues on real-valued data through the MFMA kernel: p-values, NES and the
+    binarised map equal the oracle's exactly (counts are integers; NES uses the caller's log10)."""
+    rng = np.random.default_rng(5)
+    n, m, nperm = 900, 40, 60
+    xy = rng.uniform(size=(n, 2))
+    b = _quant(rng, n, m, np.float64, 'C', nan_rows=30, nan_frac=0.02)
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    for sign in ('both', 'highest', 'lowest'):
+        want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=2,
+                                   attribute_sign=sign)
+        sf = amd.SAFE(verbose=False)
+        sf.graph = amd.LayoutGraph(xy)
+        sf.random_seed = 2
+        sf.attribute_sign = sign
+        sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.1)
+        sf.load_attributes(attribute_file=b.copy())
+        sf.compute_pvalues(num_permutations=nperm, verbose=False)
+        assert amd.Context.default(0).last_kernel()[0] == 'k_permtest_mfma'
+        np.testing.assert_allclose(sf.ns, want['ns'], rtol=1e-9, atol=1e-12)
+        for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+            np.testing.assert_array_equal(getattr(sf, key), want[key])
+
+
+@pytest.mark.parametrize('how', ['shortpath+layout', 'shortpath', 'dense'])
+def test_node_orders_do_not_change_results(amd, ctx, how):
+    """Hilbert order (layout known), Cuthill-McKee order (no layout) and a user-supplied
+    asymmetric dense membership all give the oracle's counts."""
+    rng = np.random.default_rng(17)
+    n, m, nperm, seed = 700, 48, 30, 9
+    xy = rng.uniform(size=(n, 2))
+    b = _quant(rng, n, m, np.float64, 'C', nan_rows=20)
+    if how == 'dense':
+        a = (rng.uniform(size=(n, n)) < 0.03).astype(np.int64)
+        a[3, :] = 0                                              # an empty neighborhood
+        a[:, 8] = 0                                              # a node nobody contains
+        nbr = amd.Neighborhoods.from_dense(ctx, a)
+    else:
+        from scipy.spatial import cKDTree
+        pairs = cKDTree(xy).query_pairs(0.06, output_type='ndarray')
+        eu, ev = pairs[:, 0], pairs[:, 1]
+        w = np.sqrt(((xy[eu] - xy[ev]) ** 2).sum(axis=1))
+        cutoff = 0.12
+        a, _ = orc.neighborhoods_shortpath(n, eu, ev, w, cutoff)
+        nbr = amd.Neighborhoods.shortpath(ctx, n, eu, ev, w, cutoff)
+        if how == 'shortpath+layout':
+            nbr.set_layout(xy)
+        assert np.array_equal(nbr.to_dense(), a)
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma'
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_binary_and_integer_attributes_through_mfma(amd, ctx, monkeypatch):
+    """0/1 and small-integer attributes are exactly representable: forcing them through the
+    MFMA kernel reproduces the oracle bit for bit, including the observed sums."""
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'mfma')
+    rng = np.random.default_rng(23)
+    n, m, nperm, seed = 520, 37, 25, 4
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.08)
+    b = rng.integers(-3, 4, size=(n, m)).astype(np.float64)
+    b[:, :10] = (rng.uniform(size=(n, 10)) < 0.05)
+    b[:, 11] = 0                                                 # an all-zero attribute
+    b[:, 12] = np.nan                                            # an all-NaN attribute
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.08))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma'
+    np.testing.assert_array_equal(ns, orc.compute_neighborhood_score(a, b, 'sum'))
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_column_shards_and_many_permutations(amd, ctx):
+    """Column ranges (attribute shards) with global row flags, and more permutations than one
+    span (two launches on alternating streams)."""
+    rng = np.random.default_rng(31)
+    n, m, nperm, seed = 400, 100, 150, 6
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    b = _quant(rng, n, m, np.float32, 'F', nan_rows=15)
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    for c0, c1 in ((0, 100), (0, 33), (33, 97), (97, 100)):
+        ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, c0, c1)
+        assert name == 'k_permtest_mfma'
+        np.testing.assert_array_equal(cn, cn_w[:, c0:c1])
+        np.testing.assert_array_equal(cp, cp_w[:, c0:c1])
+    nbr.close()
+
+
+def test_wide_dynamic_range_declines_to_f64_kernels(amd, ctx):
+    """A column whose values would lose bits on the fixed-point grid (1e18 next to 1e-3) makes
+    the MFMA path decline; the f64 kernels take over and the result still matches."""
+    rng = np.random.default_rng(41)
+    n, m, nperm, seed = 300, 8, 20, 3
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    b = rng.normal(size=(n, m)) * 1e-3
+    b[7, 2] = 1e18
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name != 'k_permtest_mfma'
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()

@@ -460,8 +460,8 @@ def test_column_range_arguments_of_the_c_abi(amd, ctx, golden_enr, monkeypatch):
 
 @pytest.mark.parametrize('score', ['sum', 'z-score'])
 def test_f64_kernel_forms_agree(amd, ctx, golden_enr, monkeypatch, score):
-    """Quantitative attributes: the LDS-resident f64 kernel (default for small networks) and the
-    global-tile gather kernel add the members in the same order, so even the observed scores
+    """Quantitative attributes: the LDS-resident f64 kernel (networks below one MFMA row group,
+    z-scores) and the global-tile gather kernel add the members in the same order, so even the observed scores
     are bitwise identical."""
     from safepy_amd import backend as be
     g = golden_enr
@@ -471,10 +471,7 @@ def test_f64_kernel_forms_agree(amd, ctx, golden_enr, monkeypatch, score):
     nbr = be.Neighborhoods.from_dense(ctx, a)
     res = {}
     for path in ('lds', 'gather'):
-        if path == 'gather':
-            monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'gather')
-        else:
-            monkeypatch.delenv('SAFE_HIP_FORCE_PATH', raising=False)
+        monkeypatch.setenv('SAFE_HIP_FORCE_PATH', path)
         attr = be.Attributes.from_host(ctx, b)
         perms = be.Permutations(ctx, n, attr.row_flags(), 33, 4)
         ns, neg, pos = ctx.alloc_f64(n, m), ctx.alloc_f64(n, m), ctx.alloc_f64(n, m)
