@@ -210,9 +210,9 @@ __global__ __launch_bounds__(256) void k_mfma_src(const int32_t *__restrict__ or
 // ---------------------------------------------------------------------------------------
 // the kernel
 // ---------------------------------------------------------------------------------------
-__device__ __forceinline__ uint32_t expand4(uint32_t nib) {       // 4 bits -> 4 bytes of 0/1
-    nib &= 0xFu;
-    return (nib | (nib << 7) | (nib << 14) | (nib << 21)) & 0x01010101u;
+__device__ __forceinline__ uint32_t expand4(uint32_t word, uint32_t bit) {   // bits [bit, bit+4) -> 4 bytes of 0/1
+    const uint32_t nib = __builtin_amdgcn_ubfe(word, bit, 4u);
+    return static_cast<uint32_t>(__umul24(nib, 0x204081u)) & 0x01010101u;             // copies at bit 0, 7, 14, 21: no overlap
 }
 
 // 4 x 4 byte transpose: in[r] = 4 columns of row r  ->  out[c] = 4 rows of column c
@@ -236,6 +236,8 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][MF_BUF] + kb list
     __shared__ int slot_box;
     int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * MF_BUF);
+    // observed scores of this thread's 16 outputs (exact 64-bit integers), [r][thread]: read once per permutation
+    long long *obs = reinterpret_cast<long long *>(lds + 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t)) + threadIdx.x;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lam = lane & 31, h = lane >> 5;
     // gather role: thread -> (k-step of the super-step, row quad, 16-byte chunk of the row segment)
@@ -275,13 +277,9 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             for (int s = 0; s < MF_NS; ++s)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][r] = 0;
-            long long obs[16];
             uint32_t cnt[16];
 #pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                obs[r] = 0;
-                cnt[r] = 0;
-            }
+            for (int r = 0; r < 16; ++r) cnt[r] = 0;
 
             auto load_src = [&](int q, int t) -> int4 {
                 const int kb = kb_list[4 * t + ks_g];
@@ -293,72 +291,93 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 L[2] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.z) * row_bytes);
                 L[3] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.w) * row_bytes);
             };
-            auto store_rows = [&](const uint4 (&L)[4], int buf) {
+            // column word cw (columns 4cw .. 4cw+3 of this thread's chunk) of the four rows in L:
+            // transpose to k-contiguous bytes and write the four lane slots b + 8cw (+ 4 half)
+            auto store_quarter = [&](const uint4 (&L)[4], int cw, int buf) {
                 unsigned char *dst = lds + buf * MF_BUF + w_base;
-                const uint32_t w[4][4] = {{L[0].x, L[1].x, L[2].x, L[3].x},
-                                          {L[0].y, L[1].y, L[2].y, L[3].y},
-                                          {L[0].z, L[1].z, L[2].z, L[3].z},
-                                          {L[0].w, L[1].w, L[2].w, L[3].w}};
+                const uint32_t w[4] = {cw == 0 ? L[0].x : cw == 1 ? L[0].y : cw == 2 ? L[0].z : L[0].w,
+                                       cw == 0 ? L[1].x : cw == 1 ? L[1].y : cw == 2 ? L[1].z : L[1].w,
+                                       cw == 0 ? L[2].x : cw == 1 ? L[2].y : cw == 2 ? L[2].z : L[2].w,
+                                       cw == 0 ? L[3].x : cw == 1 ? L[3].y : cw == 2 ? L[3].z : L[3].w};
+                uint32_t o[4];
+                transpose4(w, o);
 #pragma unroll
-                for (int cw = 0; cw < 4; ++cw) {                   // columns 4cw .. 4cw+3 of this chunk
-                    uint32_t o[4];
-                    transpose4(w[cw], o);
-#pragma unroll
-                    for (int b = 0; b < 4; ++b)                     // column i = 4cw + b -> lane slot b + 8cw (+ 4 half)
-                        *reinterpret_cast<uint32_t *>(dst + (b + 8 * cw) * 16) = o[b];
+                for (int b = 0; b < 4; ++b) *reinterpret_cast<uint32_t *>(dst + (b + 8 * cw) * 16) = o[b];
+            };
+            auto advance = [&](int &qq, int &tt) {
+                if (++tt == S) {
+                    tt = 0;
+                    ++qq;
                 }
             };
 
-            // prologue: super-step 0 into buffer 0, source rows of super-step 1 in flight
-            int4 src_next = make_int4(0, 0, 0, 0);
-            uint4 L[4];
-            int q1 = 0, t1 = 0;                                      // (q, t) of iteration it + 1
+            // Pipeline (one super-step = 4 k-steps = 128 gathered attribute rows per iteration):
+            //   rows of super-step it+2 are requested at the top of iteration it, land while it and
+            //   it+1 compute, and are transposed into the other LDS buffer during it+1;
+            //   their source-row indices were requested one iteration earlier still.
+            // vmcnt retires in order, so inside an iteration the loads needed soonest (membership
+            // words, source indices) are issued before the row gathers, and the two row register
+            // sets / index registers swap roles between iterations instead of being copied
+            // (a copy would wait for the gather that was just issued).
+            uint4 L_a[4], L_b[4];
+            int4 src_a = make_int4(0, 0, 0, 0), src_b = make_int4(0, 0, 0, 0);
+            int q1 = 0, t1 = 0, q2, t2, q3, t3;                      // (q, t) of iterations it + 1, + 2, + 3
+            advance(q1, t1);
+            q2 = q1, t2 = t1;
+            advance(q2, t2);
             if (gth) {
                 const int4 s0 = load_src(0, 0);
-                load_rows(s0, L);
+                load_rows(s0, L_b);
+                if (total > 1) {
+                    const int4 s1 = load_src(q1, t1);
+                    load_rows(s1, L_a);                              // stored during iteration 0
+                }
+                if (total > 2) src_a = load_src(q2, t2);            // gathered at the top of iteration 0
+#pragma unroll
+                for (int cw = 0; cw < 4; ++cw) store_quarter(L_b, cw, 0);
             }
-            t1 = 1;
-            if (t1 == S) {
-                t1 = 0;
-                q1 = 1;
-            }
-            if (gth && total > 1) src_next = load_src(q1, t1);
-            if (gth) store_rows(L, 0);
             uint32_t aw[4];
 #pragma unroll
             for (int k = 0; k < 4; ++k) aw[k] = bits_w[static_cast<int64_t>(k) * MF_R];
             __syncthreads();
 
             int q = 0, t = 0;
-            for (int it = 0; it < total; ++it) {
+            auto body = [&](int it, uint4 (&L_store)[4], uint4 (&L_load)[4], const int4 &src_use, int4 &src_load) {
                 const int buf = it & 1;
-                // (q2, t2) = iteration it + 2
-                int q2 = q1, t2 = t1 + 1;
-                if (t2 == S) {
-                    t2 = 0;
-                    q2 = q1 + 1;
-                }
-                const bool more1 = it + 1 < total, more2 = it + 2 < total;
-                if (gth && more1) load_rows(src_next, L);
-                if (gth && more2) src_next = load_src(q2, t2);
+                q3 = q2, t3 = t2;
+                advance(q3, t3);
+                const bool more1 = it + 1 < total, more2 = it + 2 < total, more3 = it + 3 < total;
                 uint32_t aw_next[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) aw_next[k] = bits_w[static_cast<int64_t>(4 * t1 + k) * MF_R];
+                if (gth && more3) src_load = load_src(q3, t3);
+                if (gth && more2) load_rows(src_use, L_load);
 
                 const unsigned char *bbuf = lds + buf * MF_BUF + r_base;
+                // B operands of k-step k+1 are read from LDS before the MFMAs of k-step k are issued
+                v4i b_cur[MF_NS], b_nxt[MF_NS];
+#pragma unroll
+                for (int s = 0; s < MF_NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    const uint32_t x = aw[k] >> (16 * h);
-                    v4i a;
-                    a[0] = static_cast<int>(expand4(x));
-                    a[1] = static_cast<int>(expand4(x >> 4));
-                    a[2] = static_cast<int>(expand4(x >> 8));
-                    a[3] = static_cast<int>(expand4(x >> 12));
+                    if (k < 3) {
 #pragma unroll
-                    for (int s = 0; s < MF_NS; ++s) {
-                        const v4i b = *reinterpret_cast<const v4i *>(bbuf + k * MF_KS + s * MF_SS);
-                        acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b, acc[s], 0, 0, 0);
+                        for (int s = 0; s < MF_NS; ++s)
+                            b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * MF_KS + s * MF_SS);
                     }
+                    __builtin_amdgcn_sched_barrier(0);               // keep the LDS reads ahead of this k-step's MFMAs
+                    v4i a;
+                    a[0] = static_cast<int>(expand4(aw[k], 16 * h));
+                    a[1] = static_cast<int>(expand4(aw[k], 16 * h + 4));
+                    a[2] = static_cast<int>(expand4(aw[k], 16 * h + 8));
+                    a[3] = static_cast<int>(expand4(aw[k], 16 * h + 12));
+#pragma unroll
+                    for (int s = 0; s < MF_NS; ++s) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[s], 0, 0, 0);
+                    // a quarter of the next super-step's tile goes to the other buffer while the
+                    // matrix pipe works through this k-step
+                    if (gth && more1) store_quarter(L_store, k, buf ^ 1);
+#pragma unroll
+                    for (int s = 0; s < MF_NS; ++s) b_cur[s] = b_nxt[s];
                 }
 
                 if (t == S - 1) {                                    // a score is complete
@@ -367,21 +386,26 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                         long long v = static_cast<long long>(acc[MF_NS - 1][r]);
 #pragma unroll
                         for (int s = MF_NS - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
-                        if (q == 0) obs[r] = v;
-                        else cnt[r] += (static_cast<uint32_t>(v < obs[r]) << 16) | static_cast<uint32_t>(v > obs[r]);
+                        if (q == 0) {
+                            obs[r * 512] = v;
+                        } else {
+                            const long long o = obs[r * 512];
+                            cnt[r] += (static_cast<uint32_t>(v < o) << 16) | static_cast<uint32_t>(v > o);
+                        }
 #pragma unroll
                         for (int s = 0; s < MF_NS; ++s) acc[s][r] = 0;
                     }
                 }
-
-                if (gth && more1) store_rows(L, buf ^ 1);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) aw[k] = aw_next[k];
                 __syncthreads();
-                q = q1;
-                t = t1;
-                q1 = q2;
-                t1 = t2;
+                q = q1, t = t1;
+                q1 = q2, t1 = t2;
+                q2 = q3, t2 = t3;
+            };
+            for (int it = 0; it < total; it += 2) {
+                body(it, L_a, L_b, src_a, src_b);
+                if (it + 1 < total) body(it + 1, L_b, L_a, src_b, src_a);
             }
 
             // ---- task epilogue: observed scores (first span only) and the counters
@@ -394,7 +418,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     if (cnt[r]) atomicAdd(&gl_counts[col * n_padr + u], cnt[r]);
                     if (ns_out) {
                         const int32_t node = rowmap[u];
-                        if (node >= 0) ns_out[static_cast<int64_t>(node) * mloc + col] = static_cast<double>(obs[r]) * sc;
+                        if (node >= 0) ns_out[static_cast<int64_t>(node) * mloc + col] = static_cast<double>(obs[r * 512]) * sc;
                     }
                 }
             }
@@ -661,7 +685,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, (8 * n_launch + 8) * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
 
-    const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t);
+    const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
     SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);

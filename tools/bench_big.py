@@ -6,7 +6,7 @@ bench line): N = 20 000 uniform layout, euclidean r = 0.1.
 usage: bench_big.py hyper M | quant M P [score]"""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import safepy_amd
 from safepy_amd import backend as be, workloads
 

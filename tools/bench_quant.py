@@ -2,7 +2,7 @@
 times the general f64 permutation kernels (LDS-resident vs global-tile gather) and z-score."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import safepy_amd
 from safepy_amd import backend as be, workloads
 

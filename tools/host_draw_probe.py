@@ -2,7 +2,7 @@
 exists and while the GPU is busy (is the draw thread slowed down by the runtime?)."""
 import os, sys, time, threading
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from safepy_amd import backend as be
 
 vals = np.arange(3789, dtype=np.int64)

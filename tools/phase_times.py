@@ -1,7 +1,7 @@
 """Diagnostic: time the phases of one bench step with a device sync after each."""
 import os, sys, time
 import numpy as np
-sys.path.insert(0, os.getcwd())
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import safepy_amd
 from safepy_amd import backend as be, workloads
 
