@@ -44,6 +44,25 @@ def parse():
     return ap.parse_args()
 
 
+def effective_cores():
+    """CPUs this process may actually use: the scheduler affinity, capped by the container's CFS
+    quota (cgroup v2 cpu.max / v1 cfs_quota_us) when there is one."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
 def cpu_baseline(a_dense, b, sample_perms):
     """The oracle's permutation loop (same NumPy calls as the reference: np.where x2,
     int64 x float np.dot, fancy-index row permutation, <= / >= accumulation) on the host,
@@ -51,6 +70,13 @@ def cpu_baseline(a_dense, b, sample_perms):
     import numpy as np
     from oracle import safe_oracle as orc
     n, m = b.shape
+    cores = effective_cores()
+    blas = None
+    try:                                           # BLAS threads = the cores we may really use (oversubscribing a CPU quota gets the process throttled)
+        from threadpoolctl import threadpool_limits, threadpool_info
+        limiter = threadpool_limits(limits=cores)
+    except Exception:
+        limiter = None
     t0 = time.perf_counter()
     orc.run_permutations(a_dense, b, 'sum', 1, 0)              # warm-up (first np.dot is ~2.5x slower)
     t_warm = time.perf_counter() - t0
@@ -58,12 +84,10 @@ def cpu_baseline(a_dense, b, sample_perms):
     orc.run_permutations(a_dense, b, 'sum', sample_perms, 0)   # computes the observed score once + P permutations
     dt = time.perf_counter() - t0
     value = n * m * sample_perms / dt
-    try:
-        from threadpoolctl import threadpool_info
+    if limiter is not None:
         blas = [(i.get('internal_api'), i.get('num_threads')) for i in threadpool_info()]
-    except Exception:
-        blas = None
-    return {'value': value, 'unit': 'enrichments/s', 'cores': os.cpu_count(), 'kind': 'port',
+        limiter.restore_original_limits()
+    return {'value': value, 'unit': 'enrichments/s', 'cores': cores, 'host_cpus': os.cpu_count(), 'kind': 'port',
             'sample': '%d permutations of the same %dx%d workload after 1 warm-up (%.1f s; warm-up %.1f s), NumPy/SciPy oracle'
                       % (sample_perms, n, m, dt, t_warm),
             'seconds_per_permutation': dt / sample_perms, 'blas': blas}
@@ -145,6 +169,7 @@ def main():
     from safepy_amd import workloads, sharding
 
     torch.cuda.set_device(local_rank)
+    torch.set_num_threads(1)      # no OpenMP spinning next to the host draw/swap threads (container CPU quotas throttle it)
     dist = None
     force_dist = os.environ.get('SAFE_BENCH_FORCE_DIST') == '1'      # exercise the collectives with a single rank
     if world > 1 or force_dist:
@@ -180,15 +205,14 @@ def main():
         stats = attr.stats()                                  # dispatch rule + >50 % NaN check inputs
         flags = attr.row_flags()
         if dist is not None:                                  # indx_vals must come from the FULL matrix
-            flags = sharding.reduce_row_flags(flags)
-            stats = sharding.reduce_stats(stats)
+            flags, stats = sharding.reduce_flags_and_stats(flags, stats)
             attr.set_row_flags(flags)
         perms = be.Permutations(ctx, n, flags, P, 0)          # seeded legacy stream (host) + upload
         be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05,
                          [t.data_ptr() for t in out] + [enriched.data_ptr()], table=table)
         kernel_ms.append(ctx.last_kernel()[1])
-        if dist is not None:
-            gathered[0] = sharding.gather_columns(out[3], m * world)   # NES blocks over RCCL / xGMI
+        if dist is not None:                                  # NES of every rank's block over RCCL / xGMI
+            gathered[0] = sharding.gather_nes(ctx, nbr, out[3], m * world, P, 'both', table=table)
         perms.close()
         attr.close()
         return stats

@@ -196,6 +196,22 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
                    int64_t col0, int64_t col1, double *pvalues_pos_dev, double *nes_dev,
                    double *nes_binary_dev, double *num_enriched_dev);
 
+/* Multi-GPU exchange in integers (replaces gathering f64 NES blocks for the np.concatenate of
+ * safepy/safe.py:1355): after safe_randomization / safe_permtest_counts on the bit-sliced or
+ * matrix-core kernel, the raw counters of the call are still resident as
+ * u32 [m][n_pad] = (#(S_p < S_obs) << 16 | #(S_p > S_obs)), attribute-major, so that a rank's
+ * block is one contiguous slab.  safe_export_packed_counts copies them into dst_dev (NULL: only
+ * report sizes); *layout is 0 / 1 for the two position orders, -1 if the last call kept no
+ * counters (then exchange the f64 outputs instead).  After an all-gather of the slabs (every
+ * rank holds the same membership handle, hence the same layout), safe_nes_from_packed_counts
+ * turns [m_total][n_pad] counters into NES f64 [n, m_total] row-major with the arithmetic of
+ * safepy/safe.py:532-554. */
+int safe_export_packed_counts(safe_ctx *ctx, uint32_t *dst_dev, int64_t capacity, int64_t *n_pad, int64_t *m,
+                              int *layout);
+int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad,
+                                int64_t m, int64_t num_permutations, int sign_mode, const double *nes_table_host,
+                                double *nes_dev);
+
 /* Name and average duration (ms) of the dominant kernel of the last enrichment call,
  * measured with HIP events on the context stream (bench.py's roofline object). */
 int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *avg_ms,

@@ -354,3 +354,25 @@ def hypergeom(ctx, nbr, attr, enrichment_threshold, out_ptrs, col0=0, col1=None)
     pp, nes, nb, ne = out_ptrs
     check(lib.safe_hypergeom(ctx.handle, nbr.handle, attr.handle, float(enrichment_threshold), col0, col1,
                              C.c_void_p(pp), C.c_void_p(nes), C.c_void_p(nb), C.c_void_p(ne)))
+
+
+def packed_counts_info(ctx):
+    """(n_pad, m, layout) of the integer counters the last randomization call left on the device;
+    layout -1 = none (f64 kernels)."""
+    n_pad, m, layout = C.c_int64(), C.c_int64(), C.c_int()
+    check(lib.safe_export_packed_counts(ctx.handle, None, 0, C.byref(n_pad), C.byref(m), C.byref(layout)))
+    return n_pad.value, m.value, layout.value
+
+
+def export_packed_counts(ctx, dst_ptr, capacity):
+    n_pad, m, layout = C.c_int64(), C.c_int64(), C.c_int()
+    check(lib.safe_export_packed_counts(ctx.handle, C.c_void_p(dst_ptr), int(capacity), C.byref(n_pad), C.byref(m),
+                                        C.byref(layout)))
+    return n_pad.value, m.value, layout.value
+
+
+def nes_from_packed_counts(ctx, nbr, counts_ptr, layout, n_pad, m, num_permutations, attribute_sign, nes_ptr, table=None):
+    if table is None:
+        table = nes_table(num_permutations)
+    check(lib.safe_nes_from_packed_counts(ctx.handle, nbr.handle, C.c_void_p(counts_ptr), int(layout), int(n_pad), int(m),
+                                          int(num_permutations), _SIGN[attribute_sign], _ptr(table), C.c_void_p(nes_ptr)))

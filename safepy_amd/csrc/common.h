@@ -66,6 +66,12 @@ struct safe_ctx {
     KernelStat last_kernel;
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
     struct safe_perms *perm_cache = nullptr;    // buffers of the last destroyed permutation handle, reused by the next
+    // packed <= / >= counters of the last integer-counter permutation kernel (scratch slot 0):
+    // u32 [packed_m][packed_n_pad] = (#less << 16 | #greater); layout 0 = SELL positions,
+    // 1 = block order of the MFMA kernel, -1 = none (safe_export_packed_counts)
+    const unsigned int *packed_counts = nullptr;
+    int64_t packed_n_pad = 0, packed_m = 0, packed_perms = 0;
+    int packed_layout = -1;
     void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
     size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 };

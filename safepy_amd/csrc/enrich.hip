@@ -964,6 +964,9 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
         if (out.mode == 1) {
             out.counts_neg[o] = static_cast<double>(cneg);
             out.counts_pos[o] = static_cast<double>(cpos);
+        } else if (out.mode == 3) {                                  // NES only (all-gathered counters of other ranks)
+            const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
+            out.nes[o] = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
         } else if (out.mode == 2) {
             const double qnan = __longlong_as_double(0x7FF8000000000000ll);
             const double en = obs_nan ? qnan : out.nes_table[cneg], ep = obs_nan ? qnan : out.nes_table[cpos];
@@ -1608,6 +1611,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
     hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, d_gl, n_pad,
                        nbr->sell_row, static_cast<const double *>(nullptr), mloc, P, out);
+    ctx->packed_counts = d_gl;
+    ctx->packed_n_pad = n_pad;
+    ctx->packed_m = mloc;
+    ctx->packed_perms = P;
+    ctx->packed_layout = 0;
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
@@ -1840,6 +1848,7 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
                  (long long)perms->n, (long long)nbr->n);
     SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_permtest_counts: bad score_type %d", score_type);
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->packed_layout = -1;
     const bool z = score_type == SAFE_SCORE_ZSCORE;
     PermOut out{};
     out.ns = ns_dev;
@@ -1884,6 +1893,7 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_randomization: bad sign_mode %d", sign_mode);
     SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_randomization: enrichment_threshold must be in (0,1)");
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    ctx->packed_layout = -1;
     const bool z = score_type == SAFE_SCORE_ZSCORE;
     const int64_t mloc = col1 - col0, P = perms->count;
     std::vector<double> tab(P + 1);
@@ -2004,6 +2014,54 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     (void)hipFree(d_size);
     (void)hipFree(d_enr);
     (void)hipFree(tiles.bt);
+    return rc;
+}
+
+int safe_export_packed_counts(safe_ctx *ctx, uint32_t *dst_dev, int64_t capacity, int64_t *n_pad, int64_t *m,
+                              int *layout) {
+    SAFE_REQUIRE(ctx && n_pad && m && layout, "safe_export_packed_counts: NULL argument");
+    *layout = ctx->packed_layout;
+    *n_pad = ctx->packed_layout >= 0 ? ctx->packed_n_pad : 0;
+    *m = ctx->packed_layout >= 0 ? ctx->packed_m : 0;
+    if (!dst_dev || ctx->packed_layout < 0) return SAFE_OK;
+    const int64_t count = ctx->packed_n_pad * ctx->packed_m;
+    SAFE_REQUIRE(capacity >= count, "safe_export_packed_counts: buffer holds %lld counters, %lld needed", (long long)capacity,
+                 (long long)count);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_HIP_CHECK(hipMemcpyAsync(dst_dev, ctx->packed_counts, static_cast<size_t>(count) * sizeof(uint32_t),
+                                  hipMemcpyDeviceToDevice, ctx->stream));
+    return SAFE_OK;
+}
+
+int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad, int64_t m,
+                                int64_t num_permutations, int sign_mode, const double *nes_table_host, double *nes_dev) {
+    SAFE_REQUIRE(ctx && nbr && counts_dev && nes_dev, "safe_nes_from_packed_counts: NULL argument");
+    SAFE_REQUIRE(layout == 0 || layout == 1, "safe_nes_from_packed_counts: bad layout %d", layout);
+    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_nes_from_packed_counts: bad sign_mode %d", sign_mode);
+    SAFE_REQUIRE(num_permutations >= 1 && num_permutations <= 65535 && m >= 1, "safe_nes_from_packed_counts: bad sizes");
+    const int32_t *rowmap = layout == 0 ? nbr->sell_row : nbr->bs_rowmap;
+    const int64_t want_pad = layout == 0 ? nbr->n_slices * 64 : nbr->bs_groups * 256;
+    SAFE_REQUIRE(rowmap && n_pad == want_pad, "safe_nes_from_packed_counts: counters are for %lld positions, the membership has %lld",
+                 (long long)n_pad, (long long)want_pad);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t P = num_permutations;
+    std::vector<double> tab(P + 1);
+    if (nes_table_host) {
+        std::copy(nes_table_host, nes_table_host + P + 1, tab.begin());
+    } else {
+        tab[0] = -std::log10(1.0 / static_cast<double>(P));
+        for (int64_t k = 1; k <= P; ++k) tab[k] = -std::log10(static_cast<double>(k) / static_cast<double>(P));
+    }
+    double *d_tab = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 7, (P + 1) * sizeof(double), reinterpret_cast<void **>(&d_tab)));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    PermOut out{};
+    out.nes = nes_dev;
+    out.nes_table = d_tab;
+    out.sign_mode = sign_mode;
+    out.mode = 3;
+    int rc = enrich_finalize_counts(ctx, counts_dev, n_pad, rowmap, m, P, out);
+    if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab is a host vector
     return rc;
 }
 

@@ -718,6 +718,11 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
     SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_padr, nbr->bs_rowmap, mloc, P, out));
+    ctx->packed_counts = d_counts;
+    ctx->packed_n_pad = n_padr;
+    ctx->packed_m = mloc;
+    ctx->packed_perms = P;
+    ctx->packed_layout = 1;
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));

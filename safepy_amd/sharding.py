@@ -66,6 +66,71 @@ def reduce_stats(local_stats, group=None):
     return {'n_other': int(sums[0]), 'n_non_integer': int(sums[1]), 'max_nan_col': int(mx[0])}
 
 
+def reduce_flags_and_stats(local_flags, local_stats, group=None):
+    """reduce_row_flags + reduce_stats in ONE collective: every rank contributes
+    [flags (n), n_other, n_non_integer, max_nan_col] as int64, the all-gathered [world, n+3]
+    table is reduced locally (MAX over flags and the worst NaN column, SUM over the counts).
+    Returns (flags uint8 [n], stats dict), identical on every rank."""
+    import torch
+    dist = _dist()
+    dev = _device_for(group)
+    world = dist.get_world_size(group)
+    n = len(local_flags)
+    # NumPy on the host side on purpose: torch CPU kernels may open an OpenMP region whose
+    # workers then spin (hundreds of CPU-milliseconds per call) -- under a container CPU quota
+    # that gets the whole process throttled for the rest of the scheduler period
+    mine = np.empty(n + 3, dtype=np.int64)
+    mine[:n] = np.asarray(local_flags, dtype=np.int64)
+    mine[n:] = (int(local_stats['n_other']), int(local_stats['n_non_integer']), int(local_stats['max_nan_col']))
+    mine = torch.from_numpy(mine).to(dev)
+    table = torch.empty(world * (n + 3), dtype=torch.int64, device=dev)     # flat: gloo wants 1-D buffers
+    dist.all_gather_into_tensor(table, mine, group=group)
+    table = table.cpu().numpy().reshape(world, n + 3)
+    flags = table[:, :n].max(axis=0).astype(np.uint8)
+    stats = {'n_other': int(table[:, n].sum()), 'n_non_integer': int(table[:, n + 1].sum()),
+             'max_nan_col': int(table[:, n + 2].max())}
+    return flags, stats
+
+
+def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, group=None, table=None):
+    """The final exchange (np.concatenate(axis=1) of the NES blocks, safe.py:1355) on every rank.
+
+    When the last randomization call on every rank left packed integer counters on the device
+    (bit-sliced / matrix-core kernels), the ranks all-gather those -- u32 per (node, attribute)
+    instead of f64, attribute-major so a rank's block is one contiguous slab and no transpose
+    copy is needed -- and each rank derives the full [N, M] NES matrix from the counters with
+    the arithmetic of safe.py:532-554.  Otherwise (f64 kernels, gloo) the f64 blocks travel
+    (gather_columns).  `local_nes`: this rank's [N, M_r] NES tensor (fallback path only)."""
+    import torch
+    from . import backend as be
+    dist = _dist()
+    world = dist.get_world_size(group)
+    n_pad, m_loc, layout = be.packed_counts_info(ctx) if dist.get_backend(group) == 'nccl' else (0, 0, -1)
+    shards = column_shards(m_total, world)
+    widest = max(c1 - c0 for c0, c1 in shards)
+    dev = local_nes.device
+    # every rank must take the same branch: agree on (layout, n_pad) with one tiny MIN/MAX reduce
+    key = torch.tensor([layout, -layout, n_pad, -n_pad], dtype=torch.int64, device=dev)
+    dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
+    key = key.tolist()
+    agreed = key[0] >= 0 and key[0] == -key[1] and key[2] == -key[3]
+    if not agreed:
+        return gather_columns(local_nes, m_total, group)
+    mine = torch.zeros(widest * n_pad, dtype=torch.int32, device=dev)       # zero counters = padding columns
+    torch.cuda.current_stream().synchronize()          # the fill ran on torch's stream, the export runs on the context's
+    be.export_packed_counts(ctx, mine.data_ptr(), m_loc * n_pad)
+    everyone = torch.empty(world * widest * n_pad, dtype=torch.int32, device=dev)
+    ctx.sync()                                         # the export ran on the context's stream
+    dist.all_gather_into_tensor(everyone, mine, group=group)
+    full = torch.empty((local_nes.shape[0], world * widest), dtype=torch.float64, device=dev)
+    torch.cuda.current_stream().synchronize()          # the collective is ordered on torch's stream
+    be.nes_from_packed_counts(ctx, nbr, everyone.data_ptr(), layout, n_pad, world * widest, num_permutations,
+                              attribute_sign, full.data_ptr(), table=table)
+    if all(c1 - c0 == widest for c0, c1 in shards):
+        return full
+    return torch.cat([full[:, r * widest:r * widest + (shards[r][1] - shards[r][0])] for r in range(world)], dim=1)
+
+
 def gather_columns(local, m_total, group=None):
     """All-gather of the per-rank [N, M_r] blocks into the full [N, M] matrix on every rank
     (the reference's np.concatenate(axis=1), safe.py:1355).  `local` is a 2-D torch tensor on

@@ -482,3 +482,94 @@ def test_f64_kernel_forms_agree(amd, ctx, golden_enr, monkeypatch, score):
         attr.close()
     for x, y in zip(res['lds'], res['gather']):
         np.testing.assert_array_equal(x, y)
+
+
+# -------------------------------------------- integer exchange of the sharded result ----
+
+@pytest.mark.parametrize('kind', ['binary', 'quantitative'])
+def test_nes_from_gathered_packed_counts(amd, ctx, kind):
+    """What sharding.gather_nes does after the all-gather, with the gather simulated on one GPU:
+    two column blocks computed separately, their packed counters laid end to end (one padded to
+    the widest block), NES derived from the concatenation == NES of the unsharded run."""
+    import torch
+    from safepy_amd import backend as be, sharding
+    rng = np.random.default_rng(3)
+    n, m, nperm, seed = 700, 75, 40, 12
+    xy = rng.uniform(size=(n, 2))
+    b = (rng.uniform(size=(n, m)) < 0.05).astype(np.float64) if kind == 'binary' else rng.normal(size=(n, m))
+    b[rng.choice(n, 30, replace=False)] = np.nan
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    flags = (~np.isnan(b)).any(axis=1).astype(np.uint8)
+    shards = sharding.column_shards(m, 2)
+    widest = max(c1 - c0 for c0, c1 in shards)
+    slabs, layouts = [], []
+    for c0, c1 in shards:
+        attr = be.Attributes.from_host(ctx, np.ascontiguousarray(b[:, c0:c1]))
+        attr.set_row_flags(flags)
+        perms = be.Permutations(ctx, n, flags, nperm, seed)
+        outs = [ctx.alloc_f64(n, c1 - c0) for _ in range(5)] + [ctx.alloc_f64(c1 - c0)]
+        be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [o.ptr for o in outs])
+        n_pad, m_loc, layout = be.packed_counts_info(ctx)
+        assert layout in (0, 1) and m_loc == c1 - c0
+        slab = torch.zeros(widest * n_pad, dtype=torch.int32, device='cuda')
+        torch.cuda.synchronize()                       # torch's fill and the context's copy run on different streams
+        be.export_packed_counts(ctx, slab.data_ptr(), m_loc * n_pad)
+        ctx.sync()
+        slabs.append(slab)
+        layouts.append((layout, n_pad))
+        np.testing.assert_array_equal(outs[3].download((n, c1 - c0)), want['nes'][:, c0:c1])
+        perms.close()
+        attr.close()
+    assert layouts[0] == layouts[1]
+    everyone = torch.cat(slabs)
+    full = torch.empty((n, 2 * widest), dtype=torch.float64, device='cuda')
+    torch.cuda.synchronize()
+    be.nes_from_packed_counts(ctx, nbr, everyone.data_ptr(), layouts[0][0], layouts[0][1], 2 * widest, nperm, 'both',
+                              full.data_ptr())
+    full = full.cpu().numpy()
+    got = np.concatenate([full[:, r * widest:r * widest + (c1 - c0)] for r, (c0, c1) in enumerate(shards)], axis=1)
+    np.testing.assert_array_equal(got, want['nes'])
+    nbr.close()
+
+
+def test_gather_nes_over_rccl_single_rank(amd, ctx):
+    """The collective path itself (RCCL process group of one rank): packed counters are
+    exported, all-gathered and turned into the NES matrix."""
+    import torch
+    import torch.distributed as dist
+    from safepy_amd import backend as be, sharding
+    created = False
+    if not dist.is_initialized():
+        import socket
+        s = socket.socket()
+        s.bind(('127.0.0.1', 0))
+        port = s.getsockname()[1]
+        s.close()
+        dist.init_process_group('nccl', init_method='tcp://127.0.0.1:%d' % port, rank=0, world_size=1,
+                                device_id=torch.device('cuda', 0))
+        created = True
+    try:
+        rng = np.random.default_rng(9)
+        n, m, nperm, seed = 500, 40, 30, 2
+        xy = rng.uniform(size=(n, 2))
+        b = (rng.uniform(size=(n, m)) < 0.08).astype(np.float32)
+        nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+        attr = be.Attributes.from_host(ctx, b)
+        flags, stats = sharding.reduce_flags_and_stats(attr.row_flags(), attr.stats())
+        assert stats['n_other'] == 0 and flags.sum() == n
+        perms = be.Permutations(ctx, n, flags, nperm, seed)
+        outs = [torch.empty((n, m), dtype=torch.float64, device='cuda') for _ in range(5)]
+        enr = torch.empty(m, dtype=torch.float64, device='cuda')
+        be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [t.data_ptr() for t in outs] + [enr.data_ptr()])
+        full = sharding.gather_nes(ctx, nbr, outs[3], m, nperm, 'both')
+        torch.cuda.synchronize()
+        ctx.sync()
+        assert torch.equal(full, outs[3])
+        perms.close()
+        attr.close()
+        nbr.close()
+    finally:
+        if created:
+            dist.destroy_process_group()

@@ -55,6 +55,12 @@ def _worker(rank, world, port, tmpdir):
                                     'max_nan_col': int(np.isnan(local).sum(axis=0).max())})
         assert st['n_other'] == int((~np.isnan(b) & ~np.isin(b, [0, 1])).sum())
         assert st['max_nan_col'] == n
+        # the same two reductions as ONE collective (what bench.py and the sharded driver use)
+        flags1, st1 = sharding.reduce_flags_and_stats(local_flags, {
+            'n_other': int((~np.isnan(local) & ~np.isin(local, [0, 1])).sum()),
+            'n_non_integer': int((~np.isnan(local) & (local != np.floor(local))).sum()),
+            'max_nan_col': int(np.isnan(local).sum(axis=0).max())})
+        assert np.array_equal(flags1, flags) and flags1.dtype == np.uint8 and st1 == st
 
         # per-rank compute (oracle stand-in for the HIP kernels) with the GLOBAL permutation stream
         table = orc.permutation_index_table(np.where(flags[:, None] > 0, 0.0, np.nan) * np.ones((n, 1)), nperm, seed)
@@ -71,6 +77,9 @@ def _worker(rank, world, port, tmpdir):
         full_cp = sharding.gather_columns(torch.from_numpy(cp), m).numpy()
         want_cn, want_cp = orc.run_permutations(a, b, 'sum', nperm, seed)
         assert np.array_equal(full_cn, want_cn) and np.array_equal(full_cp, want_cp)
+        # gather_nes without device counters (gloo): agrees on the fallback and moves the f64 blocks
+        full_again = sharding.gather_nes(None, None, torch.from_numpy(cn), m, nperm, 'both').numpy()
+        assert np.array_equal(full_again, want_cn)
         open(os.path.join(tmpdir, 'ok%d' % rank), 'w').write('ok')
     finally:
         dist.destroy_process_group()
