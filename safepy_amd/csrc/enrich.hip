@@ -1258,6 +1258,17 @@ __device__ __forceinline__ double hyp_logpmf(const double *__restrict__ lf, int6
            (lf[pop] - lf[draws] - lf[pop - draws]);
 }
 
+// 1 / x for the term ratios of the tail recurrence: hardware reciprocal estimate + two Newton
+// steps (a couple of ulp, far inside the 1e-6 relative parity bound) instead of the ~30-instruction
+// IEEE division; no table loads inside the serial loop (they left the waves waiting 80 % of the time)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+
 __device__ double hyp_sf(const double *__restrict__ lf, double x_hits, double pop_d, double good_d, double draws_d) {
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
     // _argcheck of scipy's hypergeom: integers, 0 <= good <= pop, 0 <= draws <= pop
@@ -1275,30 +1286,36 @@ __device__ double hyp_sf(const double *__restrict__ lf, double x_hits, double po
     const int64_t k = static_cast<int64_t>(floor(k_d));
     const double eps = 2.220446049250313e-16;
     const double mode = floor(static_cast<double>(good + 1) * static_cast<double>(draws + 1) / static_cast<double>(pop + 2));
+    // the loops count in doubles (exact: integers below 2^53): 64-bit integer -> double
+    // conversions would cost more than the recurrence itself
+    const int lo_i = static_cast<int>(lo), hi_i = static_cast<int>(hi);
+    const double rest_d = pop_d - good_d - draws_d;                     // may be negative; rest + t >= 0 inside the support
     double result;
     if (static_cast<double>(k) < mode) {
         // lower tail cdf(k) downwards from k, then complement
-        int64_t t = k;
+        int t = static_cast<int>(k);
+        double td = static_cast<double>(t);
         double term = exp(hyp_logpmf(lf, t, pop, good, draws));
         double sum = term;
-        while (t > lo && term > eps) {
+        while (t > lo_i && term > eps) {
             // pmf(t-1) / pmf(t)
-            term = term * (static_cast<double>(t) * static_cast<double>(pop - good - draws + t)) /
-                   (static_cast<double>(good - t + 1) * static_cast<double>(draws - t + 1));
+            term = term * (td * (rest_d + td)) * fast_rcp((good_d - td + 1.0) * (draws_d - td + 1.0));
             sum += term;
             --t;
+            td -= 1.0;
         }
         result = 1.0 - sum;
     } else {
-        int64_t t = k + 1;
+        int t = static_cast<int>(k) + 1;
+        double td = static_cast<double>(t);
         double term = exp(hyp_logpmf(lf, t, pop, good, draws));
         double sum = term;
-        while (t < hi && term > eps * sum) {
+        while (t < hi_i && term > eps * sum) {
             // pmf(t+1) / pmf(t)
-            term = term * (static_cast<double>(good - t) * static_cast<double>(draws - t)) /
-                   (static_cast<double>(t + 1) * static_cast<double>(pop - good - draws + t + 1));
+            term = term * ((good_d - td) * (draws_d - td)) * fast_rcp((td + 1.0) * (rest_d + td + 1.0));
             sum += term;
             ++t;
+            td += 1.0;
         }
         result = sum;
     }
