@@ -151,6 +151,50 @@ def hbm_kernels(ctx, torch, np, be):
     return out
 
 
+MFMA_I8_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: dense i8 MFMA = 2x the 2.5 PF bf16 rate
+
+
+def mfma_kernel(ctx, np, be):
+    """The matrix-core form of the permutation test (BASELINE.json configs[4] per-rank shape,
+    reduced in attributes and permutations so it finishes in well under a second): N = 20 000
+    uniform layout, euclidean r = 0.1, 1024 quantitative f64 attributes x 128 permutations.
+    Algorithmic work = the block-sparse GEMM the kernel runs: stored 256 x 32 membership blocks
+    x 32-column tiles x 6 i8 slices x (permutations + 1 observed pass) x 2 ops per MAC."""
+    from safepy_amd import workloads
+    n, m, nperm = 20000, 1024, 128
+    xy = workloads.uniform_layout(4, n)
+    nbr = be.Neighborhoods.euclidean(ctx, xy, 0.1 * (xy[:, 0].max() - xy[:, 0].min()))
+    b = workloads.quantitative_attributes(3, n, m)
+    attr = be.Attributes.from_host(ctx, b)
+    outs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
+    res = None
+    for _ in range(2):                                   # first call builds the block structure
+        perms = be.Permutations(ctx, n, attr.row_flags(), nperm, 0)
+        ctx.sync()
+        t0 = time.perf_counter()
+        be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [o.ptr for o in outs])
+        ctx.sync()
+        dt = time.perf_counter() - t0
+        perms.close()
+        name, ms, launches = ctx.last_kernel()
+        res = (name, ms, launches, dt)
+    name, ms, launches, dt = res
+    blocks = be.block_count(nbr)
+    ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * 6 * (nperm + 1)
+    tops = ops / (ms * launches * 1e-3) / 1e12
+    out = {name: {'bound': 'mfma', 'workload': 'N=%d x M=%d quantitative f64 attributes x %d permutations, %d members per '
+                                              'neighborhood on average (configs[4] per-rank shape, reduced M and P)'
+                                              % (n, m, nperm, int(nbr.nnz / n)),
+                  'kernel_ms': ms * launches, 'call_ms': 1e3 * dt, 'algorithmic_ops': ops, 'achieved': tops,
+                  'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS,
+                  'membership_blocks_256x32': blocks, 'block_fill': nbr.nnz / (blocks * 256.0 * 32.0),
+                  'enrichments_per_s': float(n) * m * nperm / dt,
+                  'config5_rank_share_seconds_est': dt * (6250.0 / m) * (1000.0 / nperm)}}
+    attr.close()
+    nbr.close()
+    return out
+
+
 def main():
     args = parse()
     rank = int(os.environ.get('RANK', '0'))
@@ -286,6 +330,7 @@ def main():
             line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
         if args.extras and world == 1:
             line['hbm_bound_kernels'] = hbm_kernels(ctx, torch, np, be)
+            line['mfma_bound_kernels'] = mfma_kernel(ctx, np, be)
         print(json.dumps(line))
     if dist is not None:
         dist.barrier()

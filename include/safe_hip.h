@@ -99,6 +99,10 @@ int safe_nbr_from_dense_i64(safe_ctx *ctx, const int64_t *a_host, int64_t n, saf
  * space-filling curve for the block-sparse matrix-core kernel; results never depend on it.
  * safe_nbr_euclidean records its own xy; without a layout the order is Cuthill-McKee. */
 int safe_nbr_set_layout(safe_nbr *nbr, const double *xy_host);
+/* Number of stored 256-row x 32-column blocks of the block-sparse membership used by the
+ * matrix-core permutation kernel (0 until that kernel has run once on the handle): the
+ * algorithmic GEMM size for roofline reporting. */
+int safe_nbr_block_count(const safe_nbr *nbr, int64_t *blocks);
 int safe_nbr_destroy(safe_nbr *nbr);
 int safe_nbr_info(const safe_nbr *nbr, int64_t *n, int64_t *nnz, int64_t *max_row_count);
 /* self.neighborhoods in the reference layout: int64 [n,n] row-major (safe.py:430). */

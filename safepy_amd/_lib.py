@@ -81,6 +81,7 @@ PROTOTYPES = {
     'safe_nbr_shortpath': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, C.c_double, C.c_int, _pp]),
     'safe_nbr_from_dense_i64': (C.c_int, [_vp, _vp, _i64, _pp]),
     'safe_nbr_set_layout': (C.c_int, [_vp, _vp]),
+    'safe_nbr_block_count': (C.c_int, [_vp, _pi64]),
     'safe_nbr_destroy': (C.c_int, [_vp]),
     'safe_nbr_info': (C.c_int, [_vp, _pi64, _pi64, _pi64]),
     'safe_nbr_to_dense_i64': (C.c_int, [_vp, _vp]),

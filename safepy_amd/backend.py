@@ -376,3 +376,11 @@ def nes_from_packed_counts(ctx, nbr, counts_ptr, layout, n_pad, m, num_permutati
         table = nes_table(num_permutations)
     check(lib.safe_nes_from_packed_counts(ctx.handle, nbr.handle, C.c_void_p(counts_ptr), int(layout), int(n_pad), int(m),
                                           int(num_permutations), _SIGN[attribute_sign], _ptr(table), C.c_void_p(nes_ptr)))
+
+
+def block_count(nbr):
+    """Stored 256 x 32 blocks of the block-sparse membership the matrix-core kernel multiplies
+    (built on first use by that kernel; 0 before)."""
+    c = C.c_int64()
+    check(lib.safe_nbr_block_count(nbr.handle, C.byref(c)))
+    return c.value

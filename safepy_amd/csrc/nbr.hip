@@ -488,6 +488,12 @@ int safe_nbr_euclidean(safe_ctx *ctx, const double *xy_host, int64_t n, double n
     return SAFE_OK;
 }
 
+int safe_nbr_block_count(const safe_nbr *nbr, int64_t *blocks) {
+    SAFE_REQUIRE(nbr && blocks, "safe_nbr_block_count: NULL argument");
+    *blocks = nbr->blocks_ready ? nbr->bs_blocks : 0;
+    return SAFE_OK;
+}
+
 int safe_nbr_set_layout(safe_nbr *nbr, const double *xy_host) {
     SAFE_REQUIRE(nbr && xy_host, "safe_nbr_set_layout: NULL argument");
     nbr->h_xy.assign(xy_host, xy_host + 2 * nbr->n);
