@@ -127,3 +127,54 @@ def test_config4_shape_hypergeometric_properties():
     want = hypergeom.sf(hits - 1, notnan.sum(), np.nansum(b, axis=0)[None, :], size[:, None])
     np.testing.assert_allclose(p[rows], want, rtol=1e-6, atol=1e-300)
     assert np.array_equal(sf.nes_binary[rows], (-np.log10(want) > -np.log10(0.05)).astype(np.float64))
+
+
+def test_config5_shape_quantitative_permutation_test_sampled_rows():
+    """20 000 nodes, euclidean r = 0.1 (578 members per neighborhood), quantitative f64 attributes
+    with NaN rows and scattered NaNs (a 96-column block of config 5's per-rank share) through the
+    matrix-core kernel.  Checked on sampled neighborhoods against a direct NumPy evaluation that
+    uses the device's own permutation tables (themselves pinned to NumPy's stream elsewhere):
+    every <= / >= count identical, observed scores to 1e-9."""
+    import safepy_amd
+    from safepy_amd import backend as be, workloads
+    ctx = safepy_amd.Context.default(0)
+    n, m, nperm, seed = 20000, 96, 40, 5
+    xy = workloads.uniform_layout(4, n)
+    b = workloads.quantitative_attributes(7, n, m)
+    nr = 0.1 * (xy[:, 0].max() - xy[:, 0].min())
+    nbr = be.Neighborhoods.euclidean(ctx, xy, nr)
+    attr = be.Attributes.from_host(ctx, b)
+    flags = attr.row_flags()
+    assert flags.sum() == (~np.isnan(b)).any(axis=1).sum()
+    perms = be.Permutations(ctx, n, flags, nperm, seed)
+    ns, neg, pos = (ctx.alloc_f64(n, m) for _ in range(3))
+    be.permtest_counts(ctx, nbr, attr, perms, 'sum', ns.ptr, neg.ptr, pos.ptr)
+    assert ctx.last_kernel()[0] == 'k_permtest_mfma'
+    ns, neg, pos = ns.download((n, m)), neg.download((n, m)), pos.download((n, m))
+    table = perms.read()                                         # cur[p][i]: permuted matrix p = B[cur[p]]
+    assert np.array_equal(np.sort(table[0]), np.arange(n))
+    # size-independent properties over the whole block
+    assert np.all((neg >= 0) & (neg <= nperm) & (pos >= 0) & (pos <= nperm)) and np.all(neg + pos >= nperm)
+    # sampled rows, exact
+    rng = np.random.default_rng(0)
+    rows = rng.choice(n, 24, replace=False)
+    rp, col = nbr.csr()
+    b0 = np.nan_to_num(b)
+    for i in rows:
+        members = col[rp[i]:rp[i + 1]]
+        d = np.sqrt(((xy[members] - xy[i]) ** 2).sum(axis=1))
+        assert np.all(d < nr) and len(members) == (np.sqrt(((xy - xy[i]) ** 2).sum(axis=1)) < nr).sum()
+        obs = b0[members].sum(axis=0)
+        np.testing.assert_allclose(ns[i], obs, rtol=1e-9, atol=1e-9)
+        s = b0[table[:, members]].sum(axis=1)                    # [P, m]
+        # a comparison decided by less than the f64 rounding of a 600-term sum is not checkable from here
+        clear = np.abs(s - obs) > 1e-9
+        assert clear.mean() > 0.999
+        le = ((s <= obs) & clear).sum(axis=0)
+        ge = ((s >= obs) & clear).sum(axis=0)
+        unclear = (~clear).sum(axis=0)
+        assert np.all(np.abs(neg[i] - le) <= unclear) and np.all(np.abs(pos[i] - ge) <= unclear)
+        assert np.array_equal(neg[i][unclear == 0], le[unclear == 0]) and np.array_equal(pos[i][unclear == 0], ge[unclear == 0])
+    perms.close()
+    attr.close()
+    nbr.close()
