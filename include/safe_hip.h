@@ -200,6 +200,19 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
                    int64_t col0, int64_t col1, double *pvalues_pos_dev, double *nes_dev,
                    double *nes_binary_dev, double *num_enriched_dev);
 
+/* multiple_testing=True (safepy/safe.py:536-542 and 599-605): Benjamini-Hochberg adjustment of
+ * every row of the p-value matrices across its m attributes -- statsmodels'
+ * fdrcorrection(row)[1], operation by operation -- IN PLACE on pvalues_neg_dev / pvalues_pos_dev
+ * (f64 [n,m] row-major), then NES, nes_binary and the per-attribute counts recomputed from the
+ * adjusted values (safe.py:546-554 / 608, 468-472).  num_permutations > 0: randomization form
+ * (zero p-values become 1/num_permutations inside the logarithm, sign_mode combines the two
+ * sides); num_permutations == 0: hypergeometric form (nes = -log10 pvalues_pos; pvalues_neg_dev
+ * may be NULL).  A row needs all of its attributes: under attribute sharding this runs after the
+ * p-value blocks have been gathered. */
+int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutations, int sign_mode,
+                    double enrichment_threshold, double *pvalues_neg_dev, double *pvalues_pos_dev, double *nes_dev,
+                    double *nes_binary_dev, double *num_enriched_dev);
+
 /* Multi-GPU exchange in integers (replaces gathering f64 NES blocks for the np.concatenate of
  * safepy/safe.py:1355): after safe_randomization / safe_permtest_counts on the bit-sliced or
  * matrix-core kernel, the raw counters of the call are still resident as

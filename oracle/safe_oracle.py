@@ -181,8 +181,40 @@ def wants_hypergeometric(node2attribute, enrichment_type):
     return (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and other == 0)
 
 
-def pvalues_by_hypergeom(neighborhoods, node2attribute):
-    """safe.py:573-608 without the FDR branch.  Returns dict(pvalues_pos, nes)."""
+def fdrcorrection(pvals):
+    """Benjamini-Hochberg adjusted p-values of one row: what the reference gets from
+    ``statsmodels.stats.multitest.fdrcorrection(pvals)[1]`` (alpha=0.05, method='indep',
+    is_sorted=False), called row by row at safe.py:536-542 and 599-605.
+
+    statsmodels (pinned 0.14.4 in extras/requirements.txt) is NOT in this image and there is no
+    wheel for it, so this branch is restated from the published algorithm, operation by
+    operation -- argsort; ecdf = arange(1, n+1) / float(n); sorted / ecdf;
+    np.minimum.accumulate from the right; clip at 1; scatter back -- and PARITY IS UNPINNED
+    against statsmodels itself.  It is cross-checked against SciPy's independent implementation
+    (scipy.stats.false_discovery_control, method 'bh') in tests/test_oracle_golden.py.
+    NaN p-values sort last and np.minimum propagates them through the whole accumulated row,
+    exactly as the NumPy calls above would."""
+    pvals = np.asarray(pvals, dtype=np.float64)
+    n = pvals.shape[0]
+    order = np.argsort(pvals)
+    ps = np.take(pvals, order)
+    ecdf = np.arange(1, n + 1) / float(n)
+    with np.errstate(invalid='ignore'):
+        raw = ps / ecdf
+        corrected = np.minimum.accumulate(raw[::-1])[::-1]
+        corrected[corrected > 1] = 1
+    out = np.empty_like(corrected)
+    out[order] = corrected
+    return out
+
+
+def fdr_rows(pvalues):
+    """np.apply_along_axis(fdrcorrection, 1, pvalues)[:, 1, :] (safe.py:538-542, 604-605)."""
+    return np.stack([fdrcorrection(row) for row in pvalues]) if pvalues.shape[0] else pvalues.copy()
+
+
+def pvalues_by_hypergeom(neighborhoods, node2attribute, multiple_testing=False):
+    """safe.py:573-608.  Returns dict(pvalues_pos, nes)."""
     n_nodes, n_attr = node2attribute.shape
     nodes_not_nan = np.any(~np.isnan(node2attribute), axis=1)
     total = np.sum(nodes_not_nan)
@@ -193,13 +225,15 @@ def pvalues_by_hypergeom(neighborhoods, node2attribute):
     hits = np.dot(neighborhoods, np.where(~np.isnan(node2attribute), node2attribute, 0))
     with np.errstate(invalid='ignore', divide='ignore'):
         pvalues_pos = hypergeom.sf(hits - 1, pop, in_group, in_nb)
+        if multiple_testing:                               # safe.py:599-605
+            pvalues_pos = fdr_rows(pvalues_pos)
         nes = -np.log10(pvalues_pos)
     return {'pvalues_pos': pvalues_pos, 'nes': nes}
 
 
 def pvalues_by_randomization(neighborhoods, node2attribute, neighborhood_score_type,
-                             num_permutations, random_seed, attribute_sign):
-    """safe.py:496-554 without the sleep, the (broken) multiprocessing split and FDR."""
+                             num_permutations, random_seed, attribute_sign, multiple_testing=False):
+    """safe.py:496-554 without the sleep and the (broken) multiprocessing split."""
     ns = compute_neighborhood_score(neighborhoods, node2attribute, neighborhood_score_type)
     counts_neg, counts_pos = run_permutations(neighborhoods, node2attribute,
                                               neighborhood_score_type, num_permutations, random_seed)
@@ -208,6 +242,9 @@ def pvalues_by_randomization(neighborhoods, node2attribute, neighborhood_score_t
     counts_pos[idx] = np.nan
     pvalues_neg = counts_neg / num_permutations
     pvalues_pos = counts_pos / num_permutations
+    if multiple_testing:                                   # safe.py:536-542
+        pvalues_neg = fdr_rows(pvalues_neg)
+        pvalues_pos = fdr_rows(pvalues_pos)
     with np.errstate(invalid='ignore', divide='ignore'):
         nes_pos = -np.log10(np.where(pvalues_pos == 0, 1 / num_permutations, pvalues_pos))
         nes_neg = -np.log10(np.where(pvalues_neg == 0, 1 / num_permutations, pvalues_neg))
@@ -230,16 +267,16 @@ def binarize(nes, enrichment_threshold):
 
 def compute_pvalues(neighborhoods, node2attribute, enrichment_type='auto', neighborhood_score_type='sum',
                     background='attribute_file', num_permutations=1000, random_seed=None,
-                    attribute_sign='both', enrichment_threshold=0.05):
-    """safe.py:432-472 (FDR off).  ``node2attribute`` is modified in place when
-    background == 'network' exactly as the reference does (safe.py:449-451)."""
+                    attribute_sign='both', enrichment_threshold=0.05, multiple_testing=False):
+    """safe.py:432-472.  ``node2attribute`` is modified in place when background == 'network'
+    exactly as the reference does (safe.py:449-451)."""
     if background == 'network':
         node2attribute[np.isnan(node2attribute)] = 0
     if wants_hypergeometric(node2attribute, enrichment_type):
-        out = pvalues_by_hypergeom(neighborhoods, node2attribute)
+        out = pvalues_by_hypergeom(neighborhoods, node2attribute, multiple_testing)
     else:
         out = pvalues_by_randomization(neighborhoods, node2attribute, neighborhood_score_type,
-                                       num_permutations, random_seed, attribute_sign)
+                                       num_permutations, random_seed, attribute_sign, multiple_testing)
     out['nes_binary'], out['num_neighborhoods_enriched'] = binarize(out['nes'], enrichment_threshold)
     return out
 

@@ -384,3 +384,12 @@ def block_count(nbr):
     c = C.c_int64()
     check(lib.safe_nbr_block_count(nbr.handle, C.byref(c)))
     return c.value
+
+
+def fdr_adjust(ctx, n, m, num_permutations, attribute_sign, enrichment_threshold, out_ptrs):
+    """multiple_testing=True: out_ptrs = (pvalues_neg or None, pvalues_pos, nes, nes_binary, num_enriched);
+    num_permutations = 0 selects the hypergeometric form."""
+    pn, pp, nes, nb, ne = out_ptrs
+    check(lib.safe_fdr_adjust(ctx.handle, int(n), int(m), int(num_permutations), _SIGN[attribute_sign],
+                              float(enrichment_threshold), C.c_void_p(pn) if pn else None, C.c_void_p(pp), C.c_void_p(nes),
+                              C.c_void_p(nb), C.c_void_p(ne)))

@@ -1,0 +1,173 @@
+// multiple_testing=True: Benjamini-Hochberg adjustment of every ROW of the p-value matrices
+// (across attributes), i.e. np.apply_along_axis(fdrcorrection, 1, pvalues)[:, 1, :] of
+// safepy/safe.py:536-542 (randomization) and 599-605 (hypergeometric), followed by the NES /
+// binarisation steps that depend on the adjusted values (safe.py:546-554, 608, 468-472).
+//
+// statsmodels' fdrcorrection(pvals) (method 'indep'), operation by operation:
+//     order = argsort(pvals); ps = pvals[order]
+//     raw = ps / (arange(1, n+1) / float(n))
+//     corrected = minimum.accumulate(raw[::-1])[::-1];  corrected[corrected > 1] = 1
+//     out[order] = corrected
+// Ties need no care: tied entries end up with the same value whatever their order (the running
+// minimum from the right passes through the group's last member).  NaN p-values sort last and
+// np.minimum propagates them through the whole row, so a row with any NaN becomes all NaN.
+//
+// The per-row sort is a library call (hipCUB segmented radix sort, rows batched so a call stays
+// below 2^31 keys); the BH pass and the NES epilogue are kernels here.
+#include <hipcub/hipcub.hpp>
+
+#include <algorithm>
+#include <cmath>
+
+#include "common.h"
+
+namespace {
+
+__global__ void k_fdr_cols(int32_t *__restrict__ idx, int64_t count, int64_t m) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < count) idx[i] = static_cast<int32_t>(i % m);
+}
+
+__global__ void k_fdr_offsets(int64_t *__restrict__ off, int64_t rows, int64_t m) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i <= rows) off[i] = i * m;
+}
+
+// one workgroup per row of the batch; ps / cols: the row sorted ascending with its column ids
+__global__ __launch_bounds__(256) void k_fdr_row(const double *__restrict__ ps, const int32_t *__restrict__ cols, int64_t m,
+                                                 double *__restrict__ out) {
+    __shared__ double part[256];
+    const int64_t row = blockIdx.x;
+    const double *p = ps + row * m;
+    const int32_t *c = cols + row * m;
+    double *o = out + row * m;
+    const int t = threadIdx.x;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    const double last = p[m - 1];
+    if (last != last) {                                             // a NaN anywhere poisons the whole row
+        for (int64_t r = t; r < m; r += 256) o[r] = qnan;
+        return;
+    }
+    const double n_d = static_cast<double>(m);
+    const int64_t len = (m + 255) / 256, r0 = static_cast<int64_t>(t) * len, r1 = r0 + len < m ? r0 + len : m;
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double mine = inf;
+    for (int64_t r = r1 - 1; r >= r0; --r) mine = fmin(mine, p[r] / (static_cast<double>(r + 1) / n_d));
+    part[t] = mine;
+    __syncthreads();
+    double carry = inf;                                             // minimum over everything right of this thread's chunk
+    for (int u = t + 1; u < 256; ++u) carry = fmin(carry, part[u]);
+    for (int64_t r = r1 - 1; r >= r0; --r) {
+        carry = fmin(carry, p[r] / (static_cast<double>(r + 1) / n_d));
+        o[c[r]] = carry > 1.0 ? 1.0 : carry;
+    }
+}
+
+// NES / binarisation from (adjusted) p-values; n_perm == 0: hypergeometric form nes = -log10(p_pos)
+__global__ __launch_bounds__(256) void k_nes_from_pvalues(const double *__restrict__ p_neg, const double *__restrict__ p_pos,
+                                                          int64_t n, int64_t m, double inv_perm, int sign_mode,
+                                                          double nes_threshold, double *__restrict__ nes_out,
+                                                          double *__restrict__ nes_binary, unsigned int *__restrict__ enriched) {
+    const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
+    const int64_t i0 = static_cast<int64_t>(blockIdx.y) * 64 + (threadIdx.x >> 6);
+    if (c >= m) return;
+    unsigned int hits = 0;
+    for (int64_t i = i0; i < n && i < (static_cast<int64_t>(blockIdx.y) + 1) * 64; i += 4) {
+        const int64_t o = i * m + c;
+        double nes;
+        if (inv_perm == 0.0) {
+            nes = -log10(p_pos[o]);                                  // safe.py:608
+        } else {                                                     // safe.py:546-554
+            const double pp = p_pos[o], pn = p_neg[o];
+            const double ep = -log10(pp == 0.0 ? inv_perm : pp), en = -log10(pn == 0.0 ? inv_perm : pn);
+            nes = sign_mode == SAFE_SIGN_HIGHEST ? ep : sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
+        }
+        const bool hit = (nes == nes) && (fabs(nes) > nes_threshold);   // safe.py:468-470
+        nes_out[o] = nes;
+        nes_binary[o] = hit ? 1.0 : 0.0;
+        hits += hit;
+    }
+    if (hits) atomicAdd(&enriched[c], hits);
+}
+
+__global__ void k_fdr_u32_to_f64(const unsigned int *__restrict__ in, double *__restrict__ out, int64_t count) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < count) out[i] = static_cast<double>(in[i]);
+}
+
+int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m) {
+    // rows per batch: at most 2^27 keys per library call (temporaries ~ 3 GB)
+    const int64_t batch_rows = std::max<int64_t>(1, std::min<int64_t>(n, (int64_t(1) << 27) / std::max<int64_t>(m, 1)));
+    const int64_t batch_items = batch_rows * m;
+    SAFE_REQUIRE(m < (int64_t(1) << 31) - 1 && batch_items < (int64_t(1) << 31), "safe_fdr_adjust: %lld attributes per row are too many",
+                 (long long)m);
+    double *keys_out = nullptr;
+    int32_t *vals_in = nullptr, *vals_out = nullptr;
+    int64_t *offsets = nullptr;
+    void *temp = nullptr;
+    size_t temp_bytes = 0;
+    int rc = dev_alloc(&keys_out, batch_items);
+    if (rc == SAFE_OK) rc = dev_alloc(&vals_in, batch_items);
+    if (rc == SAFE_OK) rc = dev_alloc(&vals_out, batch_items);
+    if (rc == SAFE_OK) rc = dev_alloc(&offsets, batch_rows + 1);
+    hipError_t e = hipSuccess;
+    if (rc == SAFE_OK) {
+        hipLaunchKernelGGL(k_fdr_cols, dim3(ceil_div(batch_items, 256)), dim3(256), 0, ctx->stream, vals_in, batch_items, m);
+        hipLaunchKernelGGL(k_fdr_offsets, dim3(ceil_div(batch_rows + 1, 256)), dim3(256), 0, ctx->stream, offsets, batch_rows, m);
+        e = hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, p_dev, keys_out, vals_in, vals_out,
+                                                        static_cast<int>(batch_items), static_cast<int>(batch_rows), offsets,
+                                                        offsets + 1, 0, 64, ctx->stream);
+        if (e == hipSuccess) e = hipMalloc(&temp, std::max<size_t>(temp_bytes, 16));
+    }
+    for (int64_t r0 = 0; rc == SAFE_OK && e == hipSuccess && r0 < n; r0 += batch_rows) {
+        const int64_t rows = std::min<int64_t>(batch_rows, n - r0);
+        double *block = p_dev + r0 * m;
+        e = hipcub::DeviceSegmentedRadixSort::SortPairs(temp, temp_bytes, block, keys_out, vals_in, vals_out,
+                                                        static_cast<int>(rows * m), static_cast<int>(rows), offsets, offsets + 1, 0,
+                                                        64, ctx->stream);
+        if (e != hipSuccess) break;
+        hipLaunchKernelGGL(k_fdr_row, dim3(rows), dim3(256), 0, ctx->stream, keys_out, vals_out, m, block);
+        e = hipGetLastError();
+    }
+    if (rc == SAFE_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e != hipSuccess) {
+        safe_set_error("safe_fdr_adjust: %s", hipGetErrorString(e));
+        rc = SAFE_E_HIP;
+    }
+    (void)hipFree(keys_out);
+    (void)hipFree(vals_in);
+    (void)hipFree(vals_out);
+    (void)hipFree(offsets);
+    (void)hipFree(temp);
+    return rc;
+}
+
+}  // namespace
+
+extern "C" int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutations, int sign_mode,
+                               double enrichment_threshold, double *pvalues_neg_dev, double *pvalues_pos_dev, double *nes_dev,
+                               double *nes_binary_dev, double *num_enriched_dev) {
+    SAFE_REQUIRE(ctx && pvalues_pos_dev && nes_dev && nes_binary_dev && num_enriched_dev, "safe_fdr_adjust: NULL argument");
+    SAFE_REQUIRE(n >= 1 && m >= 1 && num_permutations >= 0, "safe_fdr_adjust: bad sizes");
+    SAFE_REQUIRE(num_permutations == 0 || pvalues_neg_dev, "safe_fdr_adjust: the randomization form needs pvalues_neg");
+    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_fdr_adjust: bad sign_mode %d", sign_mode);
+    SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_fdr_adjust: enrichment_threshold must be in (0,1)");
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    if (num_permutations > 0) SAFE_TRY(fdr_matrix(ctx, pvalues_neg_dev, n, m));
+    SAFE_TRY(fdr_matrix(ctx, pvalues_pos_dev, n, m));
+    unsigned int *d_enr = nullptr;
+    SAFE_TRY(dev_alloc(&d_enr, m));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_enr, 0, m * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(k_nes_from_pvalues, dim3(ceil_div(m, 64), ceil_div(n, 64)), dim3(256), 0, ctx->stream, pvalues_neg_dev,
+                       pvalues_pos_dev, n, m, num_permutations > 0 ? 1.0 / static_cast<double>(num_permutations) : 0.0, sign_mode,
+                       -std::log10(enrichment_threshold), nes_dev, nes_binary_dev, d_enr);
+    hipLaunchKernelGGL(k_fdr_u32_to_f64, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, m);
+    hipError_t e = hipGetLastError();
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_enr);
+    if (e != hipSuccess) {
+        safe_set_error("safe_fdr_adjust: %s", hipGetErrorString(e));
+        return SAFE_E_HIP;
+    }
+    return SAFE_OK;
+}

@@ -419,11 +419,6 @@ class SAFE:
             self.attributes = pd.DataFrame({'id': np.arange(len(enriched)), 'name': [str(j) for j in range(len(enriched))]})
         self.attributes['num_neighborhoods_enriched'] = enriched
 
-    def _reject_fdr(self):
-        if self.multiple_testing:
-            raise NotImplementedError('multiple_testing=True (FDR, safe.py:536-542/599-605) is outside the hot-path '
-                                      'scope of this build (SURVEY.md section 8f)')
-
     def compute_pvalues_by_randomization(self, _attr=None, **kwargs):
         """safepy/safe.py:474-554 (no 1 s sleep, no multiprocessing split: `processes` is
         accepted and ignored -- the reference's own split is broken at this commit)."""
@@ -435,7 +430,6 @@ class SAFE:
         if 'num_permutations' in kwargs:
             self.num_permutations = kwargs['num_permutations']
         self.validate_config()
-        self._reject_fdr()
         score_type = 'z-score' if self.neighborhood_score_type == 'z-score' else 'sum'
 
         ctx = self._ctx()
@@ -447,6 +441,10 @@ class SAFE:
         try:
             be.randomization(ctx, nbr, attr, perms, score_type, self.attribute_sign, self.enrichment_threshold,
                              [b.ptr for b in bufs])
+            if self.multiple_testing:                  # safe.py:536-542, then 546-554 and 468-472 on the adjusted values
+                logging.info('Running FDR-adjustment of p-values...')
+                be.fdr_adjust(ctx, n, m, self.num_permutations, self.attribute_sign, self.enrichment_threshold,
+                              [b.ptr for b in bufs[1:]])
             self.ns = bufs[0].download((n, m))
             self.pvalues_neg = bufs[1].download((n, m))
             self.pvalues_pos = bufs[2].download((n, m))
@@ -469,7 +467,6 @@ class SAFE:
                 for k in kwargs:
                     logging.warning('\t%s=%s' % (k, str(kwargs[k])))
         self.validate_config()
-        self._reject_fdr()
         if self.verbose:
             logging.info('Using the hypergeometric test to calculate enrichment...')
         ctx = self._ctx()
@@ -479,6 +476,11 @@ class SAFE:
         bufs = [ctx.alloc_f64(n, m) for _ in range(3)] + [ctx.alloc_f64(m)]
         try:
             be.hypergeom(ctx, nbr, attr, self.enrichment_threshold, [b.ptr for b in bufs])
+            if self.multiple_testing:                  # safe.py:599-605, then 608 and 468-472 on the adjusted values
+                if self.verbose:
+                    logging.info('Running FDR-adjustment of p-values...')
+                be.fdr_adjust(ctx, n, m, 0, self.attribute_sign, self.enrichment_threshold,
+                              [None] + [b.ptr for b in bufs])
             self.pvalues_pos = bufs[0].download((n, m))
             self.nes = bufs[1].download((n, m))
             self._pending_binary = (bufs[2].download((n, m)), bufs[3].download((m,)))

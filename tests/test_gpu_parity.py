@@ -282,8 +282,6 @@ def test_config_errors_match_reference_behaviour(amd, golden_nbr):
     with pytest.raises(ValueError):
         sf.compute_pvalues(how='randomization', num_permutations=5)
     assert sf.num_permutations == 1000
-    with pytest.raises(NotImplementedError):
-        sf.compute_pvalues(multiple_testing=True)
 
 
 # ------------------------------------------------- mid-size seeded check vs the oracle ----
@@ -573,3 +571,60 @@ def test_gather_nes_over_rccl_single_rank(amd, ctx):
     finally:
         if created:
             dist.destroy_process_group()
+
+
+# ------------------------------------------------------------- multiple_testing=True ----
+
+@pytest.mark.parametrize('sign', ['both', 'highest'])
+def test_fdr_randomization_vs_oracle(amd, sign):
+    """safe.py:536-554 with multiple_testing=True: Benjamini-Hochberg per row, then NES and the
+    binarised map from the adjusted p-values.  Empirical p-values are multiples of 1/P (many
+    ties, zeros, ones), quantitative attributes, a NaN column under z-score."""
+    rng = np.random.default_rng(61)
+    n, m, nperm = 400, 150, 50
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.12)
+    b = rng.normal(size=(n, m))
+    b[rng.choice(n, 25, replace=False)] = np.nan
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=6,
+                               attribute_sign=sign, multiple_testing=True)
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(xy)
+    sf.random_seed = 6
+    sf.attribute_sign = sign
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.12)
+    sf.load_attributes(attribute_file=b.copy())
+    sf.compute_pvalues(num_permutations=nperm, multiple_testing=True, verbose=False)
+    np.testing.assert_array_equal(sf.pvalues_neg, want['pvalues_neg'])     # same divisions in the same order: bit-exact
+    np.testing.assert_array_equal(sf.pvalues_pos, want['pvalues_pos'])
+    np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-12, atol=1e-12)
+    assert (sf.nes_binary != want['nes_binary']).sum() == 0
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['num_neighborhoods_enriched'])
+    assert (sf.pvalues_pos < 1).any() and (sf.pvalues_pos == 1).any()
+
+
+def test_fdr_hypergeometric_vs_oracle_with_nan_rows(amd):
+    """safe.py:599-608 with multiple_testing=True; a non-integer column makes hypergeom.sf NaN,
+    and NumPy's minimum.accumulate then turns every adjusted p-value of those rows into NaN."""
+    rng = np.random.default_rng(62)
+    n, m = 300, 90
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.15)
+    b = (rng.uniform(size=(n, m)) < rng.uniform(0.01, 0.3, size=m)).astype(np.float64)
+    b[rng.choice(n, 12, replace=False)] = np.nan
+    for poison in (False, True):
+        bb = b.copy()
+        if poison:
+            bb[5, 7] = 0.5                                       # K_j not an integer -> NaN p-values in column 7
+        want = orc.compute_pvalues(a, bb.copy(), enrichment_type='hypergeometric', multiple_testing=True)
+        sf = amd.SAFE(verbose=False)
+        sf.graph = amd.LayoutGraph(xy)
+        sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.15)
+        sf.load_attributes(attribute_file=bb.copy())
+        sf.compute_pvalues(how='hypergeometric', multiple_testing=True)
+        assert np.array_equal(np.isnan(sf.pvalues_pos), np.isnan(want['pvalues_pos']))
+        if poison:
+            assert np.isnan(sf.pvalues_pos).all()
+        np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
+        np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
+        assert (sf.nes_binary != want['nes_binary']).sum() == 0

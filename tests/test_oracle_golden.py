@@ -137,3 +137,23 @@ def test_restated_mt19937_matches_reference_stream(golden_rng):
             for suffix in ('a', 'b'):
                 want = g['s%d_n%d_%s' % (seed, n_items, suffix)]
                 assert rng.permutation(base) == [int(v) for v in want]
+
+
+def test_bh_restatement_against_scipy_independent_implementation():
+    """statsmodels is not installable here, so the oracle restates fdrcorrection from its
+    published algorithm (parity with statsmodels itself unpinned).  SciPy ships an independent
+    Benjamini-Hochberg (p * n / rank instead of p / (rank / n)): equal to the last ulp or two."""
+    import numpy as np
+    from scipy.stats import false_discovery_control
+    from oracle import safe_oracle as orc
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 7, 100, 4373):
+        p = rng.uniform(size=n)
+        k = rng.integers(0, n, size=n // 3)
+        p[k] = rng.integers(0, 5, size=n // 3) / 4.0              # ties, zeros, ones
+        got = orc.fdrcorrection(p)
+        np.testing.assert_allclose(got, false_discovery_control(p, method='bh'), rtol=4e-16, atol=0)
+        assert got.max() <= 1 and np.all(got >= p)
+    assert np.isnan(orc.fdrcorrection(np.array([0.1, np.nan, 0.5]))).all()
+    rows = orc.fdr_rows(np.array([[0.01, 0.04, 0.03], [1.0, 0.0, 0.5]]))
+    np.testing.assert_allclose(rows, [[0.03, 0.04, 0.04], [1.0, 0.0, 0.75]])
