@@ -39,7 +39,7 @@ def parse():
     ap.add_argument('--attrs', type=int, default=4373)
     ap.add_argument('--metric', default='shortpath_weighted_layout')
     ap.add_argument('--radius', type=float, default=0.1)
-    ap.add_argument('--cpu-perms', type=int, default=8, help='permutations timed for the CPU baseline (0 = skip)')
+    ap.add_argument('--cpu-perms', type=int, default=40, help='permutations timed for the CPU baseline (0 = skip)')
     ap.add_argument('--extras', type=int, default=1, help='also time the HBM-bound kernels (K1 distance, K4 hypergeometric)')
     return ap.parse_args()
 

@@ -7,6 +7,8 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <condition_variable>
+#include <mutex>
 #include <string>
 #include <thread>
 #include <vector>
@@ -188,6 +190,15 @@ struct safe_perms {
     std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each enqueued chunk
     std::vector<uint32_t> h_targets[2];            // swap targets of a chunk (draw thread -> workers)
     std::vector<uint32_t> h_local;                 // the draw thread's private chunk buffer
+    // the draw thread: runs the sequential MT19937 / rejection stream chunk by chunk, at most two
+    // chunks ahead of the swap workers (one target buffer each), independent of the thread that
+    // launches kernels
+    std::thread drawer;
+    std::mutex draw_mu;
+    std::condition_variable draw_cv;
+    int64_t drawn_chunks = 0;                      // chunks whose targets are complete in h_targets[c & 1]
+    int64_t consumed_chunks = 0;                   // chunks whose swaps have finished (their buffer is free again)
+    bool draw_stop = false;
     int32_t *h_maps[2] = {nullptr, nullptr};       // pinned: row maps of a chunk (workers -> GPU)
     hipEvent_t staged[2] = {nullptr, nullptr};
     int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] scan ping-pong

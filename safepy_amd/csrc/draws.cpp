@@ -11,11 +11,17 @@
 // many were accepted before it), but inside a batch of 16 draws the threshold moves by at most
 // 16: a draw v <= i-16 is accepted whatever happened before it, a draw v > i is rejected
 // whatever happened before it, and only i-16 < v <= i is ambiguous -- about 16/mask of the
-// draws.  So batches without an ambiguous draw are resolved with one vector compare and one
-// compress-store (AVX-512), and the rare ambiguous batch falls back to the scalar loop.
+// draws.  So a batch is resolved with two vector compares and one compress-store (AVX-512);
+// the few ambiguous lanes are settled one by one in lane order, each against the number of
+// accepted lanes before it (a popcount of the mask built so far), which is exactly the
+// sequential rule.  The raw MT19937 output is produced by a helper thread, one block ahead.
 #include <algorithm>
+#include <atomic>
+#include <chrono>
 #include <cstdint>
+#include <cstdlib>
 #include <cstring>
+#include <thread>
 #include <vector>
 
 #if defined(__x86_64__)
@@ -92,33 +98,95 @@ inline uint32_t mask_for(uint32_t i) {
 
 }  // namespace
 
+// Raw output blocks come from a helper thread (MT19937 state update + tempering, about a
+// quarter of the stream's cost), up to kSlots - 1 blocks ahead of the consumer; single producer,
+// single consumer.  A producer that finds the ring full sleeps (it is 3-4x faster than the
+// consumer, and a spinning helper per rank would eat into a container's CPU quota).
 struct DrawStream {
+    static constexpr size_t kBlock = 1 << 15;        // words per block
+    static constexpr size_t kCarry = 128;             // unread words carried in front of a fresh block
+    static constexpr int kSlots = 8;
     MT19937 rng;
-    std::vector<uint32_t> raw;
+    std::vector<uint32_t> slot[kSlots];              // [kCarry + kBlock]
+    std::atomic<int> ready[kSlots];                  // 1 = filled by the producer, 0 = free
+    std::atomic<bool> stop{false};
+    std::thread producer;
+    bool started = false;
+    int cur = 0;                                     // slot the consumer reads
+    const uint32_t *raw_ptr = nullptr;               // words of the current slot (carry included)
     size_t rp = 0, avail = 0;
     bool use_avx512 = false;
+    bool reg_compress = false;
 
-    explicit DrawStream(uint32_t seed) : rng(seed), raw(1 << 15) {
+    explicit DrawStream(uint32_t seed) : rng(seed) {
+        for (int b = 0; b < kSlots; ++b) {
+            slot[b].resize(kCarry + kBlock);
+            ready[b].store(0, std::memory_order_relaxed);
+        }
 #if defined(__x86_64__)
         use_avx512 = __builtin_cpu_supports("avx512f");
+        // memory-form vpcompressd measured as fast as register compress + store on Zen 5 (EPYC 9575F) and
+        // faster on the Xeon of the build container; "reg" remains selectable for other cores
+        if (const char *e = getenv("SAFE_HIP_DRAW_COMPRESS")) reg_compress = e[0] == 'r';   // "reg" / "mem"
 #endif
     }
 
-    inline void ensure(size_t want) {
-        // keep at least `want` unread outputs contiguous (leftovers are moved to the front)
-        if (avail - rp >= want) return;
-        const size_t left = avail - rp;
-        memmove(raw.data(), raw.data() + rp, left * sizeof(uint32_t));
-        rng.bulk(raw.data() + left, raw.size() - left);
-        rp = 0;
-        avail = raw.size();
+    ~DrawStream() {
+        if (started) {
+            stop.store(true, std::memory_order_release);
+            producer.join();
+        }
     }
 
-    // scalar: until i leaves (stop, i0]; returns the new i
-    inline int64_t scalar_run(int64_t i, int64_t stop, uint32_t mask, int64_t k, uint32_t *steps) {
-        while (i > stop) {
+    void produce(int b) {                            // owns `rng` once started
+        for (;;) {
+            while (ready[b].load(std::memory_order_acquire) != 0) {
+                if (stop.load(std::memory_order_acquire)) return;
+                std::this_thread::sleep_for(std::chrono::microseconds(20));
+            }
+            if (stop.load(std::memory_order_acquire)) return;
+            rng.bulk(slot[b].data() + kCarry, kBlock);
+            ready[b].store(1, std::memory_order_release);
+            b = (b + 1) % kSlots;
+        }
+    }
+
+    // keep at least `want` (<= kCarry) unread outputs contiguous
+    inline void ensure(size_t want) {
+        if (avail - rp >= want) return;
+        next_block();
+    }
+
+    void next_block() {
+        if (!started) {                              // first use: block 0 inline, then the helper runs ahead
+            rng.bulk(slot[0].data() + kCarry, kBlock);
+            ready[0].store(1, std::memory_order_relaxed);
+            started = true;
+            cur = 0;
+            raw_ptr = slot[0].data();
+            rp = kCarry;
+            avail = kCarry + kBlock;
+            producer = std::thread([this] { produce(1); });
+            return;
+        }
+        const int nxt = (cur + 1) % kSlots;
+        while (ready[nxt].load(std::memory_order_acquire) == 0) std::this_thread::yield();
+        // carry the unread tail of the current slot in front of the next block (the producer
+        // only ever writes behind kCarry)
+        const size_t left = avail - rp;              // < want <= kCarry
+        memcpy(slot[nxt].data() + (kCarry - left), raw_ptr + rp, left * sizeof(uint32_t));
+        ready[cur].store(0, std::memory_order_release);      // the producer may refill the old slot
+        cur = nxt;
+        raw_ptr = slot[nxt].data();
+        rp = kCarry - left;
+        avail = kCarry + kBlock;
+    }
+
+    // scalar: until i leaves (floor_i, i0]; returns the new i
+    inline int64_t scalar_run(int64_t i, int64_t floor_i, uint32_t mask, int64_t k, uint32_t *steps) {
+        while (i > floor_i) {
             ensure(1);
-            const uint32_t v = raw[rp++] & mask;
+            const uint32_t v = raw_ptr[rp++] & mask;
             steps[k - 1 - i] = v;                 // a rejected draw is overwritten by the next one
             i -= (v <= static_cast<uint32_t>(i));
         }
@@ -126,26 +194,47 @@ struct DrawStream {
     }
 
 #if defined(__x86_64__)
-    __attribute__((target("avx512f")))
+    // NV vectors of 16 draws per batch.  The acceptance threshold moves by at most W = 16 * NV inside
+    // a batch, so v <= i - W is accepted and v > i rejected whatever came before; the lanes in
+    // between (about W / mask of them) are settled in lane order against the exact number of accepted
+    // lanes before them.  Wider batches amortise the loop-carried chain i -> compare -> mask ->
+    // popcount -> i, which is what bounds this loop.
+    template <int NV>
+    __attribute__((target("avx512f,popcnt,bmi,bmi2")))
     int64_t vector_run(int64_t i, int64_t lo, uint32_t mask, int64_t k, uint32_t *steps) {
+        constexpr int W = 16 * NV;
         const __m512i vmask = _mm512_set1_epi32(static_cast<int>(mask));
-        while (i - 16 > lo) {
-            ensure(16);
-            const __m512i v = _mm512_and_si512(_mm512_loadu_si512(raw.data() + rp), vmask);
-            const __mmask16 sure = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32(static_cast<int>(i - 16)));
-            const __mmask16 maybe = _mm512_cmple_epu32_mask(v, _mm512_set1_epi32(static_cast<int>(i)));
-            if (sure != maybe) {                  // an ambiguous draw: resolve this batch one by one
-                const size_t end = rp + 16;
-                while (rp < end) {
-                    const uint32_t x = raw[rp++] & mask;
-                    steps[k - 1 - i] = x;
-                    i -= (x <= static_cast<uint32_t>(i));
-                }
-                continue;
+        alignas(64) uint32_t lanes[W];
+        while (i - W > lo) {
+            ensure(W);
+            const __m512i sure_thr = _mm512_set1_epi32(static_cast<int>(i - W));
+            const __m512i maybe_thr = _mm512_set1_epi32(static_cast<int>(i));
+            __m512i v[NV];
+            uint64_t acc = 0, maybe = 0;
+            for (int j = 0; j < NV; ++j) {
+                v[j] = _mm512_and_si512(_mm512_loadu_si512(raw_ptr + rp + 16 * j), vmask);
+                acc |= static_cast<uint64_t>(_mm512_cmple_epu32_mask(v[j], sure_thr)) << (16 * j);
+                maybe |= static_cast<uint64_t>(_mm512_cmple_epu32_mask(v[j], maybe_thr)) << (16 * j);
             }
-            _mm512_mask_compressstoreu_epi32(steps + (k - 1 - i), sure, v);
-            i -= __builtin_popcount(static_cast<unsigned>(sure));
-            rp += 16;
+            uint64_t amb = maybe & ~acc;
+            if (amb) {
+                for (int j = 0; j < NV; ++j) _mm512_store_si512(lanes + 16 * j, v[j]);
+                do {
+                    const unsigned t = static_cast<unsigned>(__builtin_ctzll(amb));
+                    amb &= amb - 1;
+                    const unsigned before = static_cast<unsigned>(__builtin_popcountll(acc & ((1ull << t) - 1ull)));
+                    if (lanes[t] <= static_cast<uint32_t>(i) - before) acc |= 1ull << t;
+                } while (amb);
+            }
+            uint32_t *dst = steps + (k - 1 - i);
+            for (int j = 0; j < NV; ++j) {
+                const __mmask16 a = static_cast<__mmask16>(acc >> (16 * j));
+                if (reg_compress) _mm512_storeu_si512(dst, _mm512_maskz_compress_epi32(a, v[j]));   // tail lanes are overwritten later
+                else _mm512_mask_compressstoreu_epi32(dst, a, v[j]);
+                dst += __builtin_popcount(static_cast<unsigned>(a));
+            }
+            i -= __builtin_popcountll(acc);
+            rp += W;
         }
         return i;
     }
@@ -157,7 +246,11 @@ struct DrawStream {
             const uint32_t mask = mask_for(static_cast<uint32_t>(i));
             const int64_t lo = mask >> 1;         // the mask is unchanged while i is in (lo, mask]
 #if defined(__x86_64__)
-            if (use_avx512) i = vector_run(i, lo, mask, k, steps);
+            if (use_avx512) {
+                if (mask >= 2047) i = vector_run<4>(i, lo, mask, k, steps);
+                if (mask >= 511) i = vector_run<2>(i, lo, mask, k, steps);
+                i = vector_run<1>(i, lo, mask, k, steps);
+            }
 #endif
             i = scalar_run(i, lo, mask, k, steps);
         }

@@ -823,7 +823,7 @@ __device__ __forceinline__ void bits_accumulate_ids(const uint16_t *__restrict__
 }
 
 template <int CL>
-__global__ __launch_bounds__(256) void k_permtest_bits_pre(
+__global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
     const uint16_t *__restrict__ sell_col2, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
@@ -1555,6 +1555,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
     const bool wide = P >= 1024;
+    const bool narrow = span <= 255;                  // a task counts at most `span` permutations: 8 counter levels do
     const bool scaled = (n + 1) * 8 < 65536;
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
     const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
@@ -1566,8 +1567,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                  reinterpret_cast<void **>(&d_ids[b])));
     const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
     if (pre)
-        SAFE_HIP_CHECK(hipFuncSetAttribute(wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
-                                                : reinterpret_cast<const void *>(k_permtest_bits_pre<10>),
+        SAFE_HIP_CHECK(hipFuncSetAttribute(narrow ? reinterpret_cast<const void *>(k_permtest_bits_pre<8>)
+                                           : wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
+                                                  : reinterpret_cast<const void *>(k_permtest_bits_pre<10>),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
     const void *kfn = wide ? (scaled ? reinterpret_cast<const void *>(k_permtest_bits<16, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<16, false>))
@@ -1598,7 +1600,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(ctx->num_cu) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
-            if (wide)
+            if (narrow)
+                hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
+                                   nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
+                                   n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
+            else if (wide)
                 hipLaunchKernelGGL(k_permtest_bits_pre<16>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);

@@ -167,6 +167,11 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     const int64_t q0 = ci * kChunk, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
     SwapPool::get().wait();
+    {
+        std::lock_guard<std::mutex> lk(p->draw_mu);          // the chunk's target buffer may be drawn into again
+        p->consumed_chunks = std::max<int64_t>(p->consumed_chunks, ci + 1);
+    }
+    p->draw_cv.notify_all();
     safe_trace("  gen: workers joined");
     int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
     SAFE_HIP_CHECK(hipMemcpyAsync(xa, p->h_maps[b], cnt * stride * sizeof(int32_t), hipMemcpyHostToDevice, gs));
@@ -190,43 +195,93 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     return SAFE_OK;
 }
 
-// Pipeline per chunk c:  draw thread: targets(c)  ||  workers: swaps(c-1)  ||  GPU: scan(c-2).
+static void drawer_main(safe_perms *p) {
+    const int64_t k = p->k, width = std::max<int64_t>(k, 1);
+    const int64_t n_chunks = ceil_div(p->count, kChunk);
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        {
+            std::unique_lock<std::mutex> lk(p->draw_mu);
+            p->draw_cv.wait(lk, [&] { return p->draw_stop || c < p->consumed_chunks + 2; });
+            if (p->draw_stop) return;
+        }
+        safe_trace("    drawer: buffer free, drawing");
+        const int64_t q0 = c * kChunk, cnt = std::min<int64_t>(p->count, q0 + kChunk) - q0;
+        // draw into a buffer only this thread touches, then stream the chunk to the shared one
+        uint32_t *h = p->h_local.data();
+        for (int64_t q = 0; q < cnt; ++q) {
+            draw_stream_targets(p->stream, k, h + q * width);
+            if ((q & 15) == 15) {
+                std::lock_guard<std::mutex> lk(p->draw_mu);
+                if (p->draw_stop) return;
+            }
+        }
+        safe_trace("    drawer: chunk drawn");
+        draws_nt_copy(p->h_targets[c & 1].data(), h, static_cast<size_t>(cnt) * width * sizeof(uint32_t));
+        safe_trace("    drawer: chunk copied");
+        {
+            std::lock_guard<std::mutex> lk(p->draw_mu);
+            p->drawn_chunks = c + 1;
+        }
+        p->draw_cv.notify_all();
+    }
+}
+
+static void drawer_start(safe_perms *p) {
+    p->drawn_chunks = p->consumed_chunks = 0;
+    p->draw_stop = false;
+    if (p->count > 0) p->drawer = std::thread(drawer_main, p);
+}
+
+static void drawer_stop(safe_perms *p) {
+    if (!p->drawer.joinable()) return;
+    {
+        std::lock_guard<std::mutex> lk(p->draw_mu);
+        p->draw_stop = true;
+    }
+    p->draw_cv.notify_all();
+    p->drawer.join();
+}
+
+// Pipeline per chunk c:  draw thread: targets(c+1)  ||  workers: swaps(c)  ||  GPU: scan(c-1).
 // On return every row < upto has been enqueued on ctx->aux_stream.
+// hands chunk ci (already drawn) to the swap workers
+static int submit_swaps(safe_perms *p, int64_t ci) {
+    const int64_t q0 = ci * kChunk, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
+    const int b = static_cast<int>(ci & 1);
+    // the pinned map buffer of two chunks ago must have been uploaded
+    if (ci >= 2) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
+    safe_trace("  gen: staging buffer free");
+    const uint32_t *tg = p->h_targets[b].data();
+    int32_t *mp = p->h_maps[b];
+    SwapPool::get().submit([p, tg, mp, cnt](int w, int W) { swap_worker(p, tg, mp, cnt, w, W); });
+    p->swapping = q1;
+    return SAFE_OK;
+}
+
+// On return every row < upto has been enqueued on ctx->aux_stream.  The calling thread only
+// moves chunks along (drawn -> swap workers -> GPU); the draws themselves run on p->drawer.
 int perms_generate_until(safe_perms *p, int64_t upto) {
     upto = std::min<int64_t>(upto, p->count);
-    const int64_t k = p->k;
+    const int64_t n_chunks = ceil_div(p->count, kChunk);
     while (p->enqueued < upto) {
-        if (p->generated < p->count && p->generated < upto + kChunk && p->generated == p->swapping) {
-            // draw the next chunk (possibly one ahead of what was asked for: it overlaps the swaps)
-            const int64_t q0 = p->generated, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
-            const int b = static_cast<int>((q0 / kChunk) & 1);
-            // draw into a buffer only this thread touches, then stream the chunk to the shared one
-            uint32_t *h = p->h_local.data();
-            for (int64_t q = 0; q < cnt; ++q) draw_stream_targets(p->stream, k, h + q * std::max<int64_t>(k, 1));
-            draws_nt_copy(p->h_targets[b].data(), h, static_cast<size_t>(cnt) * std::max<int64_t>(k, 1) * sizeof(uint32_t));
-            p->generated = q1;
-            safe_trace("  gen: chunk drawn");
-        }
-        if (p->swapping > p->enqueued) {
-            // swaps of the previous chunk ran while we were drawing: hand it to the GPU
-            SAFE_TRY(enqueue_chunk(p, p->enqueued / kChunk));
-        }
-        if (p->swapping < p->generated) {
-            const int64_t q0 = p->swapping, q1 = p->generated, cnt = q1 - q0;
-            const int b = static_cast<int>((q0 / kChunk) & 1);
-            // the pinned map buffer of two chunks ago must have been uploaded
-            if (q0 >= 2 * kChunk) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
-            safe_trace("  gen: staging buffer free");
+        const int64_t ci = p->enqueued / kChunk;
+        if (p->swapping <= ci * kChunk) {                    // its swaps have not been started yet
             {
-                const uint32_t *tg = p->h_targets[b].data();
-                int32_t *mp = p->h_maps[b];
-                SwapPool::get().submit([p, tg, mp, cnt](int w, int W) { swap_worker(p, tg, mp, cnt, w, W); });
+                std::unique_lock<std::mutex> lk(p->draw_mu);
+                p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
+                p->generated = std::min<int64_t>(p->count, p->drawn_chunks * kChunk);
             }
-            p->swapping = q1;
-            if (p->generated >= std::min<int64_t>(p->count, upto + kChunk) || p->generated >= p->count) {
-                // nothing left to draw that could overlap: finish this chunk now
-                if (p->enqueued < upto) SAFE_TRY(enqueue_chunk(p, p->enqueued / kChunk));
+            safe_trace("  gen: chunk drawn");
+            SAFE_TRY(submit_swaps(p, ci));
+        }
+        SAFE_TRY(enqueue_chunk(p, ci));                      // joins the workers, frees the target buffer, queues the GPU part
+        if (ci + 1 < n_chunks) {                             // start the next chunk's swaps if its draws are already there
+            bool drawn;
+            {
+                std::lock_guard<std::mutex> lk(p->draw_mu);
+                drawn = p->drawn_chunks > ci + 1;
             }
+            if (drawn) SAFE_TRY(submit_swaps(p, ci + 1));
         }
     }
     return SAFE_OK;
@@ -261,6 +316,7 @@ int perms_build_inverse(safe_perms *perms) {
 
 static void perms_free(safe_perms *p) {
     if (!p) return;
+    drawer_stop(p);
     SwapPool::get().wait();
     for (int b = 0; b < 2; ++b) {
         if (p->h_maps[b]) (void)hipHostFree(p->h_maps[b]);
@@ -335,6 +391,7 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
         p->h_local.resize(kChunk * std::max<int64_t>(p->k, 1) + 16);
         hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
         SAFE_HIP_CHECK(hipGetLastError());
+        drawer_start(p);
         safe_trace("perms_create: done (buffers reused)");
         *out = p;
         return SAFE_OK;
@@ -370,6 +427,7 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
         perms_free(p);
         return rc;
     }
+    drawer_start(p);
     safe_trace("perms_create: done");
     *out = p;
     return SAFE_OK;
@@ -379,6 +437,7 @@ int safe_perms_destroy(safe_perms *perms) {
     if (!perms) return SAFE_OK;
     (void)hipSetDevice(perms->ctx->device);
     safe_ctx *ctx = perms->ctx;
+    drawer_stop(perms);
     SwapPool::get().wait();
     (void)hipStreamSynchronize(ctx->aux_stream);
     (void)hipStreamSynchronize(ctx->side_stream);
