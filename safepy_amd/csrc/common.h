@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 
+#include <algorithm>
 #include <cstdarg>
 #include <cstdint>
 #include <cstdio>
@@ -222,6 +223,29 @@ int nbr_build_transpose(safe_nbr *nbr);      // at_ptr / at_col (nbr.hip)
 int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary matrix (attr.hip)
 int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)
 int perms_generate_until(safe_perms *perms, int64_t upto);   // enqueue table rows [generated, upto) on aux_stream (rng.cpp)
+// host/GPU pipeline stages of the permutation stream: stage ci covers permutations
+// [perms_chunk_begin(ci), perms_chunk_begin(ci + 1)) -- a short first stage, then 128 each
+int64_t perms_chunk_begin(int64_t ci);
+int64_t perms_chunk_count(int64_t count);
+// launch boundaries of the permutation kernels: starts[c] .. starts[c+1]; the default follows the
+// stream's pipeline stages (so the first launch can start after 32 permutations have been drawn),
+// SAFE_HIP_BITS_SPAN=<n> forces uniform spans.  *span = the longest launch.
+static inline std::vector<int64_t> perm_launch_starts(int64_t P, int64_t *span) {
+    std::vector<int64_t> starts;
+    int64_t uniform = 0;
+    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) uniform = std::max<int64_t>(16, atoll(e));
+    if (uniform > 0) {
+        for (int64_t p = 0; p < P; p += uniform) starts.push_back(p);
+    } else {
+        const int64_t nc = perms_chunk_count(P);
+        for (int64_t c = 0; c < nc; ++c) starts.push_back(perms_chunk_begin(c));
+    }
+    if (starts.empty()) starts.push_back(0);
+    starts.push_back(std::max<int64_t>(P, 0));
+    *span = 1;
+    for (size_t c = 0; c + 1 < starts.size(); ++c) *span = std::max<int64_t>(*span, starts[c + 1] - starts[c]);
+    return starts;
+}
 int perms_wait(safe_perms *perms, int64_t upto, hipStream_t s);   // make stream s wait until rows [0, upto) exist (rng.cpp)
 // counters [column][position] (#less << 16 | #greater) -> outputs; rowmap[position] = row or -1 (enrich.hip)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,

@@ -661,6 +661,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         // this task's permutations (task ranges are relative to the launch's chunk)
         const int64_t p_begin = p_base + task.z;
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+        if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
         if (p_end > p_begin)
@@ -781,12 +782,23 @@ __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict
                                                       const uint16_t *__restrict__ sell_col2, int64_t entries,
                                                       int64_t entries_pad, int64_t p0, int64_t count, uint32_t pad_off,
                                                       uint16_t *__restrict__ out) {
-    const int64_t e = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    // one permutation row (<= 16 KB) staged in LDS per block, 4096 member entries per block: the
+    // random 2-byte reads hit LDS instead of L2 sectors
+    extern __shared__ uint16_t row[];
     const int64_t q = blockIdx.y;
-    if (e >= entries_pad || q >= count) return;
-    uint32_t v = pad_off;
-    if (e < entries) v = static_cast<uint32_t>(cur16[(p0 + q) * stride16 + (sell_col2[e] >> 1)]) << 3;
-    out[q * entries_pad + e] = static_cast<uint16_t>(v);
+    if (q >= count) return;
+    const uint4 *src = reinterpret_cast<const uint4 *>(cur16 + (p0 + q) * stride16);
+    for (int64_t v = threadIdx.x; v < stride16 / 8; v += 256) reinterpret_cast<uint4 *>(row)[v] = src[v];
+    __syncthreads();
+    const int64_t e0 = static_cast<int64_t>(blockIdx.x) * 4096;
+#pragma unroll 4
+    for (int j = 0; j < 16; ++j) {
+        const int64_t e = e0 + j * 256 + threadIdx.x;
+        if (e >= entries_pad) break;
+        uint32_t v = pad_off;
+        if (e < entries) v = static_cast<uint32_t>(row[sell_col2[e] >> 1]) << 3;
+        out[q * entries_pad + e] = static_cast<uint16_t>(v);
+    }
 }
 
 // ids: u16 LDS byte offsets (relative to T) of the members, SELL layout; SHIFT = 2 turns the
@@ -846,6 +858,7 @@ __global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
         const int wg = task.x, sg = task.y;
         const int64_t p_begin = p_base + task.z;
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+        if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
         const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
@@ -1137,6 +1150,7 @@ __global__ __launch_bounds__(64 * NW) void k_permtest_lds(
         const int tile = task.x, sg = task.y;
         const int64_t p_begin = p_base + task.z;
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+        if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
         const double *src = tiles + static_cast<int64_t>(tile) * (n + 1) * 4;
         for (int64_t i = threadIdx.x; i < (n + 1) * 4; i += NT) T[i] = src[i];
@@ -1505,9 +1519,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // stream for the next span overlaps this span's kernel.  Inside a launch, tasks = (word
     // group, group of 4 adjacent slices, permutation sub-range), sized to about equal cost
     // with several per workgroup slot, heaviest first for the dynamic queue.
-    int64_t span = 128;
-    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
-    span = std::min<int64_t>(span, std::max<int64_t>(P, 1));
+    int64_t span = 1;
+    const std::vector<int64_t> starts = perm_launch_starts(P, &span);
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
@@ -1535,7 +1548,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
     std::vector<int4> tasks(tc.size());
     for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
-    const int64_t n_launch = ceil_div(std::max<int64_t>(P, 1), span);
+    const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     safe_trace("launch_bits: tasks built");
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
@@ -1589,12 +1602,13 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
-        const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span);
+        const int64_t p_base = starts[c], p_limit = starts[c + 1];
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
         safe_trace("launch_bits: span tables enqueued");
         if (pre) {
-            hipLaunchKernelGGL(k_permute_cols, dim3(entries_pad / 256, p_limit - p_base), dim3(256), 0, ks, perms->table16,
+            hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
+                               static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
                                perms->stride16, nbr->sell_col2, nbr->sell_entries, entries_pad, p_base, p_limit - p_base,
                                static_cast<uint32_t>(8 * n), d_ids[c & 1]);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
@@ -1714,9 +1728,8 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
         else { if (f32) PREP(float, false); else PREP(double, false); }
 #undef PREP
     }
-    int64_t span = 128;
-    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
-    span = std::min<int64_t>(span, P);
+    int64_t span = 1;
+    const std::vector<int64_t> starts = perm_launch_starts(P, &span);
     const size_t lds_bytes = ldsf64_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
@@ -1747,7 +1760,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
     std::vector<int4> tasks(tc.size());
     for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
-    const int64_t n_launch = ceil_div(P, span), n_pad = nbr->n_slices * 64;
+    const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1, n_pad = nbr->n_slices * 64;
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr, *d_counts = nullptr;
     SAFE_TRY(dev_alloc(&d_tasks, tasks.size()));
@@ -1785,7 +1798,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
-        const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span);
+        const int64_t p_base = starts[c], p_limit = starts[c + 1];
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         SAFE_TRY(perms_wait(perms, p_limit, ks));
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));

@@ -666,10 +666,9 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             for (int32_t g : g_order) tasks.push_back(make_int2(g, static_cast<int>(ct)));
         q_off[qx + 1] = static_cast<int32_t>(tasks.size());
     }
-    int64_t span = 128;
-    if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) span = std::max<int64_t>(16, atoll(e));
-    span = std::min<int64_t>(span, P);
-    const int64_t n_launch = ceil_div(P, span);
+    int64_t span = 1;
+    const std::vector<int64_t> starts = perm_launch_starts(P, &span);
+    const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     void *ws = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + (8 * n_launch + 8) * sizeof(unsigned int), &ws));
     int2 *d_tasks = static_cast<int2 *>(ws);
@@ -700,7 +699,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
-        const int64_t p_base = c * span, p_limit = std::min<int64_t>(P, p_base + span), cnt = p_limit - p_base;
+        const int64_t p_base = starts[c], p_limit = starts[c + 1], cnt = p_limit - p_base;
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         SAFE_TRY(perms_wait(perms, p_limit, ks));
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,

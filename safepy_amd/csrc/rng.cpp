@@ -79,6 +79,13 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 // chunked generation
 // --------------------------------------------------------------------------------------
 static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
+static const int64_t kFirst = 32;       // the first stage is short so that the first kernel starts early
+
+// stage boundaries: [0, kFirst), [kFirst, kChunk), [kChunk, 2 kChunk), ...
+int64_t perms_chunk_begin(int64_t ci) { return ci == 0 ? 0 : ci == 1 ? kFirst : (ci - 1) * kChunk; }
+int64_t perms_chunk_count(int64_t count) { return count <= kFirst ? (count > 0 ? 1 : 0) : 1 + ceil_div(count, kChunk); }
+static int64_t chunk_of(int64_t perm) { return perm < kFirst ? 0 : 1 + perm / kChunk; }
+static int64_t chunk_end(int64_t ci, int64_t count) { return std::min<int64_t>(count, perms_chunk_begin(ci + 1)); }
 
 // A small process-wide pool of swap workers (creating threads per chunk costs more than the
 // chunk's draws).  One job at a time: parallel-for over the permutations of a chunk.
@@ -164,7 +171,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     safe_ctx *ctx = p->ctx;
     hipStream_t gs = ctx->aux_stream;
     const int64_t n = p->n, stride = n + 1;
-    const int64_t q0 = ci * kChunk, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
+    const int64_t q0 = perms_chunk_begin(ci), q1 = chunk_end(ci, p->count), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
     SwapPool::get().wait();
     {
@@ -197,7 +204,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
 
 static void drawer_main(safe_perms *p) {
     const int64_t k = p->k, width = std::max<int64_t>(k, 1);
-    const int64_t n_chunks = ceil_div(p->count, kChunk);
+    const int64_t n_chunks = perms_chunk_count(p->count);
     for (int64_t c = 0; c < n_chunks; ++c) {
         {
             std::unique_lock<std::mutex> lk(p->draw_mu);
@@ -205,7 +212,7 @@ static void drawer_main(safe_perms *p) {
             if (p->draw_stop) return;
         }
         safe_trace("    drawer: buffer free, drawing");
-        const int64_t q0 = c * kChunk, cnt = std::min<int64_t>(p->count, q0 + kChunk) - q0;
+        const int64_t q0 = perms_chunk_begin(c), cnt = chunk_end(c, p->count) - q0;
         // draw into a buffer only this thread touches, then stream the chunk to the shared one
         uint32_t *h = p->h_local.data();
         for (int64_t q = 0; q < cnt; ++q) {
@@ -246,7 +253,7 @@ static void drawer_stop(safe_perms *p) {
 // On return every row < upto has been enqueued on ctx->aux_stream.
 // hands chunk ci (already drawn) to the swap workers
 static int submit_swaps(safe_perms *p, int64_t ci) {
-    const int64_t q0 = ci * kChunk, q1 = std::min<int64_t>(p->count, q0 + kChunk), cnt = q1 - q0;
+    const int64_t q0 = perms_chunk_begin(ci), q1 = chunk_end(ci, p->count), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
     // the pinned map buffer of two chunks ago must have been uploaded
     if (ci >= 2) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
@@ -262,14 +269,14 @@ static int submit_swaps(safe_perms *p, int64_t ci) {
 // moves chunks along (drawn -> swap workers -> GPU); the draws themselves run on p->drawer.
 int perms_generate_until(safe_perms *p, int64_t upto) {
     upto = std::min<int64_t>(upto, p->count);
-    const int64_t n_chunks = ceil_div(p->count, kChunk);
+    const int64_t n_chunks = perms_chunk_count(p->count);
     while (p->enqueued < upto) {
-        const int64_t ci = p->enqueued / kChunk;
-        if (p->swapping <= ci * kChunk) {                    // its swaps have not been started yet
+        const int64_t ci = chunk_of(p->enqueued);
+        if (p->swapping <= perms_chunk_begin(ci)) {          // its swaps have not been started yet
             {
                 std::unique_lock<std::mutex> lk(p->draw_mu);
                 p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
-                p->generated = std::min<int64_t>(p->count, p->drawn_chunks * kChunk);
+                p->generated = chunk_end(p->drawn_chunks - 1, p->count);
             }
             safe_trace("  gen: chunk drawn");
             SAFE_TRY(submit_swaps(p, ci));
@@ -292,7 +299,7 @@ int perms_wait(safe_perms *p, int64_t upto, hipStream_t s) {
     SAFE_TRY(perms_generate_until(p, upto));
     upto = std::min<int64_t>(upto, p->count);
     if (upto <= 0) return SAFE_OK;
-    const int64_t ci = (upto - 1) / kChunk;
+    const int64_t ci = chunk_of(upto - 1);
     SAFE_HIP_CHECK(hipStreamWaitEvent(s, p->chunk_done[ci], 0));
     return SAFE_OK;
 }
