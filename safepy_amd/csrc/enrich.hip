@@ -1023,16 +1023,81 @@ __global__ __launch_bounds__(256) void k_bits_prep(const void *__restrict__ raw,
     bbits[idx] = make_uint2(w[0], w[1]);
 }
 
+// the same for row-major (C order) matrices: a wave reads 64 consecutive columns of one row
+// (coalesced) and the ballot of (x == 1) IS the word
+template <typename T>
+__global__ __launch_bounds__(256) void k_bits_prep_rowmajor(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                            int64_t col0, int64_t mloc, int64_t n_wg, uint2 *__restrict__ bbits) {
+    const int64_t wg = blockIdx.x, r = static_cast<int64_t>(blockIdx.y) * 4 + (threadIdx.x >> 6);
+    if (r > n) return;
+    const int lane = threadIdx.x & 63;
+    const int64_t j = wg * 64 + lane;
+    bool one = false;
+    if (r < n && j < mloc) one = reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs] == static_cast<T>(1);
+    const unsigned long long w = __builtin_amdgcn_ballot_w64(one);
+    if (lane == 0) bbits[wg * (n + 1) + r] = make_uint2(static_cast<uint32_t>(w), static_cast<uint32_t>(w >> 32));
+}
+
+static void launch_bits_prep(safe_ctx *ctx, const safe_attr *attr, int64_t col0, int64_t mloc, int64_t n_wg, uint2 *d_bits) {
+    const int64_t n = attr->n;
+    const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+    if (attr->col_stride == 1 && attr->row_stride != 1) {              // C order
+        const dim3 grid(n_wg, ceil_div(n + 1, 4)), block(256);
+        if (f32) hipLaunchKernelGGL(k_bits_prep_rowmajor<float>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                                    attr->col_stride, col0, mloc, n_wg, d_bits);
+        else hipLaunchKernelGGL(k_bits_prep_rowmajor<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                                attr->col_stride, col0, mloc, n_wg, d_bits);
+    } else {                                                            // Fortran order (consecutive rows adjacent) or general strides
+        const dim3 grid(ceil_div(n_wg * (n + 1), 256)), block(256);
+        if (f32) hipLaunchKernelGGL(k_bits_prep<float>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                                    attr->col_stride, col0, mloc, n_wg, d_bits);
+        else hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
+                                attr->col_stride, col0, mloc, n_wg, d_bits);
+    }
+}
+
 // Observed neighborhood counts of binary attributes, bit-sliced (safe.py:593-594 for the
 // hypergeometric path; safe_extras.py:15 for 'sum' scores): one wave per (SELL slice, 64-attribute
 // word group), member words gathered from the L2-resident bit matrix, vertical carry-save sums,
 // bit-matrix transpose, 512 contiguous output bytes per lane.
+// helpers of the hypergeometric kernels (K4, further down)
+__device__ __forceinline__ double hyp_logpmf(const double *__restrict__ lf, int64_t t, int64_t pop, int64_t good,
+                                             int64_t draws) {
+    return (lf[good] - lf[t] - lf[good - t]) + (lf[pop - good] - lf[draws - t] - lf[pop - good - draws + t]) -
+           (lf[pop] - lf[draws] - lf[pop - draws]);
+}
+
+// 1 / x for the term ratios of the tail recurrence: hardware reciprocal estimate + two Newton
+// steps (a couple of ulp, far inside the 1e-6 relative parity bound) instead of the ~30-instruction
+// IEEE division; no table loads inside the serial loop (they left the waves waiting 80 % of the time)
+__device__ __forceinline__ double fast_rcp(double x) {
+    double r = __builtin_amdgcn_rcp(x);
+    r = fma(fma(-x, r, 1.0), r, r);
+    r = fma(fma(-x, r, 1.0), r, r);
+    return r;
+}
+
+
+// TABLE = true: the hypergeometric epilogue is fused in -- instead of the count X the kernel writes
+// p = tab[(nid[row] * n_kid + kid[col]) * xs + X] (k_hyp_table), -log10 p, the binarised value and the
+// per-attribute enriched counts (safe.py:596-608, 468-472); the counts never reach memory.
+struct HypLookup {
+    const int32_t *nid;        // [n] index of the row's neighborhood size among the distinct sizes
+    const int32_t *kid;        // [mloc] index of the column's annotation count among the distinct counts
+    const double *tab;         // [n_nid][n_kid][xs]
+    int64_t n_kid, xs;
+    double nes_threshold;
+    double *pvalues_pos, *nes, *nes_binary;
+    unsigned int *enriched;
+};
+
+template <bool TABLE>
 __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ sell_row,
                                                     const int64_t *__restrict__ slice_off,
                                                     const int32_t *__restrict__ slice_width,
                                                     const int32_t *__restrict__ sell_col, int64_t n,
                                                     const uint2 *__restrict__ bbits, int64_t mloc,
-                                                    double *__restrict__ out) {
+                                                    double *__restrict__ out, HypLookup hl) {
     const int64_t s = blockIdx.x, wg = blockIdx.y;
     const int lane = threadIdx.x;
     const int32_t row = sell_row[s * 64 + lane];
@@ -1057,8 +1122,9 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
             vripple(s1, e1);
         }
     }
-    if (row < 0) return;
-    double *o = out + static_cast<int64_t>(row) * mloc + wg * 64;
+    // ---- epilogue: un-slice the counts (bit-matrix transpose), turn the 64 x 64 tile around through
+    //      LDS so that a lane owns a COLUMN, and write row by row: 512 contiguous bytes per store
+    __shared__ unsigned short tile[64][66];                             // [row in slice][column], padded rows
 #pragma unroll
     for (int half = 0; half < 2; ++half) {
         uint32_t m[32];
@@ -1066,8 +1132,83 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
         for (int l = 0; l < 32; ++l) m[l] = l < BT_LV ? (half ? s1[l < BT_LV ? l : 0] : s0[l < BT_LV ? l : 0]) : 0u;
         transpose32(m);
 #pragma unroll
-        for (int bit = 0; bit < 32; ++bit)
-            if (wg * 64 + half * 32 + bit < mloc) o[half * 32 + bit] = static_cast<double>(m[bit]);
+        for (int bit = 0; bit < 32; bit += 2)
+            *reinterpret_cast<uint32_t *>(&tile[lane][half * 32 + bit]) = m[bit] | (m[bit + 1] << 16);
+    }
+    __syncthreads();
+    const int64_t jc = wg * 64 + lane;                                  // this lane's column
+    const bool col_ok = jc < mloc;
+    if constexpr (!TABLE) {
+        for (int r = 0; r < 64; ++r) {
+            const int32_t rr = sell_row[s * 64 + r];                    // wave-uniform
+            if (rr < 0 || !col_ok) continue;
+            out[static_cast<int64_t>(rr) * mloc + jc] = static_cast<double>(tile[r][lane]);
+        }
+    } else {
+        const int64_t kofs = col_ok ? static_cast<int64_t>(hl.kid[jc]) * hl.xs : 0;
+        unsigned int hits = 0;
+        for (int r = 0; r < 64; ++r) {
+            const int32_t rr = sell_row[s * 64 + r];                    // wave-uniform
+            if (rr < 0 || !col_ok) continue;
+            const double *slab = hl.tab + static_cast<int64_t>(hl.nid[rr]) * hl.n_kid * hl.xs;
+            const double p = slab[kofs + tile[r][lane]];
+            const double nes = -log10(p);                               // safe.py:608
+            const bool hit = (nes == nes) && (fabs(nes) > hl.nes_threshold);   // safe.py:468-470
+            const int64_t o = static_cast<int64_t>(rr) * mloc + jc;
+            hl.pvalues_pos[o] = p;
+            hl.nes[o] = nes;
+            hl.nes_binary[o] = hit ? 1.0 : 0.0;
+            hits += hit;
+        }
+        if (hits) atomicAdd(&hl.enriched[jc], hits);
+    }
+}
+
+// tab[nid][kid][x] = P[H >= x] for H ~ Hypergeom(pop, K = kvals[kid], n = nvals[nid]), x = 0 .. xs-1, with
+// the support rules of scipy's rv_discrete.sf (below the support 1, above it 0).  One thread per (n, K)
+// pair: pmf outwards from the mode by the term recurrence (no underflow at the start), then the tail
+// sums from the top down (smallest terms first).
+__global__ __launch_bounds__(64) void k_hyp_table(const int32_t *__restrict__ nvals, int64_t n_nid,
+                                                  const int32_t *__restrict__ kvals, int64_t n_kid, int64_t xs, int64_t pop,
+                                                  const double *__restrict__ lf, double *__restrict__ tab) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
+    if (idx >= n_nid * n_kid) return;
+    const int64_t draws = nvals[idx / n_kid], good = kvals[idx % n_kid];
+    double *t_out = tab + idx * xs;
+    const int64_t lo = draws - (pop - good) > 0 ? draws - (pop - good) : 0;
+    const int64_t hi = good < draws ? good : draws;
+    const double good_d = static_cast<double>(good), draws_d = static_cast<double>(draws);
+    const double rest_d = static_cast<double>(pop) - good_d - draws_d;
+    int64_t mode = static_cast<int64_t>(floor(static_cast<double>(good + 1) * static_cast<double>(draws + 1) / static_cast<double>(pop + 2)));
+    mode = mode < lo ? lo : (mode > hi ? hi : mode);
+    const double pm = exp(hyp_logpmf(lf, mode, pop, good, draws));
+    // pmf(t) for t < xs goes to the table first; everything at or beyond xs is summed into `beyond`
+    double beyond = 0.0, term = pm, td = static_cast<double>(mode);
+    for (int64_t t = mode; t <= hi; ++t) {                              // upwards from the mode
+        if (t < xs) t_out[t] = term;
+        else beyond += term;
+        if (term == 0.0 && t >= xs) break;
+        term = term * ((good_d - td) * (draws_d - td)) * fast_rcp((td + 1.0) * (rest_d + td + 1.0));
+        td += 1.0;
+    }
+    term = pm;
+    td = static_cast<double>(mode);
+    for (int64_t t = mode - 1; t >= lo; --t) {                          // downwards from the mode
+        term = term * (td * (rest_d + td)) * fast_rcp((good_d - td + 1.0) * (draws_d - td + 1.0));
+        td -= 1.0;
+        if (t < xs) t_out[t] = term;
+        else beyond += term;
+    }
+    double running = beyond;
+    for (int64_t t = xs - 1; t >= 0; --t) {
+        if (t > hi) {
+            t_out[t] = 0.0;                                             // sf(x - 1) with x - 1 >= top of the support
+        } else if (t <= lo) {
+            t_out[t] = 1.0;                                             // x - 1 below the support
+        } else {
+            running += t_out[t];
+            t_out[t] = running > 1.0 ? 1.0 : running;
+        }
     }
 }
 
@@ -1266,23 +1407,6 @@ __global__ void k_nbr_size(const int32_t *__restrict__ row_ptr, const int32_t *_
 // to [0,1]).  pmf from a host-built log-factorial table, tail by the term recurrence,
 // summed on the side of the mode that keeps the sum short (complemented when needed).
 // --------------------------------------------------------------------------------------
-__device__ __forceinline__ double hyp_logpmf(const double *__restrict__ lf, int64_t t, int64_t pop, int64_t good,
-                                             int64_t draws) {
-    return (lf[good] - lf[t] - lf[good - t]) + (lf[pop - good] - lf[draws - t] - lf[pop - good - draws + t]) -
-           (lf[pop] - lf[draws] - lf[pop - draws]);
-}
-
-// 1 / x for the term ratios of the tail recurrence: hardware reciprocal estimate + two Newton
-// steps (a couple of ulp, far inside the 1e-6 relative parity bound) instead of the ~30-instruction
-// IEEE division; no table loads inside the serial loop (they left the waves waiting 80 % of the time)
-__device__ __forceinline__ double fast_rcp(double x) {
-    double r = __builtin_amdgcn_rcp(x);
-    r = fma(fma(-x, r, 1.0), r, r);
-    r = fma(fma(-x, r, 1.0), r, r);
-    return r;
-}
-
-
 __device__ double hyp_sf(const double *__restrict__ lf, double x_hits, double pop_d, double good_d, double draws_d) {
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
     // _argcheck of scipy's hypergeom: integers, 0 <= good <= pop, 0 <= draws <= pop
@@ -1505,15 +1629,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     safe_trace("launch_bits: enter");
     uint2 *d_bits = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
-    {
-        const dim3 grid(ceil_div(n_wg * (n + 1), 256)), block(256);
-        if (attr->dtype == SAFE_DTYPE_F32)
-            hipLaunchKernelGGL(k_bits_prep<float>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_wg, d_bits);
-        else
-            hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_wg, d_bits);
-    }
+    launch_bits_prep(ctx, attr, col0, mloc, n_wg, d_bits);
     safe_trace("launch_bits: prep launched");
     // The permutations are consumed in launches of `span` permutations so that the host's draw
     // stream for the next span overlaps this span's kernel.  Inside a launch, tasks = (word
@@ -1683,16 +1799,10 @@ static int launch_counts_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int
     const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64);
     uint2 *d_bits = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
-    const dim3 grid(ceil_div(n_wg * (n + 1), 256)), block(256);
-    if (attr->dtype == SAFE_DTYPE_F32)
-        hipLaunchKernelGGL(k_bits_prep<float>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
-                           attr->col_stride, col0, mloc, n_wg, d_bits);
-    else
-        hipLaunchKernelGGL(k_bits_prep<double>, grid, block, 0, ctx->stream, attr->raw, n, attr->row_stride,
-                           attr->col_stride, col0, mloc, n_wg, d_bits);
+    launch_bits_prep(ctx, attr, col0, mloc, n_wg, d_bits);
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-    hipLaunchKernelGGL(k_counts_bits, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
-                       nbr->slice_width, nbr->sell_col, n, d_bits, mloc, out_dev);
+    hipLaunchKernelGGL(k_counts_bits<false>, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
+                       nbr->slice_width, nbr->sell_col, n, d_bits, mloc, out_dev, HypLookup{});
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_counts_bits";
@@ -1829,6 +1939,94 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     (void)hipEventDestroy(side_done);
     (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
+    return SAFE_OK;
+}
+
+// Hypergeometric path for binary attributes with the tail looked up instead of evaluated per
+// element: P[H >= X] only depends on (X, K_j, n_i), and a matrix has few distinct neighborhood
+// sizes n_i and annotation counts K_j (17 k distinct triples among 17 M elements at config 2,
+// SURVEY C12).  k_hyp_table evaluates every (n, K) pair once for all X; the count kernel looks
+// the value up in its epilogue and writes p / NES / nes_binary directly (the counts never reach
+// memory).  *fused = false (nothing launched) when the table would be too large or K is not an
+// integer (scipy then returns NaN: the per-element kernel reproduces that).
+static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, int64_t pop,
+                           const double *d_lf, const double *d_size, double nes_threshold, double *p_dev, double *nes_dev,
+                           double *nb_dev, unsigned int *d_enr, bool *fused) {
+    *fused = false;
+    const char *force = getenv("SAFE_HIP_HYPER_TABLE");
+    if (force && !strcmp(force, "0")) return SAFE_OK;
+    const int64_t n = nbr->n, mloc = col1 - col0;
+    std::vector<double> h_size(n), h_k(mloc);
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_size.data(), d_size, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_k.data(), attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // distinct values -> dense ids (both are integers in [0, n] here, or we decline)
+    std::vector<int32_t> id_of(n + 2, -1), nvals, kvals, nid(n), kid(mloc);
+    int64_t max_n = 0, max_k = 0;
+    for (int64_t i = 0; i < n; ++i) {
+        const double v = h_size[i];
+        if (!(v >= 0.0) || v > static_cast<double>(pop) || v != std::floor(v)) return SAFE_OK;
+        const int32_t iv = static_cast<int32_t>(v);
+        if (id_of[iv] < 0) {
+            id_of[iv] = static_cast<int32_t>(nvals.size());
+            nvals.push_back(iv);
+        }
+        nid[i] = id_of[iv];
+        max_n = std::max<int64_t>(max_n, iv);
+    }
+    std::fill(id_of.begin(), id_of.end(), -1);
+    for (int64_t j = 0; j < mloc; ++j) {
+        const double v = h_k[j];
+        if (!(v >= 0.0) || v > static_cast<double>(pop) || v != std::floor(v)) return SAFE_OK;
+        const int32_t iv = static_cast<int32_t>(v);
+        if (id_of[iv] < 0) {
+            id_of[iv] = static_cast<int32_t>(kvals.size());
+            kvals.push_back(iv);
+        }
+        kid[j] = id_of[iv];
+        max_k = std::max<int64_t>(max_k, iv);
+    }
+    const int64_t xs = std::min(max_n, max_k) + 1;                      // X <= min(K, n)
+    const int64_t n_nid = static_cast<int64_t>(nvals.size()), n_kid = static_cast<int64_t>(kvals.size());
+    const double table_bytes = static_cast<double>(n_nid) * n_kid * xs * sizeof(double);
+    const double direct_cost = static_cast<double>(n) * mloc;          // elements the per-element kernel would evaluate
+    if (table_bytes > 512e6 || static_cast<double>(n_nid) * n_kid * 4.0 > direct_cost) return SAFE_OK;
+
+    double *d_tab = nullptr;
+    int32_t *d_ids = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n_nid) * n_kid * xs * sizeof(double), reinterpret_cast<void **>(&d_tab)));
+    SAFE_TRY(ctx_scratch(ctx, 6, static_cast<size_t>(n_nid + n_kid + n + mloc) * sizeof(int32_t), reinterpret_cast<void **>(&d_ids)));
+    int32_t *d_nvals = d_ids, *d_kvals = d_nvals + n_nid, *d_nid = d_kvals + n_kid, *d_kid = d_nid + n;
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_nvals, nvals.data(), n_nid * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_kvals, kvals.data(), n_kid * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_nid, nid.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_kid, kid.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
+    hipLaunchKernelGGL(k_hyp_table, dim3(ceil_div(n_nid * n_kid, 64)), dim3(64), 0, ctx->stream, d_nvals, n_nid, d_kvals, n_kid, xs,
+                       pop, d_lf, d_tab);
+
+    const int64_t n_wg = ceil_div(mloc, 64);
+    uint2 *d_bits = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
+    launch_bits_prep(ctx, attr, col0, mloc, n_wg, d_bits);
+    HypLookup hl{};
+    hl.nid = d_nid;
+    hl.kid = d_kid;
+    hl.tab = d_tab;
+    hl.n_kid = n_kid;
+    hl.xs = xs;
+    hl.nes_threshold = nes_threshold;
+    hl.pvalues_pos = p_dev;
+    hl.nes = nes_dev;
+    hl.nes_binary = nb_dev;
+    hl.enriched = d_enr;
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(k_counts_bits<true>, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
+                       nbr->slice_width, nbr->sell_col, n, d_bits, mloc, static_cast<double *>(nullptr), hl);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = "k_counts_bits<hypergeom>";
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the id vectors above are host memory
+    *fused = true;
     return SAFE_OK;
 }
 
@@ -2025,22 +2223,29 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
             rc = SAFE_E_HIP;
         }
     }
+    bool fused = false;
     if (rc == SAFE_OK) {
+        hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col,
+                           attr->row_flags, n, d_size);
+        if (bits) rc = hypergeom_fused(ctx, nbr, attr, col0, col1, pop, d_lf, d_size, -std::log10(enrichment_threshold),
+                                       pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr, &fused);
+    }
+    if (rc == SAFE_OK && !fused) {
         PermOut out{};
         out.ns = d_hits;
         out.mode = 0;
         rc = bits ? launch_counts_bits(ctx, nbr, attr, col0, col1, d_hits)
                   : launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
+        if (rc == SAFE_OK) {
+            SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+            hipLaunchKernelGGL(k_hypergeom_tail, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_hits,
+                               d_size, attr->col_sum, col0, n, mloc, static_cast<double>(pop), d_lf,
+                               -std::log10(enrichment_threshold), pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr);
+            SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+            ctx->last_kernel.name = "k_hypergeom_tail";
+        }
     }
     if (rc == SAFE_OK) {
-        hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col,
-                           attr->row_flags, n, d_size);
-        SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-        hipLaunchKernelGGL(k_hypergeom_tail, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_hits,
-                           d_size, attr->col_sum, col0, n, mloc, static_cast<double>(pop), d_lf,
-                           -std::log10(enrichment_threshold), pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr);
-        SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
-        ctx->last_kernel.name = "k_hypergeom_tail";
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);
         if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
     }
