@@ -142,7 +142,9 @@ def hbm_kernels(ctx, torch, np, be):
     be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
     be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
     name, ms, _ = ctx.last_kernel()
-    if name.startswith('k_counts_bits'):       # fused: counts never reach memory; write p, nes, nes_binary; read bit words + member ids
+    if name.startswith('k_permtest_mfma'):     # matrix-core counts + table lookup: write p, nes, nes_binary; read the 0/1 planes and the membership blocks
+        alg = n * m * 8 * 3 + (n + 1) * m + be.block_count(nbr) * 1024
+    elif name.startswith('k_counts_bits'):     # fused: counts never reach memory; write p, nes, nes_binary; read bit words + member ids
         alg = n * m * 8 * 3 + 8 * (n + 1) * ((m + 63) // 64) + 4 * int(nbr.nnz)
     else:
         alg = n * m * 8 * 4                   # read X, write p, nes, nes_binary

@@ -141,6 +141,20 @@ struct safe_nbr {
     std::vector<int32_t> h_bs_ptr;
 };
 
+// Hypergeometric epilogue by table lookup (enrich.hip: k_hyp_table builds tab): instead of a count X
+// a kernel writes p = tab[(nid[row] * n_kid + kid[col]) * xs + X], -log10 p, the binarised value and
+// the per-attribute enriched counts (safe.py:596-608, 468-472).  tab == NULL: plain counts as f64
+// into pvalues_pos (compute_neighborhood_score 'sum' of 0/1 data).
+struct HypLookup {
+    const int32_t *nid;        // [n] index of the row's neighborhood size among the distinct sizes
+    const int32_t *kid;        // [mloc] index of the column's annotation count among the distinct counts
+    const double *tab;         // [n_nid][n_kid][xs]
+    int64_t n_kid, xs;
+    double nes_threshold;
+    double *pvalues_pos, *nes, *nes_binary;
+    unsigned int *enriched;
+};
+
 // outputs of the permutation-test kernels (enrich.hip, mfma.hip)
 struct PermOut {
     double *ns;            // [n][mloc] or NULL
@@ -254,4 +268,7 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
 bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *attr, const safe_perms *perms, bool z);
 int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
                 const PermOut &out, bool *declined);
+// X = A . B0 for 0/1 attributes on the matrix cores (block-sparse, one i8 plane per 32-column tile),
+// written through `hl` (mfma.hip); sets ctx->last_kernel and the k0/k1 timing events
+int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, const HypLookup &hl);
 void nbr_free_blocks(safe_nbr *nbr);

@@ -1081,15 +1081,6 @@ __device__ __forceinline__ double fast_rcp(double x) {
 // TABLE = true: the hypergeometric epilogue is fused in -- instead of the count X the kernel writes
 // p = tab[(nid[row] * n_kid + kid[col]) * xs + X] (k_hyp_table), -log10 p, the binarised value and the
 // per-attribute enriched counts (safe.py:596-608, 468-472); the counts never reach memory.
-struct HypLookup {
-    const int32_t *nid;        // [n] index of the row's neighborhood size among the distinct sizes
-    const int32_t *kid;        // [mloc] index of the column's annotation count among the distinct counts
-    const double *tab;         // [n_nid][n_kid][xs]
-    int64_t n_kid, xs;
-    double nes_threshold;
-    double *pvalues_pos, *nes, *nes_binary;
-    unsigned int *enriched;
-};
 
 template <bool TABLE>
 __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ sell_row,
@@ -2008,6 +1999,9 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     uint2 *d_bits = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
     launch_bits_prep(ctx, attr, col0, mloc, n_wg, d_bits);
+    const char *counts_env = getenv("SAFE_HIP_COUNTS");
+    const bool dense_nbr = nbr->n >= 256 && nbr->nnz >= 128 * nbr->n;       // matrix cores pay off for large neighborhoods
+    const bool use_mfma = counts_env ? !strcmp(counts_env, "mfma") : dense_nbr;
     HypLookup hl{};
     hl.nid = d_nid;
     hl.kid = d_kid;
@@ -2019,12 +2013,16 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.nes = nes_dev;
     hl.nes_binary = nb_dev;
     hl.enriched = d_enr;
-    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-    hipLaunchKernelGGL(k_counts_bits<true>, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
-                       nbr->slice_width, nbr->sell_col, n, d_bits, mloc, static_cast<double *>(nullptr), hl);
-    SAFE_HIP_CHECK(hipGetLastError());
-    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
-    ctx->last_kernel.name = "k_counts_bits<hypergeom>";
+    if (use_mfma) {
+        SAFE_TRY(launch_mfma_counts(ctx, nbr, attr, col0, col1, hl));   // records its own timing events
+    } else {
+        SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+        hipLaunchKernelGGL(k_counts_bits<true>, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
+                           nbr->slice_width, nbr->sell_col, n, d_bits, mloc, static_cast<double *>(nullptr), hl);
+        SAFE_HIP_CHECK(hipGetLastError());
+        SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+        ctx->last_kernel.name = "k_counts_bits<hypergeom>";
+    }
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the id vectors above are host memory
     *fused = true;
     return SAFE_OK;

@@ -227,12 +227,17 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
     out[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 }
 
+// COUNTS = false: the permutation test (six i8 slices of ONE 32-column tile per task).
+// COUNTS = true : observed counts only, for 0/1 attributes (hypergeometric path, 'sum' scores): the six
+//                 planes of a task are six adjacent 32-column TILES with one plane each, n_q = 1, and
+//                 the epilogue writes through `hl` (table lookup or plain counts).
+template <bool COUNTS>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
     const unsigned char *__restrict__ bs, int64_t row_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
     const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
-    const double *__restrict__ col_scale, double *__restrict__ ns_out) {
+    const double *__restrict__ col_scale, double *__restrict__ ns_out, HypLookup hl) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][MF_BUF] + kb list
     __shared__ int slot_box;
     int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * MF_BUF);
@@ -342,7 +347,8 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             __syncthreads();
 
             int q = 0, t = 0;
-            auto body = [&](int it, uint4 (&L_store)[4], uint4 (&L_load)[4], const int4 &src_use, int4 &src_load) {
+            auto body = [&](int it, uint4 (&L_store)[4], uint4 (&L_load)[4], const int4 &src_use, int4 &src_load)
+                            __attribute__((always_inline)) {
                 const int buf = it & 1;
                 q3 = q2, t3 = t2;
                 advance(q3, t3);
@@ -380,7 +386,9 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     for (int s = 0; s < MF_NS; ++s) b_cur[s] = b_nxt[s];
                 }
 
-                if (t == S - 1) {                                    // a score is complete
+                if constexpr (COUNTS) {
+                    // (the counts are written once, after the loop)
+                } else if (t == S - 1) {                             // a score is complete
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         long long v = static_cast<long long>(acc[MF_NS - 1][r]);
@@ -408,9 +416,53 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 if (it + 1 < total) body(it + 1, L_b, L_a, src_b, src_a);
             }
 
+            if constexpr (COUNTS) {
+                // ---- the counts of six column tiles are complete (n_q = 1): write them through `hl`.
+                //      Loads first, in batches the hardware can overlap: row -> node -> table slab -> value
+                int32_t node[16];
+                uint32_t slab[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    node[r] = rowmap[static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    slab[r] = (hl.tab && node[r] >= 0) ? static_cast<uint32_t>(hl.nid[node[r]]) * static_cast<uint32_t>(hl.n_kid * hl.xs) : 0u;
+#pragma unroll
+                for (int s = 0; s < MF_NS; ++s) {
+                    const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+                    const bool col_ok = col < mloc;
+                    const uint32_t kofs = (hl.tab && col_ok) ? static_cast<uint32_t>(hl.kid[col]) * static_cast<uint32_t>(hl.xs) : 0u;
+                    unsigned int hits = 0;
+#pragma unroll
+                    for (int half = 0; half < 2; ++half) {
+                        double val[8];
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = half * 8 + rr;
+                            val[rr] = hl.tab ? hl.tab[slab[r] + kofs + ((col_ok && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) : 0u)]
+                                             : static_cast<double>(acc[s][r]);
+                        }
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = half * 8 + rr;
+                            if (!col_ok || node[r] < 0) continue;
+                            const int64_t o = static_cast<int64_t>(node[r]) * mloc + col;
+                            hl.pvalues_pos[o] = val[rr];
+                            if (hl.tab) {
+                                const double nes = -log10(val[rr]);                          // safe.py:608
+                                const bool hit = (nes == nes) && (fabs(nes) > hl.nes_threshold);   // safe.py:468-470
+                                hl.nes[o] = nes;
+                                hl.nes_binary[o] = hit ? 1.0 : 0.0;
+                                hits += hit;
+                            }
+                        }
+                    }
+                    if (hits) atomicAdd(&hl.enriched[col], hits);
+                }
+            }
             // ---- task epilogue: observed scores (first span only) and the counters
             const int64_t col = static_cast<int64_t>(ct) * 32 + col_in_tile;
-            if (col < mloc) {
+            if (!COUNTS && col < mloc) {
                 const double sc = ns_out ? col_scale[col] : 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -573,6 +625,88 @@ int build_blocks(safe_nbr *nbr) {
 
 }  // namespace
 
+namespace {
+
+// planes of 0/1 attributes: bs[row][group of six 32-column tiles][tile][32 columns] = (x == 1), row n = zeros
+template <typename T>
+__global__ __launch_bounds__(256) void k_mfma_planes01(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                       int64_t col0, int64_t mloc, int64_t n_grp, unsigned char *__restrict__ bs) {
+    __shared__ unsigned char tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t ct = blockIdx.x, r0 = static_cast<int64_t>(blockIdx.y) * 32, c0 = ct * 32;     // ct: 32-column tile
+    const bool col_major = rs == 1;
+    for (int i = 0; i < 4; ++i) {
+        const int a = ty + 8 * i;
+        const int64_t r = col_major ? r0 + tx : r0 + a, j = col_major ? c0 + a : c0 + tx;
+        unsigned char v = 0;
+        if (r < n && j < mloc) v = reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs] == static_cast<T>(1) ? 1 : 0;
+        if (col_major) tile[tx][a] = v;
+        else tile[a][tx] = v;
+    }
+    __syncthreads();
+    const int64_t row_bytes = n_grp * MF_NS * 32;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t r = r0 + ty + 8 * i;
+        if (r > n) continue;
+        bs[r * row_bytes + ct * 32 + tx] = r == n ? 0 : tile[ty + 8 * i][tx];   // tile ct = plane (ct % 6) of group ct / 6
+    }
+}
+
+}  // namespace
+
+int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, const HypLookup &hl) {
+    SAFE_TRY(build_blocks(nbr));
+    const int64_t n = nbr->n, mloc = col1 - col0;
+    const int64_t n_ct = ceil_div(mloc, 32), n_grp = ceil_div(n_ct, MF_NS), row_bytes = n_grp * MF_NS * 32, n_src = nbr->bs_src;
+    unsigned char *d_bs = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
+    {
+        const dim3 grid(n_grp * MF_NS, ceil_div(n + 1, 32));
+        if (attr->dtype == SAFE_DTYPE_F32)
+            hipLaunchKernelGGL(k_mfma_planes01<float>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, n_grp, d_bs);
+        else
+            hipLaunchKernelGGL(k_mfma_planes01<double>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                               attr->col_stride, col0, mloc, n_grp, d_bs);
+    }
+    std::vector<int32_t> g_order(nbr->bs_groups);
+    std::iota(g_order.begin(), g_order.end(), 0);
+    const std::vector<int32_t> &bp = nbr->h_bs_ptr;
+    std::stable_sort(g_order.begin(), g_order.end(), [&](int32_t a, int32_t b) { return bp[a + 1] - bp[a] > bp[b + 1] - bp[b]; });
+    std::vector<int2> tasks;
+    int32_t q_off[9] = {0};
+    for (int qx = 0; qx < 8; ++qx) {
+        for (int64_t ct = qx; ct < n_grp; ct += 8)
+            for (int32_t g : g_order) tasks.push_back(make_int2(g, static_cast<int>(ct)));
+        q_off[qx + 1] = static_cast<int32_t>(tasks.size());
+    }
+    void *ws = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + 16 * sizeof(unsigned int), &ws));
+    int2 *d_tasks = static_cast<int2 *>(ws);
+    int32_t *d_qoff = reinterpret_cast<int32_t *>(d_tasks + tasks.size());
+    unsigned int *d_qctr = reinterpret_cast<unsigned int *>(d_qoff + 16);
+    int32_t *d_src = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 4, static_cast<size_t>(n_src) * sizeof(int32_t), reinterpret_cast<void **>(&d_src)));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_qoff, q_off, sizeof(q_off), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, 16 * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
+                       static_cast<const int32_t *>(nullptr), 0, d_src);
+    const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds_bytes)));
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    hipLaunchKernelGGL(k_permtest_mfma<true>, dim3(blocks), dim3(512), lds_bytes, ctx->stream, d_bs, row_bytes, d_src, n_src, 1,
+                       nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr, mloc, static_cast<unsigned int *>(nullptr),
+                       nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), hl);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = "k_permtest_mfma<counts>";
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the task vector is host memory
+    return SAFE_OK;
+}
+
 void nbr_free_blocks(safe_nbr *nbr) {
     (void)hipFree(nbr->bs_order);
     (void)hipFree(nbr->bs_rowmap);
@@ -685,7 +819,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
 
     const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
     ctx->last_kernel.name = "k_permtest_mfma";
@@ -705,9 +839,9 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
                            p_base, d_src[c & 1]);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
-        hipLaunchKernelGGL(k_permtest_mfma, dim3(blocks), dim3(512), lds_bytes, ks, d_bs, row_bytes, d_src[c & 1], n_src,
+        hipLaunchKernelGGL(k_permtest_mfma<false>, dim3(blocks), dim3(512), lds_bytes, ks, d_bs, row_bytes, d_src[c & 1], n_src,
                            static_cast<int>(cnt + 1), nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr + 8 * c, mloc,
-                           d_counts, n_padr, nbr->bs_rowmap, d_scale, c == 0 ? out.ns : static_cast<double *>(nullptr));
+                           d_counts, n_padr, nbr->bs_rowmap, d_scale, c == 0 ? out.ns : static_cast<double *>(nullptr), HypLookup{});
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
         if (c >= 1) {

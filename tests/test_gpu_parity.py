@@ -308,7 +308,14 @@ def test_midsize_randomization_vs_oracle(amd, ctx):
                                   want['num_neighborhoods_enriched'])
 
 
-def test_midsize_hypergeometric_vs_oracle(amd, ctx):
+@pytest.mark.parametrize('counts', ['bits', 'mfma', 'per-element'])
+def test_midsize_hypergeometric_vs_oracle(amd, ctx, monkeypatch, counts):
+    """The three forms of the hypergeometric path: bit-sliced counts + (n, K, X) table lookup,
+    matrix-core counts + table lookup, and the per-element tail evaluation."""
+    if counts == 'per-element':
+        monkeypatch.setenv('SAFE_HIP_HYPER_TABLE', '0')
+    else:
+        monkeypatch.setenv('SAFE_HIP_COUNTS', counts)
     rng = np.random.default_rng(78)
     n, m = 1500, 300
     xy = rng.uniform(size=(n, 2))
@@ -321,10 +328,13 @@ def test_midsize_hypergeometric_vs_oracle(amd, ctx):
     sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.12)
     sf.load_attributes(attribute_file=b)
     sf.compute_pvalues()
+    want_kernel = {'bits': 'k_counts_bits<hypergeom>', 'mfma': 'k_permtest_mfma<counts>', 'per-element': 'k_hypergeom_tail'}[counts]
+    assert ctx.last_kernel()[0] == want_kernel
     np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
     np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
     mism = (sf.nes_binary != want['nes_binary']).sum()
     assert mism == 0
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['num_neighborhoods_enriched'])
 
 
 def test_torch_tensors_share_the_hip_runtime(amd, ctx):
