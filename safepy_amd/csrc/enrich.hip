@@ -2058,7 +2058,15 @@ int safe_score(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int score_type, in
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const bool z = score_type == SAFE_SCORE_ZSCORE;
     if (!z && counts_bits_applicable(nbr, attr)) {
-        SAFE_TRY(launch_counts_bits(ctx, nbr, attr, col0, col1, out_dev));
+        const char *counts_env = getenv("SAFE_HIP_COUNTS");
+        const bool dense_nbr = nbr->n >= 256 && nbr->nnz >= 128 * nbr->n;
+        if (counts_env ? !strcmp(counts_env, "mfma") : dense_nbr) {      // 0/1 data, large neighborhoods: matrix cores
+            HypLookup hl{};
+            hl.pvalues_pos = out_dev;                                     // tab == NULL: plain counts
+            SAFE_TRY(launch_mfma_counts(ctx, nbr, attr, col0, col1, hl));
+        } else {
+            SAFE_TRY(launch_counts_bits(ctx, nbr, attr, col0, col1, out_dev));
+        }
         return finish_kernel_timing(ctx);
     }
     Tiles tiles;
