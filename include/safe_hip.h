@@ -213,6 +213,19 @@ int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutation
                     double enrichment_threshold, double *pvalues_neg_dev, double *pvalues_pos_dev, double *nes_dev,
                     double *nes_binary_dev, double *num_enriched_dev);
 
+/* ---- consumers of nes_binary (SAFE.define_top_attributes / define_domains) ---------------- */
+/* Connected components of the subgraph induced by the enriched nodes of each candidate
+ * attribute (safepy/safe.py:640-655: nx.subgraph + nx.connected_components per attribute).
+ * member_host: f64 [n, n_cols] row-major, > 0 = enriched (nes_binary[:, cols]); undirected edges
+ * (edge_u[e], edge_v[e]).  labels_host: int32 [n_cols, n]: the smallest node id of the node's
+ * component, -1 for nodes that are not enriched. */
+int safe_enriched_components(safe_ctx *ctx, int64_t n, int64_t n_edges, const int32_t *edge_u, const int32_t *edge_v,
+                             const double *member_host, int64_t n_cols, int32_t *labels_host);
+/* scipy.spatial.distance.pdist(x, 'jaccard') as called inside linkage() at safepy/safe.py:673:
+ * x_host f64 [m_top, n] row-major (non-zero = set), out_host f64 [m_top (m_top - 1) / 2] in SciPy's
+ * condensed order; 0 where both profiles are empty. */
+int safe_jaccard_condensed(safe_ctx *ctx, int64_t m_top, int64_t n, const double *x_host, double *out_host);
+
 /* Multi-GPU exchange in integers (replaces gathering f64 NES blocks for the np.concatenate of
  * safepy/safe.py:1355): after safe_randomization / safe_permtest_counts on the bit-sliced or
  * matrix-core kernel, the raw counters of the call are still resident as

@@ -336,3 +336,55 @@ class LegacyMT19937:
             j = self.interval(i)
             a[i], a[j] = a[j], a[i]
         return a
+
+
+# ---------------------------------------------------------------------------
+# Consumers of nes_binary (safe.py:610-745), restated with the library calls the
+# reference makes (networkx connected components, SciPy linkage / fcluster,
+# pandas group-bys).  Pinned by tests/golden/domains.npz (real reference run).
+# ---------------------------------------------------------------------------
+
+def top_attributes(nes_binary, num_enriched, n_nodes, edge_u, edge_v, min_size=10):
+    """safe.py:626-656, attribute_unimodality_metric='connectivity'.  Returns dict of arrays:
+    top (bool), num_connected_components, num_large_connected_components, and a list
+    size_connected_components (None or descending sizes)."""
+    import networkx as nx
+    g = nx.Graph()
+    g.add_nodes_from(range(n_nodes))
+    g.add_edges_from(zip([int(u) for u in edge_u], [int(v) for v in edge_v]))
+    m = nes_binary.shape[1]
+    top = np.asarray(num_enriched) >= min_size
+    num_cc = np.zeros(m, dtype=np.int64)
+    num_large = np.zeros(m, dtype=np.int64)
+    sizes = [None] * m
+    for a in np.flatnonzero(top):
+        nodes = [v for v in range(n_nodes) if nes_binary[v, a] > 0]
+        comps = sorted(nx.connected_components(nx.subgraph(g, nodes)), key=len, reverse=True)
+        sz = np.array([len(c) for c in comps])
+        num_cc[a] = len(comps)
+        sizes[a] = sz
+        num_large[a] = np.sum(sz >= min_size)
+    top = top & ~(num_cc > 1)
+    return {'top': top, 'num_connected_components': num_cc, 'size_connected_components': sizes,
+            'num_large_connected_components': num_large}
+
+
+def domains(nes, nes_binary, top, distance_metric='jaccard', distance_threshold=0.75):
+    """safe.py:672-705.  Returns (domain per attribute, node2domain sums [N, D] with their domain ids,
+    primary_domain, primary_nes)."""
+    import pandas as pd
+    from scipy.cluster.hierarchy import linkage, fcluster
+    top = np.asarray(top, dtype=bool)
+    z = linkage(nes_binary[:, top].T, method='average', metric=distance_metric)
+    dom_top = fcluster(z, np.max(z[:, 2] * distance_threshold), criterion='distance')
+    dom = np.zeros(nes_binary.shape[1], dtype=np.int64)
+    dom[top] = dom_top
+    cols = pd.MultiIndex.from_arrays([np.arange(len(dom)), dom], names=[None, 'domain'])
+    sums = pd.DataFrame(nes_binary, columns=cols).T.groupby(level='domain').sum().T
+    t = sums.loc[:, 1:]
+    t_max = t.max(axis=1)
+    primary = t.idxmax(axis=1)
+    primary[t_max == 0] = 0
+    best = pd.DataFrame(nes, columns=cols).T.groupby(level='domain').max().T
+    primary_nes = np.array([best.loc[r, c] for r, c in zip(primary.index.values, primary.values)])
+    return dom, sums.columns.values.astype(np.int64), sums.values, primary.values.astype(np.int64), primary_nes

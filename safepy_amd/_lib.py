@@ -106,6 +106,8 @@ PROTOTYPES = {
     'safe_randomization': (C.c_int, [_vp, _vp, _vp, _vp, C.c_int, C.c_int, C.c_double, _vp, _i64, _i64,
                                      _vp, _vp, _vp, _vp, _vp, _vp]),
     'safe_hypergeom': (C.c_int, [_vp, _vp, _vp, C.c_double, _i64, _i64, _vp, _vp, _vp, _vp]),
+    'safe_enriched_components': (C.c_int, [_vp, _i64, _i64, _vp, _vp, _vp, _i64, _vp]),
+    'safe_jaccard_condensed': (C.c_int, [_vp, _i64, _i64, _vp, _vp]),
     'safe_fdr_adjust': (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     'safe_export_packed_counts': (C.c_int, [_vp, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_int)]),
     'safe_nes_from_packed_counts': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _vp, _vp]),

@@ -393,3 +393,24 @@ def fdr_adjust(ctx, n, m, num_permutations, attribute_sign, enrichment_threshold
     check(lib.safe_fdr_adjust(ctx.handle, int(n), int(m), int(num_permutations), _SIGN[attribute_sign],
                               float(enrichment_threshold), C.c_void_p(pn) if pn else None, C.c_void_p(pp), C.c_void_p(nes),
                               C.c_void_p(nb), C.c_void_p(ne)))
+
+
+def enriched_components(ctx, n, edge_u, edge_v, member):
+    """member: [n, n_cols] (> 0 = enriched).  Returns int32 [n_cols, n] component labels (smallest
+    node id of the component; -1 = not enriched) -- safe.py:640-655 for all attributes at once."""
+    member = np.ascontiguousarray(member, dtype=np.float64)
+    assert member.ndim == 2 and member.shape[0] == n
+    eu = np.ascontiguousarray(edge_u, dtype=np.int32)
+    ev = np.ascontiguousarray(edge_v, dtype=np.int32)
+    out = np.empty((member.shape[1], n), dtype=np.int32)
+    check(lib.safe_enriched_components(ctx.handle, int(n), eu.shape[0], _ptr(eu), _ptr(ev), _ptr(member), member.shape[1], _ptr(out)))
+    return out
+
+
+def jaccard_condensed(ctx, x):
+    """scipy pdist(x, 'jaccard') (condensed) for the rows of x [m_top, n]."""
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    m_top, n = x.shape
+    out = np.empty(m_top * (m_top - 1) // 2, dtype=np.float64)
+    check(lib.safe_jaccard_condensed(ctx.handle, m_top, n, _ptr(x), _ptr(out)))
+    return out

@@ -9,6 +9,7 @@ domains and output writers of the reference are out of scope (SURVEY.md section 
 import configparser
 import logging
 import os
+import warnings
 
 import numpy as np
 
@@ -117,6 +118,7 @@ class SAFE:
         self.nes_threshold = None
         self.nes_binary = None
 
+        self.graph_euclidean = None      # Euclidean pseudo-network of .scatter inputs (safe.py:67, 302-309), if any
         self.attribute_unimodality_metric = 'connectivity'
         self.attribute_distance_metric = 'jaccard'
         self.attribute_distance_threshold = 0.75
@@ -489,3 +491,152 @@ class SAFE:
                 b.free()
             if _attr is None:
                 attr.close()
+
+    # ------------------------------------------------------------------------------------
+    # consumers of nes_binary
+    # ------------------------------------------------------------------------------------
+    def _graph_edges(self):
+        """Edge list used for the connectivity of enriched nodes: self.graph, or the Euclidean
+        pseudo-network of .scatter inputs when one is set (safe.py:643-645)."""
+        g = getattr(self, 'graph_euclidean', None)
+        if g is None:
+            g = self.graph
+        if isinstance(g, LayoutGraph):
+            return g.edge_u, g.edge_v
+        eu = np.fromiter((u for u, _ in g.edges()), dtype=np.int64, count=g.number_of_edges())
+        ev = np.fromiter((v for _, v in g.edges()), dtype=np.int64, count=g.number_of_edges())
+        return eu, ev
+
+    def define_top_attributes(self, **kwargs):
+        """safepy/safe.py:610-659.  kwargs: attribute_unimodality_metric, attribute_enrichment_min_size.
+        Adds the columns 'top', 'num_connected_components', 'size_connected_components' (object: sizes in
+        descending order) and 'num_large_connected_components' to self.attributes.  The connected
+        components of all candidate attributes are found in one device call."""
+        if 'attribute_unimodality_metric' in kwargs:
+            self.attribute_unimodality_metric = kwargs['attribute_unimodality_metric']
+        if 'attribute_enrichment_min_size' in kwargs:
+            self.attribute_enrichment_min_size = kwargs['attribute_enrichment_min_size']
+        self.validate_config()
+        logging.info('Criteria for top attributes:')
+        logging.info('- minimum number of enriched neighborhoods: %d' % self.attribute_enrichment_min_size)
+        logging.info('- region-specific distribution of enriched neighborhoods as defined by: %s'
+                     % self.attribute_unimodality_metric)
+        min_size = self.attribute_enrichment_min_size
+        attrs = self.attributes
+        attrs['top'] = False
+        attrs.loc[attrs['num_neighborhoods_enriched'] >= min_size, 'top'] = True         # requirement 1 (safe.py:628-629)
+
+        if self.attribute_unimodality_metric == 'connectivity':                         # requirement 2 (safe.py:632-656)
+            m_all = len(attrs)
+            num_cc = np.zeros(m_all, dtype=np.int64)
+            num_large = np.zeros(m_all, dtype=np.int64)
+            sizes = np.empty(m_all, dtype=object)
+            sizes[:] = None
+            # like the reference, attribute index values are column positions of nes_binary
+            cand = attrs.index.values[attrs['top'].values]
+            if len(cand):
+                eu, ev = self._graph_edges()
+                n = self.nes_binary.shape[0]
+                labels = be.enriched_components(self._ctx(), n, eu, ev, self.nes_binary[:, cand])
+                pos_of = {a: i for i, a in enumerate(attrs.index.values)}
+                for row, a in enumerate(cand):
+                    lab = labels[row]
+                    comp = np.sort(np.bincount(lab[lab >= 0]))[::-1]
+                    comp = comp[comp > 0]
+                    i = pos_of[a]
+                    num_cc[i] = len(comp)
+                    sizes[i] = comp
+                    num_large[i] = int(np.sum(comp >= min_size))
+            attrs['num_connected_components'] = num_cc
+            attrs['size_connected_components'] = sizes
+            attrs['num_large_connected_components'] = num_large
+            attrs.loc[attrs['num_connected_components'] > 1, 'top'] = False              # safe.py:656
+        if self.verbose:
+            logging.info('Number of top attributes: %d' % np.sum(attrs['top']))
+
+    def define_domains(self, **kwargs):
+        """safepy/safe.py:661-713.  Average-linkage clustering of the top attributes on the distance
+        between their binarised enrichment profiles (default: Jaccard, computed on the device in
+        SciPy's condensed order; the linkage / fcluster calls are SciPy's, as in the reference), then
+        every node's domain sums, primary domain and primary NES."""
+        import pandas as pd
+        from scipy.cluster.hierarchy import linkage, fcluster
+        if 'attribute_distance_threshold' in kwargs:
+            self.attribute_distance_threshold = kwargs['attribute_distance_threshold']
+        self.validate_config()
+        attrs = self.attributes
+        top = attrs['top'].values.astype(bool)
+        m = self.nes_binary[:, top].T
+        if self.attribute_distance_metric == 'jaccard' and m.shape[0] >= 2:
+            z = linkage(be.jaccard_condensed(self._ctx(), m), method='average')
+        else:
+            z = linkage(m, method='average', metric=self.attribute_distance_metric)
+        max_d = np.max(z[:, 2] * self.attribute_distance_threshold)
+        domains = fcluster(z, max_d, criterion='distance')
+        attrs['domain'] = 0
+        attrs.loc[attrs['top'], 'domain'] = domains
+
+        # a node belongs to the domain holding most of the attributes it is enriched for (safe.py:693-698)
+        dom = attrs['domain'].values
+        ids = np.unique(dom)
+        onehot = (dom[:, None] == ids[None, :]).astype(np.float64)
+        sums = self.nes_binary @ onehot
+        node2domain = pd.DataFrame(sums, columns=pd.Index(ids, name='domain'))
+        real = ids >= 1
+        t = sums[:, real]
+        t_max = t.max(axis=1)
+        primary = ids[real][np.argmax(t, axis=1)]                # first maximum, like DataFrame.idxmax
+        primary = np.where(t_max == 0, 0, primary)
+        node2domain['primary_domain'] = primary
+        # the highest NES among the attributes of the primary domain (safe.py:703-705); NaNs are skipped
+        with np.errstate(invalid='ignore'), warnings.catch_warnings():
+            warnings.simplefilter('ignore', RuntimeWarning)
+            best = np.stack([np.nanmax(np.where(np.isnan(self.nes[:, dom == d]), -np.inf, self.nes[:, dom == d]), axis=1)
+                             for d in ids], axis=1)
+            allnan = np.stack([np.isnan(self.nes[:, dom == d]).all(axis=1) for d in ids], axis=1)
+        best = np.where(allnan, np.nan, best)
+        col_of = {d: i for i, d in enumerate(ids)}
+        if np.any(~np.isin(primary, ids)):
+            raise KeyError(0)                                     # the reference's o.loc[row, 0] with no attribute outside the domains
+        node2domain['primary_nes'] = best[np.arange(best.shape[0]), [col_of[d] for d in primary]]
+        self.node2domain = node2domain
+        if self.verbose:
+            per_domain = attrs.loc[attrs['domain'] > 0].groupby('domain')['id'].count()
+            logging.info('Number of domains: %d (containing %d-%d attributes)'
+                         % (len(np.unique(domains)), per_domain.min(), per_domain.max()))
+
+    def trim_domains(self, **kwargs):
+        """safepy/safe.py:715-745: drop domains that are the primary choice of fewer than
+        attribute_enrichment_min_size nodes, renumber, label each domain with its five most frequent
+        words (chop_and_filter, safe_io.py:735-745)."""
+        import pandas as pd
+        attrs, n2d = self.attributes, self.node2domain
+        domain_counts = np.zeros(len(attrs['domain'].unique())).astype(int)
+        t = n2d.groupby('primary_domain')['primary_domain'].count()
+        domain_counts[t.index] = t.values
+        to_remove = np.flatnonzero(domain_counts < self.attribute_enrichment_min_size)
+        attrs.loc[attrs['domain'].isin(to_remove), 'domain'] = 0
+        idx = n2d['primary_domain'].isin(to_remove)
+        n2d.loc[idx, ['primary_domain', 'primary_nes']] = 0
+        # simple renumbering (safe.py:729-734); the reference's drop(columns=...) result is discarded there too
+        renumber = {k: i for i, k in enumerate(np.sort(attrs['domain'].unique()))}
+        attrs['domain'] = [renumber[k] for k in attrs['domain']]
+        n2d['primary_domain'] = [renumber[k] for k in n2d['primary_domain']]
+        domains = np.sort(attrs['domain'].unique())
+        labels = attrs.groupby('domain')['name'].apply(_domain_label)
+        self.domains = pd.DataFrame(data={'id': domains, 'label': labels})
+        if self.verbose:
+            logging.info('Removed %d domains because they were the top choice for less than %d neighborhoods.'
+                         % (len(to_remove), self.attribute_enrichment_min_size))
+
+
+def _domain_label(names):
+    """The five most frequent words of a domain's attribute names, most frequent first, ties in order
+    of first appearance, without a few stop words (safe_io.py:735-745)."""
+    import re
+    from collections import Counter
+    words = re.findall(r"[\w']+", names.str.cat(sep=' '))
+    counts = Counter(words)
+    ranked = sorted(counts, key=counts.get, reverse=True)
+    skip = ('of', 'a', 'the', 'an', ',', 'via', 'to', 'into', 'from')
+    return ', '.join([w for w in ranked if w not in skip][:5])

@@ -83,6 +83,64 @@ def set_attributes(pd, sf, mat):
                                   'name': ['attr%d' % j for j in range(mat.shape[1])]})
 
 
+def make_domains(safe, safe_io, nx, pd):
+    """define_top_attributes / define_domains / trim_domains of the real reference (safe.py:610-745)
+    on a small network with spatially coherent binary attributes."""
+    import warnings
+    warnings.simplefilter('ignore')
+    rng = np.random.default_rng(5)
+    n, m = 300, 40
+    xy = clustered_layout(rng, n)
+    eu, ev = radius_graph_edges(xy, 0.08, rng)
+    g = make_graph(nx, xy, eu, ev)
+    g = safe_io.calculate_edge_lengths(g, verbose=False)
+    b = np.zeros((n, m))
+    for j in range(m):
+        c = xy[rng.integers(n)]
+        d = np.sqrt(((xy - c) ** 2).sum(1))
+        b[:, j] = (d < rng.uniform(0.05, 0.15)) & (rng.uniform(size=n) < 0.8)
+    names = ['%s %s of the %s' % (rng.choice(['dna', 'rna', 'protein']), rng.choice(['repair', 'transport', 'folding', 'splicing']),
+                                   rng.choice(['nucleus', 'membrane', 'cytosol'])) for _ in range(m)]
+    out = {'xy': xy, 'edge_u': eu, 'edge_v': ev, 'attributes': b, 'names': np.array(names)}
+    sf = new_safe(safe, g)
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.2)
+    sf.node2attribute = b.copy()
+    sf.attributes = pd.DataFrame({'id': np.arange(m), 'name': names})
+    sf.compute_pvalues()
+    out['nes'] = sf.nes
+    out['nes_binary'] = sf.nes_binary
+    out['num_enriched'] = sf.attributes['num_neighborhoods_enriched'].values.astype(np.float64)
+    sf.define_top_attributes()
+    a = sf.attributes
+    out['top'] = a['top'].values.astype(np.int8)
+    out['num_cc'] = a['num_connected_components'].values.astype(np.int64)
+    out['num_large_cc'] = a['num_large_connected_components'].values.astype(np.int64)
+    # pandas' .at stores a one-component array as a 0-d array; non-candidates hold None / NaN
+    cc = [np.atleast_1d(s) if isinstance(s, np.ndarray) else None for s in a['size_connected_components']]
+    width = max(len(s) for s in cc if s is not None)
+    sizes = np.full((m, width), -1, dtype=np.int64)                # -1 padded; row of -1 = not a candidate
+    for j, s in enumerate(cc):
+        if s is not None:
+            sizes[j, :len(s)] = s
+    out['cc_sizes'] = sizes
+    for thr in (0.75, 0.65):
+        sf.define_domains(attribute_distance_threshold=thr)
+        tag = 'thr%g_' % thr
+        out[tag + 'domain'] = sf.attributes['domain'].values.astype(np.int64)
+        dom_cols = [c for c in sf.node2domain.columns if c not in ('primary_domain', 'primary_nes')]
+        out[tag + 'domain_ids'] = np.array(dom_cols, dtype=np.int64)
+        out[tag + 'node2domain'] = sf.node2domain[dom_cols].values
+        out[tag + 'primary_domain'] = sf.node2domain['primary_domain'].values.astype(np.int64)
+        out[tag + 'primary_nes'] = sf.node2domain['primary_nes'].values
+    sf.trim_domains()
+    out['trim_domain'] = sf.attributes['domain'].values.astype(np.int64)
+    out['trim_primary_domain'] = sf.node2domain['primary_domain'].values.astype(np.int64)
+    out['trim_primary_nes'] = sf.node2domain['primary_nes'].values
+    out['trim_domain_ids'] = sf.domains['id'].values.astype(np.int64)
+    out['trim_domain_labels'] = np.array(list(sf.domains['label'].values))
+    np.savez_compressed(os.path.join(HERE, 'domains.npz'), **out)
+
+
 def main():
     import networkx as nx
     import pandas as pd
@@ -220,7 +278,9 @@ def main():
             kat['s%d_n%d_b' % (seed, n_items)] = np.random.permutation(base)
     np.savez_compressed(os.path.join(HERE, 'rng_kat.npz'), **kat)
 
-    for f in ('neighborhoods.npz', 'enrichment.npz', 'rng_kat.npz'):
+    make_domains(safe, safe_io, nx, pd)
+
+    for f in ('neighborhoods.npz', 'enrichment.npz', 'rng_kat.npz', 'domains.npz'):
         print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')
 
 

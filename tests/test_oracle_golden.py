@@ -157,3 +157,26 @@ def test_bh_restatement_against_scipy_independent_implementation():
     assert np.isnan(orc.fdrcorrection(np.array([0.1, np.nan, 0.5]))).all()
     rows = orc.fdr_rows(np.array([[0.01, 0.04, 0.03], [1.0, 0.0, 0.5]]))
     np.testing.assert_allclose(rows, [[0.03, 0.04, 0.04], [1.0, 0.0, 0.75]])
+
+
+def test_oracle_top_attributes_and_domains_vs_reference():
+    """define_top_attributes / define_domains (safe.py:610-705) restated in the oracle vs the real
+    reference's outputs (tests/golden/domains.npz)."""
+    import os
+    import numpy as np
+    from oracle import safe_oracle as orc
+    g = dict(np.load(os.path.join(os.path.dirname(__file__), 'golden', 'domains.npz')))
+    n = g['xy'].shape[0]
+    top = orc.top_attributes(g['nes_binary'], g['num_enriched'], n, g['edge_u'], g['edge_v'], min_size=10)
+    assert np.array_equal(top['top'], g['top'].astype(bool))
+    assert np.array_equal(top['num_connected_components'], g['num_cc'])
+    assert np.array_equal(top['num_large_connected_components'], g['num_large_cc'])
+    for j, s in enumerate(top['size_connected_components']):
+        want = g['cc_sizes'][j][g['cc_sizes'][j] >= 0]
+        assert (s is None and len(want) == 0) or np.array_equal(s, want)
+    for thr in (0.75, 0.65):
+        tag = 'thr%g_' % thr
+        dom, ids, sums, primary, primary_nes = orc.domains(g['nes'], g['nes_binary'], g['top'].astype(bool), 'jaccard', thr)
+        assert np.array_equal(dom, g[tag + 'domain']) and np.array_equal(ids, g[tag + 'domain_ids'])
+        assert np.array_equal(sums, g[tag + 'node2domain']) and np.array_equal(primary, g[tag + 'primary_domain'])
+        np.testing.assert_array_equal(primary_nes, g[tag + 'primary_nes'])
