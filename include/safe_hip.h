@@ -137,6 +137,25 @@ int safe_attr_create_host(safe_ctx *ctx, const void *b_host, int dtype, int64_t 
 int safe_attr_create_dev(safe_ctx *ctx, const void *b_dev, int dtype, int64_t n, int64_t m,
                          int64_t row_stride, int64_t col_stride, safe_attr **out);
 int safe_attr_destroy(safe_attr *attr);
+/* read_attributes on the device (safepy/safe_io.py:386-390 `node2attribute.reindex(index=
+ * node_label_order, fill_value=fill_value)` + `.values` at :410): uploads the file's
+ * [n_labels, m] table (f32 or f64, C or Fortran order by element strides) once, gathers its
+ * rows into network node order -- row_map_host[i] = table row of node i, -1 = label not in
+ * the file (filled with fill_value), -2 = masked duplicate node (NaN, safe_io.py:394-404) --
+ * and returns the aligned matrix as a device-resident handle, laid out C (out_order 0) or
+ * Fortran (1).  If out_host is not NULL the aligned matrix (same dtype and order) is also
+ * copied there: that is self.node2attribute. */
+int safe_attr_reindex(safe_ctx *ctx, const void *table_host, int dtype, int64_t n_labels, int64_t m,
+                      int64_t row_stride, int64_t col_stride, const int64_t *row_map_host, int64_t n,
+                      double fill_value, int out_order, void *out_host, safe_attr **out);
+/* The value census read_attributes logs (safepy/safe_io.py:426-429): #NaN, #zeros,
+ * #positives, #negatives of the whole matrix in one pass. */
+int safe_attr_value_counts(safe_attr *attr, int64_t *n_nan, int64_t *n_zero, int64_t *n_positive,
+                           int64_t *n_negative);
+/* background='network' (safepy/safe.py:449-451): NaN -> 0 in place on the device copy. */
+int safe_attr_nan_to_zero(safe_attr *attr);
+/* Copies the device matrix (its own dtype and order) to the host. */
+int safe_attr_download(safe_attr *attr, void *out_host);
 /* Whole-matrix facts compute_pvalues needs before dispatch (safepy/safe.py:453-463):
  *   n_other   = #(non-NaN values not in {0,1})          -> 'auto' rule (safe.py:461)
  *   max_nan_col = max over columns of the NaN count      -> >50% warning (safe.py:454-459)

@@ -388,3 +388,80 @@ def domains(nes, nes_binary, top, distance_metric='jaccard', distance_threshold=
     best = pd.DataFrame(nes, columns=cols).T.groupby(level='domain').max().T
     primary_nes = np.array([best.loc[r, c] for r, c in zip(primary.index.values, primary.values)])
     return dom, sums.columns.values.astype(np.int64), sums.values, primary.values.astype(np.int64), primary_nes
+
+
+# ---------------------------------------------------------------------------
+# Callers / data formats either side of the path, pinned by
+# tests/golden/io.npz (real reference run: .scatter network, weighted edge lengths,
+# read_attributes on text / gzip / DataFrame inputs).
+# ---------------------------------------------------------------------------
+
+def weighted_edge_lengths(xy, edge_u, edge_v, weight):
+    """safe_io.py:311-333 with edge weights: the reference multiplies the pdist matrix by the
+    adjacency matrix (entries = weights, zeros turned into NaN first, :325-328) and keeps the
+    non-NaN entries (:330).  Returns per edge d(u,v) * w, NaN where the edge gets no length."""
+    d = edge_lengths(xy, edge_u, edge_v)
+    w = np.asarray(weight, dtype=np.float64).copy()
+    w[w == 0] = np.nan
+    return d * w
+
+
+def pseudo_network_edges(xy, neighborhood_radius):
+    """safe.py:302-309: dense pdist matrix, radius scaled by the extent of ALL coordinates
+    (`node_coordinates.ravel()`), strict `<`; nx.from_numpy_array keeps every non-zero entry,
+    self loops included.  Returns the undirected edge list as sorted (u <= v) pairs."""
+    xy = np.asarray(xy, dtype=np.float64)
+    d = squareform(pdist(xy, 'euclidean'))
+    nr = neighborhood_radius * (np.max(xy.ravel()) - np.min(xy.ravel()))
+    u, v = np.nonzero(np.triu(d < nr))
+    return np.stack([u, v], axis=1).astype(np.int64)
+
+
+def parse_attribute_text(path):
+    """safe_io.py:358-368: the text / gzip branch up to the numeric label-indexed table.  The text
+    to float conversion and the float32 down-cast rule are pandas' (third-party; same calls)."""
+    import pandas as pd
+    t = pd.read_csv(path, sep='\t', dtype={0: str})
+    t = t.set_index(t.columns[0], drop=True)
+    t = t.apply(pd.to_numeric, downcast='float', errors='coerce')
+    names = [str(c) for c in t.columns]
+    t.columns = np.arange(t.shape[1])
+    return names, t
+
+
+def align_attributes(table, node_label_order=None, fill_value=np.nan, mask_duplicates=False):
+    """safe_io.py:380-410 restated with explicit loops instead of pandas' reindex: coerce to numeric,
+    average rows sharing a label, then one output row per network node -- the file's row of that
+    label, or `fill_value` when the label is not in the file; with mask_duplicates only one random
+    node per label (first in a `np.random.permutation` order) keeps its values.
+    Returns (node_label_order, matrix in the table's common float dtype)."""
+    import pandas as pd
+    table = table.apply(pd.to_numeric, errors='coerce')
+    if not table.index.is_unique:
+        table = table.groupby(table.index).mean()
+    labels = list(table.index.values)
+    values = table.to_numpy()
+    if values.dtype not in (np.float32, np.float64):
+        values = values.astype(np.float64)
+    if node_label_order is None or len(node_label_order) == 0:
+        node_label_order = labels
+    where = {lab: i for i, lab in enumerate(labels)}
+    out = np.full((len(node_label_order), values.shape[1]), fill_value, dtype=values.dtype)
+    for i, lab in enumerate(node_label_order):
+        if lab in where:
+            out[i] = values[where[lab]]
+    if mask_duplicates:
+        idx = np.random.permutation(np.arange(len(node_label_order)))
+        seen = set()
+        for i in idx:
+            lab = node_label_order[i]
+            if lab in seen:
+                out[i] = np.nan
+            seen.add(lab)
+    return list(node_label_order), out
+
+
+def value_census(mat):
+    """safe_io.py:426-429."""
+    ok = mat[~np.isnan(mat)]
+    return int(np.sum(np.isnan(mat))), int(np.sum(ok == 0)), int(np.sum(ok > 0)), int(np.sum(ok < 0))

@@ -94,6 +94,10 @@ PROTOTYPES = {
     'safe_attr_create_host': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _pp]),
     'safe_attr_create_dev': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _pp]),
     'safe_attr_destroy': (C.c_int, [_vp]),
+    'safe_attr_reindex': (C.c_int, [_vp, _vp, C.c_int, _i64, _i64, _i64, _i64, _vp, _i64, C.c_double, C.c_int, _vp, _pp]),
+    'safe_attr_value_counts': (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
+    'safe_attr_nan_to_zero': (C.c_int, [_vp]),
+    'safe_attr_download': (C.c_int, [_vp, _vp]),
     'safe_attr_stats': (C.c_int, [_vp, _pi64, _pi64, _pi64, _pi64]),
     'safe_attr_row_flags': (C.c_int, [_vp, _vp]),
     'safe_attr_set_row_flags': (C.c_int, [_vp, _vp]),

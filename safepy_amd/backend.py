@@ -243,6 +243,36 @@ class Attributes:
         check(lib.safe_attr_create_dev(ctx.handle, C.c_void_p(dev_ptr), dt, n, m, rs, cs, C.byref(h)))
         return cls(ctx, h, n, m, keepalive=keepalive)
 
+    @classmethod
+    def reindexed(cls, ctx, table, row_map, fill_value=np.nan, order='F', want_host=True):
+        """read_attributes' alignment step (safe_io.py:386-390, 410): rows of the file's `table`
+        gathered into node order on the device.  row_map[i] = table row of node i, -1 = absent
+        (fill_value), -2 = masked duplicate (NaN).  Returns (handle, host copy or None); the host
+        copy has the table's dtype and the requested memory order."""
+        table, dt, nl, m, rs, cs = cls._layout(np.asarray(table))
+        row_map = np.ascontiguousarray(row_map, dtype=np.int64)
+        n = row_map.shape[0]
+        host = np.empty((n, m), dtype=table.dtype, order=order) if want_host else None
+        h = C.c_void_p()
+        check(lib.safe_attr_reindex(ctx.handle, _ptr(table), dt, nl, m, rs, cs, _ptr(row_map), n, float(fill_value),
+                                    0 if order == 'C' else 1, _ptr(host) if want_host else None, C.byref(h)))
+        return cls(ctx, h, n, m), host
+
+    def value_counts(self):
+        """(#NaN, #zeros, #positives, #negatives) -- the census of safe_io.py:426-429."""
+        v = [C.c_int64() for _ in range(4)]
+        check(lib.safe_attr_value_counts(self.handle, *[C.byref(x) for x in v]))
+        return tuple(x.value for x in v)
+
+    def nan_to_zero(self):
+        """background='network' on the device copy (safe.py:449-451)."""
+        check(lib.safe_attr_nan_to_zero(self.handle))
+
+    def download(self, dtype, order='C'):
+        out = np.empty((self.n, self.m), dtype=dtype, order=order)
+        check(lib.safe_attr_download(self.handle, _ptr(out)))
+        return out
+
     def stats(self):
         a, b, c, d = C.c_int64(), C.c_int64(), C.c_int64(), C.c_int64()
         check(lib.safe_attr_stats(self.handle, C.byref(a), C.byref(b), C.byref(c), C.byref(d)))

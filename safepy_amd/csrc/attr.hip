@@ -115,6 +115,74 @@ __global__ __launch_bounds__(256) void k_fill_support(const void *__restrict__ r
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// read_attributes on the device (safepy/safe_io.py:386-390, 405-410, 426-429)
+// ---------------------------------------------------------------------------------------------
+// node2attribute.reindex(index=node_label_order, fill_value=...) followed by .values: output row i
+// is table row row_map[i] (-1: not in the file -> fill_value, -2: masked duplicate -> NaN).  64 x 64
+// tiles turned around through LDS so that the read runs along the table's contiguous axis and the
+// write along the output's, whatever the two orders are.
+template <typename T>
+__global__ __launch_bounds__(256) void k_reindex_rows(const T *__restrict__ table, int64_t n_labels, int64_t m,
+                                                      int64_t irs, int64_t ics, const int64_t *__restrict__ row_map,
+                                                      T *__restrict__ out, int64_t n, int64_t ors, int64_t ocs, T fill) {
+    __shared__ T tile[64][65];
+    const int64_t i0 = static_cast<int64_t>(blockIdx.y) * 64, j0 = static_cast<int64_t>(blockIdx.x) * 64;
+    const bool in_cols_contig = ics == 1, out_cols_contig = ocs == 1;
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int t = threadIdx.x + 256 * k;
+        const int r = in_cols_contig ? (t >> 6) : (t & 63), c = in_cols_contig ? (t & 63) : (t >> 6);
+        const int64_t i = i0 + r, j = j0 + c;
+        T v = fill;
+        if (i < n && j < m) {
+            const int64_t src = row_map[i];
+            if (src >= 0) v = table[src * irs + j * ics];
+            else if (src == -2) v = static_cast<T>(__builtin_nan(""));
+        }
+        tile[r][c] = v;
+    }
+    __syncthreads();
+#pragma unroll 4
+    for (int k = 0; k < 16; ++k) {
+        const int t = threadIdx.x + 256 * k;
+        const int r = out_cols_contig ? (t >> 6) : (t & 63), c = out_cols_contig ? (t & 63) : (t >> 6);
+        const int64_t i = i0 + r, j = j0 + c;
+        if (i < n && j < m) out[i * ors + j * ocs] = tile[r][c];
+    }
+}
+
+// the four value counts of the verbose log (safe_io.py:426-429) in one pass over the matrix
+template <typename T>
+__global__ __launch_bounds__(256) void k_value_census(const T *__restrict__ raw, int64_t count,
+                                                      unsigned long long *__restrict__ acc /*[4]*/) {
+    unsigned int c_nan = 0, c_zero = 0, c_pos = 0, c_neg = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const T v = raw[i];
+        c_nan += v != v;
+        c_zero += v == static_cast<T>(0);
+        c_pos += v > static_cast<T>(0);
+        c_neg += v < static_cast<T>(0);
+    }
+    unsigned int vals[4] = {c_nan, c_zero, c_pos, c_neg};
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+        unsigned int x = vals[q];
+        for (int off = 32; off; off >>= 1) x += __shfl_down(x, off);
+        if ((threadIdx.x & 63) == 0 && x) atomicAdd(&acc[q], static_cast<unsigned long long>(x));
+    }
+}
+
+// background='network' (safe.py:449-451): NaN -> 0 in place
+template <typename T>
+__global__ __launch_bounds__(256) void k_nan_to_zero(T *__restrict__ raw, int64_t count) {
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const T v = raw[i];
+        if (v != v) raw[i] = static_cast<T>(0);
+    }
+}
+
 int attr_build_support(safe_attr *attr) {
     if (attr->sup_ptr) return SAFE_OK;
     SAFE_TRY(safe_attr_prepare(attr));
@@ -267,6 +335,121 @@ int safe_attr_create_dev(safe_ctx *ctx, const void *b_dev, int dtype, int64_t n,
     a->raw = b_dev;
     a->owns_raw = false;
     *out = a;
+    return SAFE_OK;
+}
+
+int safe_attr_reindex(safe_ctx *ctx, const void *table_host, int dtype, int64_t n_labels, int64_t m, int64_t row_stride,
+                      int64_t col_stride, const int64_t *row_map_host, int64_t n, double fill_value, int out_order,
+                      void *out_host, safe_attr **out) {
+    SAFE_REQUIRE(ctx && table_host && row_map_host && out, "safe_attr_reindex: NULL argument");
+    SAFE_REQUIRE(dtype == SAFE_DTYPE_F32 || dtype == SAFE_DTYPE_F64, "safe_attr_reindex: dtype must be f32 or f64");
+    SAFE_REQUIRE(n_labels >= 1 && m >= 1 && n >= 1, "safe_attr_reindex: empty input (%lld labels x %lld attributes -> %lld nodes)",
+                 (long long)n_labels, (long long)m, (long long)n);
+    SAFE_REQUIRE((row_stride == m && col_stride == 1) || (row_stride == 1 && col_stride == n_labels),
+                 "safe_attr_reindex: table must be C- or Fortran-contiguous");
+    SAFE_REQUIRE(out_order == 0 || out_order == 1, "safe_attr_reindex: out_order must be 0 (C) or 1 (Fortran)");
+    for (int64_t i = 0; i < n; ++i)
+        SAFE_REQUIRE(row_map_host[i] >= -2 && row_map_host[i] < n_labels, "safe_attr_reindex: row_map[%lld] = %lld out of range",
+                     (long long)i, (long long)row_map_host[i]);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t esz = dtype == SAFE_DTYPE_F32 ? 4 : 8;
+    const size_t in_bytes = static_cast<size_t>(n_labels) * m * esz, out_bytes = static_cast<size_t>(n) * m * esz;
+    uint8_t *d_in = nullptr, *d_out = nullptr;
+    int64_t *d_map = nullptr;
+    SAFE_TRY(dev_alloc(&d_in, in_bytes));
+    int rc = dev_alloc(&d_out, out_bytes);
+    if (rc == SAFE_OK) rc = dev_alloc(&d_map, n);
+    const int64_t ors = out_order == 0 ? m : 1, ocs = out_order == 0 ? 1 : n;
+    safe_attr *a = nullptr;
+    if (rc == SAFE_OK) rc = attr_new(ctx, dtype, n, m, ors, ocs, &a);
+    hipError_t e = hipSuccess;
+    if (rc == SAFE_OK) {
+        e = hipMemcpyAsync(d_in, table_host, in_bytes, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_map, row_map_host, n * sizeof(int64_t), hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            const dim3 grid(static_cast<unsigned>(ceil_div(m, 64)), static_cast<unsigned>(ceil_div(n, 64)));
+            if (dtype == SAFE_DTYPE_F32)
+                hipLaunchKernelGGL(k_reindex_rows<float>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const float *>(d_in),
+                                   n_labels, m, row_stride, col_stride, d_map, reinterpret_cast<float *>(d_out), n, ors, ocs,
+                                   static_cast<float>(fill_value));
+            else
+                hipLaunchKernelGGL(k_reindex_rows<double>, grid, dim3(256), 0, ctx->stream, reinterpret_cast<const double *>(d_in),
+                                   n_labels, m, row_stride, col_stride, d_map, reinterpret_cast<double *>(d_out), n, ors, ocs,
+                                   fill_value);
+            e = hipGetLastError();
+        }
+        if (e == hipSuccess && out_host) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    (void)hipFree(d_in);
+    (void)hipFree(d_map);
+    if (rc != SAFE_OK || e != hipSuccess) {
+        if (e != hipSuccess) safe_set_error("safe_attr_reindex: %s", hipGetErrorString(e));
+        (void)hipFree(d_out);
+        delete a;
+        return rc != SAFE_OK ? rc : SAFE_E_HIP;
+    }
+    a->raw = d_out;
+    a->owns_raw = true;
+    *out = a;
+    return SAFE_OK;
+}
+
+int safe_attr_value_counts(safe_attr *attr, int64_t *n_nan, int64_t *n_zero, int64_t *n_positive, int64_t *n_negative) {
+    SAFE_REQUIRE(attr != nullptr, "safe_attr_value_counts: attr is NULL");
+    safe_ctx *ctx = attr->ctx;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    unsigned long long *d_acc = nullptr, h_acc[4];
+    SAFE_TRY(dev_alloc(&d_acc, 4));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_acc, 0, sizeof(h_acc), ctx->stream));
+    const int64_t count = attr->n * attr->m;
+    const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(ceil_div(count, 256), 8192));
+    if (attr->dtype == SAFE_DTYPE_F32)
+        hipLaunchKernelGGL(k_value_census<float>, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const float *>(attr->raw), count, d_acc);
+    else
+        hipLaunchKernelGGL(k_value_census<double>, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const double *>(attr->raw), count, d_acc);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    (void)hipFree(d_acc);
+    if (n_nan) *n_nan = static_cast<int64_t>(h_acc[0]);
+    if (n_zero) *n_zero = static_cast<int64_t>(h_acc[1]);
+    if (n_positive) *n_positive = static_cast<int64_t>(h_acc[2]);
+    if (n_negative) *n_negative = static_cast<int64_t>(h_acc[3]);
+    return SAFE_OK;
+}
+
+int safe_attr_nan_to_zero(safe_attr *attr) {
+    SAFE_REQUIRE(attr != nullptr, "safe_attr_nan_to_zero: attr is NULL");
+    safe_ctx *ctx = attr->ctx;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t count = attr->n * attr->m;
+    const unsigned blocks = static_cast<unsigned>(std::min<int64_t>(ceil_div(count, 256), 8192));
+    void *raw = const_cast<void *>(attr->raw);
+    if (attr->dtype == SAFE_DTYPE_F32)
+        hipLaunchKernelGGL(k_nan_to_zero<float>, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<float *>(raw), count);
+    else
+        hipLaunchKernelGGL(k_nan_to_zero<double>, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double *>(raw), count);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    // every derived fact is stale now
+    attr->stats_ready = false;
+    attr->flags_ready = false;
+    (void)hipFree(attr->sup_ptr);
+    (void)hipFree(attr->sup_row);
+    attr->sup_ptr = nullptr;
+    attr->sup_row = nullptr;
+    attr->h_sup_ptr.clear();
+    return SAFE_OK;
+}
+
+int safe_attr_download(safe_attr *attr, void *out_host) {
+    SAFE_REQUIRE(attr && out_host, "safe_attr_download: NULL argument");
+    safe_ctx *ctx = attr->ctx;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const size_t bytes = static_cast<size_t>(attr->n) * attr->m * (attr->dtype == SAFE_DTYPE_F32 ? 4 : 8);
+    SAFE_HIP_CHECK(hipMemcpyAsync(out_host, attr->raw, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     return SAFE_OK;
 }
 

@@ -132,6 +132,8 @@ class SAFE:
         self._neighborhoods_host = None
         self._node_distances = None
         self._pending_binary = None
+        self._attr_dev = None            # resident node2attribute (load_attributes(keep_on_device=True))
+        self._attr_dev_host = None
 
         self.read_config(path_to_ini_file, path_to_safe_data=self.path_to_safe_data)
         self.validate_config()
@@ -201,6 +203,8 @@ class SAFE:
         if state.get('_neighborhoods_host') is None and state.get('_nbr') is not None:
             state['_neighborhoods_host'] = self._nbr.to_dense()
         state['_nbr'] = None
+        state['_attr_dev'] = None
+        state['_attr_dev_host'] = None
         state['default_config'] = dict(self.default_config) if self.default_config is not None else None
         return state
 
@@ -213,41 +217,125 @@ class SAFE:
 
     # ------------------------------------------------------------------ inputs ----
     def load_network(self, **kwargs):
-        """Accepts an in-memory graph only: `graph=` a networkx.Graph with node attributes
-        x, y (and edge attribute 'length' for the default metric) or a `LayoutGraph`.
-        The reference's file loaders (safe.py:244-324, safe_io.py:30-285) are out of scope."""
+        """safepy/safe.py:244-324 for in-memory graphs (`graph=` / `network_file=` a networkx.Graph
+        with node attributes x, y -- and edge attribute 'length' for the default metric -- or a
+        `LayoutGraph`), `.gpickle` files and `.scatter` files (with their Euclidean pseudo-network,
+        safe.py:296-309, built on the device).  The reference's other file loaders and layouts
+        (safe_io.py:30-268, 288-308) are out of scope.  Sets self.graph, self.graph_euclidean (for
+        .scatter) and self.nodes (safe.py:311-324)."""
+        import pandas as pd
+        from . import safe_io
+        if 'network_file' in kwargs and isinstance(kwargs['network_file'], str):
+            if self.path_to_safe_data is None:
+                self.path_to_network_file = kwargs['network_file']
+            else:
+                self.path_to_network_file = os.path.join(self.path_to_safe_data, kwargs['network_file'])
+        if 'view_name' in kwargs:
+            self.view_name = kwargs['view_name']
         if 'node_key_attribute' in kwargs:
             self.node_key_attribute = kwargs['node_key_attribute']
         self.validate_config()
         graph = kwargs.get('graph', kwargs.get('network_file'))
-        if graph is None or isinstance(graph, str):
-            raise NotImplementedError('safepy_amd.SAFE.load_network takes graph=<networkx.Graph | LayoutGraph>; '
-                                      'network file parsing is out of scope for the hot-path build')
+        self.graph_euclidean = None
+        if graph is None:
+            raise NotImplementedError('safepy_amd.SAFE.load_network needs graph=<networkx.Graph | LayoutGraph> or '
+                                      'network_file=<.gpickle | .scatter>; the default safe-data network is not bundled')
+        if isinstance(graph, str):
+            path = self.path_to_network_file
+            assert os.path.exists(path), path
+            suffixes = [x for x in os.path.basename(path).split('.')[1:]]
+            ext = '.' + suffixes[0] if suffixes else ''
+            if self.verbose:
+                logging.info('Loading network from %s' % path)
+            if ext == '.gpickle':
+                graph = safe_io.load_network_from_gpickle(path, verbose=self.verbose)
+            elif ext == '.scatter':
+                graph = safe_io.load_network_from_scatter(path, node_key_attribute=self.node_key_attribute,
+                                                          verbose=self.verbose)
+                self.graph_euclidean = safe_io.euclidean_pseudo_network(
+                    graph, self.neighborhood_radius, device=self.device,
+                    as_networkx=kwargs.get('pseudo_network', 'networkx') == 'networkx')
+            else:
+                raise NotImplementedError('network files of type %r need the reference\'s loaders and layouts, which are '
+                                          'out of scope for the hot-path build (supported: .gpickle, .scatter)' % ext)
         self.graph = graph
         self._invalidate_neighborhoods()
+        if isinstance(graph, LayoutGraph):
+            ids, keys, labels = list(range(graph.number_of_nodes())), list(graph.keys), list(graph.labels)
+        else:
+            key_list = dict(graph.nodes.data(self.node_key_attribute))
+            key_list = {k: v for k, v in key_list.items() if v is not None}
+            if not key_list:
+                raise Exception('The specified node key attribute (%s) does not exist in this network. '
+                                'Set node_key_attribute to one of the attributes the nodes carry.'
+                                % self.node_key_attribute)
+            for k, v in key_list.items():
+                graph.nodes[k]['key'] = v
+            label_list = {k: v for k, v in graph.nodes.data('label') if v is not None}
+            ids, keys, labels = list(label_list.keys()), list(key_list.values()), list(label_list.values())
+        self.nodes = pd.DataFrame(data={'id': ids, 'key': keys, 'label': labels})
 
     def load_attributes(self, **kwargs):
-        """`attribute_file=` a pandas DataFrame indexed by node key (the DataFrame branch of
-        read_attributes, safe_io.py:372-410) or a ready [N,M] ndarray in node order."""
+        """safepy/safe.py:334-367 over `read_attributes` (safe_io.py:336-430): `attribute_file=` a
+        `.txt` / `.gz` path, a pandas DataFrame indexed by node key, or (additive) a ready [N,M]
+        ndarray in node order; other kwargs (`mask_duplicates`, `fill_value`) are forwarded.
+        The alignment to node order runs on the device.  `keep_on_device=True` (additive) keeps the
+        aligned matrix resident for compute_pvalues(), which then skips the upload; the host
+        `self.node2attribute` is made read-only in exchange (assign a new array to replace it)."""
         import pandas as pd
+        from . import safe_io
+        keep = bool(kwargs.pop('keep_on_device', False))
+        self._drop_device_attributes()
+        if 'attribute_file' in kwargs:
+            src = kwargs.pop('attribute_file')
+            if self.path_to_safe_data is None or isinstance(src, (pd.DataFrame, np.ndarray)):
+                self.path_to_attribute_file = src
+            elif isinstance(src, str):
+                self.path_to_attribute_file = os.path.join(self.path_to_safe_data, src)
+            else:
+                raise ValueError(type(src))
+        src = self.path_to_attribute_file
+        if isinstance(src, str):
+            assert os.path.exists(src), src
         self.validate_config()
-        src = kwargs.get('attribute_file')
         if isinstance(src, np.ndarray):
             self.node2attribute = src
             self.attributes = pd.DataFrame({'id': np.arange(src.shape[1]),
                                             'name': [str(j) for j in range(src.shape[1])]})
+            if keep:
+                self._attr_dev = be.Attributes.from_host(self._ctx(), src)
+                self._attr_dev_host = src
+                src.flags.writeable = False
             return
-        if not isinstance(src, pd.DataFrame):
-            raise NotImplementedError('safepy_amd.SAFE.load_attributes takes attribute_file=<DataFrame | ndarray>; '
-                                      'attribute file parsing is out of scope for the hot-path build')
-        table = src.apply(pd.to_numeric, errors='coerce')
-        attributes = pd.DataFrame({'id': np.arange(len(table.columns)), 'name': table.columns})
-        attributes['name'] = attributes['name'].astype(str)
-        if not table.index.is_unique:
-            table = table.groupby(table.index).mean()
-        table = table.reindex(index=self._node_keys(), fill_value=kwargs.get('fill_value', np.nan))
-        self.attributes = attributes
-        self.node2attribute = table.values
+        if self.verbose and isinstance(src, str):
+            logging.info('Loading attributes from %s' % src)
+        self.attributes, _, self.node2attribute, attr = safe_io.read_attributes_device(
+            node_label_order=self._node_keys(), verbose=self.verbose, attribute_file=src, device=self.device, **kwargs)
+        if keep:
+            self._attr_dev = attr
+            self._attr_dev_host = self.node2attribute
+            self.node2attribute.flags.writeable = False
+        else:
+            attr.close()
+
+    def _drop_device_attributes(self):
+        attr = self.__dict__.get('_attr_dev')
+        if attr is not None:
+            attr.close()
+        self._attr_dev = None
+        self._attr_dev_host = None
+
+    def _resident_attributes(self):
+        """The handle load_attributes(keep_on_device=True) left on the device, if it still mirrors
+        self.node2attribute (same object, still read-only)."""
+        attr = self.__dict__.get('_attr_dev')
+        if attr is None:
+            return None
+        host = self.node2attribute
+        if host is self._attr_dev_host and isinstance(host, np.ndarray) and not host.flags.writeable:
+            return attr
+        self._drop_device_attributes()
+        return None
 
     def _node_keys(self):
         if isinstance(self.graph, LayoutGraph):
@@ -393,11 +481,17 @@ class SAFE:
             self.background = kwargs['background']
         self.validate_config()
 
+        resident = self._resident_attributes()
         if self.background == 'network':
             logging.info('Setting all null attribute values to 0. Using the network as background for enrichment.')
+            if resident is not None:                                       # both copies, the host one stays read-only
+                resident.nan_to_zero()
+                self.node2attribute.flags.writeable = True
             self.node2attribute[np.isnan(self.node2attribute)] = 0         # in place, like safe.py:451
+            if resident is not None:
+                self.node2attribute.flags.writeable = False
 
-        attr = be.Attributes.from_host(self._ctx(), self.node2attribute)
+        attr = resident if resident is not None else be.Attributes.from_host(self._ctx(), self.node2attribute)
         try:
             stats = attr.stats()
             if stats['max_nan_col'] / self.node2attribute.shape[0] > 0.5:
@@ -411,7 +505,8 @@ class SAFE:
             else:
                 self.compute_pvalues_by_randomization(_attr=attr, **kwargs)
         finally:
-            attr.close()
+            if resident is None:
+                attr.close()
 
         # safe.py:468-472 -- computed by the same kernels, from the same nes
         self.nes_binary, enriched = self._pending_binary

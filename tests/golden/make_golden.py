@@ -141,6 +141,157 @@ def make_domains(safe, safe_io, nx, pd):
     np.savez_compressed(os.path.join(HERE, 'domains.npz'), **out)
 
 
+def make_io(safe, safe_io, nx, pd):
+    """The callers / data formats either side of the path, run through the real
+    reference: `.scatter` networks with their Euclidean pseudo-network (safe.py:296-309),
+    `calculate_edge_lengths` on weighted edges (safe_io.py:311-333) and `read_attributes`
+    (safe_io.py:336-430) for text, gzip and DataFrame inputs.  Files are stored as raw bytes."""
+    import gzip
+    import tempfile
+    import time
+    import warnings
+    warnings.simplefilter('ignore')
+    rng = np.random.default_rng(77)
+    out = {}
+    tmp = tempfile.mkdtemp()
+
+    # ---- .scatter network --------------------------------------------------------------------
+    n = 180
+    xy = clustered_layout(rng, n) * np.array([3.0, 1.0]) + np.array([-1.0, 0.25])   # x and y extents differ
+    lines = ['key\tx\ty\tlabel']
+    for i in range(n):
+        lines.append('K%03d\t%.6f\t%.6f\tgene%d' % (i, xy[i, 0], xy[i, 1], i))
+    text = ('\n'.join(lines) + '\n').encode()
+    path = os.path.join(tmp, 'points.scatter')
+    with open(path, 'wb') as f:
+        f.write(text)
+    out['scatter_file'] = np.frombuffer(text, dtype=np.uint8)
+    sf = safe.SAFE(verbose=False)
+    sf.neighborhood_radius = 0.07
+    sf.load_network(network_file=path, node_key_attribute='key')
+    out['scatter_x'] = np.array([v for _, v in sf.graph.nodes.data('x')], dtype=np.float64)
+    out['scatter_y'] = np.array([v for _, v in sf.graph.nodes.data('y')], dtype=np.float64)
+    out['scatter_node_key'] = np.array(list(sf.nodes['key']))
+    out['scatter_node_label'] = np.array(list(sf.nodes['label']))
+    out['scatter_node_id'] = np.array(list(sf.nodes['id']), dtype=np.int64)
+    e = np.array(sorted((min(u, v), max(u, v)) for u, v in sf.graph_euclidean.edges()), dtype=np.int64)
+    out['scatter_pseudo_edges'] = e
+    out['scatter_pseudo_weights'] = np.array(sorted(set(d['weight'] for _, _, d in sf.graph_euclidean.edges(data=True))))
+    # whole flow on the scatter network: euclidean neighborhoods, binary attributes, unimodality on the pseudo-network
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.07)
+    out['scatter_neighborhoods'] = sf.neighborhoods.astype(np.int8)
+    m = 30
+    b = np.zeros((n, m))
+    for j in range(m):
+        c = xy[rng.integers(n)]
+        d = np.sqrt(((xy - c) ** 2).sum(1))
+        b[:, j] = (d < rng.uniform(0.1, 0.4)) & (rng.uniform(size=n) < 0.85)
+        if j % 3 == 0:                                   # a second, distant patch: more than one component
+            c2 = xy[rng.integers(n)]
+            b[:, j] = np.maximum(b[:, j], np.sqrt(((xy - c2) ** 2).sum(1)) < 0.15)
+    frame = pd.DataFrame(b, index=['K%03d' % i for i in range(n)], columns=['term %d' % j for j in range(m)])
+    sf.load_attributes(attribute_file=frame)
+    out['scatter_attributes'] = b
+    sf.compute_pvalues()
+    sf.define_top_attributes()
+    out['scatter_nes_binary'] = sf.nes_binary
+    out['scatter_top'] = sf.attributes['top'].values.astype(np.int8)
+    out['scatter_num_cc'] = sf.attributes['num_connected_components'].values.astype(np.int64)
+    out['scatter_num_enriched'] = sf.attributes['num_neighborhoods_enriched'].values.astype(np.float64)
+
+    # ---- calculate_edge_lengths with edge weights (distance x weight; weight 0 -> no length) -----
+    nw = 90
+    xyw = clustered_layout(rng, nw)
+    eu, ev = radius_graph_edges(xyw, 0.12, rng)
+    w = rng.choice([0.0, 1.0, 2.5, 0.3], size=eu.size, p=[0.1, 0.5, 0.2, 0.2])
+    g = nx.Graph()
+    for i in range(nw):
+        g.add_node(i, x=float(xyw[i, 0]), y=float(xyw[i, 1]), label='n%d' % i, label_orf='ORF%d' % i)
+    for u, v, ww in zip(eu, ev, w):
+        g.add_edge(int(u), int(v), weight=float(ww))
+    g.add_edge(5, 5, weight=1.0)                          # a self loop: length 0
+    g = safe_io.calculate_edge_lengths(g, verbose=False)
+    out['wl_xy'] = xyw
+    out['wl_edge_u'] = np.append(eu, 5)
+    out['wl_edge_v'] = np.append(ev, 5)
+    out['wl_weight'] = np.append(w, 1.0)
+    out['wl_length'] = np.array([g.edges[int(u), int(v)].get('length', np.nan)
+                                 for u, v in zip(out['wl_edge_u'], out['wl_edge_v'])], dtype=np.float64)
+
+    # ---- read_attributes ------------------------------------------------------------------------
+    node_order = ['K%03d' % i for i in range(n)]
+    node_order[17] = node_order[3]                        # two network nodes carrying the same key
+    node_order[101] = node_order[100]
+    out['ra_node_order'] = np.array(node_order)
+
+    def file_case(tag, header, rows, gz):
+        body = ('\n'.join(['\t'.join(header)] + ['\t'.join(r) for r in rows]) + '\n').encode()
+        name = os.path.join(tmp, tag + ('.txt.gz' if gz else '.txt'))
+        if gz:
+            with gzip.GzipFile(name, 'wb', mtime=0) as f:
+                f.write(body)
+        else:
+            with open(name, 'wb') as f:
+                f.write(body)
+        out[tag + '_file'] = np.frombuffer(open(name, 'rb').read(), dtype=np.uint8)
+        attributes, order, mat = safe_io.read_attributes(attribute_file=name, node_label_order=list(node_order), verbose=False)
+        out[tag + '_matrix'] = mat
+        out[tag + '_forder'] = np.array([mat.flags['F_CONTIGUOUS'], mat.flags['C_CONTIGUOUS']])
+        out[tag + '_names'] = np.array(list(attributes['name']))
+        out[tag + '_ids'] = attributes['id'].values.astype(np.int64)
+
+    # (a) GO-like binary matrix: labels = a shuffled subset of the keys + labels that are not in the network
+    labels = ['K%03d' % i for i in rng.permutation(n)[:150]] + ['X%02d' % i for i in range(7)]
+    ma = 12
+    rows = []
+    for lab in labels:
+        rows.append([lab] + [str(int(v)) for v in (rng.uniform(size=ma) < 0.15)])
+    file_case('ra_bin', ['ORF'] + ['GO:%07d' % j for j in range(ma)], rows, gz=False)
+
+    # (b) quantitative, gzip: decimals that float32 cannot hold, empty cells, text garbage, duplicate labels (averaged)
+    labels = ['K%03d' % i for i in rng.permutation(n)[:120]] + ['K005', 'K005', 'K040']
+    mb = 9
+    rows = []
+    for lab in labels:
+        vals = []
+        for j in range(mb):
+            u = rng.uniform()
+            if u < 0.05:
+                vals.append('')
+            elif u < 0.08:
+                vals.append('n/a')
+            elif j < 3:
+                vals.append('%.2f' % rng.choice([0.5, 0.25, -1.75, 2.0, 0.0]))       # exactly representable: down-cast to f32
+            elif j < 6:
+                vals.append(repr(float(rng.normal())))
+            else:
+                vals.append('%.4e' % (rng.normal() * 10.0 ** rng.integers(-30, 30)))
+        rows.append([lab] + vals)
+    file_case('ra_q', ['gene'] + ['score %d' % j for j in range(mb)], rows, gz=True)
+
+    # (c) all columns exactly representable in float32 (pandas down-casts the whole frame), with duplicates in the file
+    labels = ['K%03d' % i for i in rng.permutation(n)[:100]] + ['K011', 'K011']
+    rows = [[lab] + ['%.3f' % (rng.integers(-8, 9) / 8.0) for _ in range(5)] for lab in labels]
+    file_case('ra_f32', ['gene'] + ['c%d' % j for j in range(5)], rows, gz=False)
+
+    # (d) DataFrame input, fill_value=0, mask_duplicates with a seeded global RNG
+    frame = pd.DataFrame(rng.normal(size=(140, 6)), index=['K%03d' % i for i in rng.permutation(n)[:140]],
+                         columns=['a', 'b', 'c', 'd', 'e', 'f'])
+    out['ra_df_values'] = frame.values.copy()
+    out['ra_df_index'] = np.array(list(frame.index))
+    np.random.seed(3)
+    attributes, order, mat = safe_io.read_attributes(attribute_file=frame.copy(), node_label_order=list(node_order),
+                                                     mask_duplicates=True, fill_value=0, verbose=False)
+    out['ra_df_matrix'] = mat
+    out['ra_df_forder'] = np.array([mat.flags['F_CONTIGUOUS'], mat.flags['C_CONTIGUOUS']])
+    out['ra_df_names'] = np.array(list(attributes['name']))
+    # (e) no node order given: the file's own (sorted-unique after averaging) order
+    attributes, order, mat = safe_io.read_attributes(attribute_file=frame.copy(), verbose=False)
+    out['ra_df_noorder_matrix'] = mat
+    out['ra_df_noorder_order'] = np.array(list(order))
+    np.savez_compressed(os.path.join(HERE, 'io.npz'), **out)
+
+
 def main():
     import networkx as nx
     import pandas as pd
@@ -279,10 +430,17 @@ def main():
     np.savez_compressed(os.path.join(HERE, 'rng_kat.npz'), **kat)
 
     make_domains(safe, safe_io, nx, pd)
+    make_io(safe, safe_io, nx, pd)
 
-    for f in ('neighborhoods.npz', 'enrichment.npz', 'rng_kat.npz', 'domains.npz'):
+    for f in ('neighborhoods.npz', 'enrichment.npz', 'rng_kat.npz', 'domains.npz', 'io.npz'):
         print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')
 
 
 if __name__ == '__main__':
-    main()
+    if len(sys.argv) > 1 and sys.argv[1] == 'io':          # only the io vectors (the others stay as committed)
+        import networkx
+        import pandas
+        _safe, _extras, _io = import_reference()
+        make_io(_safe, _io, networkx, pandas)
+    else:
+        main()
