@@ -10,6 +10,8 @@ from ._lib import SafeHipError, LIB_PATH, device_count
 from .backend import Context, Neighborhoods, Attributes, Permutations
 from .safe import SAFE, LayoutGraph
 from .safe_extras import compute_neighborhood_score, run_permutations
+from .safe_io import calculate_edge_lengths, read_attributes, load_network_from_scatter, euclidean_pseudo_network
 
-__all__ = ['SAFE', 'LayoutGraph', 'compute_neighborhood_score', 'run_permutations', 'Context', 'Neighborhoods',
+__all__ = ['SAFE', 'LayoutGraph', 'compute_neighborhood_score', 'run_permutations', 'calculate_edge_lengths',
+           'read_attributes', 'load_network_from_scatter', 'euclidean_pseudo_network', 'Context', 'Neighborhoods',
            'Attributes', 'Permutations', 'SafeHipError', 'LIB_PATH', 'device_count']

@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <cstdarg>
+#include <cmath>
 #include <cstdint>
 #include <cstdio>
 #include <cstdlib>
@@ -148,12 +149,25 @@ struct safe_nbr {
 struct HypLookup {
     const int32_t *nid;        // [n] index of the row's neighborhood size among the distinct sizes
     const int32_t *kid;        // [mloc] index of the column's annotation count among the distinct counts
-    const double *tab;         // [n_nid][n_kid][xs]
+    const double2 *tab;        // [n_nid][n_kid][xs] of (p, -log10 p)
     int64_t n_kid, xs;
-    double nes_threshold;
+    double p_cut;              // binarisation as a bound on p (nes_p_cut)
     double *pvalues_pos, *nes, *nes_binary;
     unsigned int *enriched;
 };
+
+// |nes| > -log10(enrichment_threshold) (safe.py:468-470) for nes = -log10(p), p in [0, 1], restated as a
+// bound on p itself: hit <=> p < p_cut with p_cut = the smallest double whose -log10 (host libm, the one
+// NumPy calls) does NOT exceed the threshold.  log10 is monotone, so the decision for a given p is the
+// reference's whatever the device's own log10 rounds to.
+static inline double nes_p_cut(double enrichment_threshold) {
+    const double thr = -std::log10(enrichment_threshold);
+    auto hit = [&](double p) { return -std::log10(p) > thr; };
+    double p = enrichment_threshold;
+    for (int it = 0; it < 4096 && hit(p); ++it) p = std::nextafter(p, 1.0);
+    for (int it = 0; it < 4096 && !hit(std::nextafter(p, 0.0)); ++it) p = std::nextafter(p, 0.0);
+    return p;
+}
 
 // outputs of the permutation-test kernels (enrich.hip, mfma.hip)
 struct PermOut {

@@ -1141,10 +1141,10 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
         for (int r = 0; r < 64; ++r) {
             const int32_t rr = sell_row[s * 64 + r];                    // wave-uniform
             if (rr < 0 || !col_ok) continue;
-            const double *slab = hl.tab + static_cast<int64_t>(hl.nid[rr]) * hl.n_kid * hl.xs;
-            const double p = slab[kofs + tile[r][lane]];
-            const double nes = -log10(p);                               // safe.py:608
-            const bool hit = (nes == nes) && (fabs(nes) > hl.nes_threshold);   // safe.py:468-470
+            const double2 *slab = hl.tab + static_cast<int64_t>(hl.nid[rr]) * hl.n_kid * hl.xs;
+            const double2 e = slab[kofs + tile[r][lane]];
+            const double p = e.x, nes = e.y;                            // p and -log10 p (safe.py:608), both from the table
+            const bool hit = p < hl.p_cut;                              // safe.py:468-470 (nes_p_cut)
             const int64_t o = static_cast<int64_t>(rr) * mloc + jc;
             hl.pvalues_pos[o] = p;
             hl.nes[o] = nes;
@@ -1155,51 +1155,93 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
     }
 }
 
-// tab[nid][kid][x] = P[H >= x] for H ~ Hypergeom(pop, K = kvals[kid], n = nvals[nid]), x = 0 .. xs-1, with
-// the support rules of scipy's rv_discrete.sf (below the support 1, above it 0).  One thread per (n, K)
-// pair: pmf outwards from the mode by the term recurrence (no underflow at the start), then the tail
-// sums from the top down (smallest terms first).
+// double-double helpers of the table kernel (error-free transformations; the TU is built with
+// -ffp-contract=off, every fma below is explicit)
+struct dd_t {
+    double hi, lo;
+};
+__device__ __forceinline__ dd_t dd_fast_two_sum(double a, double b) {
+    const double s = a + b;
+    return {s, b - (s - a)};
+}
+__device__ __forceinline__ dd_t dd_add(dd_t x, dd_t y) {
+    const double s = x.hi + y.hi, bb = s - x.hi;
+    const double e = ((x.hi - (s - bb)) + (y.hi - bb)) + (x.lo + y.lo);
+    return dd_fast_two_sum(s, e);
+}
+__device__ __forceinline__ dd_t dd_mul_d(dd_t x, double d) {
+    const double p = x.hi * d;
+    const double e = fma(x.lo, d, fma(x.hi, d, -p));
+    return dd_fast_two_sum(p, e);
+}
+__device__ __forceinline__ dd_t dd_div_d(dd_t x, double d) {
+    const double r = fast_rcp(d), q1 = x.hi * r, p = q1 * d;
+    const double rem = ((x.hi - p) - fma(q1, d, -p)) + x.lo;            // x - q1 * d, exactly enough
+    return dd_fast_two_sum(q1, rem * r);
+}
+__device__ __forceinline__ double dd_ratio(dd_t a, dd_t b) {            // a / b rounded to double
+    const double r = fast_rcp(b.hi), q1 = a.hi * r;
+    const dd_t prod = dd_mul_d(b, q1);
+    const double rem = ((a.hi - prod.hi) - prod.lo) + a.lo;
+    return q1 + rem * r;
+}
+
+// tab[nid][kid][x] = (p, -log10 p) with p = P[H >= x] for H ~ Hypergeom(pop, K = kvals[kid], n = nvals[nid]),
+// x = 0 .. xs-1, with the support rules of scipy's rv_discrete.sf (below the support 1, above it 0).  One
+// thread per (n, K) pair.  The pmf is carried RELATIVE to its value at the mode (term recurrence outwards
+// from the mode, so nothing underflows at the start) in double-double arithmetic; tails are summed from
+// the top down (smallest terms first) and divided by the sum over the whole support, so no log-gamma
+// rounding enters and p is the correctly rounded value except for ties of the last-but-~50th bit.  That
+// matters for the binarisation: p values that are short rationals (9/180 = 0.05 exactly) sit ON the
+// enrichment threshold, and SciPy returns them exactly.
 __global__ __launch_bounds__(64) void k_hyp_table(const int32_t *__restrict__ nvals, int64_t n_nid,
                                                   const int32_t *__restrict__ kvals, int64_t n_kid, int64_t xs, int64_t pop,
-                                                  const double *__restrict__ lf, double *__restrict__ tab) {
+                                                  double2 *__restrict__ tab) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
     if (idx >= n_nid * n_kid) return;
     const int64_t draws = nvals[idx / n_kid], good = kvals[idx % n_kid];
-    double *t_out = tab + idx * xs;
+    double2 *t_out = tab + idx * xs;                                    // scratch first: (hi, lo) of the relative pmf
     const int64_t lo = draws - (pop - good) > 0 ? draws - (pop - good) : 0;
     const int64_t hi = good < draws ? good : draws;
     const double good_d = static_cast<double>(good), draws_d = static_cast<double>(draws);
     const double rest_d = static_cast<double>(pop) - good_d - draws_d;
     int64_t mode = static_cast<int64_t>(floor(static_cast<double>(good + 1) * static_cast<double>(draws + 1) / static_cast<double>(pop + 2)));
     mode = mode < lo ? lo : (mode > hi ? hi : mode);
-    const double pm = exp(hyp_logpmf(lf, mode, pop, good, draws));
-    // pmf(t) for t < xs goes to the table first; everything at or beyond xs is summed into `beyond`
-    double beyond = 0.0, term = pm, td = static_cast<double>(mode);
+    // terms at or beyond xs are only summed (`beyond`); `below` collects the terms under the table's reach
+    dd_t beyond{0.0, 0.0}, total{0.0, 0.0}, term{1.0, 0.0};
+    double td = static_cast<double>(mode);
     for (int64_t t = mode; t <= hi; ++t) {                              // upwards from the mode
-        if (t < xs) t_out[t] = term;
-        else beyond += term;
-        if (term == 0.0 && t >= xs) break;
-        term = term * ((good_d - td) * (draws_d - td)) * fast_rcp((td + 1.0) * (rest_d + td + 1.0));
+        if (t < xs) t_out[t] = make_double2(term.hi, term.lo);
+        else beyond = dd_add(beyond, term);
+        total = dd_add(total, term);
+        if (term.hi == 0.0 && t >= xs) break;
+        term = dd_mul_d(dd_mul_d(term, good_d - td), draws_d - td);
+        term = dd_div_d(dd_div_d(term, td + 1.0), rest_d + td + 1.0);
         td += 1.0;
     }
-    term = pm;
+    term = dd_t{1.0, 0.0};
     td = static_cast<double>(mode);
     for (int64_t t = mode - 1; t >= lo; --t) {                          // downwards from the mode
-        term = term * (td * (rest_d + td)) * fast_rcp((good_d - td + 1.0) * (draws_d - td + 1.0));
+        term = dd_mul_d(dd_mul_d(term, td), rest_d + td);
+        term = dd_div_d(dd_div_d(term, good_d - td + 1.0), draws_d - td + 1.0);
         td -= 1.0;
-        if (t < xs) t_out[t] = term;
-        else beyond += term;
+        if (t < xs) t_out[t] = make_double2(term.hi, term.lo);
+        else beyond = dd_add(beyond, term);
+        total = dd_add(total, term);
     }
-    double running = beyond;
+    dd_t running = beyond;
     for (int64_t t = xs - 1; t >= 0; --t) {
+        double p;
         if (t > hi) {
-            t_out[t] = 0.0;                                             // sf(x - 1) with x - 1 >= top of the support
+            p = 0.0;                                                    // sf(x - 1) with x - 1 >= top of the support
         } else if (t <= lo) {
-            t_out[t] = 1.0;                                             // x - 1 below the support
+            p = 1.0;                                                    // x - 1 below the support
         } else {
-            running += t_out[t];
-            t_out[t] = running > 1.0 ? 1.0 : running;
+            running = dd_add(running, dd_t{t_out[t].x, t_out[t].y});
+            p = dd_ratio(running, total);
+            p = p > 1.0 ? 1.0 : p;
         }
+        t_out[t] = make_double2(p, -log10(p));                          // safe.py:608
     }
 }
 
@@ -1454,7 +1496,7 @@ __device__ double hyp_sf(const double *__restrict__ lf, double x_hits, double po
 __global__ __launch_bounds__(256) void k_hypergeom_tail(const double *__restrict__ hits, const double *__restrict__ nb_size,
                                                         const double *__restrict__ col_sum, int64_t col0, int64_t n,
                                                         int64_t mloc, double pop, const double *__restrict__ lf,
-                                                        double nes_threshold, double *__restrict__ pvalues_pos,
+                                                        double p_cut, double *__restrict__ pvalues_pos,
                                                         double *__restrict__ nes_out, double *__restrict__ nes_binary,
                                                         unsigned int *__restrict__ enriched) {
     // 2-D: x over columns (coalesced), y over rows
@@ -1465,7 +1507,7 @@ __global__ __launch_bounds__(256) void k_hypergeom_tail(const double *__restrict
     if (c < mloc) {
         const double p = hyp_sf(lf, hits[i * mloc + c], pop, col_sum[col0 + c], nb_size[i]);
         const double nes = -log10(p);                       // safe.py:608
-        hit = (nes == nes) && (fabs(nes) > nes_threshold);  // safe.py:468-470
+        hit = p < p_cut;                                    // safe.py:468-470 (nes_p_cut)
         pvalues_pos[i * mloc + c] = p;
         nes_out[i * mloc + c] = nes;
         nes_binary[i * mloc + c] = hit ? 1.0 : 0.0;
@@ -1941,7 +1983,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 // memory).  *fused = false (nothing launched) when the table would be too large or K is not an
 // integer (scipy then returns NaN: the per-element kernel reproduces that).
 static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, int64_t pop,
-                           const double *d_lf, const double *d_size, double nes_threshold, double *p_dev, double *nes_dev,
+                           const double *d_size, double p_cut, double *p_dev, double *nes_dev,
                            double *nb_dev, unsigned int *d_enr, bool *fused) {
     *fused = false;
     const char *force = getenv("SAFE_HIP_HYPER_TABLE");
@@ -1979,13 +2021,13 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     }
     const int64_t xs = std::min(max_n, max_k) + 1;                      // X <= min(K, n)
     const int64_t n_nid = static_cast<int64_t>(nvals.size()), n_kid = static_cast<int64_t>(kvals.size());
-    const double table_bytes = static_cast<double>(n_nid) * n_kid * xs * sizeof(double);
+    const double table_bytes = static_cast<double>(n_nid) * n_kid * xs * sizeof(double2);
     const double direct_cost = static_cast<double>(n) * mloc;          // elements the per-element kernel would evaluate
     if (table_bytes > 512e6 || static_cast<double>(n_nid) * n_kid * 4.0 > direct_cost) return SAFE_OK;
 
-    double *d_tab = nullptr;
+    double2 *d_tab = nullptr;
     int32_t *d_ids = nullptr;
-    SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n_nid) * n_kid * xs * sizeof(double), reinterpret_cast<void **>(&d_tab)));
+    SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n_nid) * n_kid * xs * sizeof(double2), reinterpret_cast<void **>(&d_tab)));
     SAFE_TRY(ctx_scratch(ctx, 6, static_cast<size_t>(n_nid + n_kid + n + mloc) * sizeof(int32_t), reinterpret_cast<void **>(&d_ids)));
     int32_t *d_nvals = d_ids, *d_kvals = d_nvals + n_nid, *d_nid = d_kvals + n_kid, *d_kid = d_nid + n;
     SAFE_HIP_CHECK(hipMemcpyAsync(d_nvals, nvals.data(), n_nid * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
@@ -1993,7 +2035,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     SAFE_HIP_CHECK(hipMemcpyAsync(d_nid, nid.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_kid, kid.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
     hipLaunchKernelGGL(k_hyp_table, dim3(ceil_div(n_nid * n_kid, 64)), dim3(64), 0, ctx->stream, d_nvals, n_nid, d_kvals, n_kid, xs,
-                       pop, d_lf, d_tab);
+                       pop, d_tab);
 
     const int64_t n_wg = ceil_div(mloc, 64);
     uint2 *d_bits = nullptr;
@@ -2008,7 +2050,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.tab = d_tab;
     hl.n_kid = n_kid;
     hl.xs = xs;
-    hl.nes_threshold = nes_threshold;
+    hl.p_cut = p_cut;
     hl.pvalues_pos = p_dev;
     hl.nes = nes_dev;
     hl.nes_binary = nb_dev;
@@ -2233,7 +2275,7 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col,
                            attr->row_flags, n, d_size);
-        if (bits) rc = hypergeom_fused(ctx, nbr, attr, col0, col1, pop, d_lf, d_size, -std::log10(enrichment_threshold),
+        if (bits) rc = hypergeom_fused(ctx, nbr, attr, col0, col1, pop, d_size, nes_p_cut(enrichment_threshold),
                                        pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr, &fused);
     }
     if (rc == SAFE_OK && !fused) {
@@ -2246,7 +2288,7 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
             SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
             hipLaunchKernelGGL(k_hypergeom_tail, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_hits,
                                d_size, attr->col_sum, col0, n, mloc, static_cast<double>(pop), d_lf,
-                               -std::log10(enrichment_threshold), pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr);
+                               nes_p_cut(enrichment_threshold), pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr);
             SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
             ctx->last_kernel.name = "k_hypergeom_tail";
         }

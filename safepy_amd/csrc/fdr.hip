@@ -66,7 +66,7 @@ __global__ __launch_bounds__(256) void k_fdr_row(const double *__restrict__ ps, 
 // NES / binarisation from (adjusted) p-values; n_perm == 0: hypergeometric form nes = -log10(p_pos)
 __global__ __launch_bounds__(256) void k_nes_from_pvalues(const double *__restrict__ p_neg, const double *__restrict__ p_pos,
                                                           int64_t n, int64_t m, double inv_perm, int sign_mode,
-                                                          double nes_threshold, double *__restrict__ nes_out,
+                                                          double nes_threshold, double p_cut, double *__restrict__ nes_out,
                                                           double *__restrict__ nes_binary, unsigned int *__restrict__ enriched) {
     const int64_t c = static_cast<int64_t>(blockIdx.x) * 64 + (threadIdx.x & 63);
     const int64_t i0 = static_cast<int64_t>(blockIdx.y) * 64 + (threadIdx.x >> 6);
@@ -75,14 +75,20 @@ __global__ __launch_bounds__(256) void k_nes_from_pvalues(const double *__restri
     for (int64_t i = i0; i < n && i < (static_cast<int64_t>(blockIdx.y) + 1) * 64; i += 4) {
         const int64_t o = i * m + c;
         double nes;
+        bool hit;
+        // where the NES is one logarithm, the binarisation is decided on p itself (nes_p_cut, common.h):
+        // the device's log10 may round differently from the host libm the reference calls
         if (inv_perm == 0.0) {
             nes = -log10(p_pos[o]);                                  // safe.py:608
+            hit = p_pos[o] < p_cut;                                  // safe.py:468-470
         } else {                                                     // safe.py:546-554
-            const double pp = p_pos[o], pn = p_neg[o];
-            const double ep = -log10(pp == 0.0 ? inv_perm : pp), en = -log10(pn == 0.0 ? inv_perm : pn);
+            const double pp = p_pos[o] == 0.0 ? inv_perm : p_pos[o], pn = p_neg[o] == 0.0 ? inv_perm : p_neg[o];
+            const double ep = -log10(pp), en = -log10(pn);
             nes = sign_mode == SAFE_SIGN_HIGHEST ? ep : sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
+            hit = sign_mode == SAFE_SIGN_HIGHEST ? pp < p_cut
+                  : sign_mode == SAFE_SIGN_LOWEST ? pn < p_cut
+                                                  : (nes == nes) && (fabs(nes) > nes_threshold);
         }
-        const bool hit = (nes == nes) && (fabs(nes) > nes_threshold);   // safe.py:468-470
         nes_out[o] = nes;
         nes_binary[o] = hit ? 1.0 : 0.0;
         hits += hit;
@@ -160,7 +166,7 @@ extern "C" int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_
     SAFE_HIP_CHECK(hipMemsetAsync(d_enr, 0, m * sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(k_nes_from_pvalues, dim3(ceil_div(m, 64), ceil_div(n, 64)), dim3(256), 0, ctx->stream, pvalues_neg_dev,
                        pvalues_pos_dev, n, m, num_permutations > 0 ? 1.0 / static_cast<double>(num_permutations) : 0.0, sign_mode,
-                       -std::log10(enrichment_threshold), nes_dev, nes_binary_dev, d_enr);
+                       -std::log10(enrichment_threshold), nes_p_cut(enrichment_threshold), nes_dev, nes_binary_dev, d_enr);
     hipLaunchKernelGGL(k_fdr_u32_to_f64, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, m);
     hipError_t e = hipGetLastError();
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);

@@ -435,23 +435,22 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     unsigned int hits = 0;
 #pragma unroll
                     for (int half = 0; half < 2; ++half) {
-                        double val[8];
+                        double2 val[8];
 #pragma unroll
                         for (int rr = 0; rr < 8; ++rr) {
                             const int r = half * 8 + rr;
                             val[rr] = hl.tab ? hl.tab[slab[r] + kofs + ((col_ok && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) : 0u)]
-                                             : static_cast<double>(acc[s][r]);
+                                             : make_double2(static_cast<double>(acc[s][r]), 0.0);
                         }
 #pragma unroll
                         for (int rr = 0; rr < 8; ++rr) {
                             const int r = half * 8 + rr;
                             if (!col_ok || node[r] < 0) continue;
                             const int64_t o = static_cast<int64_t>(node[r]) * mloc + col;
-                            hl.pvalues_pos[o] = val[rr];
+                            hl.pvalues_pos[o] = val[rr].x;
                             if (hl.tab) {
-                                const double nes = -log10(val[rr]);                          // safe.py:608
-                                const bool hit = (nes == nes) && (fabs(nes) > hl.nes_threshold);   // safe.py:468-470
-                                hl.nes[o] = nes;
+                                const bool hit = val[rr].x < hl.p_cut;                      // safe.py:468-470 (nes_p_cut)
+                                hl.nes[o] = val[rr].y;                                      // -log10 p from the table (safe.py:608)
                                 hl.nes_binary[o] = hit ? 1.0 : 0.0;
                                 hits += hit;
                             }

@@ -337,6 +337,55 @@ def test_midsize_hypergeometric_vs_oracle(amd, ctx, monkeypatch, counts):
     np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['num_neighborhoods_enriched'])
 
 
+@pytest.mark.parametrize('counts', ['bits', 'mfma'])
+def test_hypergeometric_p_on_the_threshold(amd, ctx, monkeypatch, counts):
+    """p-values that sit exactly ON the enrichment threshold: a singleton attribute (K = 1) gives
+    p = n / N, which is 0.05 for n = 9 of N = 180 -- SciPy returns 0.05 exactly and the reference
+    calls such a neighborhood NOT enriched (`>` at safe.py:470).  The table kernel carries the tail in
+    double-double and divides by the sum over the support, so p comes out correctly rounded; the
+    binarisation is decided on p (common.h nes_p_cut), not on the device's log10.  Table p-values
+    are within a few ulp of the exact rational value (SciPy itself is up to ~25 ulp off it)."""
+    from fractions import Fraction
+    from math import comb
+    monkeypatch.setenv('SAFE_HIP_COUNTS', counts)
+    n = 360 if counts == 'mfma' else 180
+    rng = np.random.default_rng(9)
+    # a ring of nodes: node i's neighborhood = the 9 (18) nodes around it -> n_i / N = 0.05 exactly
+    width = n // 20
+    a = np.zeros((n, n), dtype=np.int64)
+    for i in range(n):
+        a[i, (i + np.arange(width) - width // 2) % n] = 1
+    b = np.zeros((n, 12))
+    b[rng.choice(n, 12, replace=False), np.arange(12)] = 1          # singletons: K = 1
+    b[:, 10] = rng.uniform(size=n) < 0.1
+    b[:, 11] = rng.uniform(size=n) < 0.3
+    want = orc.compute_pvalues(a, b.copy())
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(rng.uniform(size=(n, 2)))
+    sf.neighborhoods = a
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues()
+    assert ctx.last_kernel()[0] == {'bits': 'k_counts_bits<hypergeom>', 'mfma': 'k_permtest_mfma<counts>'}[counts]
+    on_threshold = want['pvalues_pos'] == 0.05
+    assert on_threshold.sum() >= 10 * width
+    assert np.array_equal(sf.pvalues_pos[on_threshold], want['pvalues_pos'][on_threshold])
+    assert not sf.nes_binary[on_threshold].any() and not want['nes_binary'][on_threshold].any()
+    np.testing.assert_array_equal(sf.nes_binary, want['nes_binary'])
+    np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-13, atol=0)
+    # against the exact rational tail
+    x = a @ b
+    k_col = b.sum(axis=0).astype(int)
+    worst = 0.0
+    for i in range(0, n, 7):
+        for j in range(12):
+            hi = min(k_col[j], width)
+            num = sum(comb(int(k_col[j]), t) * comb(n - int(k_col[j]), width - t) for t in range(int(x[i, j]), hi + 1))
+            exact = float(Fraction(num, comb(n, width)))
+            if exact > 0:
+                worst = max(worst, abs(sf.pvalues_pos[i, j] - exact) / np.spacing(exact))
+    assert worst <= 1.0, worst
+
+
 def test_torch_tensors_share_the_hip_runtime(amd, ctx):
     """Device pointers of torch tensors are usable by the library (one HIP runtime per
     process, see safepy_amd/_lib.py) and torch sees the library's results."""
