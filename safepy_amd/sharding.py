@@ -182,3 +182,56 @@ def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, 
     finally:
         perms.close()
         attr.close()
+
+
+def sharded_hypergeom(ctx, nbr, local_attr_host, m_total, global_flags, enrichment_threshold=0.05, group=None,
+                      gather=('nes',)):
+    """compute_pvalues_by_hypergeom for this rank's column block.  The population N
+    (safe.py:574-578) and the neighborhood sizes count the rows holding a value in ANY column of
+    the full matrix, so the flags of the whole matrix are installed before the kernels run."""
+    import torch
+    from . import backend as be
+    attr = be.Attributes.from_host(ctx, local_attr_host)
+    n, mloc = attr.n, attr.m
+    attr.stats()
+    attr.set_row_flags(global_flags)
+    names = ('pvalues_pos', 'nes', 'nes_binary')
+    dev = torch.device('cuda', ctx.device)
+    bufs = {k: torch.empty((n, mloc), dtype=torch.float64, device=dev) for k in names}
+    enriched = torch.empty((mloc,), dtype=torch.float64, device=dev)
+    try:
+        torch.cuda.current_stream().synchronize()
+        be.hypergeom(ctx, nbr, attr, enrichment_threshold, [bufs[k].data_ptr() for k in names] + [enriched.data_ptr()])
+        ctx.sync()
+        out = {k: v.cpu().numpy() for k, v in bufs.items()}
+        out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
+        for k in gather:
+            out['full_' + k] = gather_columns(bufs[k], m_total, group).cpu().numpy()
+        return out
+    finally:
+        attr.close()
+
+
+def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type='auto', num_permutations=1000,
+                            random_seed=None, neighborhood_score_type='sum', attribute_sign='both',
+                            enrichment_threshold=0.05, group=None, gather=('nes',)):
+    """SAFE.compute_pvalues (safe.py:432-472) over attribute shards with WHOLE-MATRIX semantics:
+    the 'auto' rule (safe.py:461-463) looks at every column of the full matrix (one all-gather of
+    the per-shard statistics), so all ranks take the same branch and the result equals the
+    single-process call on the unsplit matrix -- unlike the reference's CLI (safe.py:1321-1361),
+    whose worker processes each decide for their own chunk."""
+    from . import backend as be
+    probe = be.Attributes.from_host(ctx, local_attr_host)
+    try:
+        flags, stats = reduce_flags_and_stats(probe.row_flags(), probe.stats(), group)
+    finally:
+        probe.close()
+    if (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and stats['n_other'] == 0):
+        out = sharded_hypergeom(ctx, nbr, local_attr_host, m_total, flags, enrichment_threshold, group, gather)
+        out['how'] = 'hypergeometric'
+    else:
+        out = sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
+                                    neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather)
+        out['how'] = 'randomization'
+    out['stats'] = stats
+    return out

@@ -232,3 +232,78 @@ def test_resident_attributes_equal_uploaded(amd, g, tmp_path):
         assert b._resident_attributes() is None
         b.compute_pvalues(background=background)
         assert np.array_equal(a.nes, b.nes, equal_nan=True)
+
+
+# ------------------------------------------------------------------ batch driver (CLI) ----
+def _batch_inputs(g, tmp_path, quantitative):
+    net = _write(tmp_path, 'points.scatter', g['scatter_file'])
+    n = len(g['scatter_x'])
+    rng = np.random.default_rng(8)
+    m = 23
+    keys = ['K%03d' % i for i in range(n)]
+    if quantitative:
+        rows = [[k] + ['%.4f' % v for v in rng.normal(size=m)] for k in keys[:170]]
+    else:
+        rows = [[k] + [str(int(v)) for v in (rng.uniform(size=m) < 0.2)] for k in keys[:170]]
+    body = '\n'.join(['\t'.join(['ORF'] + ['t%d' % j for j in range(m)])] + ['\t'.join(r) for r in rows]) + '\n'
+    attr = _write(tmp_path, 'attrs_q.txt' if quantitative else 'attrs_b.txt', body.encode())
+    return net, attr
+
+
+@pytest.mark.parametrize('quantitative', [False, True])
+def test_run_batch_single_gpu_equals_safe(amd, g, tmp_path, quantitative):
+    """python -m safepy_amd.run_batch on one GPU writes <attribute_file>_safe_nes.p (safe.py:1357)
+    holding the NES matrix SAFE.compute_pvalues produces for the same inputs."""
+    import pickle
+    from safepy_amd import run_batch
+    net, attr = _batch_inputs(g, tmp_path, quantitative)
+    assert run_batch.main([attr, '--network', net, '--radius', '0.07', '--permutations', '50', '--seed', '5']) == 0
+    with open(attr + '_safe_nes.p', 'rb') as f:
+        got = pickle.load(f)
+    sf = amd.SAFE(verbose=False)
+    sf.random_seed = 5
+    sf.neighborhood_radius = 0.07
+    sf.load_network(network_file=net, node_key_attribute='key')
+    sf.define_neighborhoods(node_distance_metric='euclidean')
+    sf.load_attributes(attribute_file=attr)
+    sf.compute_pvalues(num_permutations=50)
+    assert (sf.pvalues_neg is None) == (not quantitative)      # binary -> hypergeometric, quantitative -> permutations
+    assert np.array_equal(got, sf.nes, equal_nan=True)
+    want = orc.compute_pvalues(sf.neighborhoods, sf.node2attribute.copy(), num_permutations=50, random_seed=5)
+    np.testing.assert_allclose(got, want['nes'], rtol=1e-6, atol=1e-9)
+
+
+@pytest.mark.parametrize('quantitative', [False, True])
+def test_sharded_compute_pvalues_one_rank_rccl(amd, g, tmp_path, quantitative):
+    """sharding.sharded_compute_pvalues over a one-rank RCCL group == SAFE.compute_pvalues (both
+    branches of the whole-matrix 'auto' rule, the collectives really run)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from safepy_amd import sharding
+    net, attr = _batch_inputs(g, tmp_path, quantitative)
+    sf = amd.SAFE(verbose=False)
+    sf.random_seed = 11
+    sf.neighborhood_radius = 0.07
+    sf.load_network(network_file=net, node_key_attribute='key', pseudo_network='arrays')
+    sf.define_neighborhoods(node_distance_metric='euclidean')
+    sf.load_attributes(attribute_file=attr)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        out = sharding.sharded_compute_pvalues(sf._ctx(), sf._device_neighborhoods(), np.ascontiguousarray(sf.node2attribute),
+                                               sf.node2attribute.shape[1], num_permutations=40, random_seed=11,
+                                               gather=('nes', 'nes_binary'))
+    finally:
+        dist.destroy_process_group()
+    sf.compute_pvalues(num_permutations=40)
+    assert out['how'] == ('randomization' if quantitative else 'hypergeometric')
+    assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+    assert np.array_equal(out['full_nes_binary'], sf.nes_binary, equal_nan=True)
+    assert np.array_equal(out['num_neighborhoods_enriched'], sf.attributes['num_neighborhoods_enriched'].values)
