@@ -330,7 +330,7 @@ def main():
                          'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3)},
             'kernel_share_of_step': k_ms * launches / ms_per_step,
         }
-        if args.cpu_perms > 0:
+        if args.cpu_perms > 0 and world == 1:                 # the CPU leg runs on rank 0 at N = 1 only
             a_dense = sf.neighborhoods
             line['cpu_baseline'] = cpu_baseline(a_dense, b_host, args.cpu_perms)
             line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']

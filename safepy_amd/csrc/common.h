@@ -152,6 +152,7 @@ struct HypLookup {
     const double2 *tab;        // [n_nid][n_kid][xs] of (p, -log10 p)
     int64_t n_kid, xs;
     double p_cut;              // binarisation as a bound on p (nes_p_cut)
+    double *dummy;             // [64] write-only slots for the padding rows / columns of branch-free epilogues
     double *pvalues_pos, *nes, *nes_binary;
     unsigned int *enriched;
 };

@@ -2051,6 +2051,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.n_kid = n_kid;
     hl.xs = xs;
     hl.p_cut = p_cut;
+    SAFE_TRY(ctx_scratch(ctx, 7, 64 * sizeof(double), reinterpret_cast<void **>(&hl.dummy)));
     hl.pvalues_pos = p_dev;
     hl.nes = nes_dev;
     hl.nes_binary = nb_dev;

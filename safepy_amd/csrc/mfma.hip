@@ -427,36 +427,70 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     slab[r] = (hl.tab && node[r] >= 0) ? static_cast<uint32_t>(hl.nid[node[r]]) * static_cast<uint32_t>(hl.n_kid * hl.xs) : 0u;
+                uint32_t kofs[MF_NS];
+                bool col_ok[MF_NS];
 #pragma unroll
                 for (int s = 0; s < MF_NS; ++s) {
                     const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
-                    const bool col_ok = col < mloc;
-                    const uint32_t kofs = (hl.tab && col_ok) ? static_cast<uint32_t>(hl.kid[col]) * static_cast<uint32_t>(hl.xs) : 0u;
-                    unsigned int hits = 0;
+                    col_ok[s] = col < mloc;
+                    kofs[s] = (hl.tab && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) * static_cast<uint32_t>(hl.xs) : 0u;
+                }
+                if (!hl.tab) {                                        // plain counts ('sum' scores of 0/1 attributes)
 #pragma unroll
-                    for (int half = 0; half < 2; ++half) {
-                        double2 val[8];
+                    for (int s = 0; s < MF_NS; ++s) {
+                        const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
 #pragma unroll
-                        for (int rr = 0; rr < 8; ++rr) {
-                            const int r = half * 8 + rr;
-                            val[rr] = hl.tab ? hl.tab[slab[r] + kofs + ((col_ok && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) : 0u)]
-                                             : make_double2(static_cast<double>(acc[s][r]), 0.0);
-                        }
-#pragma unroll
-                        for (int rr = 0; rr < 8; ++rr) {
-                            const int r = half * 8 + rr;
-                            if (!col_ok || node[r] < 0) continue;
-                            const int64_t o = static_cast<int64_t>(node[r]) * mloc + col;
-                            hl.pvalues_pos[o] = val[rr].x;
-                            if (hl.tab) {
-                                const bool hit = val[rr].x < hl.p_cut;                      // safe.py:468-470 (nes_p_cut)
-                                hl.nes[o] = val[rr].y;                                      // -log10 p from the table (safe.py:608)
-                                hl.nes_binary[o] = hit ? 1.0 : 0.0;
-                                hits += hit;
-                            }
-                        }
+                        for (int r = 0; r < 16; ++r)
+                            if (col_ok[s] && node[r] >= 0)
+                                hl.pvalues_pos[static_cast<int64_t>(node[r]) * mloc + col] = static_cast<double>(acc[s][r]);
                     }
-                    if (hits) atomicAdd(&hl.enriched[col], hits);
+                } else {
+                    // Software pipeline over the 12 (column tile, row half) rounds: the table values of round k+1
+                    // are requested BEFORE the stores of round k are issued.  vmcnt retires in order, so a round
+                    // that gathers only after storing waits for its predecessor's 24 write acknowledgements on
+                    // top of its own gather latency, twelve times per task; in this order the wait for round
+                    // k+1's values lets the stores of round k stay in flight.  The rounds are branch-free
+                    // (padding rows / columns store to a per-lane dummy slot): with branches around the stores
+                    // the compiler's wait-count pass cannot count them and serialises the rounds again.
+                    double *const dummy = hl.dummy + lane;
+                    auto fetch = [&](int s, int half, double2 (&val)[8]) __attribute__((always_inline)) {
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = half * 8 + rr;
+                            val[rr] = hl.tab[slab[r] + kofs[s] + ((col_ok[s] && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) : 0u)];
+                        }
+                    };
+                    unsigned int hits[MF_NS];
+#pragma unroll
+                    for (int s = 0; s < MF_NS; ++s) hits[s] = 0;
+                    auto emit = [&](int s, int half, const double2 (&val)[8]) __attribute__((always_inline)) {
+                        const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+#pragma unroll
+                        for (int rr = 0; rr < 8; ++rr) {
+                            const int r = half * 8 + rr;
+                            const bool ok = col_ok[s] && node[r] >= 0;
+                            const int64_t o = static_cast<int64_t>(node[r]) * mloc + col;
+                            const bool hit = ok && val[rr].x < hl.p_cut;                    // safe.py:468-470 (nes_p_cut)
+                            *(ok ? hl.pvalues_pos + o : dummy) = val[rr].x;
+                            *(ok ? hl.nes + o : dummy) = val[rr].y;                         // -log10 p from the table (safe.py:608)
+                            *(ok ? hl.nes_binary + o : dummy) = hit ? 1.0 : 0.0;
+                            hits[s] += hit;
+                        }
+                    };
+                    double2 va[8], vb[8];
+                    fetch(0, 0, va);
+#pragma unroll
+                    for (int k = 0; k < 2 * MF_NS; k += 2) {
+                        fetch(k >> 1, 1, vb);
+                        emit(k >> 1, 0, va);
+                        if (k + 2 < 2 * MF_NS) fetch((k >> 1) + 1, 0, va);
+                        emit(k >> 1, 1, vb);
+                    }
+#pragma unroll
+                    for (int s = 0; s < MF_NS; ++s) {
+                        const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+                        if (hits[s]) atomicAdd(&hl.enriched[col], hits[s]);
+                    }
                 }
             }
             // ---- task epilogue: observed scores (first span only) and the counters
