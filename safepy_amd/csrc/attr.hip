@@ -19,7 +19,8 @@ template <typename T, int GC>
 __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw, int64_t n, int64_t m,
                                                     int64_t rs, int64_t cs, unsigned int *__restrict__ row_bits,
                                                     unsigned long long *__restrict__ acc /*[4]*/,
-                                                    double *__restrict__ col_sum, unsigned long long *__restrict__ max_abs_bits) {
+                                                    double *__restrict__ col_sum, unsigned long long *__restrict__ max_abs_bits,
+                                                    unsigned int *__restrict__ col_nan, int64_t rows_per_block) {
     extern __shared__ unsigned int s_bits[];           // [ceil(n/32)]
     constexpr int RL = 256 / GC;                       // row lanes per column
     const int cx = GC == 1 ? 0 : (threadIdx.x & (GC - 1));
@@ -30,14 +31,19 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     __shared__ double s_sum[256];
     __shared__ double s_max[256];
     __shared__ unsigned int s_nan[256], s_other[256], s_nonint[256];
-    for (int64_t w = threadIdx.x; w < n_words; w += 256) s_bits[w] = 0;
+    // blockIdx.y: a chunk of rows_per_block rows (a multiple of 64), so that a matrix with few column
+    // groups still fills the chip; per-column sums / NaN counts of the chunks meet in global atomics
+    const int64_t r_begin = static_cast<int64_t>(blockIdx.y) * rows_per_block;
+    const int64_t r_end = r_begin + rows_per_block < n ? r_begin + rows_per_block : n;
+    const int64_t w_begin = r_begin >> 5, w_end = (r_end + 31) >> 5;
+    for (int64_t w = w_begin + threadIdx.x; w < w_end; w += 256) s_bits[w] = 0;
     __syncthreads();
     unsigned int c_nan = 0, c_other = 0, c_nonint = 0;
     double mx = 0.0, sum = 0.0;
-    const int64_t n_round = (n + RL - 1) / RL * RL;    // every thread runs the same trip count (ballots)
-    for (int64_t i = ry; i < n_round; i += RL) {
+    const int64_t n_round = r_begin + (r_end - r_begin + RL - 1) / RL * RL;    // every thread runs the same trip count (ballots)
+    for (int64_t i = r_begin + ry; i < n_round; i += RL) {
         bool has = false;
-        if (i < n && j < m) {
+        if (i < r_end && j < m) {
             const double v = load_attr<T>(raw, i * rs + j * cs);
             if (v != v) {
                 ++c_nan;
@@ -55,12 +61,12 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
             // the wave holds 64 consecutive rows starting at i - lane: two bitmap words, owned by this wave
             const int64_t r0 = i - lane;
             if (lane == 0 && bal) {
-                if (r0 < n) s_bits[r0 >> 5] |= static_cast<unsigned int>(bal);
-                if (r0 + 32 < n) s_bits[(r0 >> 5) + 1] |= static_cast<unsigned int>(bal >> 32);
+                if (r0 < r_end) s_bits[r0 >> 5] |= static_cast<unsigned int>(bal);
+                if (r0 + 32 < r_end) s_bits[(r0 >> 5) + 1] |= static_cast<unsigned int>(bal >> 32);
             }
         } else {
             // the wave holds ONE row (i) across 64 columns
-            if (lane == 0 && bal && i < n) atomicOr(&s_bits[i >> 5], 1u << (i & 31));
+            if (lane == 0 && bal && i < r_end) atomicOr(&s_bits[i >> 5], 1u << (i & 31));
         }
     }
     s_sum[threadIdx.x] = sum;
@@ -69,7 +75,7 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     s_other[threadIdx.x] = c_other;
     s_nonint[threadIdx.x] = c_nonint;
     __syncthreads();
-    for (int64_t w = threadIdx.x; w < n_words; w += 256) {
+    for (int64_t w = w_begin + threadIdx.x; w < w_end; w += 256) {
         const unsigned int mine = s_bits[w];
         if (mine & ~row_bits[w]) atomicOr(&row_bits[w], mine);       // racy pre-check is benign
     }
@@ -84,12 +90,23 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
             t_other += s_other[t];
             t_nonint += s_nonint[t];
         }
-        col_sum[j] = total;
+        if (gridDim.y == 1) col_sum[j] = total;
+        else atomicAdd(&col_sum[j], total);               // integer-valued data (the consumers' case) adds exactly in any order
+        if (t_nan) atomicAdd(&col_nan[j], static_cast<unsigned int>(t_nan));
         if (t_other) atomicAdd(&acc[0], t_other);
-        atomicMax(&acc[1], t_nan);
         if (t_nonint) atomicAdd(&acc[2], t_nonint);
         atomicMax(max_abs_bits, static_cast<unsigned long long>(__double_as_longlong(tmx)));
     }
+}
+
+__global__ __launch_bounds__(256) void k_max_u32(const unsigned int *__restrict__ v, int64_t count, unsigned long long *__restrict__ out) {
+    unsigned int mx = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<int64_t>(gridDim.x) * 256) mx = v[i] > mx ? v[i] : mx;
+    for (int off = 32; off; off >>= 1) {
+        const unsigned int o = __shfl_down(mx, off);
+        mx = o > mx ? o : mx;
+    }
+    if ((threadIdx.x & 63) == 0) atomicMax(out, static_cast<unsigned long long>(mx));
 }
 
 __global__ void k_bits_to_bytes(const unsigned int *__restrict__ bits, int64_t n, uint8_t *__restrict__ bytes) {
@@ -231,26 +248,37 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_HIP_CHECK(hipMemsetAsync(d_rowbits, 0, n_words * sizeof(unsigned int), ctx->stream));
     SAFE_REQUIRE(n_words * sizeof(unsigned int) <= 150 * 1024, "safe_attr_stats: too many rows for the LDS row bitmap");
     if (!attr->col_sum) SAFE_TRY(dev_alloc(&attr->col_sum, m));
+    unsigned int *d_colnan = nullptr;
+    SAFE_TRY(dev_alloc(&d_colnan, m));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_colnan, 0, m * sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(attr->col_sum, 0, m * sizeof(double), ctx->stream));
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
     const bool c_order = attr->col_stride == 1 && m > 1;
-#define STATS(T, GC)                                                                                               \
+#define STATS(T, GC, RPB)                                                                                          \
     do {                                                                                                           \
         if (n_words * sizeof(unsigned int) > 32 * 1024)                                                            \
             SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_attr_stats<T, GC>),                \
                                                hipFuncAttributeMaxDynamicSharedMemorySize,                         \
                                                static_cast<int>(n_words * sizeof(unsigned int))));                 \
-        hipLaunchKernelGGL((k_attr_stats<T, GC>), dim3(ceil_div(m, GC)), dim3(256), n_words * sizeof(unsigned int), \
-                           ctx->stream, attr->raw, n, m, attr->row_stride, attr->col_stride, d_rowbits, d_acc,     \
-                           attr->col_sum, d_acc + 3);                                                              \
+        hipLaunchKernelGGL((k_attr_stats<T, GC>), dim3(ceil_div(m, GC), ceil_div(n, RPB)), dim3(256),              \
+                           n_words * sizeof(unsigned int), ctx->stream, attr->raw, n, m, attr->row_stride,         \
+                           attr->col_stride, d_rowbits, d_acc, attr->col_sum, d_acc + 3, d_colnan,                 \
+                           static_cast<int64_t>(RPB));                                                             \
     } while (0)
     if (c_order) {
-        if (f32) STATS(float, 64);
-        else STATS(double, 64);
+        // a C-order matrix has only m / 64 column groups: split the rows as well until ~2048 workgroups exist
+        const int64_t groups = ceil_div(m, 64);
+        const int64_t want_chunks = std::max<int64_t>(1, 2048 / groups);
+        const int64_t rpb = std::max<int64_t>(256, ceil_div(ceil_div(n, want_chunks), 64) * 64);
+        if (f32) STATS(float, 64, rpb);
+        else STATS(double, 64, rpb);
     } else {
-        if (f32) STATS(float, 1);
-        else STATS(double, 1);
+        if (f32) STATS(float, 1, n);
+        else STATS(double, 1, n);
     }
 #undef STATS
+    hipLaunchKernelGGL(k_max_u32, dim3(static_cast<unsigned>(std::min<int64_t>(ceil_div(m, 256), 64))), dim3(256), 0, ctx->stream,
+                       d_colnan, m, d_acc + 1);
     hipLaunchKernelGGL(k_bits_to_bytes, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_rowbits, n, flags);
     SAFE_HIP_CHECK(hipGetLastError());
     unsigned long long h_acc[4];
@@ -260,6 +288,7 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     (void)hipFree(d_acc);
     (void)hipFree(d_rowbits);
+    (void)hipFree(d_colnan);
     attr->n_other = static_cast<int64_t>(h_acc[0]);
     attr->max_nan_col = static_cast<int64_t>(h_acc[1]);
     attr->n_non_integer = static_cast<int64_t>(h_acc[2]);

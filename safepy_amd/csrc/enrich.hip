@@ -2038,9 +2038,6 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
                        pop, d_tab);
 
     const int64_t n_wg = ceil_div(mloc, 64);
-    uint2 *d_bits = nullptr;
-    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
-    launch_bits_prep(ctx, attr, col0, mloc, n_wg, d_bits);
     const char *counts_env = getenv("SAFE_HIP_COUNTS");
     const bool dense_nbr = nbr->n >= 256 && nbr->nnz >= 128 * nbr->n;       // matrix cores pay off for large neighborhoods
     const bool use_mfma = counts_env ? !strcmp(counts_env, "mfma") : dense_nbr;
@@ -2059,6 +2056,9 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     if (use_mfma) {
         SAFE_TRY(launch_mfma_counts(ctx, nbr, attr, col0, col1, hl));   // records its own timing events
     } else {
+        uint2 *d_bits = nullptr;                                       // bit-packed attributes: only the bit-sliced form reads them
+        SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n_wg) * (n + 1) * sizeof(uint2), reinterpret_cast<void **>(&d_bits)));
+        launch_bits_prep(ctx, attr, col0, mloc, n_wg, d_bits);
         SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
         hipLaunchKernelGGL(k_counts_bits<true>, dim3(nbr->n_slices, n_wg), dim3(64), 0, ctx->stream, nbr->sell_row, nbr->slice_off,
                            nbr->slice_width, nbr->sell_col, n, d_bits, mloc, static_cast<double *>(nullptr), hl);

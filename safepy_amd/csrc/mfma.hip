@@ -30,6 +30,7 @@ namespace {
 
 constexpr int MF_R = 256;             // rows per group = 8 waves x 32
 constexpr int MF_NS = 6;              // i8 slices per value
+constexpr int MF_CN = 6;              // counts form: 32-column tiles per task (one i8 plane each)
 constexpr int MF_SS = 1024 + 16;      // LDS bytes per (k-step, slice): [2 halves][32 lanes][16 B] + 16 B skew
 constexpr int MF_KS = MF_NS * MF_SS;  // LDS bytes per k-step (32 attribute rows)
 constexpr int MF_BUF = 4 * MF_KS;     // one buffer = one super-step = 4 k-steps
@@ -231,28 +232,29 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
 // COUNTS = true : observed counts only, for 0/1 attributes (hypergeometric path, 'sum' scores): the six
 //                 planes of a task are six adjacent 32-column TILES with one plane each, n_q = 1, and
 //                 the epilogue writes through `hl` (table lookup or plain counts).
-template <bool COUNTS>
+template <bool COUNTS, int NS>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
     const unsigned char *__restrict__ bs, int64_t row_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
     const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
     const double *__restrict__ col_scale, double *__restrict__ ns_out, HypLookup hl) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][MF_BUF] + kb list
+    constexpr int KS = NS * MF_SS, BUF = 4 * KS;                            // LDS bytes per k-step / per super-step buffer
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] + kb list
     __shared__ int slot_box;
-    int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * MF_BUF);
+    int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * BUF);
     // observed scores of this thread's 16 outputs (exact 64-bit integers), [r][thread]: read once per permutation
-    long long *obs = reinterpret_cast<long long *>(lds + 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t)) + threadIdx.x;
+    long long *obs = reinterpret_cast<long long *>(lds + 2 * BUF + MF_MAXBLK * sizeof(int32_t)) + threadIdx.x;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lam = lane & 31, h = lane >> 5;
     // gather role: thread -> (k-step of the super-step, row quad, 16-byte chunk of the row segment)
-    constexpr int CH = 2 * MF_NS, GT = 4 * 8 * CH;
+    constexpr int CH = 2 * NS, GT = 4 * 8 * CH;
     const bool gth = tid < GT;
     const int chunk = tid % CH, rq = (tid / CH) % 8, ks_g = tid / (8 * CH);
     const int s_g = chunk >> 1, half_g = chunk & 1;
     // this thread's LDS write base inside a buffer; column i of its 16 goes to lane slot
     // (i & 3) + 4 * half + 8 * (i >> 2)
-    const uint32_t w_base = static_cast<uint32_t>(ks_g * MF_KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
+    const uint32_t w_base = static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
     const uint32_t r_base = static_cast<uint32_t>(h * 512 + lam * 16);        // MFMA B operand of this lane
     const int col_in_tile = 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
 
@@ -273,13 +275,13 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             for (int i = tid; i < nb; i += 512) kb_list[i] = blk_kb[b0 + i];
             __syncthreads();
 
-            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * (MF_NS * 32) + chunk * 16;
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * (NS * 32) + chunk * 16;
             const uint32_t *bits_w = blk_bits + static_cast<int64_t>(b0) * MF_R + wave * 32 + lam;
             const int total = n_q * S;
 
-            v16i acc[MF_NS];
+            v16i acc[NS];
 #pragma unroll
-            for (int s = 0; s < MF_NS; ++s)
+            for (int s = 0; s < NS; ++s)
 #pragma unroll
                 for (int r = 0; r < 16; ++r) acc[s][r] = 0;
             uint32_t cnt[16];
@@ -299,7 +301,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             // column word cw (columns 4cw .. 4cw+3 of this thread's chunk) of the four rows in L:
             // transpose to k-contiguous bytes and write the four lane slots b + 8cw (+ 4 half)
             auto store_quarter = [&](const uint4 (&L)[4], int cw, int buf) {
-                unsigned char *dst = lds + buf * MF_BUF + w_base;
+                unsigned char *dst = lds + buf * BUF + w_base;
                 const uint32_t w[4] = {cw == 0 ? L[0].x : cw == 1 ? L[0].y : cw == 2 ? L[0].z : L[0].w,
                                        cw == 0 ? L[1].x : cw == 1 ? L[1].y : cw == 2 ? L[1].z : L[1].w,
                                        cw == 0 ? L[2].x : cw == 1 ? L[2].y : cw == 2 ? L[2].z : L[2].w,
@@ -359,17 +361,17 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 if (gth && more3) src_load = load_src(q3, t3);
                 if (gth && more2) load_rows(src_use, L_load);
 
-                const unsigned char *bbuf = lds + buf * MF_BUF + r_base;
+                const unsigned char *bbuf = lds + buf * BUF + r_base;
                 // B operands of k-step k+1 are read from LDS before the MFMAs of k-step k are issued
-                v4i b_cur[MF_NS], b_nxt[MF_NS];
+                v4i b_cur[NS], b_nxt[NS];
 #pragma unroll
-                for (int s = 0; s < MF_NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
+                for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k < 3) {
 #pragma unroll
-                        for (int s = 0; s < MF_NS; ++s)
-                            b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * MF_KS + s * MF_SS);
+                        for (int s = 0; s < NS; ++s)
+                            b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
                     }
                     __builtin_amdgcn_sched_barrier(0);               // keep the LDS reads ahead of this k-step's MFMAs
                     v4i a;
@@ -378,12 +380,12 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     a[2] = static_cast<int>(expand4(aw[k], 16 * h + 8));
                     a[3] = static_cast<int>(expand4(aw[k], 16 * h + 12));
 #pragma unroll
-                    for (int s = 0; s < MF_NS; ++s) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[s], 0, 0, 0);
+                    for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[s], 0, 0, 0);
                     // a quarter of the next super-step's tile goes to the other buffer while the
                     // matrix pipe works through this k-step
                     if (gth && more1) store_quarter(L_store, k, buf ^ 1);
 #pragma unroll
-                    for (int s = 0; s < MF_NS; ++s) b_cur[s] = b_nxt[s];
+                    for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
                 }
 
                 if constexpr (COUNTS) {
@@ -391,9 +393,9 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 } else if (t == S - 1) {                             // a score is complete
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        long long v = static_cast<long long>(acc[MF_NS - 1][r]);
+                        long long v = static_cast<long long>(acc[NS - 1][r]);
 #pragma unroll
-                        for (int s = MF_NS - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
+                        for (int s = NS - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
                         if (q == 0) {
                             obs[r * 512] = v;
                         } else {
@@ -401,7 +403,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                             cnt[r] += (static_cast<uint32_t>(v < o) << 16) | static_cast<uint32_t>(v > o);
                         }
 #pragma unroll
-                        for (int s = 0; s < MF_NS; ++s) acc[s][r] = 0;
+                        for (int s = 0; s < NS; ++s) acc[s][r] = 0;
                     }
                 }
 #pragma unroll
@@ -427,18 +429,18 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 #pragma unroll
                 for (int r = 0; r < 16; ++r)
                     slab[r] = (hl.tab && node[r] >= 0) ? static_cast<uint32_t>(hl.nid[node[r]]) * static_cast<uint32_t>(hl.n_kid * hl.xs) : 0u;
-                uint32_t kofs[MF_NS];
-                bool col_ok[MF_NS];
+                uint32_t kofs[NS];
+                bool col_ok[NS];
 #pragma unroll
-                for (int s = 0; s < MF_NS; ++s) {
-                    const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+                for (int s = 0; s < NS; ++s) {
+                    const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
                     col_ok[s] = col < mloc;
                     kofs[s] = (hl.tab && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) * static_cast<uint32_t>(hl.xs) : 0u;
                 }
                 if (!hl.tab) {                                        // plain counts ('sum' scores of 0/1 attributes)
 #pragma unroll
-                    for (int s = 0; s < MF_NS; ++s) {
-                        const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+                    for (int s = 0; s < NS; ++s) {
+                        const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
 #pragma unroll
                         for (int r = 0; r < 16; ++r)
                             if (col_ok[s] && node[r] >= 0)
@@ -460,11 +462,11 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                             val[rr] = hl.tab[slab[r] + kofs[s] + ((col_ok[s] && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) : 0u)];
                         }
                     };
-                    unsigned int hits[MF_NS];
+                    unsigned int hits[NS];
 #pragma unroll
-                    for (int s = 0; s < MF_NS; ++s) hits[s] = 0;
+                    for (int s = 0; s < NS; ++s) hits[s] = 0;
                     auto emit = [&](int s, int half, const double2 (&val)[8]) __attribute__((always_inline)) {
-                        const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+                        const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
 #pragma unroll
                         for (int rr = 0; rr < 8; ++rr) {
                             const int r = half * 8 + rr;
@@ -480,15 +482,15 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     double2 va[8], vb[8];
                     fetch(0, 0, va);
 #pragma unroll
-                    for (int k = 0; k < 2 * MF_NS; k += 2) {
+                    for (int k = 0; k < 2 * NS; k += 2) {
                         fetch(k >> 1, 1, vb);
                         emit(k >> 1, 0, va);
-                        if (k + 2 < 2 * MF_NS) fetch((k >> 1) + 1, 0, va);
+                        if (k + 2 < 2 * NS) fetch((k >> 1) + 1, 0, va);
                         emit(k >> 1, 1, vb);
                     }
 #pragma unroll
-                    for (int s = 0; s < MF_NS; ++s) {
-                        const int64_t col = (static_cast<int64_t>(ct) * MF_NS + s) * 32 + col_in_tile;
+                    for (int s = 0; s < NS; ++s) {
+                        const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
                         if (hits[s]) atomicAdd(&hl.enriched[col], hits[s]);
                     }
                 }
@@ -677,7 +679,7 @@ __global__ __launch_bounds__(256) void k_mfma_planes01(const void *__restrict__ 
         else tile[a][tx] = v;
     }
     __syncthreads();
-    const int64_t row_bytes = n_grp * MF_NS * 32;
+    const int64_t row_bytes = n_grp * MF_CN * 32;
     for (int i = 0; i < 4; ++i) {
         const int64_t r = r0 + ty + 8 * i;
         if (r > n) continue;
@@ -690,11 +692,11 @@ __global__ __launch_bounds__(256) void k_mfma_planes01(const void *__restrict__ 
 int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, const HypLookup &hl) {
     SAFE_TRY(build_blocks(nbr));
     const int64_t n = nbr->n, mloc = col1 - col0;
-    const int64_t n_ct = ceil_div(mloc, 32), n_grp = ceil_div(n_ct, MF_NS), row_bytes = n_grp * MF_NS * 32, n_src = nbr->bs_src;
+    const int64_t n_ct = ceil_div(mloc, 32), n_grp = ceil_div(n_ct, MF_CN), row_bytes = n_grp * MF_CN * 32, n_src = nbr->bs_src;
     unsigned char *d_bs = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
     {
-        const dim3 grid(n_grp * MF_NS, ceil_div(n + 1, 32));
+        const dim3 grid(n_grp * MF_CN, ceil_div(n + 1, 32));
         if (attr->dtype == SAFE_DTYPE_F32)
             hipLaunchKernelGGL(k_mfma_planes01<float>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_grp, d_bs);
@@ -725,12 +727,14 @@ int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t co
     SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, 16 * sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
                        static_cast<const int32_t *>(nullptr), 0, d_src);
-    const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<true>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    // (tried: three tiles per task at 128 VGPRs so that two workgroups share a CU and one's store epilogue
+    // overlaps the other's matrix phase -- the main loop spills and the kernel is 1.5x slower)
+    const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-    hipLaunchKernelGGL(k_permtest_mfma<true>, dim3(blocks), dim3(512), lds_bytes, ctx->stream, d_bs, row_bytes, d_src, n_src, 1,
+    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, d_bs, row_bytes, d_src, n_src, 1,
                        nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr, mloc, static_cast<unsigned int *>(nullptr),
                        nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), hl);
     SAFE_HIP_CHECK(hipGetLastError());
@@ -852,7 +856,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
 
     const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<false>), hipFuncAttributeMaxDynamicSharedMemorySize,
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
     ctx->last_kernel.name = "k_permtest_mfma";
@@ -872,7 +876,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
                            p_base, d_src[c & 1]);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
-        hipLaunchKernelGGL(k_permtest_mfma<false>, dim3(blocks), dim3(512), lds_bytes, ks, d_bs, row_bytes, d_src[c & 1], n_src,
+        hipLaunchKernelGGL((k_permtest_mfma<false, MF_NS>), dim3(blocks), dim3(512), lds_bytes, ks, d_bs, row_bytes, d_src[c & 1], n_src,
                            static_cast<int>(cnt + 1), nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr + 8 * c, mloc,
                            d_counts, n_padr, nbr->bs_rowmap, d_scale, c == 0 ? out.ns : static_cast<double *>(nullptr), HypLookup{});
         SAFE_HIP_CHECK(hipGetLastError());
