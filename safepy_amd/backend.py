@@ -20,18 +20,32 @@ def _ptr(a):
 
 
 class DeviceBuffer:
-    """A raw device allocation owned by the library allocator (f64/i64 element views)."""
+    """A raw device allocation owned by the library allocator (f64/i64 element views).  Freed buffers
+    of 1 MiB and more go back to a per-context pool keyed by size: hipMalloc / hipFree of the result
+    matrices (GBs at 20 000 nodes) cost tens of milliseconds per call, more than the kernels."""
+
+    POOL_LIMIT = 48 << 30                 # bytes kept for reuse per context (of 288 GB)
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
         self.nbytes = int(nbytes)
+        pooled = ctx._pool.get(self.nbytes)
+        if pooled:
+            self.ptr = pooled.pop()
+            ctx._pool_bytes -= self.nbytes
+            return
         p = C.c_void_p()
         check(lib.safe_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p)))
         self.ptr = p.value
 
     def free(self):
         if self.ptr:
-            check(lib.safe_dev_free(self.ctx.handle, C.c_void_p(self.ptr)))
+            ctx = self.ctx
+            if self.nbytes >= (1 << 20) and ctx._pool_bytes + self.nbytes <= self.POOL_LIMIT:
+                ctx._pool.setdefault(self.nbytes, []).append(self.ptr)
+                ctx._pool_bytes += self.nbytes
+            else:
+                check(lib.safe_dev_free(ctx.handle, C.c_void_p(self.ptr)))
             self.ptr = None
 
     def __del__(self):
@@ -70,6 +84,8 @@ class Context:
         self.num_cu = ncu.value
         self.hbm_bytes = hbm.value
         self.arch = arch.value.decode()
+        self._pool = {}                   # size -> [device pointers] of released DeviceBuffers
+        self._pool_bytes = 0
 
     @classmethod
     def default(cls, device=0):
@@ -86,6 +102,14 @@ class Context:
 
     def alloc(self, nbytes):
         return DeviceBuffer(self, nbytes)
+
+    def trim(self):
+        """Return the pooled device buffers to the driver."""
+        for ptrs in self._pool.values():
+            for p in ptrs:
+                check(lib.safe_dev_free(self.handle, C.c_void_p(p)))
+        self._pool.clear()
+        self._pool_bytes = 0
 
     def alloc_f64(self, *shape):
         return DeviceBuffer(self, int(np.prod(shape)) * 8)

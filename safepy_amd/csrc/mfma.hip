@@ -25,6 +25,8 @@
 #include <numeric>
 
 #include "common.h"
+#include <atomic>
+#include <thread>
 
 namespace {
 
@@ -605,39 +607,64 @@ int build_blocks(safe_nbr *nbr) {
         h_order[u] = order[u];
         h_rowmap[u] = order[u];
     }
+    // row groups are independent: built by a few host threads into per-group lists, then laid end to end
     std::vector<int32_t> ptr(n_groups + 1, 0), kbs;
     std::vector<uint32_t> bits;
-    std::vector<int32_t> slot(n_kb, -1), touched;
-    for (int64_t g = 0; g < n_groups; ++g) {
-        touched.clear();
-        const int64_t u0 = g * MF_R, u1 = std::min<int64_t>(n, u0 + MF_R);
-        for (int64_t u = u0; u < u1; ++u) {
-            const int32_t node = order[u];
-            for (int32_t e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
-                const int32_t kb = pos[col[e]] >> 5;
-                if (slot[kb] < 0) {
-                    slot[kb] = 0;
-                    touched.push_back(kb);
+    std::vector<std::vector<int32_t>> g_kbs(n_groups);
+    std::vector<std::vector<uint32_t>> g_bits(n_groups);
+    const int n_thr = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({8, n_groups, static_cast<int64_t>(std::thread::hardware_concurrency())})));
+    std::atomic<int64_t> next_group{0};
+    auto worker = [&]() {
+        std::vector<int32_t> slot(n_kb, -1), touched;
+        for (;;) {
+            const int64_t g = next_group.fetch_add(1);
+            if (g >= n_groups) break;
+            touched.clear();
+            const int64_t u0 = g * MF_R, u1 = std::min<int64_t>(n, u0 + MF_R);
+            for (int64_t u = u0; u < u1; ++u) {
+                const int32_t node = order[u];
+                for (int32_t e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
+                    const int32_t kb = pos[col[e]] >> 5;
+                    if (slot[kb] < 0) {
+                        slot[kb] = 0;
+                        touched.push_back(kb);
+                    }
                 }
             }
-        }
-        std::sort(touched.begin(), touched.end());
-        const int64_t base = static_cast<int64_t>(kbs.size());
-        const int64_t count = ceil_div(static_cast<int64_t>(touched.size()), 4) * 4;
-        for (size_t i = 0; i < touched.size(); ++i) slot[touched[i]] = static_cast<int32_t>(i);
-        kbs.insert(kbs.end(), touched.begin(), touched.end());
-        kbs.resize(base + count, static_cast<int32_t>(n_kb));       // padding blocks: all-zero rows, no members
-        bits.resize((base + count) * MF_R, 0u);
-        for (int64_t u = u0; u < u1; ++u) {
-            const int32_t node = order[u];
-            for (int32_t e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
-                const int32_t p = pos[col[e]];
-                bits[(base + slot[p >> 5]) * MF_R + (u - u0)] |= 1u << (p & 31);
+            std::sort(touched.begin(), touched.end());
+            const int64_t count = ceil_div(static_cast<int64_t>(touched.size()), 4) * 4;
+            for (size_t i = 0; i < touched.size(); ++i) slot[touched[i]] = static_cast<int32_t>(i);
+            std::vector<int32_t> &kb_out = g_kbs[g];
+            std::vector<uint32_t> &bit_out = g_bits[g];
+            kb_out.assign(touched.begin(), touched.end());
+            kb_out.resize(count, static_cast<int32_t>(n_kb));          // padding blocks: all-zero rows, no members
+            bit_out.assign(count * MF_R, 0u);
+            for (int64_t u = u0; u < u1; ++u) {
+                const int32_t node = order[u];
+                for (int32_t e = row_ptr[node]; e < row_ptr[node + 1]; ++e) {
+                    const int32_t p = pos[col[e]];
+                    bit_out[static_cast<int64_t>(slot[p >> 5]) * MF_R + (u - u0)] |= 1u << (p & 31);
+                }
             }
+            for (int32_t kb : touched) slot[kb] = -1;
         }
-        for (int32_t kb : touched) slot[kb] = -1;
-        ptr[g + 1] = static_cast<int32_t>(base + count);
+    };
+    {
+        std::vector<std::thread> pool;
+        for (int t = 1; t < n_thr; ++t) pool.emplace_back(worker);
+        worker();
+        for (auto &th : pool) th.join();
+    }
+    for (int64_t g = 0; g < n_groups; ++g) {
+        const int64_t count = static_cast<int64_t>(g_kbs[g].size());
         SAFE_REQUIRE(count <= MF_MAXBLK, "membership row group touches %lld column blocks (limit %d)", (long long)count, MF_MAXBLK);
+        ptr[g + 1] = ptr[g] + static_cast<int32_t>(count);
+    }
+    kbs.resize(ptr[n_groups]);
+    bits.resize(static_cast<size_t>(ptr[n_groups]) * MF_R);
+    for (int64_t g = 0; g < n_groups; ++g) {
+        std::copy(g_kbs[g].begin(), g_kbs[g].end(), kbs.begin() + ptr[g]);
+        std::copy(g_bits[g].begin(), g_bits[g].end(), bits.begin() + static_cast<size_t>(ptr[g]) * MF_R);
     }
     nbr->bs_groups = n_groups;
     nbr->bs_blocks = static_cast<int64_t>(kbs.size());

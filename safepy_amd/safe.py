@@ -76,8 +76,57 @@ def _graph_arrays(graph):
     return xy, eu, ev, length, weight
 
 
+class _DeviceResult:
+    """An [n, m] float64 result of compute_pvalues still on the device: copied to the host the first
+    time the attribute is read (see `_LazyArray`).  Owns its device buffer."""
+
+    def __init__(self, buf, shape):
+        self.buf, self.shape = buf, shape
+
+    def get(self):
+        host = self.buf.download(self.shape)
+        self.buf.free()
+        return host
+
+    def drop(self):
+        self.buf.free()
+
+
+class _LazyArray:
+    """Descriptor behind SAFE.ns / pvalues_neg / pvalues_pos / nes / nes_binary.  To the caller these
+    are plain attributes holding host `float64 [N, M]` arrays (or None) exactly as in the reference
+    (safe.py:530-554, 596-608, 468-472); compute_pvalues() leaves the matrices on the device and the
+    copy (139 MB each at 3971 x 4373, 1.6 GB each at 20 000 x 10 000 -- ten to a hundred times the
+    compute) happens on the first read of each one, so results that are never looked at are never
+    moved.  `SAFE.lazy_outputs = False` restores the eager copies."""
+
+    def __init__(self, name):
+        self.slot = '_r_' + name
+
+    def __get__(self, obj, objtype=None):
+        if obj is None:
+            return self
+        v = obj.__dict__.get(self.slot)
+        if isinstance(v, _DeviceResult):
+            v = v.get()
+            obj.__dict__[self.slot] = v
+        return v
+
+    def __set__(self, obj, value):
+        old = obj.__dict__.get(self.slot)
+        if isinstance(old, _DeviceResult):
+            old.drop()
+        obj.__dict__[self.slot] = value
+
+
 class SAFE:
     """Defines an instance of SAFE analysis (hot path only); see module docstring."""
+
+    ns = _LazyArray('ns')
+    pvalues_neg = _LazyArray('pvalues_neg')
+    pvalues_pos = _LazyArray('pvalues_pos')
+    nes = _LazyArray('nes')
+    nes_binary = _LazyArray('nes_binary')
 
     def __init__(self, path_to_ini_file='', path_to_safe_data=None, verbose=True, device=0):
         self.verbose = verbose
@@ -128,6 +177,7 @@ class SAFE:
 
         # device state (never pickled)
         self.device = device
+        self.lazy_outputs = True         # result matrices stay on the device until first read (_LazyArray)
         self._nbr = None                 # backend.Neighborhoods matching _neighborhoods_host / lazily downloaded
         self._neighborhoods_host = None
         self._node_distances = None
@@ -199,6 +249,8 @@ class SAFE:
 
     # pickling drops device handles (the reference pickles the whole object, safe.py:237-242)
     def __getstate__(self):
+        for name in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+            getattr(self, name)              # results still on the device come to the host first
         state = self.__dict__.copy()
         if state.get('_neighborhoods_host') is None and state.get('_nbr') is not None:
             state['_neighborhoods_host'] = self._nbr.to_dense()
@@ -516,6 +568,11 @@ class SAFE:
             self.attributes = pd.DataFrame({'id': np.arange(len(enriched)), 'name': [str(j) for j in range(len(enriched))]})
         self.attributes['num_neighborhoods_enriched'] = enriched
 
+    def _result(self, buf, shape):
+        """A finished [n, m] device buffer as the value of a result attribute: left on the device
+        (lazy_outputs, the default) or copied to the host right away."""
+        return _DeviceResult(buf, shape) if self.lazy_outputs else buf.download(shape)
+
     def compute_pvalues_by_randomization(self, _attr=None, **kwargs):
         """safepy/safe.py:474-554 (no 1 s sleep, no multiprocessing split: `processes` is
         accepted and ignored -- the reference's own split is broken at this commit)."""
@@ -542,11 +599,11 @@ class SAFE:
                 logging.info('Running FDR-adjustment of p-values...')
                 be.fdr_adjust(ctx, n, m, self.num_permutations, self.attribute_sign, self.enrichment_threshold,
                               [b.ptr for b in bufs[1:]])
-            self.ns = bufs[0].download((n, m))
-            self.pvalues_neg = bufs[1].download((n, m))
-            self.pvalues_pos = bufs[2].download((n, m))
-            self.nes = bufs[3].download((n, m))
-            self._pending_binary = (bufs[4].download((n, m)), bufs[5].download((m,)))
+            enriched = bufs[5].download((m,))
+            res = [self._result(b, (n, m)) for b in bufs[:5]]
+            bufs = bufs[5:] if self.lazy_outputs else bufs       # handed over: the results own their buffers now
+            self.ns, self.pvalues_neg, self.pvalues_pos, self.nes = res[:4]
+            self._pending_binary = (res[4], enriched)
         finally:
             for b in bufs:
                 b.free()
@@ -578,9 +635,11 @@ class SAFE:
                     logging.info('Running FDR-adjustment of p-values...')
                 be.fdr_adjust(ctx, n, m, 0, self.attribute_sign, self.enrichment_threshold,
                               [None] + [b.ptr for b in bufs])
-            self.pvalues_pos = bufs[0].download((n, m))
-            self.nes = bufs[1].download((n, m))
-            self._pending_binary = (bufs[2].download((n, m)), bufs[3].download((m,)))
+            enriched = bufs[3].download((m,))
+            res = [self._result(b, (n, m)) for b in bufs[:3]]
+            bufs = bufs[3:] if self.lazy_outputs else bufs       # handed over: the results own their buffers now
+            self.pvalues_pos, self.nes = res[:2]
+            self._pending_binary = (res[2], enriched)
         finally:
             for b in bufs:
                 b.free()

@@ -307,3 +307,47 @@ def test_sharded_compute_pvalues_one_rank_rccl(amd, g, tmp_path, quantitative):
     assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
     assert np.array_equal(out['full_nes_binary'], sf.nes_binary, equal_nan=True)
     assert np.array_equal(out['num_neighborhoods_enriched'], sf.attributes['num_neighborhoods_enriched'].values)
+
+
+# ------------------------------------------------------------------ lazy result attributes ----
+def test_lazy_outputs_equal_eager_and_pickle(amd, golden_nbr, golden_enr):
+    """compute_pvalues() leaves the result matrices on the device; each is copied on its first read
+    and behaves as the plain ndarray attribute of the reference from then on (same values as the
+    eager copies, settable, picklable while still on the device)."""
+    import pickle
+    g = golden_enr
+    xy = golden_nbr['xy']
+
+    def run(lazy, **kw):
+        sf = amd.SAFE(verbose=False)
+        sf.lazy_outputs = lazy
+        sf.random_seed = 11
+        sf.graph = amd.LayoutGraph(xy)
+        sf.neighborhoods = g['A'].astype(np.int64)
+        sf.load_attributes(attribute_file=g['b_q'].copy())
+        sf.compute_pvalues(num_permutations=40, **kw)
+        return sf
+
+    a, b = run(True), run(False)
+    assert type(b.__dict__['_r_nes']) is np.ndarray and type(a.__dict__['_r_nes']).__name__ == '_DeviceResult'
+    blob = pickle.dumps(a)                                   # materialises what is still on the device
+    for name in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        x, y = getattr(a, name), getattr(b, name)
+        assert type(x) is np.ndarray and x.dtype == np.float64 and x.flags['C_CONTIGUOUS']
+        assert np.array_equal(x, y, equal_nan=True)
+        assert getattr(a, name) is x                         # the copy happens once
+        assert np.array_equal(getattr(pickle.loads(blob), name), y, equal_nan=True)
+    a.nes = None
+    assert a.nes is None
+    # a second run replaces results that were never read (their device buffers are released)
+    c = run(True)
+    c.compute_pvalues(num_permutations=40)
+    assert np.array_equal(c.nes, b.nes, equal_nan=True)
+    # hypergeometric path: ns / pvalues_neg keep whatever they held (None here), like the reference
+    h = amd.SAFE(verbose=False)
+    h.graph = amd.LayoutGraph(xy)
+    h.neighborhoods = g['A'].astype(np.int64)
+    h.load_attributes(attribute_file=g['b_bin'].copy())
+    h.compute_pvalues()
+    assert h.ns is None and h.pvalues_neg is None
+    np.testing.assert_array_equal(h.nes_binary, g['hyp_f64_nes_binary'])
