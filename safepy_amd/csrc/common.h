@@ -76,8 +76,9 @@ struct safe_ctx {
     const unsigned int *packed_counts = nullptr;
     int64_t packed_n_pad = 0, packed_m = 0, packed_perms = 0;
     int packed_layout = -1;
-    void *scratch[8] = {nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr};
-    size_t scratch_bytes[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    static constexpr int N_SCRATCH = 12;
+    void *scratch[N_SCRATCH] = {};
+    size_t scratch_bytes[N_SCRATCH] = {};
 };
 
 // returns a device buffer of at least `bytes` from slot `slot`, valid until the next request
@@ -140,6 +141,7 @@ struct safe_nbr {
     int32_t *bs_kb = nullptr;       // [bs_blocks] ordered column block of a stored block
     uint32_t *bs_bits = nullptr;    // [bs_blocks][256] membership bits of the block's 256 rows
     std::vector<int32_t> h_bs_ptr;
+    std::vector<int32_t> h_bs_rowmap;   // host copy of bs_rowmap
 };
 
 // Hypergeometric epilogue by table lookup (enrich.hip: k_hyp_table builds tab): instead of a count X
@@ -155,6 +157,8 @@ struct HypLookup {
     double *dummy;             // [64] write-only slots for the padding rows / columns of branch-free epilogues
     double *pvalues_pos, *nes, *nes_binary;
     unsigned int *enriched;
+    unsigned int *cnt16;       // split form of the matrix-core counts: packed u16 counts [group][position][32][6], else NULL
+    unsigned int *xmax;        // split form: largest count of the call (written by the count kernel, read by the emit kernel)
 };
 
 // |nes| > -log10(enrichment_threshold) (safe.py:468-470) for nes = -log10(p), p in [0, 1], restated as a
@@ -286,4 +290,9 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
 // X = A . B0 for 0/1 attributes on the matrix cores (block-sparse, one i8 plane per 32-column tile),
 // written through `hl` (mfma.hip); sets ctx->last_kernel and the k0/k1 timing events
 int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, const HypLookup &hl);
+struct MfmaCountsSplit;
+bool mfma_counts_split_applicable(const safe_nbr *nbr);
+int mfma_counts_split_begin(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, MfmaCountsSplit **out);
+int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl, const int32_t *h_nid);
+void mfma_counts_split_free(MfmaCountsSplit *st);
 void nbr_free_blocks(safe_nbr *nbr);

@@ -105,7 +105,7 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->k0) (void)hipEventDestroy(ctx->k0);
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
     perms_cache_drop(ctx);
-    for (int i = 0; i < 8; ++i)
+    for (int i = 0; i < safe_ctx::N_SCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);

@@ -1424,13 +1424,17 @@ __global__ void k_u32_to_f64(const unsigned int *__restrict__ in, double *__rest
 }
 
 // neighborhood_size = A . nodes_not_nan (safe.py:587-588)
-__global__ void k_nbr_size(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
-                           const uint8_t *__restrict__ row_flags, int64_t n, double *__restrict__ out) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
+// one wave per row: the member list is read coalesced
+__global__ __launch_bounds__(256) void k_nbr_size(const int32_t *__restrict__ row_ptr, const int32_t *__restrict__ col,
+                                                  const uint8_t *__restrict__ row_flags, int64_t n, double *__restrict__ out) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 4 + (threadIdx.x >> 6);
     if (i >= n) return;
+    const int lane = threadIdx.x & 63;
     int c = 0;
-    for (int32_t e = row_ptr[i]; e < row_ptr[i + 1]; ++e) c += row_flags[col[e]] != 0;
-    out[i] = static_cast<double>(c);
+    for (int32_t e = row_ptr[i] + lane; e < row_ptr[i + 1]; e += 64) c += row_flags[col[e]] != 0;
+#pragma unroll
+    for (int d = 32; d >= 1; d >>= 1) c += __shfl_xor(c, d);
+    if (lane == 0) out[i] = static_cast<double>(c);
 }
 
 // --------------------------------------------------------------------------------------
@@ -1984,15 +1988,16 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 // integer (scipy then returns NaN: the per-element kernel reproduces that).
 static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, int64_t pop,
                            const double *d_size, double p_cut, double *p_dev, double *nes_dev,
-                           double *nb_dev, unsigned int *d_enr, bool *fused) {
+                           double *nb_dev, unsigned int *d_enr, bool use_mfma, hipStream_t hs, MfmaCountsSplit *split,
+                           bool *fused) {
+    // hs = the stream of the table's own work: ctx->stream, or the side stream while the first half of the
+    // split matrix-core form (which needs nothing from here) runs on ctx->stream
     *fused = false;
-    const char *force = getenv("SAFE_HIP_HYPER_TABLE");
-    if (force && !strcmp(force, "0")) return SAFE_OK;
     const int64_t n = nbr->n, mloc = col1 - col0;
     std::vector<double> h_size(n), h_k(mloc);
-    SAFE_HIP_CHECK(hipMemcpyAsync(h_size.data(), d_size, n * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(h_k.data(), attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_size.data(), d_size, n * sizeof(double), hipMemcpyDeviceToHost, hs));
+    SAFE_HIP_CHECK(hipMemcpyAsync(h_k.data(), attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, hs));
+    SAFE_HIP_CHECK(hipStreamSynchronize(hs));
     // distinct values -> dense ids (both are integers in [0, n] here, or we decline)
     std::vector<int32_t> id_of(n + 2, -1), nvals, kvals, nid(n), kid(mloc);
     int64_t max_n = 0, max_k = 0;
@@ -2030,17 +2035,14 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n_nid) * n_kid * xs * sizeof(double2), reinterpret_cast<void **>(&d_tab)));
     SAFE_TRY(ctx_scratch(ctx, 6, static_cast<size_t>(n_nid + n_kid + n + mloc) * sizeof(int32_t), reinterpret_cast<void **>(&d_ids)));
     int32_t *d_nvals = d_ids, *d_kvals = d_nvals + n_nid, *d_nid = d_kvals + n_kid, *d_kid = d_nid + n;
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_nvals, nvals.data(), n_nid * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_kvals, kvals.data(), n_kid * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_nid, nid.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_kid, kid.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, ctx->stream));
-    hipLaunchKernelGGL(k_hyp_table, dim3(ceil_div(n_nid * n_kid, 64)), dim3(64), 0, ctx->stream, d_nvals, n_nid, d_kvals, n_kid, xs,
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_nvals, nvals.data(), n_nid * sizeof(int32_t), hipMemcpyHostToDevice, hs));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_kvals, kvals.data(), n_kid * sizeof(int32_t), hipMemcpyHostToDevice, hs));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_nid, nid.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, hs));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_kid, kid.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, hs));
+    hipLaunchKernelGGL(k_hyp_table, dim3(ceil_div(n_nid * n_kid, 64)), dim3(64), 0, hs, d_nvals, n_nid, d_kvals, n_kid, xs,
                        pop, d_tab);
 
     const int64_t n_wg = ceil_div(mloc, 64);
-    const char *counts_env = getenv("SAFE_HIP_COUNTS");
-    const bool dense_nbr = nbr->n >= 256 && nbr->nnz >= 128 * nbr->n;       // matrix cores pay off for large neighborhoods
-    const bool use_mfma = counts_env ? !strcmp(counts_env, "mfma") : dense_nbr;
     HypLookup hl{};
     hl.nid = d_nid;
     hl.kid = d_kid;
@@ -2053,7 +2055,16 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.nes = nes_dev;
     hl.nes_binary = nb_dev;
     hl.enriched = d_enr;
-    if (use_mfma) {
+    if (split) {
+        hipEvent_t table_done = nullptr;
+        SAFE_HIP_CHECK(hipEventCreateWithFlags(&table_done, hipEventDisableTiming));
+        SAFE_HIP_CHECK(hipEventRecord(table_done, hs));
+        SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, table_done, 0));
+        const int rc = mfma_counts_split_emit(ctx, nbr, split, hl, nid.data());       // synchronises ctx->stream
+        (void)hipStreamSynchronize(hs);                                    // the id vectors above are host memory
+        (void)hipEventDestroy(table_done);
+        SAFE_TRY(rc);
+    } else if (use_mfma) {
         SAFE_TRY(launch_mfma_counts(ctx, nbr, attr, col0, col1, hl));   // records its own timing events
     } else {
         uint2 *d_bits = nullptr;                                       // bit-packed attributes: only the bit-sliced form reads them
@@ -2252,39 +2263,65 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     SAFE_TRY(safe_attr_prepare(attr));
     const int64_t n = nbr->n, mloc = col1 - col0;
     const int64_t pop = attr->n_rows_with_value;
-    // log-factorial table lf[k] = log(k!) for k = 0..n
-    std::vector<double> lf(n + 2);
-    for (int64_t k = 0; k <= n + 1; ++k) lf[k] = std::lgamma(static_cast<double>(k) + 1.0);
     double *d_lf = nullptr, *d_hits = nullptr, *d_size = nullptr;
     unsigned int *d_enr = nullptr;
     Tiles tiles;
     const bool bits = counts_bits_applicable(nbr, attr);
-    int rc = dev_alloc(&d_lf, n + 2);
-    if (rc == SAFE_OK) rc = ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&d_hits));
-    if (rc == SAFE_OK) rc = dev_alloc(&d_size, n);
-    if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 64);
-    if (rc == SAFE_OK && !bits) rc = build_tiles(ctx, attr, col0, col1, false, &tiles);
+    const char *table_env = getenv("SAFE_HIP_HYPER_TABLE");
+    const bool table = bits && !(table_env && !strcmp(table_env, "0"));
+    const char *counts_env = getenv("SAFE_HIP_COUNTS");
+    const bool dense_nbr = nbr->n >= 256 && nbr->nnz >= 128 * nbr->n;       // matrix cores pay off for large neighborhoods
+    const bool use_mfma = counts_env ? !strcmp(counts_env, "mfma") : dense_nbr;
+    void *small = nullptr;                                                  // d_size f64 [n] | d_enr u32 [mloc + 64]
+    int rc = ctx_scratch(ctx, 9, static_cast<size_t>(n) * sizeof(double) + static_cast<size_t>(mloc + 64) * sizeof(unsigned int), &small);
     if (rc == SAFE_OK) {
-        hipError_t e = hipMemcpyAsync(d_lf, lf.data(), (n + 2) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 64) * sizeof(unsigned int), ctx->stream);
-        if (e != hipSuccess) {
-            safe_set_error("safe_hypergeom: %s", hipGetErrorString(e));
+        d_size = static_cast<double *>(small);
+        d_enr = reinterpret_cast<unsigned int *>(d_size + n);
+        if (hipMemsetAsync(d_enr, 0, (mloc + 64) * sizeof(unsigned int), ctx->stream) != hipSuccess) {
+            safe_set_error("safe_hypergeom: hipMemsetAsync failed");
             rc = SAFE_E_HIP;
         }
     }
+    // Split matrix-core form: bit planes and counts start on ctx->stream right away; neighborhood sizes,
+    // the distinct (n, K) ids and the table are prepared on the side stream meanwhile (hypergeom_fused)
+    MfmaCountsSplit *split = nullptr;
+    hipStream_t hs = ctx->stream;
+    hipEvent_t ev = nullptr;
+    if (rc == SAFE_OK && table && use_mfma && mfma_counts_split_applicable(nbr)) {
+        hs = ctx->side_stream;
+        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, ctx->stream) != hipSuccess ||
+            hipStreamWaitEvent(hs, ev, 0) != hipSuccess) {
+            safe_set_error("safe_hypergeom: stream fork failed");
+            rc = SAFE_E_HIP;
+        }
+        if (rc == SAFE_OK) rc = mfma_counts_split_begin(ctx, nbr, attr, col0, col1, &split);
+    }
     bool fused = false;
     if (rc == SAFE_OK) {
-        hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col,
-                           attr->row_flags, n, d_size);
-        if (bits) rc = hypergeom_fused(ctx, nbr, attr, col0, col1, pop, d_size, nes_p_cut(enrichment_threshold),
-                                       pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr, &fused);
+        hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 4)), dim3(256), 0, hs, nbr->row_ptr, nbr->col, attr->row_flags, n, d_size);
+        if (table) rc = hypergeom_fused(ctx, nbr, attr, col0, col1, pop, d_size, nes_p_cut(enrichment_threshold),
+                                        pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr, use_mfma, hs, split, &fused);
+    }
+    if (hs != ctx->stream) {                                                // join (the fallback below reads d_size)
+        if (ev && hipEventRecord(ev, hs) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, ev, 0);
     }
     if (rc == SAFE_OK && !fused) {
+        // per-element evaluation: counts through memory, pmf from a log-factorial table lf[k] = log(k!), k = 0..n
+        std::vector<double> lf(n + 2);
+        for (int64_t k = 0; k <= n + 1; ++k) lf[k] = std::lgamma(static_cast<double>(k) + 1.0);
+        rc = dev_alloc(&d_lf, n + 2);
+        if (rc == SAFE_OK) rc = ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&d_hits));
+        if (rc == SAFE_OK && !bits) rc = build_tiles(ctx, attr, col0, col1, false, &tiles);
+        if (rc == SAFE_OK && hipMemcpyAsync(d_lf, lf.data(), (n + 2) * sizeof(double), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) {
+            safe_set_error("safe_hypergeom: hipMemcpyAsync failed");
+            rc = SAFE_E_HIP;
+        }
         PermOut out{};
         out.ns = d_hits;
         out.mode = 0;
-        rc = bits ? launch_counts_bits(ctx, nbr, attr, col0, col1, d_hits)
-                  : launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
+        if (rc == SAFE_OK)
+            rc = bits ? launch_counts_bits(ctx, nbr, attr, col0, col1, d_hits)
+                      : launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
         if (rc == SAFE_OK) {
             SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
             hipLaunchKernelGGL(k_hypergeom_tail, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_hits,
@@ -2293,16 +2330,18 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
             SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
             ctx->last_kernel.name = "k_hypergeom_tail";
         }
+        if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // lf is host memory
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);
         if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
     }
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
-    if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;
+    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == SAFE_OK) rc = SAFE_E_HIP;
+    if (hs != ctx->stream) (void)hipStreamSynchronize(hs);
+    if (split) mfma_counts_split_free(split);
+    if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(d_lf);
-    (void)hipFree(d_size);
-    (void)hipFree(d_enr);
     (void)hipFree(tiles.bt);
     return rc;
 }

@@ -439,7 +439,30 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     col_ok[s] = col < mloc;
                     kofs[s] = (hl.tab && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) * static_cast<uint32_t>(hl.xs) : 0u;
                 }
-                if (!hl.tab) {                                        // plain counts ('sum' scores of 0/1 attributes)
+                if (hl.cnt16) {
+                    // split form: the counts leave as u16, six tiles of one (row, column-in-tile) packed into
+                    // 12 bytes, 384 contiguous bytes per row and half-wave; k_hyp_emit streams the results out
+                    static_assert(NS == 6, "packed counts hold six tiles");
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        unsigned int *dst = hl.cnt16 + ((static_cast<int64_t>(ct) * n_padr + u) * 32 + col_in_tile) * 3;
+                        uint3 w;
+                        w.x = static_cast<uint32_t>(acc[0][r]) | (static_cast<uint32_t>(acc[1][r]) << 16);
+                        w.y = static_cast<uint32_t>(acc[2][r]) | (static_cast<uint32_t>(acc[3][r]) << 16);
+                        w.z = static_cast<uint32_t>(acc[4][r]) | (static_cast<uint32_t>(acc[5][r]) << 16);
+                        *reinterpret_cast<uint3 *>(dst) = w;             // stays in L2 / MALL for the emit kernel
+                    }
+                    // largest count of the call: the emit kernel stages table columns [0, max] in LDS
+                    int mx = 0;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mx = max(mx, acc[s][r]);
+#pragma unroll
+                    for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
+                    if (lane == 0) atomicMax(hl.xmax, static_cast<unsigned int>(mx));
+                } else if (!hl.tab) {                                 // plain counts ('sum' scores of 0/1 attributes)
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
@@ -670,6 +693,7 @@ int build_blocks(safe_nbr *nbr) {
     nbr->bs_blocks = static_cast<int64_t>(kbs.size());
     nbr->bs_src = n_src;
     nbr->h_bs_ptr = ptr;
+    nbr->h_bs_rowmap = h_rowmap;
     SAFE_TRY(dev_alloc(&nbr->bs_order, n_src));
     SAFE_TRY(dev_alloc(&nbr->bs_rowmap, n_groups * MF_R));
     SAFE_TRY(dev_alloc(&nbr->bs_ptr, n_groups + 1));
@@ -714,60 +738,278 @@ __global__ __launch_bounds__(256) void k_mfma_planes01(const void *__restrict__ 
     }
 }
 
-}  // namespace
+// Second half of the split hypergeometric form.  A workgroup = (one neighborhood size, <= 64 of the rows
+// that have it, 8 groups of six 32-column tiles); wave w owns one group, lane (c, hh) the columns
+// (6 grp + hh + 2j) * 32 + c, j = 0..2, so every store instruction of a wave covers 64 consecutive
+// columns = 512 contiguous bytes of one row of p / nes / nes_binary.
+// The table slab of the size -- [annotation count id][0 .. largest count of the call] -- is staged in
+// LDS once per workgroup, so a lookup is one ds_read_b128 instead of a 64-line global gather (which
+// costs the texture path 64 cycles and was a third of the kernel).  Rows are software-pipelined and the
+// loop is branch-free: vmcnt counts stores too and retires in order, so the counts of batch i+1 are
+// requested BEFORE the stores of batch i are issued (waiting for them then leaves those stores in
+// flight); padding rows / columns store to a per-lane dummy slot.
+// rows[i] = {row position, node, neighborhood-size id, -}; tasks[t] = [first, last) into rows.
+template <int UN, bool STAGED>
+__device__ __forceinline__ void hyp_emit_rows(const unsigned int *__restrict__ src, const int4 *__restrict__ rows, int2 task,
+                                              const double2 *__restrict__ lut, const uint32_t (&kofs)[3], const bool (&ok)[3],
+                                              const int64_t (&col)[3], int hh, int lane, int64_t mloc, const HypLookup &hl) {
+    double *const dummy = hl.dummy + lane;
+    unsigned int hits[3] = {0u, 0u, 0u};
+    int4 r[UN];
+    uint32_t w[UN][3];
+    auto load_batch = [&](int i0, int4 (&rr)[UN], uint32_t (&ww)[UN][3]) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            rr[i] = rows[min(i0 + i, task.y - 1)];                           // wave-uniform: scalar loads
+            rr[i].w = i0 + i < task.y;
+        }
+#pragma unroll
+        for (int i = 0; i < UN; ++i)                                         // three dword loads: a 96-bit tuple carried round
+#pragma unroll
+            for (int q = 0; q < 3; ++q) ww[i][q] = src[static_cast<int64_t>(rr[i].x) * 96 + q];   // the loop gets copied (= waited for) at once
+    };
+    // two batches per trip, the register sets swapping roles (a copy would wait for the loads just issued);
+    // rows past the end of the task are dead (dummy stores), so the trip needs no branch
+    auto batch = [&](int i0, const int4 (&rc)[UN], const uint32_t (&wc)[UN][3], int4 (&rn)[UN], uint32_t (&wn)[UN][3]) __attribute__((always_inline)) {
+        load_batch(i0 + UN, rn, wn);
+        __builtin_amdgcn_sched_barrier(0);                                   // the loads stay ahead of this batch's stores
+        double2 val[UN][3];
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            const uint32_t x[3] = {hh ? wc[i][0] >> 16 : wc[i][0] & 0xffffu, hh ? wc[i][1] >> 16 : wc[i][1] & 0xffffu,
+                                   hh ? wc[i][2] >> 16 : wc[i][2] & 0xffffu};
+#pragma unroll
+            for (int j = 0; j < 3; ++j) val[i][j] = lut[kofs[j] + (ok[j] ? x[j] : 0u)];
+        }
+#pragma unroll
+        for (int i = 0; i < UN; ++i) {
+            const int64_t o = static_cast<int64_t>(rc[i].y) * mloc;
+#pragma unroll
+            for (int j = 0; j < 3; ++j) {
+                // a row past the end of the task is a second copy of the task's last row: it stores the same
+                // values to the same addresses again (a shared dummy slot would be one hot L2 line) and counts no hits
+                const bool live = ok[j];
+                const bool hit = live && val[i][j].x < hl.p_cut;                   // safe.py:468-470 (nes_p_cut)
+                __builtin_nontemporal_store(val[i][j].x, live ? hl.pvalues_pos + o + col[j] : dummy);
+                __builtin_nontemporal_store(val[i][j].y, live ? hl.nes + o + col[j] : dummy);   // -log10 p from the table (safe.py:608)
+                __builtin_nontemporal_store(hit ? 1.0 : 0.0, live ? hl.nes_binary + o + col[j] : dummy);
+                hits[j] += hit && rc[i].w != 0;
+            }
+        }
+        __builtin_amdgcn_sched_barrier(0);
+    };
+    int4 r2[UN];
+    uint32_t w2[UN][3];
+    load_batch(task.x, r, w);
+    for (int i0 = task.x; i0 < task.y; i0 += 2 * UN) {
+        batch(i0, r, w, r2, w2);
+        batch(i0 + UN, r2, w2, r, w);
+    }
+#pragma unroll
+    for (int j = 0; j < 3; ++j)
+        if (hits[j]) atomicAdd(&hl.enriched[col[j]], hits[j]);
+}
 
-int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, const HypLookup &hl) {
+template <int UN>
+__global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict__ cnt16, int64_t n_padr, int64_t n_grp,
+                                                  const int4 *__restrict__ rows, const int2 *__restrict__ tasks, int64_t mloc,
+                                                  HypLookup hl, int lds_entries) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
+    double2 *slab = reinterpret_cast<double2 *>(emit_lds);
+    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int c = lane & 31, hh = lane >> 5;
+    const int2 task = tasks[blockIdx.y];
+    const int nid = rows[task.x].z;
+    const uint32_t xc = min(static_cast<uint32_t>(*hl.xmax) + 1u, static_cast<uint32_t>(hl.xs));
+    const uint32_t n_kid = static_cast<uint32_t>(hl.n_kid), xs = static_cast<uint32_t>(hl.xs);
+    const bool staged = n_kid * xc <= static_cast<uint32_t>(lds_entries);      // uniform over the whole launch
+    const double2 *tab_n = hl.tab + static_cast<int64_t>(nid) * n_kid * xs;
+    if (staged) {
+        const uint32_t total = n_kid * xc;
+        for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 512) {         // four loads in flight per thread
+            double2 v[4];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+                const uint32_t e = min(e0 + q * 512u, total - 1u), k = e / xc, x = e - k * xc;
+                v[q] = tab_n[k * xs + x];
+            }
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if (e0 + q * 512u < total) slab[e0 + q * 512u] = v[q];
+        }
+        __syncthreads();
+    }
+    const int64_t grp = static_cast<int64_t>(blockIdx.x) * 8 + wave;
+    if (grp >= n_grp) return;
+    int64_t col[3];
+    uint32_t kofs[3];
+    bool ok[3];
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+        col[j] = (grp * 6 + hh + 2 * j) * 32 + c;
+        ok[j] = col[j] < mloc;
+        kofs[j] = ok[j] ? static_cast<uint32_t>(hl.kid[col[j]]) * (staged ? xc : xs) : 0u;
+    }
+    const unsigned int *src = cnt16 + (grp * n_padr * 32 + c) * 3;
+    if (staged) hyp_emit_rows<UN, true>(src, rows, task, slab, kofs, ok, col, hh, lane, mloc, hl);
+    else hyp_emit_rows<UN, false>(src, rows, task, tab_n, kofs, ok, col, hh, lane, mloc, hl);
+}
+
+// planes, task queues and source map of the counts form, enqueued on ctx->stream
+struct CountsSetup {
+    std::vector<int2> tasks;              // host memory behind an asynchronous copy: lives until the stream is synchronised
+    int32_t q_off[9] = {0};
+    unsigned char *d_bs = nullptr;
+    int2 *d_tasks = nullptr;
+    int32_t *d_qoff = nullptr, *d_src = nullptr;
+    unsigned int *d_qctr = nullptr;       // [0..7] queue counters, [12] largest count (split form)
+    int64_t n_grp = 0, row_bytes = 0, n_src = 0, mloc = 0;
+};
+
+int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, CountsSetup *cs) {
     SAFE_TRY(build_blocks(nbr));
     const int64_t n = nbr->n, mloc = col1 - col0;
     const int64_t n_ct = ceil_div(mloc, 32), n_grp = ceil_div(n_ct, MF_CN), row_bytes = n_grp * MF_CN * 32, n_src = nbr->bs_src;
-    unsigned char *d_bs = nullptr;
-    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
+    cs->n_grp = n_grp, cs->row_bytes = row_bytes, cs->n_src = n_src, cs->mloc = mloc;
+    SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&cs->d_bs)));
     {
         const dim3 grid(n_grp * MF_CN, ceil_div(n + 1, 32));
         if (attr->dtype == SAFE_DTYPE_F32)
             hipLaunchKernelGGL(k_mfma_planes01<float>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_grp, d_bs);
+                               attr->col_stride, col0, mloc, n_grp, cs->d_bs);
         else
             hipLaunchKernelGGL(k_mfma_planes01<double>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_grp, d_bs);
+                               attr->col_stride, col0, mloc, n_grp, cs->d_bs);
     }
     std::vector<int32_t> g_order(nbr->bs_groups);
     std::iota(g_order.begin(), g_order.end(), 0);
     const std::vector<int32_t> &bp = nbr->h_bs_ptr;
     std::stable_sort(g_order.begin(), g_order.end(), [&](int32_t a, int32_t b) { return bp[a + 1] - bp[a] > bp[b + 1] - bp[b]; });
-    std::vector<int2> tasks;
-    int32_t q_off[9] = {0};
+    std::vector<int2> &tasks = cs->tasks;
     for (int qx = 0; qx < 8; ++qx) {
         for (int64_t ct = qx; ct < n_grp; ct += 8)
             for (int32_t g : g_order) tasks.push_back(make_int2(g, static_cast<int>(ct)));
-        q_off[qx + 1] = static_cast<int32_t>(tasks.size());
+        cs->q_off[qx + 1] = static_cast<int32_t>(tasks.size());
     }
     void *ws = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + 16 * sizeof(unsigned int), &ws));
-    int2 *d_tasks = static_cast<int2 *>(ws);
-    int32_t *d_qoff = reinterpret_cast<int32_t *>(d_tasks + tasks.size());
-    unsigned int *d_qctr = reinterpret_cast<unsigned int *>(d_qoff + 16);
-    int32_t *d_src = nullptr;
-    SAFE_TRY(ctx_scratch(ctx, 4, static_cast<size_t>(n_src) * sizeof(int32_t), reinterpret_cast<void **>(&d_src)));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_qoff, q_off, sizeof(q_off), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, 16 * sizeof(unsigned int), ctx->stream));
+    cs->d_tasks = static_cast<int2 *>(ws);
+    cs->d_qoff = reinterpret_cast<int32_t *>(cs->d_tasks + tasks.size());
+    cs->d_qctr = reinterpret_cast<unsigned int *>(cs->d_qoff + 16);
+    SAFE_TRY(ctx_scratch(ctx, 4, static_cast<size_t>(n_src) * sizeof(int32_t), reinterpret_cast<void **>(&cs->d_src)));
+    SAFE_HIP_CHECK(hipMemcpyAsync(cs->d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(cs->d_qoff, cs->q_off, sizeof(cs->q_off), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(cs->d_qctr, 0, 16 * sizeof(unsigned int), ctx->stream));
     hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
-                       static_cast<const int32_t *>(nullptr), 0, d_src);
-    // (tried: three tiles per task at 128 VGPRs so that two workgroups share a CU and one's store epilogue
-    // overlaps the other's matrix phase -- the main loop spills and the kernel is 1.5x slower)
+                       static_cast<const int32_t *>(nullptr), 0, cs->d_src);
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
     SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN>), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds_bytes)));
-    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    return SAFE_OK;
+}
+
+void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl) {
+    const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks.size()), ctx->num_cu);
+    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs, cs.row_bytes, cs.d_src,
+                       cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, cs.d_tasks, cs.d_qoff, cs.d_qctr, cs.mloc,
+                       static_cast<unsigned int *>(nullptr), nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr),
+                       static_cast<double *>(nullptr), hl);
+}
+
+}  // namespace
+
+// Fused form: counts + epilogue (table lookup when hl.tab, plain counts otherwise) in one kernel.
+// (tried: three tiles per task at 128 VGPRs so that two workgroups share a CU and one's store epilogue
+// overlaps the other's matrix phase -- the main loop spills and the kernel is 1.5x slower)
+int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, const HypLookup &hl) {
+    CountsSetup cs;
+    SAFE_TRY(counts_setup(ctx, nbr, attr, col0, col1, &cs));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, d_bs, row_bytes, d_src, n_src, 1,
-                       nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr, mloc, static_cast<unsigned int *>(nullptr),
-                       nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), hl);
+    counts_launch(ctx, nbr, cs, hl);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_permtest_mfma<counts>";
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the task vector is host memory
+    return SAFE_OK;
+}
+
+// Split form of the table lookup (default): the matrix-core kernel leaves packed u16 counts (8 % of the
+// output bytes) and k_hyp_emit streams p / nes / nes_binary out, instead of a fused epilogue whose
+// stores cannot overlap the next task's matrix phase (one workgroup per CU).  The first half needs
+// nothing from the hypergeometric table, so the caller builds the table on the side stream meanwhile.
+struct MfmaCountsSplit {
+    CountsSetup cs;
+    unsigned int *cnt16 = nullptr;
+    std::vector<int4> rows;
+    std::vector<int2> tasks;
+};
+
+bool mfma_counts_split_applicable(const safe_nbr *nbr) {
+    const char *split_env = getenv("SAFE_HIP_HYP_SPLIT");
+    return nbr->max_count < 65536 && !(split_env && !strcmp(split_env, "0"));
+}
+
+int mfma_counts_split_begin(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, MfmaCountsSplit **out) {
+    MfmaCountsSplit *st = new MfmaCountsSplit;
+    *out = st;
+    SAFE_TRY(counts_setup(ctx, nbr, attr, col0, col1, &st->cs));
+    const int64_t n_padr = nbr->bs_groups * MF_R;
+    SAFE_TRY(ctx_scratch(ctx, 5, static_cast<size_t>(st->cs.n_grp) * n_padr * 32 * 3 * sizeof(unsigned int), reinterpret_cast<void **>(&st->cnt16)));
+    HypLookup hl{};
+    hl.cnt16 = st->cnt16;
+    hl.xmax = st->cs.d_qctr + 12;
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    counts_launch(ctx, nbr, st->cs, hl);
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
+}
+
+void mfma_counts_split_free(MfmaCountsSplit *st) { delete st; }
+
+// second half: hl carries the table, the ids and the outputs; h_nid[node] = neighborhood-size id (host)
+int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl_in, const int32_t *h_nid) {
+    HypLookup hl = hl_in;
+    hl.cnt16 = st->cnt16;
+    hl.xmax = st->cs.d_qctr + 12;
+    const int64_t n_padr = nbr->bs_groups * MF_R, n_grp = st->cs.n_grp;
+    constexpr int EMIT_UN = 4, EMIT_CHUNK = 64;
+    // rows grouped by neighborhood size, every group cut into chunks of <= 64 rows, long chunks first
+    // (counting sort: the ids are dense)
+    int32_t n_ids = 0;
+    for (int64_t i = 0; i < nbr->n; ++i) n_ids = std::max(n_ids, h_nid[i] + 1);
+    std::vector<int32_t> first(n_ids + 1, 0);
+    for (int64_t i = 0; i < nbr->n; ++i) ++first[h_nid[i] + 1];
+    for (int32_t k = 0; k < n_ids; ++k) first[k + 1] += first[k];
+    st->rows.resize(nbr->n);
+    for (int64_t u = 0; u < n_padr; ++u) {
+        const int32_t node = nbr->h_bs_rowmap[u];
+        if (node >= 0) st->rows[first[h_nid[node]]++] = make_int4(static_cast<int>(u), node, h_nid[node], 1);
+    }
+    for (size_t a = 0; a < st->rows.size();) {
+        size_t b = a;
+        while (b < st->rows.size() && st->rows[b].z == st->rows[a].z) ++b;
+        for (size_t c = a; c < b; c += EMIT_CHUNK) st->tasks.push_back(make_int2(static_cast<int>(c), static_cast<int>(std::min(b, c + EMIT_CHUNK))));
+        a = b;
+    }
+    std::stable_sort(st->tasks.begin(), st->tasks.end(), [](const int2 &a, const int2 &b) { return a.y - a.x > b.y - b.x; });
+    void *ws = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 8, st->rows.size() * sizeof(int4) + st->tasks.size() * sizeof(int2), &ws));
+    int4 *d_rows = static_cast<int4 *>(ws);
+    int2 *d_tasks = reinterpret_cast<int2 *>(d_rows + st->rows.size());
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_rows, st->rows.data(), st->rows.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, st->tasks.data(), st->tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    const int64_t want = hl.n_kid * hl.xs * static_cast<int64_t>(sizeof(double2));
+    const char *lds_env = getenv("SAFE_HIP_EMIT_LDS_KB");                // tests: 0 forces the global-gather loop
+    const int64_t lds_cap = lds_env ? std::max(0, atoi(lds_env)) * 1024ll : (64ll << 10);
+    const int lds_bytes = static_cast<int>(std::min<int64_t>(want, std::min<int64_t>(lds_cap, 64 << 10)));
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit<EMIT_UN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
+    hipLaunchKernelGGL((k_hyp_emit<EMIT_UN>), dim3(ceil_div(n_grp, 8), st->tasks.size()), dim3(512), lds_bytes, ctx->stream, st->cnt16,
+                       n_padr, n_grp, d_rows, d_tasks, st->cs.mloc, hl, lds_bytes / static_cast<int>(sizeof(double2)));
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+    ctx->last_kernel.name = "k_permtest_mfma<counts> + k_hyp_emit";
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the row / task vectors are host memory
     return SAFE_OK;
 }
 

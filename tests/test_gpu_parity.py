@@ -308,12 +308,19 @@ def test_midsize_randomization_vs_oracle(amd, ctx):
                                   want['num_neighborhoods_enriched'])
 
 
-@pytest.mark.parametrize('counts', ['bits', 'mfma', 'per-element'])
+@pytest.mark.parametrize('counts', ['bits', 'mfma', 'mfma-nolds', 'mfma-fused', 'per-element'])
 def test_midsize_hypergeometric_vs_oracle(amd, ctx, monkeypatch, counts):
-    """The three forms of the hypergeometric path: bit-sliced counts + (n, K, X) table lookup,
-    matrix-core counts + table lookup, and the per-element tail evaluation."""
+    """The forms of the hypergeometric path: bit-sliced counts + (n, K, X) table lookup, matrix-core
+    counts + table lookup (split: packed u16 counts, then the streaming k_hyp_emit with the table slab
+    in LDS; fused: lookup in the count kernel's epilogue), and the per-element tail evaluation."""
     if counts == 'per-element':
         monkeypatch.setenv('SAFE_HIP_HYPER_TABLE', '0')
+    elif counts == 'mfma-fused':
+        monkeypatch.setenv('SAFE_HIP_COUNTS', 'mfma')
+        monkeypatch.setenv('SAFE_HIP_HYP_SPLIT', '0')
+    elif counts == 'mfma-nolds':                       # table slab too large for LDS: lookups gathered from memory
+        monkeypatch.setenv('SAFE_HIP_COUNTS', 'mfma')
+        monkeypatch.setenv('SAFE_HIP_EMIT_LDS_KB', '0')
     else:
         monkeypatch.setenv('SAFE_HIP_COUNTS', counts)
     rng = np.random.default_rng(78)
@@ -328,7 +335,8 @@ def test_midsize_hypergeometric_vs_oracle(amd, ctx, monkeypatch, counts):
     sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.12)
     sf.load_attributes(attribute_file=b)
     sf.compute_pvalues()
-    want_kernel = {'bits': 'k_counts_bits<hypergeom>', 'mfma': 'k_permtest_mfma<counts>', 'per-element': 'k_hypergeom_tail'}[counts]
+    want_kernel = {'bits': 'k_counts_bits<hypergeom>', 'mfma': 'k_permtest_mfma<counts> + k_hyp_emit',
+                   'mfma-nolds': 'k_permtest_mfma<counts> + k_hyp_emit', 'mfma-fused': 'k_permtest_mfma<counts>', 'per-element': 'k_hypergeom_tail'}[counts]
     assert ctx.last_kernel()[0] == want_kernel
     np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
     np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
@@ -365,7 +373,7 @@ def test_hypergeometric_p_on_the_threshold(amd, ctx, monkeypatch, counts):
     sf.neighborhoods = a
     sf.load_attributes(attribute_file=b)
     sf.compute_pvalues()
-    assert ctx.last_kernel()[0] == {'bits': 'k_counts_bits<hypergeom>', 'mfma': 'k_permtest_mfma<counts>'}[counts]
+    assert ctx.last_kernel()[0] == {'bits': 'k_counts_bits<hypergeom>', 'mfma': 'k_permtest_mfma<counts> + k_hyp_emit'}[counts]
     on_threshold = want['pvalues_pos'] == 0.05
     assert on_threshold.sum() >= 10 * width
     assert np.array_equal(sf.pvalues_pos[on_threshold], want['pvalues_pos'][on_threshold])

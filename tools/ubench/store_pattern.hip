@@ -70,8 +70,39 @@ __global__ __launch_bounds__(512) void k_store(double *__restrict__ a, double *_
     }
 }
 
-int main() {
-    const int64_t n = 20000, m = 9984;
+// mode 3/4/5: the split form's k_hyp_emit pattern -- one block = 4 waves x 192 columns, UN rows per wave (no loop),
+// a wave instruction writes 512 contiguous bytes of one row; NT = nontemporal stores
+template <int UN, bool NT>
+__global__ __launch_bounds__(256) void k_emit_like(double *__restrict__ a, double *__restrict__ b, double *__restrict__ c, int64_t m,
+                                                   const int32_t *__restrict__ rowmap, int64_t n_grp) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cc = lane & 31, hh = lane >> 5;
+    const int64_t grp = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    if (grp >= n_grp) return;
+    int row[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i) row[i] = rowmap[static_cast<int64_t>(blockIdx.y) * UN + i];
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int64_t col = (grp * 6 + hh + 2 * j) * 32 + cc;
+            const int64_t o = static_cast<int64_t>(row[i]) * m + (col < m ? col : 0);
+            if (NT) {
+                __builtin_nontemporal_store(1.0 + j, a + o);
+                __builtin_nontemporal_store(2.0 + i, b + o);
+                __builtin_nontemporal_store(3.0, c + o);
+            } else {
+                a[o] = 1.0 + j;
+                b[o] = 2.0 + i;
+                c[o] = 3.0;
+            }
+        }
+}
+
+int main(int argc, char **argv) {
+    const int64_t n = 20000, m = argc > 1 ? atoll(argv[1]) : 9984;
+    const bool sorted_rows = argc > 2 && atoi(argv[2]);
     const int n_grp = (n + 255) / 256, n_ct = m / 192, n_tasks = n_grp * n_ct;
     double *a, *b, *c;
     hipMalloc(&a, n * m * 8);
@@ -82,7 +113,8 @@ int main() {
     std::iota(perm.begin(), perm.end(), 0);
     std::mt19937 rng(1);
     std::shuffle(perm.begin(), perm.end(), rng);
-    for (int64_t i = 0; i < n; ++i) rowmap[i] = perm[i];
+    for (int64_t i = 0; i < n; ++i) rowmap[i] = sorted_rows ? static_cast<int32_t>(i) : perm[i];
+    printf("m = %lld, rows %s\n", (long long)m, sorted_rows ? "in order" : "shuffled");
     int32_t *d_map;
     unsigned int *d_ctr;
     hipMalloc(&d_map, rowmap.size() * 4);
@@ -91,13 +123,18 @@ int main() {
     hipEvent_t e0, e1;
     hipEventCreate(&e0);
     hipEventCreate(&e1);
-    for (int mode = 0; mode < 3; ++mode) {
+    const int64_t n_g6 = (m + 191) / 192;
+    for (int mode = 0; mode < 7; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             hipMemset(d_ctr, 0, 4);
             hipEventRecord(e0);
             if (mode == 0) hipLaunchKernelGGL(k_store<0>, dim3(256), dim3(512), 0, 0, a, b, c, n, m, d_map, n_tasks, n_ct, d_ctr);
             if (mode == 1) hipLaunchKernelGGL(k_store<1>, dim3(256), dim3(512), 0, 0, a, b, c, n, m, d_map, n_tasks, n_ct, d_ctr);
             if (mode == 2) hipLaunchKernelGGL(k_store<2>, dim3(256), dim3(512), 0, 0, a, b, c, n, m, d_map, n_tasks, n_ct, d_ctr);
+            if (mode == 3) hipLaunchKernelGGL((k_emit_like<4, true>), dim3((n_g6 + 3) / 4, n / 4), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
+            if (mode == 4) hipLaunchKernelGGL((k_emit_like<4, false>), dim3((n_g6 + 3) / 4, n / 4), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
+            if (mode == 5) hipLaunchKernelGGL((k_emit_like<8, false>), dim3((n_g6 + 3) / 4, n / 8), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
+            if (mode == 6) hipLaunchKernelGGL((k_emit_like<16, false>), dim3((n_g6 + 3) / 4, n / 16), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
