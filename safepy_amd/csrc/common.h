@@ -76,6 +76,8 @@ struct safe_ctx {
     const unsigned int *packed_counts = nullptr;
     int64_t packed_n_pad = 0, packed_m = 0, packed_perms = 0;
     int packed_layout = -1;
+    void *pinned = nullptr;
+    size_t pinned_bytes = 0;
     static constexpr int N_SCRATCH = 12;
     void *scratch[N_SCRATCH] = {};
     size_t scratch_bytes[N_SCRATCH] = {};
@@ -84,6 +86,9 @@ struct safe_ctx {
 // returns a device buffer of at least `bytes` from slot `slot`, valid until the next request
 // for the same slot; contents are undefined
 int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out);
+// grow-only pinned host buffer (device-to-host copies into it go through the DMA engines: no copy kernel
+// that would have to wait for a CU while a persistent kernel holds all of them)
+int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out);
 void perms_cache_drop(safe_ctx *ctx);   // frees ctx->perm_cache (rng.cpp)
 
 // RAII-less device buffer helper: all frees go through the owning handle's destroy.
@@ -295,4 +300,5 @@ bool mfma_counts_split_applicable(const safe_nbr *nbr);
 int mfma_counts_split_begin(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, MfmaCountsSplit **out);
 int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl, const int32_t *h_nid);
 void mfma_counts_split_free(MfmaCountsSplit *st);
+const unsigned int *mfma_counts_split_xmax(const MfmaCountsSplit *st);   // device: largest count of the call
 void nbr_free_blocks(safe_nbr *nbr);

@@ -42,6 +42,27 @@ int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out) {
     return SAFE_OK;
 }
 
+int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out) {
+    if (ctx->pinned_bytes < bytes) {
+        if (ctx->pinned) {
+            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->side_stream));
+            SAFE_HIP_CHECK(hipHostFree(ctx->pinned));
+            ctx->pinned = nullptr;
+            ctx->pinned_bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4 + 4096;
+        hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
+        if (e != hipSuccess) {
+            safe_set_error("hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+            return SAFE_E_NOMEM;
+        }
+        ctx->pinned_bytes = want;
+    }
+    *out = ctx->pinned;
+    return SAFE_OK;
+}
+
 extern "C" {
 
 int safe_abi_version(void) { return SAFE_HIP_ABI_VERSION; }
@@ -105,6 +126,7 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->k0) (void)hipEventDestroy(ctx->k0);
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
     perms_cache_drop(ctx);
+    if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (int i = 0; i < safe_ctx::N_SCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);

@@ -1079,7 +1079,7 @@ __device__ __forceinline__ double fast_rcp(double x) {
 
 
 // TABLE = true: the hypergeometric epilogue is fused in -- instead of the count X the kernel writes
-// p = tab[(nid[row] * n_kid + kid[col]) * xs + X] (k_hyp_table), -log10 p, the binarised value and the
+// p = tab[(nid[row] * xs + X) * n_kid + kid[col]] (k_hyp_table), -log10 p, the binarised value and the
 // per-attribute enriched counts (safe.py:596-608, 468-472); the counts never reach memory.
 
 template <bool TABLE>
@@ -1136,13 +1136,13 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
             out[static_cast<int64_t>(rr) * mloc + jc] = static_cast<double>(tile[r][lane]);
         }
     } else {
-        const int64_t kofs = col_ok ? static_cast<int64_t>(hl.kid[jc]) * hl.xs : 0;
+        const int64_t kofs = col_ok ? static_cast<int64_t>(hl.kid[jc]) : 0;
         unsigned int hits = 0;
         for (int r = 0; r < 64; ++r) {
             const int32_t rr = sell_row[s * 64 + r];                    // wave-uniform
             if (rr < 0 || !col_ok) continue;
             const double2 *slab = hl.tab + static_cast<int64_t>(hl.nid[rr]) * hl.n_kid * hl.xs;
-            const double2 e = slab[kofs + tile[r][lane]];
+            const double2 e = slab[static_cast<int64_t>(tile[r][lane]) * hl.n_kid + kofs];
             const double p = e.x, nes = e.y;                            // p and -log10 p (safe.py:608), both from the table
             const bool hit = p < hl.p_cut;                              // safe.py:468-470 (nes_p_cut)
             const int64_t o = static_cast<int64_t>(rr) * mloc + jc;
@@ -1196,53 +1196,70 @@ __device__ __forceinline__ double dd_ratio(dd_t a, dd_t b) {            // a / b
 // enrichment threshold, and SciPy returns them exactly.
 __global__ __launch_bounds__(64) void k_hyp_table(const int32_t *__restrict__ nvals, int64_t n_nid,
                                                   const int32_t *__restrict__ kvals, int64_t n_kid, int64_t xs, int64_t pop,
-                                                  double2 *__restrict__ tab) {
+                                                  const unsigned int *__restrict__ xmax, double2 *__restrict__ tab) {
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * 64 + threadIdx.x;
     if (idx >= n_nid * n_kid) return;
+    // xmax (split matrix-core form: the counts are known before the lookup) = the largest count of the call;
+    // only x <= xmax is ever looked up, so the table stops there and the serial recurrences stop as soon as
+    // the terms can no longer reach the last bit of a double-double sum (a few dozen steps past the mode
+    // instead of the whole support: 5x fewer at 20 000 nodes / 1 % density).  xc = entries per column.
+    const int64_t xc = xmax ? (static_cast<int64_t>(*xmax) + 1 < xs ? static_cast<int64_t>(*xmax) + 1 : xs) : xs;
     const int64_t draws = nvals[idx / n_kid], good = kvals[idx % n_kid];
-    double2 *t_out = tab + idx * xs;                                    // scratch first: (hi, lo) of the relative pmf
+    // layout [size id][x][count id]: consecutive lanes (count ids) touch consecutive entries, and the
+    // entries of the small x that counts actually reach are one contiguous run per size (k_hyp_emit's LDS slab)
+    double2 *t_base = tab + (idx / n_kid) * xs * n_kid + idx % n_kid;    // scratch first: (hi, lo) of the relative pmf
+#define t_out(t) t_base[(t) * n_kid]
     const int64_t lo = draws - (pop - good) > 0 ? draws - (pop - good) : 0;
     const int64_t hi = good < draws ? good : draws;
     const double good_d = static_cast<double>(good), draws_d = static_cast<double>(draws);
     const double rest_d = static_cast<double>(pop) - good_d - draws_d;
     int64_t mode = static_cast<int64_t>(floor(static_cast<double>(good + 1) * static_cast<double>(draws + 1) / static_cast<double>(pop + 2)));
     mode = mode < lo ? lo : (mode > hi ? hi : mode);
-    // terms at or beyond xs are only summed (`beyond`); `below` collects the terms under the table's reach
+    // terms at or beyond xc are only summed (`beyond`).  The pmf is unimodal and falls faster than
+    // geometrically away from the mode, so once a term is below 1e-40 of a sum every needed quantity
+    // contains (`beyond` <= every tail P[H >= x], x < xc, and <= total), the rest of that side adds
+    // nothing at double-double precision (1e-32).
     dd_t beyond{0.0, 0.0}, total{0.0, 0.0}, term{1.0, 0.0};
     double td = static_cast<double>(mode);
     for (int64_t t = mode; t <= hi; ++t) {                              // upwards from the mode
-        if (t < xs) t_out[t] = make_double2(term.hi, term.lo);
+        if (t < xc) t_out(t) = make_double2(term.hi, term.lo);
         else beyond = dd_add(beyond, term);
         total = dd_add(total, term);
-        if (term.hi == 0.0 && t >= xs) break;
+        if (t >= xc && (term.hi == 0.0 || term.hi < beyond.hi * 1e-40)) break;
         term = dd_mul_d(dd_mul_d(term, good_d - td), draws_d - td);
         term = dd_div_d(dd_div_d(term, td + 1.0), rest_d + td + 1.0);
         td += 1.0;
     }
     term = dd_t{1.0, 0.0};
     td = static_cast<double>(mode);
+    int64_t t_stop = lo;                                                // terms below t_stop are zero at this precision
     for (int64_t t = mode - 1; t >= lo; --t) {                          // downwards from the mode
         term = dd_mul_d(dd_mul_d(term, td), rest_d + td);
         term = dd_div_d(dd_div_d(term, good_d - td + 1.0), draws_d - td + 1.0);
         td -= 1.0;
-        if (t < xs) t_out[t] = make_double2(term.hi, term.lo);
+        if (term.hi < total.hi * 1e-45) {                               // (and every tail that would contain it is >= the mode's term = 1)
+            t_stop = t + 1;
+            break;
+        }
+        if (t < xc) t_out(t) = make_double2(term.hi, term.lo);
         else beyond = dd_add(beyond, term);
         total = dd_add(total, term);
     }
     dd_t running = beyond;
-    for (int64_t t = xs - 1; t >= 0; --t) {
+    for (int64_t t = xc - 1; t >= 0; --t) {
         double p;
         if (t > hi) {
             p = 0.0;                                                    // sf(x - 1) with x - 1 >= top of the support
         } else if (t <= lo) {
             p = 1.0;                                                    // x - 1 below the support
         } else {
-            running = dd_add(running, dd_t{t_out[t].x, t_out[t].y});
+            if (t >= t_stop) running = dd_add(running, dd_t{t_out(t).x, t_out(t).y});
             p = dd_ratio(running, total);
             p = p > 1.0 ? 1.0 : p;
         }
-        t_out[t] = make_double2(p, -log10(p));                          // safe.py:608
+        t_out(t) = make_double2(p, -log10(p));                          // safe.py:608
     }
+#undef t_out
 }
 
 // --------------------------------------------------------------------------------------
@@ -1994,9 +2011,11 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     // split matrix-core form (which needs nothing from here) runs on ctx->stream
     *fused = false;
     const int64_t n = nbr->n, mloc = col1 - col0;
-    std::vector<double> h_size(n), h_k(mloc);
-    SAFE_HIP_CHECK(hipMemcpyAsync(h_size.data(), d_size, n * sizeof(double), hipMemcpyDeviceToHost, hs));
-    SAFE_HIP_CHECK(hipMemcpyAsync(h_k.data(), attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, hs));
+    void *pinned = nullptr;
+    SAFE_TRY(ctx_pinned(ctx, static_cast<size_t>(n + mloc) * sizeof(double), &pinned));
+    const double *h_size = static_cast<const double *>(pinned), *h_k = h_size + n;
+    SAFE_HIP_CHECK(hipMemcpyAsync(pinned, d_size, n * sizeof(double), hipMemcpyDeviceToHost, hs));
+    SAFE_HIP_CHECK(hipMemcpyAsync(static_cast<double *>(pinned) + n, attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, hs));
     SAFE_HIP_CHECK(hipStreamSynchronize(hs));
     // distinct values -> dense ids (both are integers in [0, n] here, or we decline)
     std::vector<int32_t> id_of(n + 2, -1), nvals, kvals, nid(n), kid(mloc);
@@ -2039,8 +2058,15 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     SAFE_HIP_CHECK(hipMemcpyAsync(d_kvals, kvals.data(), n_kid * sizeof(int32_t), hipMemcpyHostToDevice, hs));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_nid, nid.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, hs));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_kid, kid.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, hs));
-    hipLaunchKernelGGL(k_hyp_table, dim3(ceil_div(n_nid * n_kid, 64)), dim3(64), 0, hs, d_nvals, n_nid, d_kvals, n_kid, xs,
-                       pop, d_tab);
+    hipEvent_t ids_done = nullptr;
+    if (split) {
+        // the counts are under way on ctx->stream: the table follows them there, cut at their largest value
+        SAFE_HIP_CHECK(hipEventCreateWithFlags(&ids_done, hipEventDisableTiming));
+        SAFE_HIP_CHECK(hipEventRecord(ids_done, hs));
+        SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ids_done, 0));
+    }
+    hipLaunchKernelGGL(k_hyp_table, dim3(ceil_div(n_nid * n_kid, 64)), dim3(64), 0, split ? ctx->stream : hs, d_nvals, n_nid, d_kvals,
+                       n_kid, xs, pop, split ? mfma_counts_split_xmax(split) : static_cast<const unsigned int *>(nullptr), d_tab);
 
     const int64_t n_wg = ceil_div(mloc, 64);
     HypLookup hl{};
@@ -2056,13 +2082,9 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.nes_binary = nb_dev;
     hl.enriched = d_enr;
     if (split) {
-        hipEvent_t table_done = nullptr;
-        SAFE_HIP_CHECK(hipEventCreateWithFlags(&table_done, hipEventDisableTiming));
-        SAFE_HIP_CHECK(hipEventRecord(table_done, hs));
-        SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, table_done, 0));
         const int rc = mfma_counts_split_emit(ctx, nbr, split, hl, nid.data());       // synchronises ctx->stream
         (void)hipStreamSynchronize(hs);                                    // the id vectors above are host memory
-        (void)hipEventDestroy(table_done);
+        (void)hipEventDestroy(ids_done);
         SAFE_TRY(rc);
     } else if (use_mfma) {
         SAFE_TRY(launch_mfma_counts(ctx, nbr, attr, col0, col1, hl));   // records its own timing events

@@ -433,11 +433,12 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     slab[r] = (hl.tab && node[r] >= 0) ? static_cast<uint32_t>(hl.nid[node[r]]) * static_cast<uint32_t>(hl.n_kid * hl.xs) : 0u;
                 uint32_t kofs[NS];
                 bool col_ok[NS];
+                const uint32_t n_kid_u = static_cast<uint32_t>(hl.n_kid);     // table layout [size id][x][count id]
 #pragma unroll
                 for (int s = 0; s < NS; ++s) {
                     const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
                     col_ok[s] = col < mloc;
-                    kofs[s] = (hl.tab && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) * static_cast<uint32_t>(hl.xs) : 0u;
+                    kofs[s] = (hl.tab && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) : 0u;
                 }
                 if (hl.cnt16) {
                     // split form: the counts leave as u16, six tiles of one (row, column-in-tile) packed into
@@ -484,7 +485,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 #pragma unroll
                         for (int rr = 0; rr < 8; ++rr) {
                             const int r = half * 8 + rr;
-                            val[rr] = hl.tab[slab[r] + kofs[s] + ((col_ok[s] && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) : 0u)];
+                            val[rr] = hl.tab[slab[r] + kofs[s] + ((col_ok[s] && node[r] >= 0) ? static_cast<uint32_t>(acc[s][r]) * n_kid_u : 0u)];
                         }
                     };
                     unsigned int hits[NS];
@@ -738,11 +739,48 @@ __global__ __launch_bounds__(256) void k_mfma_planes01(const void *__restrict__ 
     }
 }
 
+// the same planes from a C-order matrix (column stride 1): no transpose, a thread turns four consecutive
+// columns into four bytes (16- / 32-byte loads when the row pitch and the shard offset allow it), a wave
+// reads 1 KiB (f32) of one row
+template <typename T, bool VEC>
+__global__ __launch_bounds__(256) void k_mfma_planes01_rows(const T *__restrict__ raw, int64_t n, int64_t rs, int64_t col0, int64_t mloc,
+                                                            int64_t row_bytes, unsigned char *__restrict__ bs) {
+    const int64_t j = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
+    if (j >= row_bytes) return;
+    const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 8;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+        const int64_t r = r0 + i;
+        if (r > n) break;
+        uint32_t w = 0;
+        if (r < n) {
+            const T *src = raw + r * rs + col0 + j;
+            if (VEC && j + 4 <= mloc) {
+                T v[4];
+                if constexpr (sizeof(T) == 4) {
+                    const float4 q = *reinterpret_cast<const float4 *>(src);
+                    v[0] = q.x, v[1] = q.y, v[2] = q.z, v[3] = q.w;
+                } else {
+                    const double2 q0 = *reinterpret_cast<const double2 *>(src), q1 = *reinterpret_cast<const double2 *>(src + 2);
+                    v[0] = q0.x, v[1] = q0.y, v[2] = q1.x, v[3] = q1.y;
+                }
+#pragma unroll
+                for (int k = 0; k < 4; ++k) w |= (v[k] == static_cast<T>(1) ? 1u : 0u) << (8 * k);
+            } else {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    if (j + k < mloc) w |= (src[k] == static_cast<T>(1) ? 1u : 0u) << (8 * k);
+            }
+        }
+        *reinterpret_cast<uint32_t *>(bs + r * row_bytes + j) = w;
+    }
+}
+
 // Second half of the split hypergeometric form.  A workgroup = (one neighborhood size, <= 64 of the rows
 // that have it, 8 groups of six 32-column tiles); wave w owns one group, lane (c, hh) the columns
 // (6 grp + hh + 2j) * 32 + c, j = 0..2, so every store instruction of a wave covers 64 consecutive
 // columns = 512 contiguous bytes of one row of p / nes / nes_binary.
-// The table slab of the size -- [annotation count id][0 .. largest count of the call] -- is staged in
+// The table slab of the size -- [0 .. largest count of the call][annotation count id], one contiguous run -- is staged in
 // LDS once per workgroup, so a lookup is one ds_read_b128 instead of a 64-line global gather (which
 // costs the texture path 64 cycles and was a third of the kernel).  Rows are software-pipelined and the
 // loop is branch-free: vmcnt counts stores too and retires in order, so the counts of batch i+1 are
@@ -751,7 +789,7 @@ __global__ __launch_bounds__(256) void k_mfma_planes01(const void *__restrict__ 
 // rows[i] = {row position, node, neighborhood-size id, -}; tasks[t] = [first, last) into rows.
 template <int UN, bool STAGED>
 __device__ __forceinline__ void hyp_emit_rows(const unsigned int *__restrict__ src, const int4 *__restrict__ rows, int2 task,
-                                              const double2 *__restrict__ lut, const uint32_t (&kofs)[3], const bool (&ok)[3],
+                                              const double2 *__restrict__ lut, uint32_t n_kid, const uint32_t (&kofs)[3], const bool (&ok)[3],
                                               const int64_t (&col)[3], int hh, int lane, int64_t mloc, const HypLookup &hl) {
     double *const dummy = hl.dummy + lane;
     unsigned int hits[3] = {0u, 0u, 0u};
@@ -779,7 +817,7 @@ __device__ __forceinline__ void hyp_emit_rows(const unsigned int *__restrict__ s
             const uint32_t x[3] = {hh ? wc[i][0] >> 16 : wc[i][0] & 0xffffu, hh ? wc[i][1] >> 16 : wc[i][1] & 0xffffu,
                                    hh ? wc[i][2] >> 16 : wc[i][2] & 0xffffu};
 #pragma unroll
-            for (int j = 0; j < 3; ++j) val[i][j] = lut[kofs[j] + (ok[j] ? x[j] : 0u)];
+            for (int j = 0; j < 3; ++j) val[i][j] = lut[kofs[j] + (ok[j] ? x[j] * n_kid : 0u)];   // [x][count id]
         }
 #pragma unroll
         for (int i = 0; i < UN; ++i) {
@@ -825,14 +863,11 @@ __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict
     const bool staged = n_kid * xc <= static_cast<uint32_t>(lds_entries);      // uniform over the whole launch
     const double2 *tab_n = hl.tab + static_cast<int64_t>(nid) * n_kid * xs;
     if (staged) {
-        const uint32_t total = n_kid * xc;
+        const uint32_t total = n_kid * xc;                                   // [x < xc][count id]: one contiguous run of the table
         for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 512) {         // four loads in flight per thread
             double2 v[4];
 #pragma unroll
-            for (int q = 0; q < 4; ++q) {
-                const uint32_t e = min(e0 + q * 512u, total - 1u), k = e / xc, x = e - k * xc;
-                v[q] = tab_n[k * xs + x];
-            }
+            for (int q = 0; q < 4; ++q) v[q] = tab_n[min(e0 + q * 512u, total - 1u)];
 #pragma unroll
             for (int q = 0; q < 4; ++q)
                 if (e0 + q * 512u < total) slab[e0 + q * 512u] = v[q];
@@ -848,11 +883,11 @@ __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict
     for (int j = 0; j < 3; ++j) {
         col[j] = (grp * 6 + hh + 2 * j) * 32 + c;
         ok[j] = col[j] < mloc;
-        kofs[j] = ok[j] ? static_cast<uint32_t>(hl.kid[col[j]]) * (staged ? xc : xs) : 0u;
+        kofs[j] = ok[j] ? static_cast<uint32_t>(hl.kid[col[j]]) : 0u;
     }
     const unsigned int *src = cnt16 + (grp * n_padr * 32 + c) * 3;
-    if (staged) hyp_emit_rows<UN, true>(src, rows, task, slab, kofs, ok, col, hh, lane, mloc, hl);
-    else hyp_emit_rows<UN, false>(src, rows, task, tab_n, kofs, ok, col, hh, lane, mloc, hl);
+    if (staged) hyp_emit_rows<UN, true>(src, rows, task, slab, n_kid, kofs, ok, col, hh, lane, mloc, hl);
+    else hyp_emit_rows<UN, false>(src, rows, task, tab_n, n_kid, kofs, ok, col, hh, lane, mloc, hl);
 }
 
 // planes, task queues and source map of the counts form, enqueued on ctx->stream
@@ -872,7 +907,23 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
     const int64_t n_ct = ceil_div(mloc, 32), n_grp = ceil_div(n_ct, MF_CN), row_bytes = n_grp * MF_CN * 32, n_src = nbr->bs_src;
     cs->n_grp = n_grp, cs->row_bytes = row_bytes, cs->n_src = n_src, cs->mloc = mloc;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&cs->d_bs)));
-    {
+    if (attr->col_stride == 1) {                                          // C order: straight through
+        const dim3 grid(ceil_div(row_bytes / 4, 256), ceil_div(n + 1, 8));
+        const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+        const int64_t per16 = f32 ? 4 : 2;                                   // elements per 16 bytes
+        const bool vec = attr->row_stride % per16 == 0 && col0 % per16 == 0 && reinterpret_cast<uintptr_t>(attr->raw) % 16 == 0;
+#define PLANES_ROWS(T, V)                                                                                                      \
+    hipLaunchKernelGGL((k_mfma_planes01_rows<T, V>), grid, dim3(256), 0, ctx->stream, static_cast<const T *>(attr->raw), n,   \
+                       attr->row_stride, col0, mloc, row_bytes, cs->d_bs)
+        if (f32) {
+            if (vec) PLANES_ROWS(float, true);
+            else PLANES_ROWS(float, false);
+        } else {
+            if (vec) PLANES_ROWS(double, true);
+            else PLANES_ROWS(double, false);
+        }
+#undef PLANES_ROWS
+    } else {
         const dim3 grid(n_grp * MF_CN, ceil_div(n + 1, 32));
         if (attr->dtype == SAFE_DTYPE_F32)
             hipLaunchKernelGGL(k_mfma_planes01<float>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
@@ -908,9 +959,9 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
     return SAFE_OK;
 }
 
-void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl) {
+void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl, int spare_cus = 0) {
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
-    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks.size()), ctx->num_cu);
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks.size()), std::max(1, ctx->num_cu - spare_cus));
     hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs, cs.row_bytes, cs.d_src,
                        cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, cs.d_tasks, cs.d_qoff, cs.d_qctr, cs.mloc,
                        static_cast<unsigned int *>(nullptr), nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr),
@@ -956,16 +1007,21 @@ int mfma_counts_split_begin(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64
     SAFE_TRY(counts_setup(ctx, nbr, attr, col0, col1, &st->cs));
     const int64_t n_padr = nbr->bs_groups * MF_R;
     SAFE_TRY(ctx_scratch(ctx, 5, static_cast<size_t>(st->cs.n_grp) * n_padr * 32 * 3 * sizeof(unsigned int), reinterpret_cast<void **>(&st->cnt16)));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+    // The count kernel is persistent and takes a CU whole (256 VGPRs x 2 waves per SIMD): with one workgroup
+    // per CU nothing else runs until it ends -- not even the copy kernels of the side stream.
+    // A few CUs are left to the side stream (neighborhood sizes and the copy kernels of the id vectors).
     HypLookup hl{};
     hl.cnt16 = st->cnt16;
     hl.xmax = st->cs.d_qctr + 12;
-    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
-    counts_launch(ctx, nbr, st->cs, hl);
+    counts_launch(ctx, nbr, st->cs, hl, 8);
     SAFE_HIP_CHECK(hipGetLastError());
     return SAFE_OK;
 }
 
 void mfma_counts_split_free(MfmaCountsSplit *st) { delete st; }
+
+const unsigned int *mfma_counts_split_xmax(const MfmaCountsSplit *st) { return st->cs.d_qctr + 12; }
 
 // second half: hl carries the table, the ids and the outputs; h_nid[node] = neighborhood-size id (host)
 int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl_in, const int32_t *h_nid) {

@@ -180,19 +180,23 @@ def test_wide_dynamic_range_declines_to_f64_kernels(amd, ctx):
     nbr.close()
 
 
-def test_binary_neighborhood_score_on_matrix_cores(amd, ctx, monkeypatch):
+@pytest.mark.parametrize('order,m,dtype', [('F', 205, np.float32), ('C', 205, np.float32), ('C', 208, np.float32),
+                                           ('C', 205, np.float64), ('C', 206, np.float64), ('F', 206, np.float64)])
+def test_binary_neighborhood_score_on_matrix_cores(amd, ctx, monkeypatch, order, m, dtype):
     """compute_neighborhood_score 'sum' of 0/1 attributes through the matrix-core count kernel
-    (one i8 plane per 32-column tile): exact integer counts, ragged column count, NaN rows."""
+    (one i8 plane per 32-column tile): exact integer counts, ragged column count, NaN rows; bit planes
+    from Fortran-order (transposing kernel) and C-order matrices (vector loads when the row pitch is a
+    multiple of 16 bytes, scalar loads otherwise)."""
     monkeypatch.setenv('SAFE_HIP_COUNTS', 'mfma')
     rng = np.random.default_rng(71)
-    n, m = 777, 205
+    n = 777
     xy = rng.uniform(size=(n, 2))
     a = orc.neighborhoods_euclidean(xy, 0.11)
-    b = (rng.uniform(size=(n, m)) < 0.07).astype(np.float32)
+    b = (rng.uniform(size=(n, m)) < 0.07).astype(dtype)
     b[rng.choice(n, 30, replace=False)] = np.nan
     sf = amd.SAFE(verbose=False)
     sf.graph = amd.LayoutGraph(xy)
     sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.11)
-    got = amd.compute_neighborhood_score(sf.neighborhoods, np.asfortranarray(b), 'sum')
+    got = amd.compute_neighborhood_score(sf.neighborhoods, np.asfortranarray(b) if order == 'F' else np.ascontiguousarray(b), 'sum')
     assert ctx.last_kernel()[0] == 'k_permtest_mfma<counts>'
     np.testing.assert_array_equal(got, orc.compute_neighborhood_score(a, b, 'sum'))

@@ -100,6 +100,52 @@ __global__ __launch_bounds__(256) void k_emit_like(double *__restrict__ a, doubl
         }
 }
 
+// mode 7/8: mode 4 plus the emit kernel's reads (12 bytes per lane and row from a 0.4 GB count buffer, all requested
+// before the first store); mode 8 reads the same 64 KB over and over (cache hits)
+template <int UN, bool HOT>
+__global__ __launch_bounds__(256) void k_emit_rw(double *__restrict__ a, double *__restrict__ b, double *__restrict__ c, int64_t m,
+                                                 const int32_t *__restrict__ rowmap, int64_t n_grp, const unsigned int *__restrict__ cnt,
+                                                 int64_t n_rows) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int cc = lane & 31, hh = lane >> 5;
+    const int64_t grp = static_cast<int64_t>(blockIdx.x) * 4 + wave;
+    if (grp >= n_grp) return;
+    int row[UN];
+    uint3 w[UN];
+#pragma unroll
+    for (int i = 0; i < UN; ++i) row[i] = rowmap[static_cast<int64_t>(blockIdx.y) * UN + i];
+#pragma unroll
+    for (int i = 0; i < UN; ++i) {
+        const int64_t u = HOT ? (row[i] & 127) : row[i];
+        w[i] = *reinterpret_cast<const uint3 *>(cnt + ((HOT ? 0 : grp) * n_rows + u) * 96 + cc * 3);
+    }
+#pragma unroll
+    for (int i = 0; i < UN; ++i)
+#pragma unroll
+        for (int j = 0; j < 3; ++j) {
+            const int64_t col = (grp * 6 + hh + 2 * j) * 32 + cc;
+            const int64_t o = static_cast<int64_t>(row[i]) * m + (col < m ? col : 0);
+            const unsigned int x = j == 0 ? w[i].x : j == 1 ? w[i].y : w[i].z;
+            a[o] = 1.0 + x;
+            b[o] = 2.0 + i;
+            c[o] = x > 100 ? 1.0 : 0.0;
+        }
+}
+
+__global__ __launch_bounds__(256) void k_read_cnt(const uint4 *__restrict__ cnt, int64_t vecs, unsigned int *__restrict__ sink) {
+    unsigned int acc = 0;
+    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < vecs; i += static_cast<int64_t>(gridDim.x) * 256) {
+        const uint4 v = cnt[i];
+        acc += v.x ^ v.y ^ v.z ^ v.w;
+    }
+    if (acc == 0xdeadbeefu) *sink = acc;
+}
+
+__global__ void k_fill_cnt(unsigned int *__restrict__ cnt, int64_t words) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (i < words) cnt[i] = static_cast<unsigned int>(i & 15);
+}
+
 int main(int argc, char **argv) {
     const int64_t n = 20000, m = argc > 1 ? atoll(argv[1]) : 9984;
     const bool sorted_rows = argc > 2 && atoi(argv[2]);
@@ -124,7 +170,64 @@ int main(int argc, char **argv) {
     hipEventCreate(&e0);
     hipEventCreate(&e1);
     const int64_t n_g6 = (m + 191) / 192;
-    for (int mode = 0; mode < 7; ++mode) {
+    unsigned int *d_cnt;
+    hipMalloc(&d_cnt, n_g6 * n * 96 * 4);
+    hipMemset(d_cnt, 0, n_g6 * n * 96 * 4);
+    // chunked: the counts of a chunk of column groups are written right before the chunk is emitted (are they
+    // still in the memory-side cache?); prints the emit time summed over the chunks
+    for (int chunks : {1, 2, 4, 8, 16}) {
+        const int64_t gpc = (n_g6 + chunks - 1) / chunks;
+        float emit_ms = 0.f, fill_ms = 0.f;
+        for (int ch = 0; ch < chunks; ++ch) {
+            const int64_t g0 = ch * gpc, g1 = std::min<int64_t>(n_g6, g0 + gpc);
+            if (g0 >= g1) break;
+            const int64_t words = (g1 - g0) * n * 96;
+            hipEventRecord(e0);
+            hipLaunchKernelGGL(k_fill_cnt, dim3((words + 255) / 256), dim3(256), 0, 0, d_cnt + g0 * n * 96, words);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            fill_ms += ms;
+            hipEventRecord(e0);
+            hipLaunchKernelGGL((k_emit_rw<4, false>), dim3((g1 - g0 + 3) / 4, n / 4), dim3(256), 0, 0, a + g0 * 192, b + g0 * 192, c + g0 * 192, m,
+                               d_map, g1 - g0, d_cnt + g0 * n * 96, n);
+            hipEventRecord(e1);
+            hipEventSynchronize(e1);
+            hipEventElapsedTime(&ms, e0, e1);
+            emit_ms += ms;
+        }
+        printf("chunks %2d: fill %.3f ms, emit %.3f ms\n", chunks, fill_ms, emit_ms);
+    }
+    {   // stores only on one stream, the 0.4 GB of reads by another kernel on a second stream, at the same time
+        hipStream_t s1, s2;
+        hipStreamCreate(&s1);
+        hipStreamCreate(&s2);
+        const int64_t vecs = n_g6 * n * 96 / 4;
+        for (int rep = 0; rep < 3; ++rep) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0, s1);
+            hipLaunchKernelGGL((k_emit_like<4, false>), dim3((n_g6 + 3) / 4, n / 4), dim3(256), 0, s1, a, b, c, m, d_map, n_g6);
+            hipLaunchKernelGGL(k_read_cnt, dim3(64), dim3(256), 0, s2, reinterpret_cast<const uint4 *>(d_cnt), vecs, d_ctr);
+            hipEventRecord(e1, s1);
+            hipStreamSynchronize(s2);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("stores (stream 1) beside a 64-block read kernel (stream 2): stores took %.3f ms\n", ms);
+        }
+        for (int rep = 0; rep < 2; ++rep) {
+            hipDeviceSynchronize();
+            hipEventRecord(e0, s2);
+            hipLaunchKernelGGL(k_read_cnt, dim3(64), dim3(256), 0, s2, reinterpret_cast<const uint4 *>(d_cnt), vecs, d_ctr);
+            hipEventRecord(e1, s2);
+            hipEventSynchronize(e1);
+            float ms;
+            hipEventElapsedTime(&ms, e0, e1);
+            printf("read kernel alone: %.3f ms\n", ms);
+        }
+    }
+    for (int mode = 0; mode < 9; ++mode) {
         for (int rep = 0; rep < 3; ++rep) {
             hipMemset(d_ctr, 0, 4);
             hipEventRecord(e0);
@@ -135,6 +238,8 @@ int main(int argc, char **argv) {
             if (mode == 4) hipLaunchKernelGGL((k_emit_like<4, false>), dim3((n_g6 + 3) / 4, n / 4), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
             if (mode == 5) hipLaunchKernelGGL((k_emit_like<8, false>), dim3((n_g6 + 3) / 4, n / 8), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
             if (mode == 6) hipLaunchKernelGGL((k_emit_like<16, false>), dim3((n_g6 + 3) / 4, n / 16), dim3(256), 0, 0, a, b, c, m, d_map, n_g6);
+            if (mode == 7) hipLaunchKernelGGL((k_emit_rw<4, false>), dim3((n_g6 + 3) / 4, n / 4), dim3(256), 0, 0, a, b, c, m, d_map, n_g6, d_cnt, n);
+            if (mode == 8) hipLaunchKernelGGL((k_emit_rw<4, true>), dim3((n_g6 + 3) / 4, n / 4), dim3(256), 0, 0, a, b, c, m, d_map, n_g6, d_cnt, n);
             hipEventRecord(e1);
             hipEventSynchronize(e1);
             float ms;
