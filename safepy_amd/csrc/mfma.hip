@@ -1029,7 +1029,7 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     hl.cnt16 = st->cnt16;
     hl.xmax = st->cs.d_qctr + 12;
     const int64_t n_padr = nbr->bs_groups * MF_R, n_grp = st->cs.n_grp;
-    constexpr int EMIT_UN = 4, EMIT_CHUNK = 64;
+    constexpr int EMIT_UN = 2, EMIT_CHUNK = 64;             // rows per batch: 2 measured best of 1, 2, 3, 4, 8 (1.21 / 1.30 / 1.53 ms at 4 / 8)
     // rows grouped by neighborhood size, every group cut into chunks of <= 64 rows, long chunks first
     // (counting sort: the ids are dense)
     int32_t n_ids = 0;
@@ -1059,12 +1059,24 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     const char *lds_env = getenv("SAFE_HIP_EMIT_LDS_KB");                // tests: 0 forces the global-gather loop
     const int64_t lds_cap = lds_env ? std::max(0, atoi(lds_env)) * 1024ll : (64ll << 10);
     const int lds_bytes = static_cast<int>(std::min<int64_t>(want, std::min<int64_t>(lds_cap, 64 << 10)));
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit<EMIT_UN>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-    hipLaunchKernelGGL((k_hyp_emit<EMIT_UN>), dim3(ceil_div(n_grp, 8), st->tasks.size()), dim3(512), lds_bytes, ctx->stream, st->cnt16,
-                       n_padr, n_grp, d_rows, d_tasks, st->cs.mloc, hl, lds_bytes / static_cast<int>(sizeof(double2)));
+    SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                 // the timed kernel of this form is the HBM-bound one
+    const char *un_env = getenv("SAFE_HIP_EMIT_UN");
+    const int un = un_env ? atoi(un_env) : EMIT_UN;
+    const dim3 egrid(ceil_div(n_grp, 8), st->tasks.size());
+    const int lds_entries = lds_bytes / static_cast<int>(sizeof(double2));
+#define EMIT_LAUNCH(U)                                                                                                              \
+    do {                                                                                                                            \
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit<U>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                           lds_bytes));                                                                             \
+        hipLaunchKernelGGL((k_hyp_emit<U>), egrid, dim3(512), lds_bytes, ctx->stream, st->cnt16, n_padr, n_grp, d_rows, d_tasks,       \
+                           st->cs.mloc, hl, lds_entries);                                                                           \
+    } while (0)
+    if (un == 4) EMIT_LAUNCH(4);
+    else EMIT_LAUNCH(2);
+#undef EMIT_LAUNCH
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
-    ctx->last_kernel.name = "k_permtest_mfma<counts> + k_hyp_emit";
+    ctx->last_kernel.name = "k_hyp_emit";                               // (after k_permtest_mfma<counts> and k_hyp_table)
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the row / task vectors are host memory
     return SAFE_OK;
 }
