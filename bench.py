@@ -131,7 +131,7 @@ def hbm_kernels(ctx, torch, np, be):
     alg = 16 * n + 8 * n * n
     out['k_euclid_dense'] = {'bound': 'hbm', 'workload': 'N=%d, int64 [N,N] membership (reference layout)' % n,
                              'kernel_ms': ms, 'algorithmic_bytes': alg, 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS,
-                             'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS}
+                             'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic('k_euclid_dense')}
     del t_mask
     m = 10000                                # configs[3]: 20 000 nodes x 10 000 binary attributes
     b = (rng.uniform(size=(n, m)) < 0.01).astype(np.float32)
@@ -160,7 +160,7 @@ def hbm_kernels(ctx, torch, np, be):
     out[name] = {'bound': 'hbm', 'workload': 'N=%d x M=%d binary attributes, %d members per neighborhood on average'
                                              % (n, m, int(nbr.nnz / n)),
                  'kernel_ms': ms, 'algorithmic_bytes': alg, 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS,
-                 'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'compute_pvalues_call_ms': call_ms,
+                 'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic(name), 'compute_pvalues_call_ms': call_ms,
                  'enrichments_per_s_call': n * m / (call_ms * 1e-3)}
     attr.close()
     nbr.close()
