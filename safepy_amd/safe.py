@@ -251,6 +251,9 @@ class SAFE:
     def __getstate__(self):
         for name in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
             getattr(self, name)              # results still on the device come to the host first
+        nd = self._node_distances
+        if isinstance(nd, tuple) and nd[0] == 'device-shortpath':
+            self._node_distances = ('dense-shortpath', nd[1].distances())
         state = self.__dict__.copy()
         if state.get('_neighborhoods_host') is None and state.get('_nbr') is not None:
             state['_neighborhoods_host'] = self._nbr.to_dense()
@@ -409,6 +412,9 @@ class SAFE:
         self._neighborhoods_host = value
 
     def _invalidate_neighborhoods(self):
+        nd = self._node_distances
+        if isinstance(nd, tuple) and nd[0] == 'device-shortpath':     # still on the device, owned by the handle that goes away
+            self._node_distances = ('dense-shortpath', nd[1].distances()) if nd[1] is self._nbr and nd[1].handle else None
         if self._nbr is not None:
             self._nbr.close()
         self._nbr = None
@@ -435,6 +441,8 @@ class SAFE:
         """Shortest-path metrics: dict-of-dicts {source: {target: distance}} over reached
         pairs (safe.py:417).  Euclidean (additive, via compute_node_distances): f64 [N,N]."""
         nd = self._node_distances
+        if isinstance(nd, tuple) and nd[0] == 'device-shortpath':     # the [N,N] f64 copy (126 MB at 3971 nodes) is made on first read
+            nd = self._node_distances = ('dense-shortpath', nd[1].distances())
         if isinstance(nd, tuple) and nd[0] == 'dense-shortpath':
             dmat = nd[1]
             rows, cols = np.nonzero(np.isfinite(dmat))
@@ -480,6 +488,8 @@ class SAFE:
         self._override_neighborhood_settings(kwargs)
         xy, eu, ev, length, weight = _graph_arrays(self.graph)
         ctx = self._ctx()
+        if self.node_distance_metric != 'euclidean':
+            self._node_distances = None          # replaced below (a copy still on the device is not fetched first)
         self._invalidate_neighborhoods()
         if self.node_distance_metric == 'euclidean':
             self._nbr = be.Neighborhoods.euclidean(ctx, xy, self._radius(xy))
@@ -487,7 +497,7 @@ class SAFE:
             w, cutoff = self._shortpath_inputs(xy, eu, ev, length, weight)
             self._nbr = be.Neighborhoods.shortpath(ctx, xy.shape[0], eu, ev, w, cutoff, keep_distances=True)
             self._nbr.set_layout(xy)
-            self._node_distances = ('dense-shortpath', self._nbr.distances())
+            self._node_distances = ('device-shortpath', self._nbr)
         if self.verbose:
             num_neighbors = self._nbr.row_counts()
             logging.info('Node distance metric: %s' % self.node_distance_metric)

@@ -107,6 +107,35 @@ def test_weighted_shortpath_vs_reference(amd, golden_nbr, radius):
     assert np.array_equal(got, want)                          # bit-exact path lengths
 
 
+def test_shortpath_distances_outlive_their_device_handle(amd, golden_nbr):
+    """node_distances of a shortest-path metric stay on the device until first read; they must survive the
+    neighborhoods being redefined with the euclidean metric (which leaves node_distances alone, safe.py:389-399),
+    a user-supplied membership, and pickling -- all before anybody looked at them."""
+    import pickle
+    want = golden_nbr['swl_dist_r0.2']
+
+    def dense(nd):
+        got = np.full(want.shape, np.inf)
+        for s, row in nd.items():
+            for t, d in row.items():
+                got[s, t] = d
+        return got
+
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.2)
+    assert sf.__dict__['_node_distances'][0] == 'device-shortpath'
+    blob = pickle.dumps(sf)
+    assert np.array_equal(dense(pickle.loads(blob).node_distances), want)
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.2)
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.1)
+    assert np.array_equal(dense(sf.node_distances), want)
+    sf = _safe(amd, _layout_graph(amd, golden_nbr))
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.2)
+    sf.neighborhoods = np.eye(want.shape[0], dtype=np.int64)
+    assert np.array_equal(dense(sf.node_distances), want)
+
+
 @pytest.mark.parametrize('radius', [1, 2, 3])
 def test_unweighted_shortpath_vs_reference(amd, golden_nbr, radius):
     g = golden_nbr
