@@ -235,6 +235,7 @@ def main():
     from safepy_amd import workloads, sharding
 
     torch.cuda.set_device(local_rank)
+    numa_node = None if os.environ.get('SAFE_BENCH_NO_PIN') == '1' else be.pin_threads_to_device_numa(local_rank)
     torch.set_num_threads(1)      # no OpenMP spinning next to the host draw/swap threads (container CPU quotas throttle it)
     dist = None
     force_dist = os.environ.get('SAFE_BENCH_FORCE_DIST') == '1'      # exercise the collectives with a single rank
@@ -294,10 +295,15 @@ def main():
     kernel_ms.clear()
     fence()
     t0 = time.perf_counter()
+    cpu0 = time.process_time()
+    step_ms = []
     for _ in range(args.steps):
+        ts = time.perf_counter()
         step()
+        step_ms.append(1e3 * (time.perf_counter() - ts))         # (a step returns after its own stream synchronisation)
     fence()
     elapsed = time.perf_counter() - t0
+    host_cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps     # all threads of this rank: draws, swaps, launches
     if dist is not None:
         t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -345,6 +351,9 @@ def main():
                                              'profiles/ for the PMC evidence',
                          'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3)},
             'kernel_share_of_step': k_ms * launches / ms_per_step,
+            'host_cpu_ms_per_step': host_cpu_ms, 'host_cores_usable': effective_cores(),
+            'swap_threads': int(os.environ.get('SAFE_HIP_SWAP_THREADS', '4')), 'pinned_to_numa_node': numa_node,
+            'step_ms_min_median_max': [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
         }
         if args.cpu_perms > 0 and world == 1:                 # the CPU leg runs on rank 0 at N = 1 only
             a_dense = sf.neighborhoods

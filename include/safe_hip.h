@@ -57,6 +57,10 @@ typedef struct safe_perms safe_perms;   /* composed row-permutation tables, devi
 int safe_abi_version(void);
 const char *safe_last_error(void);
 int safe_device_count(int *count);
+/* PCI address of a device ("0000:c1:00.0"): lets the host side keep a rank's threads on the NUMA node of its GPU
+ * (safepy_amd.backend.pin_threads_to_device_numa; the reference has no counterpart -- its multiprocessing
+ * workers, safe.py:503-524, run wherever the OS puts them). */
+int safe_device_pci_bus_id(int device, char *buf, size_t buf_len);
 int safe_ctx_create(int device, safe_ctx **out);
 int safe_ctx_destroy(safe_ctx *ctx);
 /* Use an existing hipStream_t (passed as void*) for all subsequent work; NULL restores

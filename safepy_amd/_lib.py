@@ -65,6 +65,7 @@ PROTOTYPES = {
     'safe_abi_version': (C.c_int, []),
     'safe_last_error': (C.c_char_p, []),
     'safe_device_count': (C.c_int, [C.POINTER(C.c_int)]),
+    'safe_device_pci_bus_id': (C.c_int, [C.c_int, C.c_char_p, C.c_size_t]),
     'safe_ctx_create': (C.c_int, [C.c_int, _pp]),
     'safe_ctx_destroy': (C.c_int, [_vp]),
     'safe_ctx_set_stream': (C.c_int, [_vp, _vp]),

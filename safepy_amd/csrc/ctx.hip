@@ -81,6 +81,12 @@ int safe_device_count(int *count) {
     return SAFE_OK;
 }
 
+int safe_device_pci_bus_id(int device, char *buf, size_t buf_len) {
+    SAFE_REQUIRE(buf != nullptr && buf_len >= 16, "safe_device_pci_bus_id: buffer of at least 16 bytes needed");
+    SAFE_HIP_CHECK(hipDeviceGetPCIBusId(buf, static_cast<int>(buf_len), device));
+    return SAFE_OK;
+}
+
 int safe_ctx_create(int device, safe_ctx **out) {
     SAFE_REQUIRE(out != nullptr, "safe_ctx_create: out is NULL");
     *out = nullptr;

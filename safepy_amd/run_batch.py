@@ -49,7 +49,8 @@ def main(argv=None):
         dist.init_process_group('nccl')
 
     import safepy_amd
-    from safepy_amd import sharding
+    from safepy_amd import sharding, backend
+    backend.pin_threads_to_device_numa(local_rank)       # this rank's host threads next to its GPU
     sf = safepy_amd.SAFE(verbose=(rank == 0), device=local_rank)
     if args.seed is not None:
         sf.random_seed = args.seed
