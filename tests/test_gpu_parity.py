@@ -374,6 +374,36 @@ def test_midsize_hypergeometric_vs_oracle(amd, ctx, monkeypatch, counts):
     np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['num_neighborhoods_enriched'])
 
 
+@pytest.mark.parametrize('n,m', [(257, 5), (300, 193), (1000, 1)])
+def test_split_hypergeometric_edge_shapes(amd, ctx, monkeypatch, n, m):
+    """Split matrix-core form on awkward shapes: one row past a row group, fewer columns than one lane group,
+    one column past a column group; columns without any annotation (every count 0: the table is cut at x = 0),
+    a column annotating every node (K = N, p = 1 everywhere), an all-NaN row, isolated nodes."""
+    monkeypatch.setenv('SAFE_HIP_COUNTS', 'mfma')
+    rng = np.random.default_rng(n + m)
+    xy = rng.uniform(size=(n, 2))
+    xy[:3] += 10.0                                           # three nodes far away: neighborhoods of one
+    b = (rng.uniform(size=(n, m)) < 0.1).astype(np.float64)
+    b[:, 0] = 0.0
+    if m > 2:
+        b[:, 1] = 1.0
+        b[:, 2] = 0.0
+        b[7, 2] = 1.0
+    b[11, :] = np.nan
+    a = orc.neighborhoods_euclidean(xy, 0.02)
+    want = orc.compute_pvalues(a, b.copy())
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(xy)
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.02)
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues()
+    assert ctx.last_kernel()[0] == 'k_hyp_emit'
+    np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
+    np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
+    np.testing.assert_array_equal(sf.nes_binary, want['nes_binary'])
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['num_neighborhoods_enriched'])
+
+
 @pytest.mark.parametrize('counts', ['bits', 'mfma'])
 def test_hypergeometric_p_on_the_threshold(amd, ctx, monkeypatch, counts):
     """p-values that sit exactly ON the enrichment threshold: a singleton attribute (K = 1) gives
