@@ -354,6 +354,7 @@ def main():
             'host_cpu_ms_per_step': host_cpu_ms, 'host_cores_usable': effective_cores(),
             'swap_threads': int(os.environ.get('SAFE_HIP_SWAP_THREADS', '4')), 'pinned_to_numa_node': numa_node,
             'step_ms_min_median_max': [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
+            'step_ms_slowest3': [float(x) for x in sorted(step_ms)[-3:]],
         }
         if args.cpu_perms > 0 and world == 1:                 # the CPU leg runs on rank 0 at N = 1 only
             a_dense = sf.neighborhoods

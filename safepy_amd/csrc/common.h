@@ -268,7 +268,9 @@ int64_t perms_chunk_count(int64_t count);
 // launch boundaries of the permutation kernels: starts[c] .. starts[c+1]; the default follows the
 // stream's pipeline stages (so the first launch can start after 32 permutations have been drawn),
 // SAFE_HIP_BITS_SPAN=<n> forces uniform spans.  *span = the longest launch.
-static inline std::vector<int64_t> perm_launch_starts(int64_t P, int64_t *span) {
+// merge > 1: after the three start-up stages (32, 96, 128 permutations) a launch covers `merge` stages -- fewer,
+// longer launches once the stream is ahead of the kernels.
+static inline std::vector<int64_t> perm_launch_starts(int64_t P, int64_t *span, int merge = 1) {
     std::vector<int64_t> starts;
     int64_t uniform = 0;
     if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) uniform = std::max<int64_t>(16, atoll(e));
@@ -276,7 +278,8 @@ static inline std::vector<int64_t> perm_launch_starts(int64_t P, int64_t *span) 
         for (int64_t p = 0; p < P; p += uniform) starts.push_back(p);
     } else {
         const int64_t nc = perms_chunk_count(P);
-        for (int64_t c = 0; c < nc; ++c) starts.push_back(perms_chunk_begin(c));
+        for (int64_t c = 0; c < nc; ++c)
+            if (c < 3 || merge <= 1 || (c - 3) % merge == 0) starts.push_back(perms_chunk_begin(c));
     }
     if (starts.empty()) starts.push_back(0);
     starts.push_back(std::max<int64_t>(P, 0));

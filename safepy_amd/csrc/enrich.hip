@@ -1690,7 +1690,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // group, group of 4 adjacent slices, permutation sub-range), sized to about equal cost
     // with several per workgroup slot, heaviest first for the dynamic queue.
     int64_t span = 1;
-    const std::vector<int64_t> starts = perm_launch_starts(P, &span);
+    // launches follow the stream's stages (32, 96, then 128 permutations each).  SAFE_HIP_BITS_MERGE=m lets a
+    // launch cover m stages after the start-up: fewer tails and less per-task fixed cost (kernel time per 1000
+    // permutations 4.06 -> 3.94 / 3.89 ms at m = 2 / 3), but the step gets LONGER (5.2 -> 5.5 / 5.8 ms): the
+    // host draw thread delivers 128 permutations per 0.36-0.41 ms, barely ahead of the kernels, and a merged
+    // launch waits for its last stage.
+    int merge = 1;
+    if (const char *e = getenv("SAFE_HIP_BITS_MERGE")) merge = std::max(1, atoi(e));
+    const std::vector<int64_t> starts = perm_launch_starts(P, &span, merge);
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
@@ -1705,7 +1712,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     std::vector<TaskCost> tc;
     for (int64_t g = 0; g < n_sg; ++g) {
         const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
-        int64_t ppt = std::min<int64_t>(span, std::max<int64_t>(16, target / bl));
+        int64_t ppt = std::min<int64_t>(std::min<int64_t>(span, 255), std::max<int64_t>(16, target / bl));   // <= 255: eight counter levels
         const int64_t chunks = ceil_div(span, ppt);
         ppt = ceil_div(span, chunks);
         for (int64_t c = 0; c < chunks; ++c) {
@@ -1738,7 +1745,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
     const int64_t n_tasks = static_cast<int64_t>(tasks.size());
     const bool wide = P >= 1024;
-    const bool narrow = span <= 255;                  // a task counts at most `span` permutations: 8 counter levels do
+    const bool narrow = true;                         // a task counts at most 255 permutations (ppt above): 8 counter levels do
     const bool scaled = (n + 1) * 8 < 65536;
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
     const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
@@ -1782,7 +1789,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                perms->stride16, nbr->sell_col2, nbr->sell_entries, entries_pad, p_base, p_limit - p_base,
                                static_cast<uint32_t>(8 * n), d_ids[c & 1]);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
-            const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(ctx->num_cu) *
+            // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD), so the
+            // table kernels of the next stage (aux stream) start in this kernel's tail; leaving them CUs
+            // (SAFE_HIP_BITS_SPARE) changes nothing measurable: the stage is not ready earlier (host draws)
+            int spare = 0;
+            if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
+            const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
             if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,

@@ -151,11 +151,54 @@ private:
     bool stop_ = false;
 };
 
-// swaps of permutations [w, cnt) step W of one chunk -> row maps (host worker thread)
+// swaps of permutations [w, cnt) step W of one chunk -> row maps (host worker thread).
+// A shuffle is one dependent chain (load a[j], load a[i], store both: ~3 ns per swap through the store
+// buffer), so a thread replays NL permutations in lock step -- NL independent chains, 16-bit positions so
+// that all NL arrays stay in L1 -- and maps positions to rows only when it writes the row map.
+template <int NL>
+static void replay_lockstep(const safe_perms *p, const uint32_t *targets, int32_t *maps, const int64_t (&qs)[4], uint16_t *a) {
+    const int64_t k = p->k, stride = p->n + 1, width = std::max<int64_t>(k, 1), kpad = (k + 31) & ~int64_t(31);
+    const int32_t *mov = p->h_movable.data();
+    const uint32_t *j[NL];
+    uint16_t *ar[NL];
+    for (int r = 0; r < NL; ++r) {
+        j[r] = targets + qs[r] * width;
+        ar[r] = a + r * kpad;
+        for (int64_t t = 0; t < k; ++t) ar[r][t] = static_cast<uint16_t>(t);
+    }
+    for (int64_t i = k - 1, st = 0; i > 0; --i, ++st)                       // safe_extras.py:58 / legacy shuffle
+        for (int r = 0; r < NL; ++r) {
+            const uint32_t jj = j[r][st];
+            const uint16_t x = ar[r][i], y = ar[r][jj];
+            ar[r][i] = y;
+            ar[r][jj] = x;
+        }
+    for (int r = 0; r < NL; ++r) {
+        int32_t *m = maps + qs[r] * stride;
+        for (int64_t i = 0; i < stride; ++i) m[i] = static_cast<int32_t>(i);
+        for (int64_t t = 0; t < k; ++t) m[mov[t]] = mov[ar[r][t]];
+    }
+}
+
 static void swap_worker(const safe_perms *p, const uint32_t *targets, int32_t *maps, int64_t cnt, int w, int W) {
     const int64_t k = p->k, stride = p->n + 1;
-    std::vector<int32_t> a(std::max<int64_t>(k, 1));
     const int32_t *mov = p->h_movable.data();
+    if (k >= 2 && k < 65536) {
+        const int64_t kpad = (k + 31) & ~int64_t(31);
+        std::vector<uint16_t> a(4 * kpad);
+        for (int64_t q = w; q < cnt; q += 4 * W) {
+            int64_t qs[4];
+            int nl = 0;
+            for (int r = 0; r < 4; ++r)
+                if (q + r * W < cnt) qs[nl++] = q + r * W;
+            if (nl == 4) replay_lockstep<4>(p, targets, maps, qs, a.data());
+            else if (nl == 3) replay_lockstep<3>(p, targets, maps, qs, a.data());
+            else if (nl == 2) replay_lockstep<2>(p, targets, maps, qs, a.data());
+            else replay_lockstep<1>(p, targets, maps, qs, a.data());
+        }
+        return;
+    }
+    std::vector<int32_t> a(std::max<int64_t>(k, 1));
     for (int64_t q = w; q < cnt; q += W) {
         const uint32_t *j = targets + q * std::max<int64_t>(k, 1);
         memcpy(a.data(), mov, k * sizeof(int32_t));
