@@ -35,6 +35,7 @@ def main(argv=None):
     ap.add_argument('--permutations', type=int, default=1000)
     ap.add_argument('--score', default='sum', choices=['sum', 'z-score'])
     ap.add_argument('--seed', type=int, default=None)
+    ap.add_argument('--multiple-testing', action='store_true', help='Benjamini-Hochberg per row across all attributes (safe.py:536-542)')
     ap.add_argument('--output', default=None, help='default: <attribute_file>_safe_nes.p (safe.py:1357)')
     args = ap.parse_args(argv)
     start = time.time()
@@ -67,7 +68,8 @@ def main(argv=None):
     m_total = sf.node2attribute.shape[1]
 
     if world == 1:
-        sf.compute_pvalues(how=args.how, num_permutations=args.permutations, neighborhood_score_type=args.score)
+        sf.compute_pvalues(how=args.how, num_permutations=args.permutations, neighborhood_score_type=args.score,
+                           multiple_testing=args.multiple_testing)
         all_nes = sf.nes
     else:
         c0, c1 = sharding.column_shards(m_total, world)[rank]
@@ -77,7 +79,7 @@ def main(argv=None):
             sf._ctx(), sf._device_neighborhoods(), np.ascontiguousarray(sf.node2attribute[:, c0:c1]), m_total,
             enrichment_type=args.how, num_permutations=args.permutations, random_seed=sf.random_seed,
             neighborhood_score_type=args.score, attribute_sign=sf.attribute_sign,
-            enrichment_threshold=sf.enrichment_threshold, gather=('nes',))
+            enrichment_threshold=sf.enrichment_threshold, gather=('nes',), multiple_testing=args.multiple_testing)
         all_nes = out['full_nes']
 
     if rank == 0:

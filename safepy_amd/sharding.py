@@ -152,9 +152,48 @@ def gather_columns(local, m_total, group=None):
     return torch.cat([parts[r][:, :shards[r][1] - shards[r][0]] for r in range(world)], dim=1)
 
 
+def _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold, group):
+    """multiple_testing=True under attribute sharding, with whole-matrix semantics: Benjamini-Hochberg runs
+    along a ROW across all attributes (safe.py:536-542, 599-605), so the p-value blocks are all-gathered
+    first and every rank adjusts the full [N, M] matrices (safe_fdr_adjust also rebuilds NES, nes_binary and
+    the enriched counts from the adjusted values, safe.py:546-554 / 608 and 468-472).  `bufs`: this rank's
+    device blocks by name; returns the full device tensors by name (+ 'num_neighborhoods_enriched')."""
+    import torch
+    from . import backend as be
+    full = {k: gather_columns(bufs[k], m_total, group).contiguous() for k in ('pvalues_neg', 'pvalues_pos') if k in bufs}
+    n = full['pvalues_pos'].shape[0]
+    dev = full['pvalues_pos'].device
+    full['nes'] = torch.empty((n, m_total), dtype=torch.float64, device=dev)
+    full['nes_binary'] = torch.empty((n, m_total), dtype=torch.float64, device=dev)
+    full['num_neighborhoods_enriched'] = torch.empty((m_total,), dtype=torch.float64, device=dev)
+    torch.cuda.current_stream().synchronize()          # gathered on torch's stream, adjusted on the context's
+    be.fdr_adjust(ctx, n, m_total, int(num_permutations), attribute_sign, enrichment_threshold,
+                  [full['pvalues_neg'].data_ptr() if 'pvalues_neg' in full else None, full['pvalues_pos'].data_ptr(),
+                   full['nes'].data_ptr(), full['nes_binary'].data_ptr(), full['num_neighborhoods_enriched'].data_ptr()])
+    ctx.sync()
+    return full
+
+
+def _outputs(bufs, enriched, full, m_total, group, gather):
+    """Local blocks (NumPy) + the requested full matrices; `full` = whole-matrix tensors after FDR, or None."""
+    dist = _dist()
+    if full is None:
+        out = {k: v.cpu().numpy() for k, v in bufs.items()}
+        out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
+        for k in gather:
+            out['full_' + k] = gather_columns(bufs[k], m_total, group).cpu().numpy()
+        return out
+    c0, c1 = column_shards(m_total, dist.get_world_size(group))[dist.get_rank(group)]
+    out = {k: (full[k][:, c0:c1] if k in full else v).cpu().numpy() for k, v in bufs.items()}
+    out['num_neighborhoods_enriched'] = full['num_neighborhoods_enriched'][c0:c1].cpu().numpy()
+    for k in gather:
+        out['full_' + k] = (full[k] if k in full else gather_columns(bufs[k], m_total, group)).cpu().numpy()
+    return out
+
+
 def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
                           neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05,
-                          group=None, gather=('nes',)):
+                          group=None, gather=('nes',), multiple_testing=False):
     """compute_pvalues_by_randomization for this rank's column block + the two exchange steps.
     `local_attr_host`: this rank's [N, M_r] block of node2attribute (NumPy).  Returns a dict
     with the local blocks (NumPy) and, for every name in `gather`, the all-gathered full matrix
@@ -174,18 +213,16 @@ def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, 
         be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
                          [bufs[k].data_ptr() for k in names] + [enriched.data_ptr()])
         ctx.sync()
-        out = {k: v.cpu().numpy() for k, v in bufs.items()}
-        out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
-        for k in gather:
-            out['full_' + k] = gather_columns(bufs[k], m_total, group).cpu().numpy()
-        return out
+        full = _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold,
+                                 group) if multiple_testing else None
+        return _outputs(bufs, enriched, full, m_total, group, gather)
     finally:
         perms.close()
         attr.close()
 
 
 def sharded_hypergeom(ctx, nbr, local_attr_host, m_total, global_flags, enrichment_threshold=0.05, group=None,
-                      gather=('nes',)):
+                      gather=('nes',), multiple_testing=False, attribute_sign='both'):
     """compute_pvalues_by_hypergeom for this rank's column block.  The population N
     (safe.py:574-578) and the neighborhood sizes count the rows holding a value in ANY column of
     the full matrix, so the flags of the whole matrix are installed before the kernels run."""
@@ -203,23 +240,21 @@ def sharded_hypergeom(ctx, nbr, local_attr_host, m_total, global_flags, enrichme
         torch.cuda.current_stream().synchronize()
         be.hypergeom(ctx, nbr, attr, enrichment_threshold, [bufs[k].data_ptr() for k in names] + [enriched.data_ptr()])
         ctx.sync()
-        out = {k: v.cpu().numpy() for k, v in bufs.items()}
-        out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
-        for k in gather:
-            out['full_' + k] = gather_columns(bufs[k], m_total, group).cpu().numpy()
-        return out
+        full = _fdr_whole_matrix(ctx, bufs, m_total, 0, attribute_sign, enrichment_threshold, group) if multiple_testing else None
+        return _outputs(bufs, enriched, full, m_total, group, gather)
     finally:
         attr.close()
 
 
 def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type='auto', num_permutations=1000,
                             random_seed=None, neighborhood_score_type='sum', attribute_sign='both',
-                            enrichment_threshold=0.05, group=None, gather=('nes',)):
+                            enrichment_threshold=0.05, group=None, gather=('nes',), multiple_testing=False):
     """SAFE.compute_pvalues (safe.py:432-472) over attribute shards with WHOLE-MATRIX semantics:
     the 'auto' rule (safe.py:461-463) looks at every column of the full matrix (one all-gather of
     the per-shard statistics), so all ranks take the same branch and the result equals the
     single-process call on the unsplit matrix -- unlike the reference's CLI (safe.py:1321-1361),
-    whose worker processes each decide for their own chunk."""
+    whose worker processes each decide for their own chunk.  multiple_testing=True adjusts every row
+    across ALL attributes as the unsplit call does (the p-value blocks are gathered first)."""
     from . import backend as be
     probe = be.Attributes.from_host(ctx, local_attr_host)
     try:
@@ -227,11 +262,13 @@ def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type=
     finally:
         probe.close()
     if (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and stats['n_other'] == 0):
-        out = sharded_hypergeom(ctx, nbr, local_attr_host, m_total, flags, enrichment_threshold, group, gather)
+        out = sharded_hypergeom(ctx, nbr, local_attr_host, m_total, flags, enrichment_threshold, group, gather,
+                                multiple_testing=multiple_testing, attribute_sign=attribute_sign)
         out['how'] = 'hypergeometric'
     else:
         out = sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
-                                    neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather)
+                                    neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
+                                    multiple_testing=multiple_testing)
         out['how'] = 'randomization'
     out['stats'] = stats
     return out

@@ -309,6 +309,47 @@ def test_sharded_compute_pvalues_one_rank_rccl(amd, g, tmp_path, quantitative):
     assert np.array_equal(out['num_neighborhoods_enriched'], sf.attributes['num_neighborhoods_enriched'].values)
 
 
+@pytest.mark.parametrize('quantitative', [False, True])
+def test_sharded_fdr_equals_unsplit(amd, g, tmp_path, quantitative):
+    """multiple_testing=True through the sharded driver (one-rank RCCL group: gather, whole-matrix
+    Benjamini-Hochberg, NES / nes_binary / enriched counts rebuilt) == SAFE.compute_pvalues(multiple_testing=True)."""
+    import socket
+    import torch
+    import torch.distributed as dist
+    from safepy_amd import sharding
+    net, attr = _batch_inputs(g, tmp_path, quantitative)
+    sf = amd.SAFE(verbose=False)
+    sf.random_seed = 11
+    sf.neighborhood_radius = 0.07
+    sf.load_network(network_file=net, node_key_attribute='key', pseudo_network='arrays')
+    sf.define_neighborhoods(node_distance_metric='euclidean')
+    sf.load_attributes(attribute_file=attr)
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    port = s.getsockname()[1]
+    s.close()
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    torch.cuda.set_device(0)
+    dist.init_process_group('nccl', rank=0, world_size=1)
+    try:
+        out = sharding.sharded_compute_pvalues(sf._ctx(), sf._device_neighborhoods(), np.ascontiguousarray(sf.node2attribute),
+                                               sf.node2attribute.shape[1], num_permutations=40, random_seed=11,
+                                               gather=('nes', 'nes_binary', 'pvalues_pos'), multiple_testing=True)
+    finally:
+        dist.destroy_process_group()
+    sf.compute_pvalues(num_permutations=40, multiple_testing=True)
+    assert np.array_equal(out['full_pvalues_pos'], sf.pvalues_pos, equal_nan=True)
+    assert np.array_equal(out['pvalues_pos'], sf.pvalues_pos, equal_nan=True)          # one rank: the local block is everything
+    assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+    assert np.array_equal(out['full_nes_binary'], sf.nes_binary, equal_nan=True)
+    assert np.array_equal(out['num_neighborhoods_enriched'], sf.attributes['num_neighborhoods_enriched'].values)
+    if quantitative:
+        assert np.array_equal(out['pvalues_neg'], sf.pvalues_neg, equal_nan=True)
+    sf.compute_pvalues(num_permutations=40, multiple_testing=False)
+    assert not np.array_equal(out['full_pvalues_pos'], sf.pvalues_pos, equal_nan=True)      # the adjustment did something
+
+
 # ------------------------------------------------------------------ lazy result attributes ----
 def test_lazy_outputs_equal_eager_and_pickle(amd, golden_nbr, golden_enr):
     """compute_pvalues() leaves the result matrices on the device; each is copied on its first read
