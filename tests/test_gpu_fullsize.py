@@ -98,11 +98,15 @@ def test_config2_kernel_forms_agree_at_full_size(cfg2, monkeypatch):
         assert np.array_equal(out[path][0], out['bits'][0]) and np.array_equal(out[path][1], out['bits'][1])
 
 
-def test_config4_shape_hypergeometric_properties():
-    """20 000 nodes, euclidean r = 0.1, binary attributes (a 512-column block of config 4)."""
+@pytest.mark.parametrize('m', [512, 3001])
+def test_config4_shape_hypergeometric_properties(m):
+    """20 000 nodes, euclidean r = 0.1, binary attributes (a column block of config 4; 3001 is neither a multiple
+    of the 192-column groups nor of 4): split matrix-core form, sampled rows against SciPy, whole-matrix
+    properties (NES = -log10 p, binarisation, per-attribute counts)."""
     import safepy_amd
+    from safepy_amd import backend as be
     rng = np.random.default_rng(12)
-    n, m = 20000, 512
+    n = 20000
     xy = rng.uniform(size=(n, 2))
     b = (rng.uniform(size=(n, m)) < 0.01).astype(np.float32)
     b[rng.choice(n, 1000, replace=False)] = np.nan
@@ -111,9 +115,15 @@ def test_config4_shape_hypergeometric_properties():
     sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.1)
     sf.load_attributes(attribute_file=b)
     sf.compute_pvalues()                                        # 'auto' -> hypergeometric
+    assert be.Context.default(0).last_kernel()[0] == 'k_hyp_emit'
     assert sf.pvalues_neg is None
     p = sf.pvalues_pos
     assert p.shape == (n, m) and np.all((p >= 0) & (p <= 1))
+    with np.errstate(divide='ignore'):
+        np.testing.assert_allclose(sf.nes, -np.log10(p), rtol=1e-12, atol=1e-12)          # safe.py:608
+    assert np.array_equal(sf.nes_binary, (sf.nes > -np.log10(0.05)).astype(np.float64)) or \
+        np.abs(sf.nes_binary - (sf.nes > -np.log10(0.05))).sum() <= 1e-6 * n * m            # (ties at the threshold: decided on p)
+    assert np.array_equal(sf.nes_binary.sum(axis=0), sf.attributes['num_neighborhoods_enriched'].values)
     # rows sampled against scipy through the oracle
     rows = rng.choice(n, 40, replace=False)
     a_rows = np.zeros((40, n), dtype=np.int64)
