@@ -107,6 +107,25 @@ def pmc_traffic(kernel_name):
         return None
 
 
+def binding_resources(num_cu):
+    """Utilisation of the resources that actually bound the dominant kernel (it is neither HBM- nor MFMA-bound), from the
+    committed PMC passes of this bench command (profiles/pmc_bits.json; counters cannot be read inside the timed process):
+    LDS pipe busy cycles per CU and VALU issue cycles per SIMD over the kernel's GPU cycles."""
+    try:
+        with open(os.path.join(ROOT, 'profiles', 'pmc_bits.json')) as f:
+            c = json.load(f)
+        gpu_cycles = c['GRBM_GUI_ACTIVE'] / 8.0               # the counter is summed over the 8 XCDs
+        return {'kernel': c['kernel'],
+                'lds_pipe_busy_frac': c['SQ_LDS_IDX_ACTIVE'] / num_cu / gpu_cycles,
+                'lds_bank_conflict_share_of_busy': c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'],
+                'valu_issue_frac': c['SQ_INSTS_VALU'] / (4 * num_cu) / c['valu_wave_insts_per_clock_per_simd_sustained'] / gpu_cycles,
+                'waves_issuing_parked_stalled': [c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES'], c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'],
+                                                 c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']],
+                'source': c['_source']}
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
+
+
 def hbm_kernels(ctx, torch, np, be):
     """The two HBM-bound kernels of the path at BASELINE.json configs[3] size, timed with HIP
     events on the context stream: K1 fused all-pairs distance + threshold writing the reference's
@@ -349,7 +368,8 @@ def main():
                          'algorithmic_bytes': alg_bytes,
                          'binding_resource': 'VALU issue + LDS gather (not HBM, not MFMA): see DESIGN.md section 4 and '
                                              'profiles/ for the PMC evidence',
-                         'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3)},
+                         'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3),
+                         'binding_resource_utilisation': binding_resources(ctx.num_cu)},
             'kernel_share_of_step': k_ms * launches / ms_per_step,
             'host_cpu_ms_per_step': host_cpu_ms, 'host_cores_usable': effective_cores(),
             'swap_threads': int(os.environ.get('SAFE_HIP_SWAP_THREADS', '4')), 'pinned_to_numa_node': numa_node,
