@@ -1186,7 +1186,7 @@ __device__ __forceinline__ double dd_ratio(dd_t a, dd_t b) {            // a / b
     return q1 + rem * r;
 }
 
-// tab[nid][kid][x] = (p, -log10 p) with p = P[H >= x] for H ~ Hypergeom(pop, K = kvals[kid], n = nvals[nid]),
+// tab[nid][x][kid] = (p, -log10 p) with p = P[H >= x] for H ~ Hypergeom(pop, K = kvals[kid], n = nvals[nid]),
 // x = 0 .. xs-1, with the support rules of scipy's rv_discrete.sf (below the support 1, above it 0).  One
 // thread per (n, K) pair.  The pmf is carried RELATIVE to its value at the mode (term recurrence outwards
 // from the mode, so nothing underflows at the start) in double-double arithmetic; tails are summed from
@@ -2011,10 +2011,13 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 // Hypergeometric path for binary attributes with the tail looked up instead of evaluated per
 // element: P[H >= X] only depends on (X, K_j, n_i), and a matrix has few distinct neighborhood
 // sizes n_i and annotation counts K_j (17 k distinct triples among 17 M elements at config 2,
-// SURVEY C12).  k_hyp_table evaluates every (n, K) pair once for all X; the count kernel looks
-// the value up in its epilogue and writes p / NES / nes_binary directly (the counts never reach
-// memory).  *fused = false (nothing launched) when the table would be too large or K is not an
-// integer (scipy then returns NaN: the per-element kernel reproduces that).
+// SURVEY C12).  k_hyp_table evaluates every (n, K) pair once for all X and every element is a lookup:
+//   * small neighborhoods: in the epilogue of the bit-sliced count kernel (the counts never reach memory);
+//   * large neighborhoods, split form (default): matrix-core counts -> packed u16 counts -> k_hyp_table cut
+//     at the largest count -> k_hyp_emit streams p / NES / nes_binary out (mfma.hip);
+//   * large neighborhoods, fused form (SAFE_HIP_HYP_SPLIT=0): in the epilogue of the matrix-core kernel.
+// *fused = false (nothing launched) when the table would be too large or K is not an integer (scipy then
+// returns NaN: the per-element kernel reproduces that).
 static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, int64_t pop,
                            const double *d_size, double p_cut, double *p_dev, double *nes_dev,
                            double *nb_dev, unsigned int *d_enr, bool use_mfma, hipStream_t hs, MfmaCountsSplit *split,
