@@ -80,6 +80,23 @@ def _worker(rank, world, port, tmpdir):
         # gather_nes without device counters (gloo): agrees on the fallback and moves the f64 blocks
         full_again = sharding.gather_nes(None, None, torch.from_numpy(cn), m, nperm, 'both').numpy()
         assert np.array_equal(full_again, want_cn)
+        # multiple_testing=True under sharding: p-value blocks gathered, full rows adjusted on every rank (the oracle stands in
+        # for safe_fdr_adjust), local blocks = slices of the adjusted matrix; untouched outputs stay the rank's own
+        p_local = cp / nperm
+        p_full = sharding.gather_columns(torch.from_numpy(p_local), m).numpy()
+        adj = np.apply_along_axis(orc.fdrcorrection, 1, p_full)
+        assert np.array_equal(adj, np.apply_along_axis(orc.fdrcorrection, 1, want_cp / nperm))
+        full = {'pvalues_pos': torch.from_numpy(adj), 'nes': torch.from_numpy(-np.log10(adj)),
+                'nes_binary': torch.from_numpy((adj < 0.05).astype(np.float64)),
+                'num_neighborhoods_enriched': torch.from_numpy((adj < 0.05).sum(axis=0).astype(np.float64))}
+        bufs = {'ns': torch.from_numpy(obs), 'pvalues_pos': torch.from_numpy(p_local), 'nes': torch.from_numpy(p_local * 0),
+                'nes_binary': torch.from_numpy(p_local * 0)}
+        out = sharding._outputs(bufs, torch.zeros(c1 - c0, dtype=torch.float64), full, m, None, ('nes', 'pvalues_pos'))
+        assert np.array_equal(out['pvalues_pos'], adj[:, c0:c1]) and np.array_equal(out['full_pvalues_pos'], adj)
+        assert np.array_equal(out['nes'], -np.log10(adj)[:, c0:c1]) and np.array_equal(out['ns'], obs, equal_nan=True)
+        assert np.array_equal(out['num_neighborhoods_enriched'], (adj < 0.05).sum(axis=0)[c0:c1])
+        plain = sharding._outputs(bufs, torch.ones(c1 - c0, dtype=torch.float64), None, m, None, ('pvalues_pos',))
+        assert np.array_equal(plain['full_pvalues_pos'], p_full) and np.array_equal(plain['pvalues_pos'], p_local)
         open(os.path.join(tmpdir, 'ok%d' % rank), 'w').write('ok')
     finally:
         dist.destroy_process_group()
