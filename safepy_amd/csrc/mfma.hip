@@ -848,7 +848,7 @@ __device__ __forceinline__ void hyp_emit_rows(const unsigned int *__restrict__ s
         if (hits[j]) atomicAdd(&hl.enriched[col[j]], hits[j]);
 }
 
-template <int UN>
+template <int UN, bool TAIL>
 __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict__ cnt16, int64_t n_padr, int64_t n_grp,
                                                   const int4 *__restrict__ rows, const int2 *__restrict__ tasks, int64_t mloc,
                                                   HypLookup hl, int lds_entries) {
@@ -886,8 +886,16 @@ __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict
         kofs[j] = ok[j] ? static_cast<uint32_t>(hl.kid[col[j]]) : 0u;
     }
     const unsigned int *src = cnt16 + (grp * n_padr * 32 + c) * 3;
-    if (staged) hyp_emit_rows<UN, true>(src, rows, task, slab, n_kid, kofs, ok, col, hh, lane, mloc, hl);
-    else hyp_emit_rows<UN, false>(src, rows, task, tab_n, n_kid, kofs, ok, col, hh, lane, mloc, hl);
+    // whole trips of 2 UN rows first, the last 1 .. 2 UN - 1 rows in trips of two: at most one repeated row per task
+    // instead of up to 2 UN - 1 (tasks are short -- 26 rows on average at 20 000 nodes -- and repeated rows are real stores)
+    const int bulk = TAIL ? task.x + (task.y - task.x) / (2 * UN) * (2 * UN) : task.y;
+    if (staged) {
+        if (bulk > task.x) hyp_emit_rows<UN, true>(src, rows, make_int2(task.x, bulk), slab, n_kid, kofs, ok, col, hh, lane, mloc, hl);
+        if (bulk < task.y) hyp_emit_rows<1, true>(src, rows, make_int2(bulk, task.y), slab, n_kid, kofs, ok, col, hh, lane, mloc, hl);
+    } else {
+        if (bulk > task.x) hyp_emit_rows<UN, false>(src, rows, make_int2(task.x, bulk), tab_n, n_kid, kofs, ok, col, hh, lane, mloc, hl);
+        if (bulk < task.y) hyp_emit_rows<1, false>(src, rows, make_int2(bulk, task.y), tab_n, n_kid, kofs, ok, col, hh, lane, mloc, hl);
+    }
 }
 
 // planes, task queues and source map of the counts form, enqueued on ctx->stream
@@ -1064,15 +1072,18 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     const int un = un_env ? atoi(un_env) : EMIT_UN;
     const dim3 egrid(ceil_div(n_grp, 8), st->tasks.size());
     const int lds_entries = lds_bytes / static_cast<int>(sizeof(double2));
-#define EMIT_LAUNCH(U)                                                                                                              \
+#define EMIT_LAUNCH(U, T)                                                                                                              \
     do {                                                                                                                            \
-        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit<U>), hipFuncAttributeMaxDynamicSharedMemorySize, \
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit<U, T>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                            lds_bytes));                                                                             \
-        hipLaunchKernelGGL((k_hyp_emit<U>), egrid, dim3(512), lds_bytes, ctx->stream, st->cnt16, n_padr, n_grp, d_rows, d_tasks,       \
+        hipLaunchKernelGGL((k_hyp_emit<U, T>), egrid, dim3(512), lds_bytes, ctx->stream, st->cnt16, n_padr, n_grp, d_rows, d_tasks,    \
                            st->cs.mloc, hl, lds_entries);                                                                           \
     } while (0)
-    if (un == 4) EMIT_LAUNCH(4);
-    else EMIT_LAUNCH(2);
+    const char *tail_env = getenv("SAFE_HIP_EMIT_TAIL");
+    const bool tail = !(tail_env && !strcmp(tail_env, "0"));
+    if (un == 4) EMIT_LAUNCH(4, false);
+    else if (tail) EMIT_LAUNCH(2, true);
+    else EMIT_LAUNCH(2, false);
 #undef EMIT_LAUNCH
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
