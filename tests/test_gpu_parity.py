@@ -754,3 +754,32 @@ def test_fdr_hypergeometric_vs_oracle_with_nan_rows(amd):
         np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
         np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
         assert (sf.nes_binary != want['nes_binary']).sum() == 0
+
+
+def test_numa_pinning_and_paired_draw_threads(amd, ctx, monkeypatch):
+    """Launcher helpers: pin_threads_to_device_numa keeps the process on CPUs it was allowed before (or changes
+    nothing), and the permutation stream is still NumPy's with the draw thread and its helper pinned to one
+    core's SMT pair (SAFE_HIP_DRAW_PAIR=1)."""
+    import os
+    from safepy_amd import backend as be
+    before = os.sched_getaffinity(0)
+    node = be.pin_threads_to_device_numa(0)
+    after = os.sched_getaffinity(0)
+    assert after <= before and len(after) >= 1
+    assert node is None or (isinstance(node, int) and node >= 0 and after != set())
+    monkeypatch.setenv('SAFE_HIP_DRAW_PAIR', '1')
+    n, nperm, seed = 777, 300, 12345
+    flags = np.ones(n, dtype=np.uint8)
+    flags[::7] = 0
+    perms = amd.Permutations(ctx, n, flags, nperm, seed)
+    got = perms.read()
+    perms.close()
+    movable = np.flatnonzero(flags)
+    np.random.seed(seed)
+    cur = np.arange(n)
+    for k in range(nperm):
+        p = np.random.permutation(movable)                  # safe_extras.py:58
+        cur[movable] = cur[p]                               # safe_extras.py:59-60 (cumulative)
+        assert np.array_equal(got[k], cur), k
+    os.sched_setaffinity(0, before)
+
