@@ -701,11 +701,15 @@ def test_gather_nes_over_rccl_single_rank(amd, ctx):
 
 # ------------------------------------------------------------- multiple_testing=True ----
 
+@pytest.mark.parametrize('sort', ['block', 'cub'])
 @pytest.mark.parametrize('sign', ['both', 'highest'])
-def test_fdr_randomization_vs_oracle(amd, sign):
+def test_fdr_randomization_vs_oracle(amd, sign, sort, monkeypatch):
     """safe.py:536-554 with multiple_testing=True: Benjamini-Hochberg per row, then NES and the
     binarised map from the adjusted p-values.  Empirical p-values are multiples of 1/P (many
-    ties, zeros, ones), quantitative attributes, a NaN column under z-score."""
+    ties, zeros, ones), quantitative attributes, a NaN column under z-score.  Both row sorts: the
+    bitonic network in LDS (rows up to 8192 attributes) and the library's segmented radix sort."""
+    if sort == 'cub':
+        monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
     rng = np.random.default_rng(61)
     n, m, nperm = 400, 150, 50
     xy = rng.uniform(size=(n, 2))
@@ -729,9 +733,12 @@ def test_fdr_randomization_vs_oracle(amd, sign):
     assert (sf.pvalues_pos < 1).any() and (sf.pvalues_pos == 1).any()
 
 
-def test_fdr_hypergeometric_vs_oracle_with_nan_rows(amd):
+@pytest.mark.parametrize('sort', ['block', 'cub'])
+def test_fdr_hypergeometric_vs_oracle_with_nan_rows(amd, sort, monkeypatch):
     """safe.py:599-608 with multiple_testing=True; a non-integer column makes hypergeom.sf NaN,
     and NumPy's minimum.accumulate then turns every adjusted p-value of those rows into NaN."""
+    if sort == 'cub':
+        monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
     rng = np.random.default_rng(62)
     n, m = 300, 90
     xy = rng.uniform(size=(n, 2))
@@ -754,6 +761,33 @@ def test_fdr_hypergeometric_vs_oracle_with_nan_rows(amd):
         np.testing.assert_allclose(sf.pvalues_pos, want['pvalues_pos'], rtol=1e-6, atol=1e-300)
         np.testing.assert_allclose(sf.nes, want['nes'], rtol=1e-6, atol=1e-9)
         assert (sf.nes_binary != want['nes_binary']).sum() == 0
+
+
+@pytest.mark.parametrize('m', [1, 2, 3, 129, 4373])
+def test_fdr_row_lengths_lds_equals_library_sort(amd, ctx, monkeypatch, m):
+    """safe_fdr_adjust on random p-value rows with ties, zeros, ones and a NaN row: the in-LDS row kernel equals the
+    library-sort path and the oracle bit for bit at awkward row lengths (1, 2, a power of two + 1, configs[1]'s 4373)."""
+    import torch
+    from safepy_amd import backend as be
+    rng = np.random.default_rng(1000 + m)
+    n = 37
+    p = rng.integers(0, 41, size=(n, m)) / 40.0
+    p[3, :] = rng.uniform(size=m)
+    if m > 2:
+        p[5, m // 2] = np.nan
+    want = np.apply_along_axis(orc.fdrcorrection, 1, p)
+    got = {}
+    for sort in ('block', 'cub'):
+        if sort == 'cub':
+            monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
+        t = [torch.from_numpy(p.copy()).to('cuda'), torch.empty((n, m), dtype=torch.float64, device='cuda'),
+             torch.empty((n, m), dtype=torch.float64, device='cuda'), torch.empty((m,), dtype=torch.float64, device='cuda')]
+        torch.cuda.synchronize()
+        be.fdr_adjust(ctx, n, m, 0, 'both', 0.05, [None] + [x.data_ptr() for x in t])
+        ctx.sync()
+        got[sort] = t[0].cpu().numpy()
+    assert np.array_equal(got['block'], want, equal_nan=True)
+    assert np.array_equal(got['cub'], want, equal_nan=True)
 
 
 def test_numa_pinning_and_paired_draw_threads(amd, ctx, monkeypatch):
