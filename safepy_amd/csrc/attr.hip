@@ -237,20 +237,20 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const int64_t n = attr->n, m = attr->m;
     const size_t flag_bytes = static_cast<size_t>(ceil_div(n, 4)) * 4;
-    unsigned long long *d_acc = nullptr;
-    SAFE_TRY(dev_alloc(&d_acc, 4));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_acc, 0, 4 * sizeof(unsigned long long), ctx->stream));
+    // temporaries in one grow-only scratch block of the context (five hipMalloc / hipFree pairs per call cost more
+    // than the kernel): accumulators u64 [4] | row bitmap u32 [n_words] | NaN count per column u32 [m]
+    const int64_t n_words = (n + 31) / 32;
+    SAFE_REQUIRE(n_words * sizeof(unsigned int) <= 150 * 1024, "safe_attr_stats: too many rows for the LDS row bitmap");
+    void *tmp = nullptr;
+    const size_t tmp_bytes = 4 * sizeof(unsigned long long) + static_cast<size_t>(n_words + m) * sizeof(unsigned int);
+    SAFE_TRY(ctx_scratch(ctx, 11, tmp_bytes, &tmp));
+    unsigned long long *d_acc = static_cast<unsigned long long *>(tmp);
+    unsigned int *d_rowbits = reinterpret_cast<unsigned int *>(d_acc + 4);
+    unsigned int *d_colnan = d_rowbits + n_words;
+    SAFE_HIP_CHECK(hipMemsetAsync(tmp, 0, tmp_bytes, ctx->stream));
     uint8_t *flags = nullptr;
     SAFE_TRY(dev_alloc(&flags, flag_bytes));
-    const int64_t n_words = (n + 31) / 32;
-    unsigned int *d_rowbits = nullptr;
-    SAFE_TRY(dev_alloc(&d_rowbits, n_words));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_rowbits, 0, n_words * sizeof(unsigned int), ctx->stream));
-    SAFE_REQUIRE(n_words * sizeof(unsigned int) <= 150 * 1024, "safe_attr_stats: too many rows for the LDS row bitmap");
     if (!attr->col_sum) SAFE_TRY(dev_alloc(&attr->col_sum, m));
-    unsigned int *d_colnan = nullptr;
-    SAFE_TRY(dev_alloc(&d_colnan, m));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_colnan, 0, m * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(attr->col_sum, 0, m * sizeof(double), ctx->stream));
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
     const bool c_order = attr->col_stride == 1 && m > 1;
@@ -286,9 +286,6 @@ int safe_attr_prepare(safe_attr *attr) {
     std::vector<uint8_t> h_flags(flag_bytes);
     SAFE_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-    (void)hipFree(d_acc);
-    (void)hipFree(d_rowbits);
-    (void)hipFree(d_colnan);
     attr->n_other = static_cast<int64_t>(h_acc[0]);
     attr->max_nan_col = static_cast<int64_t>(h_acc[1]);
     attr->n_non_integer = static_cast<int64_t>(h_acc[2]);

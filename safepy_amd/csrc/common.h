@@ -78,6 +78,7 @@ struct safe_ctx {
     int packed_layout = -1;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    std::vector<hipEvent_t> ev_timing, ev_plain;   // reused per-launch events (creating 20 per call costs ~0.1 ms)
     static constexpr int N_SCRATCH = 12;
     void *scratch[N_SCRATCH] = {};
     size_t scratch_bytes[N_SCRATCH] = {};
@@ -89,6 +90,8 @@ int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out);
 // grow-only pinned host buffer (device-to-host copies into it go through the DMA engines: no copy kernel
 // that would have to wait for a CU while a persistent kernel holds all of them)
 int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out);
+// `count` reusable events of the context (timing-enabled, or hipEventDisableTiming); valid until the next request of the same kind
+int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out);
 void perms_cache_drop(safe_ctx *ctx);   // frees ctx->perm_cache (rng.cpp)
 
 // RAII-less device buffer helper: all frees go through the owning handle's destroy.

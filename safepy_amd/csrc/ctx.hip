@@ -42,6 +42,17 @@ int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out) {
     return SAFE_OK;
 }
 
+int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out) {
+    std::vector<hipEvent_t> &pool = timing ? ctx->ev_timing : ctx->ev_plain;
+    while (pool.size() < count) {
+        hipEvent_t e = nullptr;
+        SAFE_HIP_CHECK(timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        pool.push_back(e);
+    }
+    *out = pool.data();
+    return SAFE_OK;
+}
+
 int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out) {
     if (ctx->pinned_bytes < bytes) {
         if (ctx->pinned) {
@@ -133,6 +144,8 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
     perms_cache_drop(ctx);
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    for (hipEvent_t e : ctx->ev_timing) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->ev_plain) (void)hipEventDestroy(e);
     for (int i = 0; i < safe_ctx::N_SCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);

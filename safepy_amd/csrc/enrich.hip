@@ -1769,13 +1769,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     ctx->last_kernel.name = pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
-    std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
-    for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
+    hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
+    SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
+    SAFE_TRY(ctx_events(ctx, false, 2, &plain));
     // consecutive spans alternate between two streams so the tail of one launch (a few long
     // tasks) overlaps the head of the next; both wait for the inputs prepared on ctx->stream
-    hipEvent_t ready = nullptr, side_done = nullptr;
-    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    SAFE_HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    hipEvent_t ready = plain[0], side_done = plain[1];
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
@@ -1847,9 +1846,6 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         ctx->last_kernel.total_ms += ms;
         ctx->last_kernel.launches += 1;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ready);
-    (void)hipEventDestroy(side_done);
     return SAFE_OK;
 }
 
@@ -1966,11 +1962,10 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     ctx->last_kernel.name = "k_permtest_lds";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
-    std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
-    for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
-    hipEvent_t ready = nullptr, side_done = nullptr;
-    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    SAFE_HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
+    SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
+    SAFE_TRY(ctx_events(ctx, false, 2, &plain));
+    hipEvent_t ready = plain[0], side_done = plain[1];
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
@@ -2000,9 +1995,6 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
         ctx->last_kernel.total_ms += ms;
         ctx->last_kernel.launches += 1;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ready);
-    (void)hipEventDestroy(side_done);
     (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
     return SAFE_OK;
@@ -2240,8 +2232,12 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const PermPath path = choose_path(ctx, nbr, attr, P, z);
     bool mfma = path == PATH_GATHER && mfma_applicable(ctx, nbr, attr, perms, z);
     const bool lds64 = path == PATH_GATHER && lds_f64_applicable(nbr, perms);
-    int rc = dev_alloc(&d_tab, P + 1);
-    if (rc == SAFE_OK) rc = dev_alloc(&d_enr, mloc + 16);
+    void *small = nullptr;                           // NES table f64 [P + 1] | enriched counters u32 [mloc + 16] (grow-only scratch)
+    int rc = ctx_scratch(ctx, 10, static_cast<size_t>(P + 1) * sizeof(double) + static_cast<size_t>(mloc + 16) * sizeof(unsigned int), &small);
+    if (rc == SAFE_OK) {
+        d_tab = static_cast<double *>(small);
+        d_enr = reinterpret_cast<unsigned int *>(d_tab + P + 1);
+    }
     if (rc == SAFE_OK) {
         hipError_t e = hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream);
         if (e == hipSuccess) e = hipMemsetAsync(d_enr, 0, (mloc + 16) * sizeof(unsigned int), ctx->stream);
@@ -2284,8 +2280,6 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     }
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
     if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab (host) + temporaries
-    (void)hipFree(d_tab);
-    (void)hipFree(d_enr);
     (void)hipFree(tiles.bt);
     return rc;
 }

@@ -1210,11 +1210,10 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     ctx->last_kernel.name = "k_permtest_mfma";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
-    std::vector<hipEvent_t> ev(2 * n_launch, nullptr);
-    for (auto &e : ev) SAFE_HIP_CHECK(hipEventCreate(&e));
-    hipEvent_t ready = nullptr, side_done = nullptr;
-    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ready, hipEventDisableTiming));
-    SAFE_HIP_CHECK(hipEventCreateWithFlags(&side_done, hipEventDisableTiming));
+    hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
+    SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
+    SAFE_TRY(ctx_events(ctx, false, 2, &plain));
+    hipEvent_t ready = plain[0], side_done = plain[1];
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
@@ -1250,8 +1249,5 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         ctx->last_kernel.total_ms += ms;
         ctx->last_kernel.launches += 1;
     }
-    for (auto &e : ev) (void)hipEventDestroy(e);
-    (void)hipEventDestroy(ready);
-    (void)hipEventDestroy(side_done);
     return SAFE_OK;
 }
