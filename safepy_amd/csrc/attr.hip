@@ -18,7 +18,7 @@ __device__ __forceinline__ double load_attr(const void *raw, int64_t idx) {
 template <typename T, int GC>
 __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw, int64_t n, int64_t m,
                                                     int64_t rs, int64_t cs, unsigned int *__restrict__ row_bits,
-                                                    unsigned long long *__restrict__ acc /*[4]*/,
+                                                    unsigned long long *__restrict__ acc /*[4 + 64 + 64]*/,
                                                     double *__restrict__ col_sum, unsigned long long *__restrict__ max_abs_bits,
                                                     unsigned int *__restrict__ col_nan, int64_t rows_per_block) {
     extern __shared__ unsigned int s_bits[];           // [ceil(n/32)]
@@ -93,9 +93,25 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
         if (gridDim.y == 1) col_sum[j] = total;
         else atomicAdd(&col_sum[j], total);               // integer-valued data (the consumers' case) adds exactly in any order
         if (t_nan) atomicAdd(&col_nan[j], static_cast<unsigned int>(t_nan));
-        if (t_other) atomicAdd(&acc[0], t_other);
-        if (t_nonint) atomicAdd(&acc[2], t_nonint);
-        atomicMax(max_abs_bits, static_cast<unsigned long long>(__double_as_longlong(tmx)));
+        // sums over all columns: 64 slots each instead of one address for thousands of workgroups (k_fold_parts adds them up)
+        if (t_other) atomicAdd(&acc[4 + (j & 63)], t_other);
+        if (t_nonint) atomicAdd(&acc[68 + (j & 63)], t_nonint);
+        // thousands of workgroups hit this one address: look first (a stale look only costs a redundant atomic)
+        const unsigned long long mine = static_cast<unsigned long long>(__double_as_longlong(tmx));
+        if (mine > __builtin_nontemporal_load(max_abs_bits)) atomicMax(max_abs_bits, mine);
+    }
+}
+
+// acc[0] = sum of acc[4 .. 68), acc[2] = sum of acc[68 .. 132)  (one wave)
+__global__ __launch_bounds__(64) void k_fold_parts(unsigned long long *__restrict__ acc) {
+    unsigned long long a = acc[4 + threadIdx.x], b = acc[68 + threadIdx.x];
+    for (int off = 32; off; off >>= 1) {
+        a += __shfl_down(a, off);
+        b += __shfl_down(b, off);
+    }
+    if (threadIdx.x == 0) {
+        acc[0] = a;
+        acc[2] = b;
     }
 }
 
@@ -238,14 +254,14 @@ int safe_attr_prepare(safe_attr *attr) {
     const int64_t n = attr->n, m = attr->m;
     const size_t flag_bytes = static_cast<size_t>(ceil_div(n, 4)) * 4;
     // temporaries in one grow-only scratch block of the context (five hipMalloc / hipFree pairs per call cost more
-    // than the kernel): accumulators u64 [4] | row bitmap u32 [n_words] | NaN count per column u32 [m]
+    // than the kernel): accumulators u64 [4 + 2 x 64 partial sums] | row bitmap u32 [n_words] | NaN count per column u32 [m]
     const int64_t n_words = (n + 31) / 32;
     SAFE_REQUIRE(n_words * sizeof(unsigned int) <= 150 * 1024, "safe_attr_stats: too many rows for the LDS row bitmap");
     void *tmp = nullptr;
-    const size_t tmp_bytes = 4 * sizeof(unsigned long long) + static_cast<size_t>(n_words + m) * sizeof(unsigned int);
+    const size_t tmp_bytes = 132 * sizeof(unsigned long long) + static_cast<size_t>(n_words + m) * sizeof(unsigned int);
     SAFE_TRY(ctx_scratch(ctx, 11, tmp_bytes, &tmp));
     unsigned long long *d_acc = static_cast<unsigned long long *>(tmp);
-    unsigned int *d_rowbits = reinterpret_cast<unsigned int *>(d_acc + 4);
+    unsigned int *d_rowbits = reinterpret_cast<unsigned int *>(d_acc + 132);
     unsigned int *d_colnan = d_rowbits + n_words;
     SAFE_HIP_CHECK(hipMemsetAsync(tmp, 0, tmp_bytes, ctx->stream));
     uint8_t *flags = nullptr;
@@ -277,6 +293,7 @@ int safe_attr_prepare(safe_attr *attr) {
         else STATS(double, 1, n);
     }
 #undef STATS
+    hipLaunchKernelGGL(k_fold_parts, dim3(1), dim3(64), 0, ctx->stream, d_acc);
     hipLaunchKernelGGL(k_max_u32, dim3(static_cast<unsigned>(std::min<int64_t>(ceil_div(m, 256), 64))), dim3(256), 0, ctx->stream,
                        d_colnan, m, d_acc + 1);
     hipLaunchKernelGGL(k_bits_to_bytes, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_rowbits, n, flags);
