@@ -244,6 +244,9 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     constexpr int KS = NS * MF_SS, BUF = 4 * KS;                            // LDS bytes per k-step / per super-step buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] + kb list
     __shared__ int slot_box;
+    __shared__ unsigned int wg_xmax;
+    unsigned int published = 0;
+    if (threadIdx.x == 0) wg_xmax = 0;                                        // (ordered before its first use by the task-fetch barriers)
     int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * BUF);
     // observed scores of this thread's 16 outputs (exact 64-bit integers), [r][thread]: read once per permutation
     long long *obs = reinterpret_cast<long long *>(lds + 2 * BUF + MF_MAXBLK * sizeof(int32_t)) + threadIdx.x;
@@ -462,7 +465,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                         for (int r = 0; r < 16; ++r) mx = max(mx, acc[s][r]);
 #pragma unroll
                     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
-                    if (lane == 0) atomicMax(hl.xmax, static_cast<unsigned int>(mx));
+                    if (lane == 0) atomicMax(&wg_xmax, static_cast<unsigned int>(mx));   // (LDS; published below, once per task at most)
                 } else if (!hl.tab) {                                 // plain counts ('sum' scores of 0/1 attributes)
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
@@ -536,6 +539,14 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 }
             }
             __syncthreads();                                         // kb_list / buffers are reused by the next task
+            if constexpr (COUNTS) {
+                // the call's largest count: every wave of every task on ONE global address cost 8 % of the kernel; the
+                // workgroup keeps its own maximum in LDS and publishes it only when it grew
+                if (tid == 0 && hl.cnt16 && wg_xmax > published) {
+                    published = wg_xmax;
+                    atomicMax(hl.xmax, published);
+                }
+            }
         }
     }
 }
