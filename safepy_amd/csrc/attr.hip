@@ -316,6 +316,7 @@ int safe_attr_prepare(safe_attr *attr) {
         int64_t cnt = 0;
         for (int64_t i = 0; i < n; ++i) cnt += h_flags[i] != 0;
         attr->n_rows_with_value = cnt;
+        attr->h_row_flags.assign(h_flags.begin(), h_flags.begin() + n);
     } else {
         (void)hipFree(flags);    // caller supplied global flags (sharded run): keep them
     }
@@ -523,6 +524,10 @@ int safe_attr_stats(safe_attr *attr, int64_t *n_other, int64_t *max_nan_col, int
 int safe_attr_row_flags(safe_attr *attr, uint8_t *out_host) {
     SAFE_REQUIRE(attr && out_host, "safe_attr_row_flags: NULL argument");
     SAFE_TRY(safe_attr_prepare(attr));
+    if (static_cast<int64_t>(attr->h_row_flags.size()) == attr->n) {   // the host copy made by the statistics pass / set_row_flags
+        memcpy(out_host, attr->h_row_flags.data(), attr->n);
+        return SAFE_OK;
+    }
     safe_ctx *ctx = attr->ctx;
     SAFE_HIP_CHECK(hipMemcpyAsync(out_host, attr->row_flags, attr->n, hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
@@ -545,6 +550,7 @@ int safe_attr_set_row_flags(safe_attr *attr, const uint8_t *flags_host) {
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
     attr->flags_ready = true;
     attr->n_rows_with_value = cnt;
+    attr->h_row_flags.assign(tmp.begin(), tmp.begin() + attr->n);
     return SAFE_OK;
 }
 

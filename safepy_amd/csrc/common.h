@@ -206,6 +206,7 @@ struct safe_attr {
     const void *raw = nullptr;      // device
     bool owns_raw = false;
     uint8_t *row_flags = nullptr;   // [n] device, 1 = row has >= 1 non-NaN value
+    std::vector<uint8_t> h_row_flags;   // host copy of row_flags (kept in step: safe_attr_row_flags answers without a device sync)
     bool flags_ready = false;
     bool stats_ready = false;
     int64_t n_other = 0, max_nan_col = 0, n_rows_with_value = 0, n_non_integer = 0;
