@@ -39,7 +39,7 @@ entry('k_euclid_dense', 'k_euclid_dense')
 entry('k_hyp_emit', 'k_hyp_emit', 1.0,
       'reads are 12 B/lane count records + 16 B/lane table slabs (mostly L2 hits): the x2 correction of 16 B/lane streams is not '
       'applied (uncalibrated width); algorithmic bytes 5.21 GB (4.80 GB written + 0.41 GB of packed counts read); 4 % of the writes '
-      'are repeated last rows of short row batches')
+      'are repeated last rows of short row batches (1-2 % with the tail rule)')
 entry('k_permtest_mfma<counts> (split form)', 'k_permtest_mfma<true, 6>', 2.0)
 entry('k_mfma_planes01_rows', 'k_mfma_planes01_rows', 2.0)
 entry('k_permute_cols', 'k_permute_cols')
