@@ -11,10 +11,12 @@ seeded surrogate (safe-data is not available offline; safepy_amd/workloads.py).
 
     python bench.py [--gpus N] [--steps K] [--warmup W]
 
-N > 1 is launched by torch.distributed.run, one rank per GPU; every rank owns its own
-4373-attribute shard (weak scaling: per-GPU work fixed), the network and the permutation
-stream are replicated, results are all-gathered over RCCL.
-Prints ONE JSON line on rank 0.
+N > 1: one rank per GPU (launched by torch.distributed.run; when WORLD_SIZE is not set the script
+starts that launcher itself as a child process, before anything touches a GPU, and relays rank
+0's line and the exit code); every rank owns its own 4373-attribute shard (weak scaling: per-GPU
+work fixed), the network and the permutation stream are replicated, results are all-gathered
+over RCCL.  The step is sharding.randomization_step -- the function the product's sharded driver
+(safepy_amd.run_batch) runs.  Prints ONE JSON line on rank 0.
 """
 import argparse
 import json
@@ -93,24 +95,55 @@ def cpu_baseline(a_dense, b, sample_perms):
             'seconds_per_permutation': dt / sample_perms, 'blas': blas}
 
 
-def pmc_traffic(kernel_name):
+def kernel_source_sha256():
+    """Hash of the kernel sources the library is built from (safepy_amd/csrc/*.hip|*.h|*.cpp + include/):
+    what the committed PMC figures are stamped with (tools/update_profiles.py, tools/pmc_bits.sh)."""
+    import glob
+    import hashlib
+    h = hashlib.sha256()
+    files = sorted(glob.glob(os.path.join(ROOT, 'safepy_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(ROOT, 'safepy_amd', 'csrc', '*.h')) +
+                   glob.glob(os.path.join(ROOT, 'safepy_amd', 'csrc', '*.cpp')) + glob.glob(os.path.join(ROOT, 'include', '*.h')))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        h.update(open(f, 'rb').read())
+    return h.hexdigest()
+
+
+def _stamp_is_stale(stamp, kernel_name):
+    """A committed PMC figure is stale when the kernel sources changed after it was profiled, or it belongs to another kernel."""
+    if not isinstance(stamp, dict):
+        return True
+    if kernel_name is not None and not str(stamp.get('kernel', '')).startswith(kernel_name):
+        return True
+    return stamp.get('kernel_source_sha256') != kernel_source_sha256()
+
+
+def pmc_traffic(kernel_name, with_stamp=False):
     """HBM bytes per launch of `kernel_name` from the committed rocprofv3 PMC passes
     (profiles/pmc_traffic.json: FETCH_SIZE x2 gfx950 correction + WRITE_SIZE, separate --pmc
     passes of this same bench command; tools/rocpd_counters.py).  PMC counters cannot be
     collected from inside the timed process, so this is the offline measurement; None if the
-    profile has no entry for the kernel."""
+    profile has no entry for the kernel.  with_stamp: (bytes, {commit, stale}) -- stale = the kernel
+    sources differ from the ones that were profiled."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json')) as f:
-            entry = json.load(f).get(kernel_name)
-        return None if entry is None else entry['hbm_bytes_per_launch']
+            doc = json.load(f)
+        entry = doc.get(kernel_name)
+        val = None if entry is None else entry['hbm_bytes_per_launch']
+        stamp = doc.get('_stamp')
     except (OSError, ValueError, KeyError):
-        return None
+        val, stamp = None, None
+    if not with_stamp:
+        return val
+    stamp = stamp if isinstance(stamp, dict) else {}
+    return val, {'profiled_at_commit': stamp.get('commit'), 'stale': _stamp_is_stale(dict(stamp, kernel=kernel_name), kernel_name)}
 
 
-def binding_resources(num_cu):
+def binding_resources(num_cu, kernel_name=None):
     """Utilisation of the resources that actually bound the dominant kernel (it is neither HBM- nor MFMA-bound), from the
     committed PMC passes of this bench command (profiles/pmc_bits.json; counters cannot be read inside the timed process):
-    LDS pipe busy cycles per CU and VALU issue cycles per SIMD over the kernel's GPU cycles."""
+    LDS pipe busy cycles per CU and VALU issue cycles per SIMD over the kernel's GPU cycles.  Stamped with the commit and
+    kernel they were profiled at; "stale": true when the kernel sources changed since (or the dominant kernel is another one)."""
     try:
         with open(os.path.join(ROOT, 'profiles', 'pmc_bits.json')) as f:
             c = json.load(f)
@@ -121,7 +154,8 @@ def binding_resources(num_cu):
                 'valu_issue_frac': c['SQ_INSTS_VALU'] / (4 * num_cu) / c['valu_wave_insts_per_clock_per_simd_sustained'] / gpu_cycles,
                 'waves_issuing_parked_stalled': [c['SQ_ACTIVE_INST_ANY'] / c['SQ_WAVE_CYCLES'], c['SQ_WAIT_ANY'] / c['SQ_WAVE_CYCLES'],
                                                  c['SQ_WAIT_INST_ANY'] / c['SQ_WAVE_CYCLES']],
-                'source': c['_source']}
+                'source': c['_source'], 'profiled_at_commit': c.get('commit'),
+                'stale': _stamp_is_stale(c, kernel_name)}
     except (OSError, ValueError, KeyError, ZeroDivisionError):
         return None
 
@@ -230,16 +264,32 @@ def mfma_kernel(ctx, np, be):
     return out
 
 
+def launch_ranks(n_gpus):
+    """`python bench.py --gpus N` without a launcher: start `torch.distributed.run` with N ranks of this same script as a
+    CHILD process (nothing here has touched a GPU yet -- no exec from a GPU-initialised process), pass its output through
+    and return its exit code."""
+    import socket
+    import subprocess
+    with socket.socket() as sock:
+        sock.bind(('127.0.0.1', 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')          # dmabuf IPC: RCCL across processes needs it on this driver
+    env.setdefault('OMP_NUM_THREADS', '1')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(n_gpus),
+           '--master-addr', '127.0.0.1', '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    return subprocess.run(cmd, env=env).returncode
+
+
 def main():
     args = parse()
+    if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
+        sys.exit(launch_ranks(args.gpus))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     world = int(os.environ.get('WORLD_SIZE', '1'))
     if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            sys.exit('bench.py --gpus %d must be launched with torch.distributed.run --nproc-per-node %d'
-                     % (args.gpus, args.gpus))
-        args.gpus = world
+        args.gpus = world                          # under a launcher the launcher's world size is the truth
 
     import numpy as np
     import torch
@@ -260,6 +310,11 @@ def main():
     force_dist = os.environ.get('SAFE_BENCH_FORCE_DIST') == '1'      # exercise the collectives with a single rank
     if world > 1 or force_dist:
         import torch.distributed as dist
+        if force_dist and world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+            os.environ.setdefault('MASTER_PORT', '29533')
+            os.environ.setdefault('RANK', '0')
+            os.environ.setdefault('WORLD_SIZE', '1')
         dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
 
     # ---------------- inputs (untimed): network, membership, attributes resident in HBM ----
@@ -280,28 +335,23 @@ def main():
     b_dev = torch.from_numpy(np.ascontiguousarray(b_host.T)).to('cuda')      # F-order [n,m] == C-order [m,n]
     P = args.perms
 
-    out = [torch.empty((n, m), dtype=torch.float64, device='cuda') for _ in range(5)]
+    out = {k: torch.empty((n, m), dtype=torch.float64, device='cuda') for k in sharding.RANDOMIZATION_OUTPUTS}
     enriched = torch.empty((m,), dtype=torch.float64, device='cuda')
     gathered = [None]
     table = be.nes_table(P)
     kernel_ms = []
 
-    def step():
+    def step(exchange=True):
+        # one compute_pvalues pass of this rank's block: statistics for the dispatch rule, whole-matrix row flags (N > 1:
+        # one small all-gather), the seeded legacy stream (host) + table kernels, the permutation-test kernels with the fused
+        # p-value / NES / binarisation epilogue and -- N > 1 -- the all-gather of every rank's result over RCCL / xGMI
         attr = be.Attributes.from_device(ctx, b_dev.data_ptr(), np.float32, n, m, order='F')
-        stats = attr.stats()                                  # dispatch rule + >50 % NaN check inputs
-        flags = attr.row_flags()
-        if dist is not None:                                  # indx_vals must come from the FULL matrix
-            flags, stats = sharding.reduce_flags_and_stats(flags, stats)
-            attr.set_row_flags(flags)
-        perms = be.Permutations(ctx, n, flags, P, 0)          # seeded legacy stream (host) + upload
-        be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05,
-                         [t.data_ptr() for t in out] + [enriched.data_ptr()], table=table)
-        kernel_ms.append(ctx.last_kernel()[1])
-        if dist is not None:                                  # NES of every rank's block over RCCL / xGMI
-            gathered[0] = sharding.gather_nes(ctx, nbr, out[3], m * world, P, 'both', table=table)
-        perms.close()
-        attr.close()
-        return stats
+        try:
+            gathered[0] = sharding.randomization_step(ctx, nbr, attr, m * world, P, 0, out, enriched, 'sum', 'both', 0.05,
+                                                      table=table, exchange=exchange)
+            kernel_ms.append(ctx.last_kernel()[1])
+        finally:
+            attr.close()
 
     def fence():
         torch.cuda.synchronize()
@@ -309,24 +359,52 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    def timed(n_steps, fn):
+        fence()
+        t_begin = time.perf_counter()
+        per_step = []
+        for _ in range(n_steps):
+            ts = time.perf_counter()
+            fn()
+            per_step.append(1e3 * (time.perf_counter() - ts))     # (a step returns after its own stream synchronisation)
+        fence()
+        seconds = time.perf_counter() - t_begin
+        if dist is not None:                                       # the slowest rank's clock
+            t = torch.tensor([seconds], dtype=torch.float64, device='cuda')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        return seconds, per_step
+
     for _ in range(args.warmup):
         step()
     kernel_ms.clear()
-    fence()
-    t0 = time.perf_counter()
     cpu0 = time.process_time()
-    step_ms = []
-    for _ in range(args.steps):
-        ts = time.perf_counter()
-        step()
-        step_ms.append(1e3 * (time.perf_counter() - ts))         # (a step returns after its own stream synchronisation)
-    fence()
-    elapsed = time.perf_counter() - t0
+    elapsed, step_ms = timed(args.steps, step)
     host_cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps     # all threads of this rank: draws, swaps, launches
+    kernel_ms_timed = list(kernel_ms)
+
+    # the same step with the exchange replaced by a D2H copy of the rank's own NES block (what a host that only
+    # wants the results on disk needs), and with no exchange at all -- diagnostics outside the timed region, N > 1 only
+    exchange_report = None
     if dist is not None:
-        t = torch.tensor([elapsed], dtype=torch.float64, device='cuda')
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        k_diag = max(2, min(args.steps, 5))
+        host_nes = torch.empty((n, m), dtype=torch.float64).pin_memory()
+
+        def step_d2h():
+            step(exchange=False)
+            host_nes.copy_(out['nes'], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+
+        t_d2h, _ = timed(k_diag, step_d2h)
+        t_none, _ = timed(k_diag, lambda: step(exchange=False))
+        exchange_report = {'all_gather_ms_per_step': 1e3 * elapsed / args.steps, 'd2h_only_ms_per_step': 1e3 * t_d2h / k_diag,
+                           'no_exchange_ms_per_step': 1e3 * t_none / k_diag, 'steps_timed': k_diag,
+                           'form': 'packed u32 counters (4 B per node x attribute), NES rebuilt on every rank'
+                                   if be.packed_counts_info(ctx)[2] >= 0 else 'f64 NES blocks',
+                           'bytes_received_per_rank': int(4 * be.packed_counts_info(ctx)[0] * m * (world - 1))
+                                                      if be.packed_counts_info(ctx)[2] >= 0 else int(8 * n * m * (world - 1)),
+                           'd2h_bytes_per_rank': int(8 * n * m)}
+    kernel_ms = kernel_ms_timed
 
     if rank == 0:
         ms_per_step = 1e3 * elapsed / args.steps
@@ -350,7 +428,7 @@ def main():
         else:
             alg_bytes = n * m * 4 + P * (n + 1) * 4 + int(nbr.nnz) * 4 + 5 * n * m * 8
         achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic = pmc_traffic(kname)
+        traffic, traffic_stamp = pmc_traffic(kname, with_stamp=True)
         line = {
             'metric': 'node-attribute enrichments/sec (nodes x attrs x perms), compute_pvalues permutation test',
             'value': value, 'unit': 'enrichments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
@@ -363,19 +441,21 @@ def main():
                        'neighbors_per_node_mean': float(counts.mean()), 'neighbors_per_node_std': float(counts.std()),
                        'parallelism': 'attribute shards x%d' % world},
             'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'kernel_ms': k_ms,
+                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_stamp, 'kernel_ms': k_ms,
                          'launches_per_step': launches, 'permutations_per_launch': span,
                          'algorithmic_bytes': alg_bytes,
                          'binding_resource': 'VALU issue + LDS gather (not HBM, not MFMA): see DESIGN.md section 4 and '
                                              'profiles/ for the PMC evidence',
                          'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3),
-                         'binding_resource_utilisation': binding_resources(ctx.num_cu)},
+                         'binding_resource_utilisation': binding_resources(ctx.num_cu, kname)},
             'kernel_share_of_step': k_ms * launches / ms_per_step,
             'host_cpu_ms_per_step': host_cpu_ms, 'host_cores_usable': effective_cores(),
             'swap_threads': int(os.environ.get('SAFE_HIP_SWAP_THREADS', '4')), 'pinned_to_numa_node': numa_node,
             'step_ms_min_median_max': [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
             'step_ms_slowest3': [float(x) for x in sorted(step_ms)[-3:]],
         }
+        if exchange_report is not None:
+            line['exchange'] = exchange_report
         if args.cpu_perms > 0 and world == 1:                 # the CPU leg runs on rank 0 at N = 1 only
             a_dense = sf.neighborhoods
             line['cpu_baseline'] = cpu_baseline(a_dense, b_host, args.cpu_perms)

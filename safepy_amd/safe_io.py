@@ -19,7 +19,6 @@ There is no CPU fallback: every function that computes needs a HIP device.
 import logging
 import os
 import pickle
-from os.path import expanduser
 
 import numpy as np
 
@@ -80,8 +79,7 @@ def calculate_edge_lengths(G, verbose=True, device=0):
 
 def load_network_from_gpickle(filename, verbose=True):
     """safepy/safe_io.py:124-130."""
-    filename = filename.replace('~', expanduser('~'))
-    with open(filename, 'rb') as f:
+    with open(os.path.expanduser(filename), 'rb') as f:
         return pickle.load(f)
 
 
@@ -90,10 +88,9 @@ def load_network_from_scatter(filename, node_key_attribute='key', verbose=True):
     (key, x, y, label) -> an edgeless networkx graph, nodes 0..N-1 with those attributes."""
     import networkx as nx
     import pandas as pd
-    filename = filename.replace('~', expanduser('~'))
     if verbose:
-        print('Loading the file of node coordinates...')
-    scatter = pd.read_csv(filename, sep='\t')
+        logging.info('Loading the file of node coordinates...')
+    scatter = pd.read_csv(os.path.expanduser(filename), sep='\t')
     scatter.columns = ['key', 'x', 'y', 'label']
     G = nx.Graph()
     G.add_nodes_from([(i, row) for i, row in scatter.T.to_dict().items()])
@@ -133,35 +130,43 @@ def euclidean_pseudo_network(graph, neighborhood_radius, device=0, as_networkx=T
 # ------------------------------------------------------------------------------------------------
 # read_attributes
 # ------------------------------------------------------------------------------------------------
-def _parse_attribute_source(attribute_file):
-    """Everything of safe_io.py:338-377 that produces the label-indexed numeric table and the
-    `attributes` frame: pandas calls identical to the reference's (third-party arithmetic: the
-    text-to-float conversion is pandas')."""
+def _numeric_table_from_text(path):
+    """A tab-separated attribute file (first column = node labels, header = attribute names) as a
+    label-indexed frame of floats.  Non-numeric cells become NaN and every column is stored in the
+    narrowest float type that holds it -- which is why matrices loaded from text are float32
+    (safe_io.py:358-365)."""
     import pandas as pd
-    if isinstance(attribute_file, str):
-        file_name = attribute_file.replace('~', expanduser('~'))
-        [_, file_extension] = os.path.splitext(file_name)
-        if file_extension == '.mat':
+    raw = pd.read_csv(path, sep='\t', dtype={0: str})
+    raw = raw.set_index(raw.columns[0], drop=True)
+    return raw.apply(pd.to_numeric, downcast='float', errors='coerce')
+
+
+def _parse_attribute_source(attribute_file):
+    """(attributes frame [id, name], label-indexed numeric table) from a `.txt` / `.gz` path or a
+    DataFrame indexed by node label -- the input half of read_attributes (safe_io.py:338-388).  The
+    text-to-float conversion and the averaging of repeated labels are pandas' own, as in the
+    reference; columns are renamed 0..M-1 for files and kept for DataFrames."""
+    import pandas as pd
+    if isinstance(attribute_file, pd.DataFrame):
+        table, names = attribute_file, attribute_file.columns
+    elif isinstance(attribute_file, str):
+        path = os.path.expanduser(attribute_file)
+        ext = os.path.splitext(path)[1]
+        if ext == '.mat':
             raise NotImplementedError('MATLAB attribute files (safe_io.py:346-356) are out of scope; '
                                       'pass a .txt / .gz file or a DataFrame')
-        elif (file_extension == '.txt') or (file_extension == '.gz'):
-            table = pd.read_csv(file_name, sep='\t', dtype={0: str})
-            table.set_index(table.columns[0], drop=True, inplace=True)
-            table = table.apply(pd.to_numeric, downcast='float', errors='coerce')
-            attributes = pd.DataFrame(data={'id': np.arange(len(table.columns)), 'name': table.columns})
-            table.columns = np.arange(len(table.columns))
-        else:
+        if ext not in ('.txt', '.gz'):
             raise ValueError("Only attribute files with the following extensions are accepted: .mat, .txt, .gz.")
-    elif isinstance(attribute_file, pd.DataFrame):
-        table = attribute_file
-        attributes = pd.DataFrame(data={'id': np.arange(len(table.columns)), 'name': table.columns})
+        table = _numeric_table_from_text(path)
+        names = table.columns
+        table.columns = np.arange(table.shape[1])
     else:
         raise ValueError('attribute_file must be a path or a pandas DataFrame, got %s' % type(attribute_file))
-    table = table.apply(pd.to_numeric, errors='coerce')               # safe_io.py:380
-    attributes['name'] = attributes['name'].astype(str)               # :383
-    if not table.index.is_unique:                                     # :386-388
+    attributes = pd.DataFrame({'id': np.arange(len(names)), 'name': pd.Index(names).astype(str)})
+    table = table.apply(pd.to_numeric, errors='coerce')
+    if table.index.has_duplicates:
         logging.info('\nThe attribute file contains multiple values for the same labels. Their values will be averaged.')
-        table = table.groupby(table.index).mean()
+        table = table.groupby(level=0).mean()
     return attributes, table
 
 
@@ -199,21 +204,16 @@ def read_attributes_device(attribute_file='', node_label_order=None, mask_duplic
     order = 'C' if (probe.flags['C_CONTIGUOUS'] and not probe.flags['F_CONTIGUOUS']) else 'F'
     attr, node2attribute = be.Attributes.reindexed(ctx, values, row_map, fill_value=fill_value, order=order)
 
-    if verbose:                                       # :414-431, the four counts in one device pass
-        logging.info('\nAttribute data provided: %d labels x %d attributes' % (len(node_label_in_file), attributes.shape[0]))
-        n = min(len(node_label_not_mapped), 3)
-        m = len(node_label_not_mapped) - n
-        if n > 0:
-            msg1 = ', '.join(str(x) for x in node_label_not_mapped[:n])
-            msg2 = format(' and %d other labels in the attribute file were not found in the network.' % m)
-            logging.info(msg1 + msg2)
-        n_nlm = len(node_label_in_file) - len(node_label_not_mapped)
-        logging.info('\nAttribute data mapped onto the network: %d labels x %d attributes' % (n_nlm, attributes.shape[0]))
-        n_nan, n_zero, n_pos, n_neg = attr.value_counts()
-        logging.info('Values: %d NaNs' % n_nan)
-        logging.info('Values: %d zeros' % n_zero)
-        logging.info('Values: %d positives' % n_pos)
-        logging.info('Values: %d negatives' % n_neg)
+    if verbose:                                       # the summary of safe_io.py:414-431; the value census is one device pass
+        n_file, n_attr, n_lost = len(node_label_in_file), attributes.shape[0], len(node_label_not_mapped)
+        logging.info('\nAttribute data provided: %d labels x %d attributes' % (n_file, n_attr))
+        if n_lost:
+            shown = [str(x) for x in node_label_not_mapped[:3]]
+            logging.info('%s and %d other labels in the attribute file were not found in the network.'
+                         % (', '.join(shown), n_lost - len(shown)))
+        logging.info('\nAttribute data mapped onto the network: %d labels x %d attributes' % (n_file - n_lost, n_attr))
+        for what, count in zip(('NaNs', 'zeros', 'positives', 'negatives'), attr.value_counts()):
+            logging.info('Values: %d %s' % (count, what))
     return attributes, node_label_order, node2attribute, attr
 
 

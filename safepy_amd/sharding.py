@@ -66,11 +66,14 @@ def reduce_stats(local_stats, group=None):
     return {'n_other': int(sums[0]), 'n_non_integer': int(sums[1]), 'max_nan_col': int(mx[0])}
 
 
-def reduce_flags_and_stats(local_flags, local_stats, group=None):
+def reduce_flags_and_stats(local_flags, local_stats, group=None, random_seed=0):
     """reduce_row_flags + reduce_stats in ONE collective: every rank contributes
-    [flags (n), n_other, n_non_integer, max_nan_col] as int64, the all-gathered [world, n+3]
+    [flags (n), n_other, n_non_integer, max_nan_col, seed] as int64, the all-gathered [world, n+4]
     table is reduced locally (MAX over flags and the worst NaN column, SUM over the counts).
-    Returns (flags uint8 [n], stats dict), identical on every rank."""
+    Returns (flags uint8 [n], stats dict), identical on every rank.  stats['random_seed'] is the
+    seed all ranks must use: `random_seed` itself when it is given, else ONE value drawn from OS
+    entropy by rank 0 -- the reference permutes whole rows, one stream shared by all attributes
+    (safe_extras.py:46, 58), so ranks that each seeded themselves would not be a split of one run."""
     import torch
     dist = _dist()
     dev = _device_for(group)
@@ -79,17 +82,28 @@ def reduce_flags_and_stats(local_flags, local_stats, group=None):
     # NumPy on the host side on purpose: torch CPU kernels may open an OpenMP region whose
     # workers then spin (hundreds of CPU-milliseconds per call) -- under a container CPU quota
     # that gets the whole process throttled for the rest of the scheduler period
-    mine = np.empty(n + 3, dtype=np.int64)
+    mine = np.empty(n + 4, dtype=np.int64)
     mine[:n] = np.asarray(local_flags, dtype=np.int64)
-    mine[n:] = (int(local_stats['n_other']), int(local_stats['n_non_integer']), int(local_stats['max_nan_col']))
+    seed = int.from_bytes(__import__('os').urandom(4), 'little') if random_seed is None else int(random_seed)
+    mine[n:] = (int(local_stats['n_other']), int(local_stats['n_non_integer']), int(local_stats['max_nan_col']), seed)
     mine = torch.from_numpy(mine).to(dev)
-    table = torch.empty(world * (n + 3), dtype=torch.int64, device=dev)     # flat: gloo wants 1-D buffers
+    table = torch.empty(world * (n + 4), dtype=torch.int64, device=dev)     # flat: gloo wants 1-D buffers
     dist.all_gather_into_tensor(table, mine, group=group)
-    table = table.cpu().numpy().reshape(world, n + 3)
+    table = table.cpu().numpy().reshape(world, n + 4)
     flags = table[:, :n].max(axis=0).astype(np.uint8)
     stats = {'n_other': int(table[:, n].sum()), 'n_non_integer': int(table[:, n + 1].sum()),
-             'max_nan_col': int(table[:, n + 2].max())}
+             'max_nan_col': int(table[:, n + 2].max()), 'random_seed': int(table[0, n + 3])}
     return flags, stats
+
+
+def agree_on_seed(random_seed, group=None):
+    """The seed every rank uses: `random_seed` when given, else rank 0's draw from OS entropy."""
+    import torch
+    dist = _dist()
+    seed = int.from_bytes(__import__('os').urandom(4), 'little') if random_seed is None else int(random_seed)
+    t = torch.tensor([seed], dtype=torch.int64, device=_device_for(group))
+    dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+    return int(t.item())
 
 
 def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, group=None, table=None):
@@ -99,18 +113,22 @@ def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, g
     (bit-sliced / matrix-core kernels), the ranks all-gather those -- u32 per (node, attribute)
     instead of f64, attribute-major so a rank's block is one contiguous slab and no transpose
     copy is needed -- and each rank derives the full [N, M] NES matrix from the counters with
-    the arithmetic of safe.py:532-554.  Otherwise (f64 kernels, gloo) the f64 blocks travel
-    (gather_columns).  `local_nes`: this rank's [N, M_r] NES tensor (fallback path only)."""
+    the arithmetic of safe.py:532-554.  Otherwise (f64 kernels, no device) the f64 blocks travel
+    (gather_columns).  `local_nes`: this rank's [N, M_r] NES tensor (its values are only used on
+    the fallback path).  Over RCCL the slabs move device to device; over gloo (tests: several
+    ranks on one GPU) they are staged through the host."""
     import torch
     from . import backend as be
     dist = _dist()
     world = dist.get_world_size(group)
-    n_pad, m_loc, layout = be.packed_counts_info(ctx) if dist.get_backend(group) == 'nccl' else (0, 0, -1)
+    on_device = ctx is not None and local_nes.is_cuda
+    n_pad, m_loc, layout = be.packed_counts_info(ctx) if on_device else (0, 0, -1)
     shards = column_shards(m_total, world)
     widest = max(c1 - c0 for c0, c1 in shards)
     dev = local_nes.device
-    # every rank must take the same branch: agree on (layout, n_pad) with one tiny MIN/MAX reduce
-    key = torch.tensor([layout, -layout, n_pad, -n_pad], dtype=torch.int64, device=dev)
+    xdev = _device_for(group)                          # where the collective's buffers live
+    # every rank must take the same branch: agree on (layout, n_pad) with one tiny MIN reduce
+    key = torch.tensor([layout, -layout, n_pad, -n_pad], dtype=torch.int64, device=xdev)
     dist.all_reduce(key, op=dist.ReduceOp.MIN, group=group)
     key = key.tolist()
     agreed = key[0] >= 0 and key[0] == -key[1] and key[2] == -key[3]
@@ -119,13 +137,19 @@ def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, g
     mine = torch.zeros(widest * n_pad, dtype=torch.int32, device=dev)       # zero counters = padding columns
     torch.cuda.current_stream().synchronize()          # the fill ran on torch's stream, the export runs on the context's
     be.export_packed_counts(ctx, mine.data_ptr(), m_loc * n_pad)
-    everyone = torch.empty(world * widest * n_pad, dtype=torch.int32, device=dev)
     ctx.sync()                                         # the export ran on the context's stream
-    dist.all_gather_into_tensor(everyone, mine, group=group)
+    if xdev.type == 'cuda':
+        everyone = torch.empty(world * widest * n_pad, dtype=torch.int32, device=dev)
+        dist.all_gather_into_tensor(everyone, mine, group=group)
+    else:
+        staged = torch.empty(world * widest * n_pad, dtype=torch.int32)
+        dist.all_gather_into_tensor(staged, mine.cpu(), group=group)
+        everyone = staged.to(dev)
     full = torch.empty((local_nes.shape[0], world * widest), dtype=torch.float64, device=dev)
     torch.cuda.current_stream().synchronize()          # the collective is ordered on torch's stream
     be.nes_from_packed_counts(ctx, nbr, everyone.data_ptr(), layout, n_pad, world * widest, num_permutations,
                               attribute_sign, full.data_ptr(), table=table)
+    ctx.sync()
     if all(c1 - c0 == widest for c0, c1 in shards):
         return full
     return torch.cat([full[:, r * widest:r * widest + (shards[r][1] - shards[r][0])] for r in range(world)], dim=1)
@@ -133,23 +157,29 @@ def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, g
 
 def gather_columns(local, m_total, group=None):
     """All-gather of the per-rank [N, M_r] blocks into the full [N, M] matrix on every rank
-    (the reference's np.concatenate(axis=1), safe.py:1355).  `local` is a 2-D torch tensor on
-    the backend's device; blocks may differ by one column (array_split), so they travel padded
-    to the widest block."""
+    (the reference's np.concatenate(axis=1), safe.py:1355).  `local` is a 2-D torch tensor;
+    blocks may differ by one column (array_split), so they travel padded to the widest block.
+    A device tensor under a host backend (gloo) is staged through the host and comes back on
+    its device."""
     import torch
     dist = _dist()
     world = dist.get_world_size(group)
     shards = column_shards(m_total, world)
     widest = max(c1 - c0 for c0, c1 in shards)
     n = local.shape[0]
+    home = local.device
+    xdev = _device_for(group)
     if local.shape[1] != widest:
-        padded = torch.zeros((n, widest), dtype=local.dtype, device=local.device)
+        padded = torch.zeros((n, widest), dtype=local.dtype, device=home)
         padded[:, :local.shape[1]] = local
     else:
         padded = local.contiguous()
+    if padded.device.type != xdev.type:
+        padded = padded.to(xdev)
     parts = [torch.empty_like(padded) for _ in range(world)]
     dist.all_gather(parts, padded, group=group)
-    return torch.cat([parts[r][:, :shards[r][1] - shards[r][0]] for r in range(world)], dim=1)
+    full = torch.cat([parts[r][:, :shards[r][1] - shards[r][0]] for r in range(world)], dim=1)
+    return full if full.device == home else full.to(home)
 
 
 def _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold, group):
@@ -174,14 +204,16 @@ def _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enri
     return full
 
 
-def _outputs(bufs, enriched, full, m_total, group, gather):
-    """Local blocks (NumPy) + the requested full matrices; `full` = whole-matrix tensors after FDR, or None."""
+def _outputs(bufs, enriched, full, m_total, group, gather, ready=None):
+    """Local blocks (NumPy) + the requested full matrices; `full` = whole-matrix tensors after FDR, or None;
+    `ready` = full matrices some earlier step already produced (the integer exchange's NES)."""
     dist = _dist()
+    ready = ready or {}
     if full is None:
         out = {k: v.cpu().numpy() for k, v in bufs.items()}
         out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
         for k in gather:
-            out['full_' + k] = gather_columns(bufs[k], m_total, group).cpu().numpy()
+            out['full_' + k] = (ready[k] if k in ready else gather_columns(bufs[k], m_total, group)).cpu().numpy()
         return out
     c0, c1 = column_shards(m_total, dist.get_world_size(group))[dist.get_rank(group)]
     out = {k: (full[k][:, c0:c1] if k in full else v).cpu().numpy() for k, v in bufs.items()}
@@ -191,34 +223,100 @@ def _outputs(bufs, enriched, full, m_total, group, gather):
     return out
 
 
+RANDOMIZATION_OUTPUTS = ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')
+HYPERGEOM_OUTPUTS = ('pvalues_pos', 'nes', 'nes_binary')
+
+
+def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
+                       neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05, group=None,
+                       table=None, flags=None, exchange=True):
+    """One rank's share of compute_pvalues_by_randomization (safe.py:474-554) on DEVICE-resident inputs and
+    outputs, plus the path's exchange steps -- the function bench.py times and the host-level drivers below
+    call, so what is measured is what runs.
+
+    attr: this rank's column block (backend.Attributes).  bufs: dict name -> f64 [N, M_r] device tensor for
+    RANDOMIZATION_OUTPUTS; enriched: f64 [M_r].  flags: whole-matrix row flags when the caller already
+    exchanged them (then `random_seed` must already be the agreed seed), else they are exchanged here together
+    with the seed.  exchange=True all-gathers the result (integer counters when the kernel left them, f64 NES
+    blocks otherwise) and returns the full [N, m_total] NES device tensor; False returns None (D2H-only runs:
+    every rank keeps its block).  Without a process group it is the plain single-GPU step."""
+    from . import backend as be
+    alone = not _dist().is_initialized()               # a single process: the same step without the two exchanges
+    if flags is None:
+        stats = attr.stats()                           # (the dispatch rule's inputs: part of every compute_pvalues pass)
+        flags = attr.row_flags()
+        if not alone:
+            flags, stats = reduce_flags_and_stats(flags, stats, group, random_seed)
+            random_seed = stats['random_seed']
+    if not alone:
+        attr.set_row_flags(flags)                      # indx_vals of the FULL matrix (safe_extras.py:51)
+    perms = be.Permutations(ctx, attr.n, flags, int(num_permutations), random_seed)
+    try:
+        be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
+                         [bufs[k].data_ptr() for k in RANDOMIZATION_OUTPUTS] + [enriched.data_ptr()], table=table)
+        if not exchange:
+            return None
+        if alone:
+            return bufs['nes']
+        return gather_nes(ctx, nbr, bufs['nes'], m_total, int(num_permutations), attribute_sign, group, table=table)
+    finally:
+        perms.close()
+
+
+def _alloc_outputs(ctx, n, mloc, names):
+    import torch
+    dev = torch.device('cuda', ctx.device)
+    return ({k: torch.empty((n, mloc), dtype=torch.float64, device=dev) for k in names},
+            torch.empty((mloc,), dtype=torch.float64, device=dev))
+
+
+def _randomization_host(ctx, nbr, attr, m_total, num_permutations, random_seed, flags, neighborhood_score_type,
+                        attribute_sign, enrichment_threshold, group, gather, multiple_testing):
+    import torch
+    bufs, enriched = _alloc_outputs(ctx, attr.n, attr.m, RANDOMIZATION_OUTPUTS)
+    torch.cuda.current_stream().synchronize()
+    want_nes = ('nes' in gather) and not multiple_testing
+    full_nes = randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
+                                  neighborhood_score_type, attribute_sign, enrichment_threshold, group, flags=flags,
+                                  exchange=want_nes)
+    ctx.sync()
+    full = _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold,
+                             group) if multiple_testing else None
+    return _outputs(bufs, enriched, full, m_total, group, gather, ready={'nes': full_nes} if want_nes else None)
+
+
 def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
                           neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05,
                           group=None, gather=('nes',), multiple_testing=False):
     """compute_pvalues_by_randomization for this rank's column block + the two exchange steps.
     `local_attr_host`: this rank's [N, M_r] block of node2attribute (NumPy).  Returns a dict
     with the local blocks (NumPy) and, for every name in `gather`, the all-gathered full matrix
-    under 'full_<name>'.  Needs a HIP device on every rank (no CPU fallback)."""
-    import torch
+    under 'full_<name>' ('nes' travels as integer counters when the kernel keeps them, see
+    gather_nes).  random_seed=None: rank 0's entropy seed is used by every rank (the result is
+    then one unseeded run of the whole matrix, not `world` unrelated ones).  Needs a HIP device
+    on every rank (no CPU fallback)."""
     from . import backend as be
     attr = be.Attributes.from_host(ctx, local_attr_host)
-    n, mloc = attr.n, attr.m
-    flags = reduce_row_flags(attr.row_flags(), group)          # global indx_vals
-    attr.set_row_flags(flags)
-    perms = be.Permutations(ctx, n, flags, int(num_permutations), random_seed)
-    names = ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')
-    dev = torch.device('cuda', ctx.device)
-    bufs = {k: torch.empty((n, mloc), dtype=torch.float64, device=dev) for k in names}
-    enriched = torch.empty((mloc,), dtype=torch.float64, device=dev)
     try:
-        be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
-                         [bufs[k].data_ptr() for k in names] + [enriched.data_ptr()])
-        ctx.sync()
-        full = _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold,
-                                 group) if multiple_testing else None
-        return _outputs(bufs, enriched, full, m_total, group, gather)
+        flags, stats = reduce_flags_and_stats(attr.row_flags(), attr.stats(), group, random_seed)
+        return _randomization_host(ctx, nbr, attr, m_total, num_permutations, stats['random_seed'], flags,
+                                   neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
+                                   multiple_testing)
     finally:
-        perms.close()
         attr.close()
+
+
+def _hypergeom_host(ctx, nbr, attr, m_total, flags, enrichment_threshold, group, gather, multiple_testing, attribute_sign):
+    import torch
+    from . import backend as be
+    attr.stats()
+    attr.set_row_flags(flags)
+    bufs, enriched = _alloc_outputs(ctx, attr.n, attr.m, HYPERGEOM_OUTPUTS)
+    torch.cuda.current_stream().synchronize()
+    be.hypergeom(ctx, nbr, attr, enrichment_threshold, [bufs[k].data_ptr() for k in HYPERGEOM_OUTPUTS] + [enriched.data_ptr()])
+    ctx.sync()
+    full = _fdr_whole_matrix(ctx, bufs, m_total, 0, attribute_sign, enrichment_threshold, group) if multiple_testing else None
+    return _outputs(bufs, enriched, full, m_total, group, gather)
 
 
 def sharded_hypergeom(ctx, nbr, local_attr_host, m_total, global_flags, enrichment_threshold=0.05, group=None,
@@ -226,22 +324,11 @@ def sharded_hypergeom(ctx, nbr, local_attr_host, m_total, global_flags, enrichme
     """compute_pvalues_by_hypergeom for this rank's column block.  The population N
     (safe.py:574-578) and the neighborhood sizes count the rows holding a value in ANY column of
     the full matrix, so the flags of the whole matrix are installed before the kernels run."""
-    import torch
     from . import backend as be
     attr = be.Attributes.from_host(ctx, local_attr_host)
-    n, mloc = attr.n, attr.m
-    attr.stats()
-    attr.set_row_flags(global_flags)
-    names = ('pvalues_pos', 'nes', 'nes_binary')
-    dev = torch.device('cuda', ctx.device)
-    bufs = {k: torch.empty((n, mloc), dtype=torch.float64, device=dev) for k in names}
-    enriched = torch.empty((mloc,), dtype=torch.float64, device=dev)
     try:
-        torch.cuda.current_stream().synchronize()
-        be.hypergeom(ctx, nbr, attr, enrichment_threshold, [bufs[k].data_ptr() for k in names] + [enriched.data_ptr()])
-        ctx.sync()
-        full = _fdr_whole_matrix(ctx, bufs, m_total, 0, attribute_sign, enrichment_threshold, group) if multiple_testing else None
-        return _outputs(bufs, enriched, full, m_total, group, gather)
+        return _hypergeom_host(ctx, nbr, attr, m_total, global_flags, enrichment_threshold, group, gather,
+                               multiple_testing, attribute_sign)
     finally:
         attr.close()
 
@@ -254,21 +341,22 @@ def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type=
     the per-shard statistics), so all ranks take the same branch and the result equals the
     single-process call on the unsplit matrix -- unlike the reference's CLI (safe.py:1321-1361),
     whose worker processes each decide for their own chunk.  multiple_testing=True adjusts every row
-    across ALL attributes as the unsplit call does (the p-value blocks are gathered first)."""
+    across ALL attributes as the unsplit call does (the p-value blocks are gathered first).  One upload
+    of the block, one exchange of flags / statistics / seed, then the branch."""
     from . import backend as be
-    probe = be.Attributes.from_host(ctx, local_attr_host)
+    attr = be.Attributes.from_host(ctx, local_attr_host)
     try:
-        flags, stats = reduce_flags_and_stats(probe.row_flags(), probe.stats(), group)
+        flags, stats = reduce_flags_and_stats(attr.row_flags(), attr.stats(), group, random_seed)
+        if (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and stats['n_other'] == 0):
+            out = _hypergeom_host(ctx, nbr, attr, m_total, flags, enrichment_threshold, group, gather,
+                                  multiple_testing, attribute_sign)
+            out['how'] = 'hypergeometric'
+        else:
+            out = _randomization_host(ctx, nbr, attr, m_total, num_permutations, stats['random_seed'], flags,
+                                      neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
+                                      multiple_testing)
+            out['how'] = 'randomization'
     finally:
-        probe.close()
-    if (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and stats['n_other'] == 0):
-        out = sharded_hypergeom(ctx, nbr, local_attr_host, m_total, flags, enrichment_threshold, group, gather,
-                                multiple_testing=multiple_testing, attribute_sign=attribute_sign)
-        out['how'] = 'hypergeometric'
-    else:
-        out = sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
-                                    neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
-                                    multiple_testing=multiple_testing)
-        out['how'] = 'randomization'
+        attr.close()
     out['stats'] = stats
     return out

@@ -1,0 +1,119 @@
+"""One rank of the multi-process GPU parity test (tests/test_gpu_multirank.py starts `world` of these as
+fresh child processes).  Every rank builds the same seeded inputs, runs the product's sharded driver
+(safepy_amd.sharding.sharded_compute_pvalues) on its np.array_split column block, and checks
+
+    all-gathered result == the single-process SAFE.compute_pvalues on the unsplit matrix == the oracle
+
+usage: multirank_worker.py RANK WORLD PORT BACKEND OUTDIR
+BACKEND nccl = RCCL, one GPU per rank (needs >= WORLD devices); gloo = every rank on device 0 with the
+exchange staged through the host (runs on a one-GPU box; same kernels, same integer-counter exchange)."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+
+def cases(rng, n):
+    """(name, attribute matrix, kwargs of compute_pvalues).  Column counts are odd so the split is uneven."""
+    binary = (rng.uniform(size=(n, 131)) < 0.04).astype(np.float32)
+    binary[rng.choice(n, 12, replace=False)] = np.nan
+    binary[5, :] = np.nan
+    binary[5, 130] = 1.0                        # a row whose only value sits in the LAST rank's block
+    quant = rng.normal(size=(n, 45))
+    quant[rng.choice(n, 10, replace=False)] = np.nan
+    quant[rng.uniform(size=quant.shape) < 0.01] = np.nan
+    quant[7, :] = np.nan
+    quant[7, 44] = 0.25
+    return [('binary-randomization', np.asfortranarray(binary), dict(how='randomization', num_permutations=60)),
+            ('binary-auto-hypergeometric', binary.astype(np.float64), dict(how='auto')),
+            ('quantitative-sum', quant, dict(how='auto', num_permutations=50)),
+            ('quantitative-zscore', quant.astype(np.float32), dict(how='auto', num_permutations=30, neighborhood_score_type='z-score')),
+            ('quantitative-fdr', quant, dict(how='auto', num_permutations=40, multiple_testing=True))]
+
+
+def main():
+    rank, world, port, backend, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    import torch
+    import torch.distributed as dist
+    device = rank if backend == 'nccl' else 0
+    torch.cuda.set_device(device)
+    if backend == 'nccl':
+        dist.init_process_group('nccl', rank=rank, world_size=world, device_id=torch.device('cuda', device))
+    else:
+        dist.init_process_group('gloo', rank=rank, world_size=world)
+    try:
+        import safepy_amd
+        from safepy_amd import sharding
+        from oracle import safe_oracle as orc               # the checker
+        rng = np.random.default_rng(21)
+        n = 700
+        xy = rng.uniform(size=(n, 2))
+        sf = safepy_amd.SAFE(verbose=False, device=device)
+        sf.graph = safepy_amd.LayoutGraph(xy)
+        sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.08)
+        a = sf.neighborhoods
+        assert np.array_equal(a, orc.neighborhoods_euclidean(xy, 0.08))
+        ctx, nbr = sf._ctx(), sf._device_neighborhoods()
+        for name, b, kw in cases(rng, n):
+            m = b.shape[1]
+            c0, c1 = sharding.column_shards(m, world)[rank]
+            score = kw.get('neighborhood_score_type', 'sum')
+            fdr = kw.get('multiple_testing', False)
+            out = sharding.sharded_compute_pvalues(
+                ctx, nbr, np.ascontiguousarray(b[:, c0:c1]), m, enrichment_type=kw['how'],
+                num_permutations=kw.get('num_permutations', 1000), random_seed=9, neighborhood_score_type=score,
+                gather=('nes', 'nes_binary', 'pvalues_pos'), multiple_testing=fdr)
+            # ---- single process, unsplit matrix
+            sf.random_seed = 9
+            sf.load_attributes(attribute_file=b.copy())
+            sf.compute_pvalues(**kw)
+            assert out['how'] == ('hypergeometric' if name == 'binary-auto-hypergeometric' else 'randomization'), name
+            for key in ('nes', 'nes_binary', 'pvalues_pos'):
+                assert np.array_equal(out['full_' + key], getattr(sf, key), equal_nan=True), (name, key, rank)
+                assert np.array_equal(out[key], getattr(sf, key)[:, c0:c1], equal_nan=True), (name, key, rank)
+            assert np.array_equal(out['num_neighborhoods_enriched'],
+                                  sf.attributes['num_neighborhoods_enriched'].values[c0:c1]), name
+            if out['how'] == 'randomization':
+                assert np.array_equal(out['pvalues_neg'], sf.pvalues_neg[:, c0:c1], equal_nan=True), name
+                np.testing.assert_allclose(out['ns'], sf.ns[:, c0:c1], rtol=1e-12, atol=0, equal_nan=True)
+            # ---- the oracle on the unsplit matrix
+            want = orc.compute_pvalues(a, b.astype(b.dtype).copy(), enrichment_type=kw['how'],
+                                       num_permutations=kw.get('num_permutations', 1000), random_seed=9,
+                                       neighborhood_score_type=score, multiple_testing=fdr)
+            assert np.array_equal(out['full_nes_binary'], want['nes_binary'], equal_nan=True), name
+            if out['how'] == 'randomization':
+                assert np.array_equal(out['full_pvalues_pos'], want['pvalues_pos'], equal_nan=True), name
+                assert np.array_equal(out['full_nes'], want['nes'], equal_nan=True), name
+            else:
+                np.testing.assert_allclose(out['full_pvalues_pos'], want['pvalues_pos'], rtol=1e-6, atol=1e-300)
+                np.testing.assert_allclose(out['full_nes'], want['nes'], rtol=1e-6, atol=1e-9)
+
+        # random_seed=None: ONE unseeded run of the whole matrix -- every rank must have used rank 0's seed, so the
+        # all-gathered matrix is a consistent run: rank r's own block equals its slice of everyone's full matrix, and
+        # the full matrices are identical on all ranks
+        name, b, kw = cases(np.random.default_rng(21), n)[0]
+        m = b.shape[1]
+        c0, c1 = sharding.column_shards(m, world)[rank]
+        out = sharding.sharded_compute_pvalues(ctx, nbr, np.ascontiguousarray(b[:, c0:c1]), m, enrichment_type='randomization',
+                                               num_permutations=40, random_seed=None, gather=('nes',))
+        seed = out['stats']['random_seed']
+        seeds = [None] * world
+        dist.all_gather_object(seeds, seed)
+        assert len(set(seeds)) == 1, seeds
+        sf.random_seed = seed
+        sf.load_attributes(attribute_file=b.copy())
+        sf.compute_pvalues(how='randomization', num_permutations=40)
+        assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+        open(os.path.join(outdir, 'ok%d' % rank), 'w').write('ok')
+    finally:
+        dist.destroy_process_group()
+
+
+if __name__ == '__main__':
+    main()

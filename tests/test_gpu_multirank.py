@@ -1,0 +1,98 @@
+"""N > 1 on real devices: `world` fresh child processes run the product's sharded driver and check
+sharded == unsharded == oracle (tests/multirank_worker.py).  Two forms:
+
+  * RCCL: one GPU per rank over the nccl backend -- needs >= 2 visible devices, skipped otherwise;
+  * one-GPU form: two ranks share device 0 and exchange through gloo (host-staged) -- the same kernels,
+    the same integer-counter exchange and seed agreement, runnable on the single-GPU test box.
+
+`bench.py --gpus N` without a launcher must start its own ranks: checked with N = 2 when two devices exist,
+and for every box through the launcher-less single-rank RCCL group (SAFE_BENCH_FORCE_DIST)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def _device_count():
+    import safepy_amd
+    return safepy_amd.device_count()
+
+
+def _run_ranks(world, backend, tmp_path, timeout=900):
+    port = _free_port()
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', SAFE_HIP_SWAP_THREADS='1')
+    procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'multirank_worker.py'), str(r), str(world), str(port),
+                               backend, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    logs = []
+    for p in procs:
+        try:
+            out, _ = p.communicate(timeout=timeout)
+        except subprocess.TimeoutExpired:
+            for q in procs:
+                q.kill()
+            out = 'TIMEOUT'
+        logs.append(out)
+    for r, p in enumerate(procs):
+        assert p.returncode == 0 and (tmp_path / ('ok%d' % r)).exists(), 'rank %d failed:\n%s' % (r, logs[r][-4000:])
+
+
+def test_two_ranks_one_gpu_sharded_equals_unsharded_equals_oracle(tmp_path):
+    if _device_count() < 1:
+        pytest.skip('needs a HIP device')
+    _run_ranks(2, 'gloo', tmp_path)
+
+
+def test_three_ranks_one_gpu_uneven_split(tmp_path):
+    if _device_count() < 1:
+        pytest.skip('needs a HIP device')
+    _run_ranks(3, 'gloo', tmp_path)
+
+
+def test_two_ranks_rccl_sharded_equals_unsharded_equals_oracle(tmp_path):
+    if _device_count() < 2:
+        pytest.skip('RCCL with 2 ranks needs 2 devices (one GPU per rank)')
+    _run_ranks(2, 'nccl', tmp_path)
+
+
+def _bench_line(args, env=None, timeout=900):
+    cmd = [sys.executable, os.path.join(ROOT, 'bench.py')] + args
+    res = subprocess.run(cmd, env=dict(os.environ, **(env or {})), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=timeout, cwd=ROOT)
+    assert res.returncode == 0, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` (no torchrun around it) prints one JSON line with n_gpus 2."""
+    if _device_count() < 2:
+        pytest.skip('needs 2 devices')
+    line = _bench_line(['--gpus', '2', '--steps', '3', '--warmup', '1', '--nodes', '1200', '--attrs', '640', '--perms', '200',
+                        '--cpu-perms', '0', '--extras', '0'])
+    assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
+    assert line['exchange']['d2h_only_ms_per_step'] > 0 and line['exchange']['all_gather_ms_per_step'] > 0
+
+
+def test_bench_single_rank_rccl_group_reports_the_exchange():
+    """The N > 1 code path of bench.py (process group, flag/seed exchange, all-gather, the D2H-only comparison)
+    on a one-rank RCCL group."""
+    if _device_count() < 1:
+        pytest.skip('needs a HIP device')
+    line = _bench_line(['--gpus', '1', '--steps', '3', '--warmup', '1', '--nodes', '1200', '--attrs', '640', '--perms', '200',
+                        '--cpu-perms', '0', '--extras', '0'],
+                       env={'SAFE_BENCH_FORCE_DIST': '1', 'MASTER_PORT': str(_free_port())})
+    assert line['n_gpus'] == 1 and 'exchange' in line and line['exchange']['form'].startswith('packed u32')

@@ -60,7 +60,19 @@ def _worker(rank, world, port, tmpdir):
             'n_other': int((~np.isnan(local) & ~np.isin(local, [0, 1])).sum()),
             'n_non_integer': int((~np.isnan(local) & (local != np.floor(local))).sum()),
             'max_nan_col': int(np.isnan(local).sum(axis=0).max())})
-        assert np.array_equal(flags1, flags) and flags1.dtype == np.uint8 and st1 == st
+        assert np.array_equal(flags1, flags) and flags1.dtype == np.uint8
+        assert {k: v for k, v in st1.items() if k != 'random_seed'} == st and st1['random_seed'] == 0
+        # one permutation stream for the whole matrix (safe_extras.py:46, 58): a given seed is kept, an unset one
+        # (random_seed=None) becomes rank 0's draw on EVERY rank
+        _, st2 = sharding.reduce_flags_and_stats(local_flags, st, random_seed=1234 + rank)
+        assert st2['random_seed'] == 1234                       # rank 0's value wins
+        _, st3 = sharding.reduce_flags_and_stats(local_flags, st, random_seed=None)
+        seeds = [None, None]
+        dist.all_gather_object(seeds, st3['random_seed'])
+        assert seeds[0] == seeds[1] and 0 <= seeds[0] <= 0xFFFFFFFF
+        agreed = sharding.agree_on_seed(None)
+        dist.all_gather_object(seeds, agreed)
+        assert seeds[0] == seeds[1] and sharding.agree_on_seed(77) == 77
 
         # per-rank compute (oracle stand-in for the HIP kernels) with the GLOBAL permutation stream
         table = orc.permutation_index_table(np.where(flags[:, None] > 0, 0.0, np.nan) * np.ones((n, 1)), nperm, seed)
