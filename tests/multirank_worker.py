@@ -72,7 +72,7 @@ def main():
             # ---- single process, unsplit matrix
             sf.random_seed = 9
             sf.load_attributes(attribute_file=b.copy())
-            sf.compute_pvalues(**kw)
+            sf.compute_pvalues(**dict(kw, neighborhood_score_type=score, multiple_testing=fdr))     # (kwargs persist on the object, like the reference's)
             assert out['how'] == ('hypergeometric' if name == 'binary-auto-hypergeometric' else 'randomization'), name
             for key in ('nes', 'nes_binary', 'pvalues_pos'):
                 assert np.array_equal(out['full_' + key], getattr(sf, key), equal_nan=True), (name, key, rank)
@@ -108,7 +108,7 @@ def main():
         assert len(set(seeds)) == 1, seeds
         sf.random_seed = seed
         sf.load_attributes(attribute_file=b.copy())
-        sf.compute_pvalues(how='randomization', num_permutations=40)
+        sf.compute_pvalues(how='randomization', num_permutations=40, neighborhood_score_type='sum', multiple_testing=False)
         assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
         open(os.path.join(outdir, 'ok%d' % rank), 'w').write('ok')
     finally:
