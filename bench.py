@@ -419,7 +419,7 @@ def main():
         # consumes, the membership, and one read-modify-write of its per-(node, attribute) counters.
         n_wg = -(-m // 64)
         n_pad = -(-n // 64) * 64
-        if kname == 'k_permtest_bits_pre':
+        if kname in ('k_permtest_bits_pre', 'k_permtest_bits_blk'):
             # attribute bit words + the span's pre-permuted member lists (2 B per membership entry and
             # permutation) + the resident member list (observed pass) + counter read-modify-write
             alg_bytes = 8 * (n + 1) * n_wg + 2 * int(nbr.nnz) * span + 2 * int(nbr.nnz) + 2 * 4 * n_pad * m

@@ -935,6 +935,225 @@ __global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
     }
 }
 
+// --------------------------------------------------------------------------------------
+// K5 bit-sliced form, BLOCKED member lists (the default when 8*(N+1) < 65536).  Same arithmetic as
+// k_permtest_bits_pre; what changed is how a lane gets at its members and how much it carries:
+//   * ids of 8 members are adjacent (k_sell_blocked16 / k_permute_cols on the blocked list): ONE 16-byte
+//     load per lane and block instead of eight 2-byte loads -- an eighth of the vector-memory instructions,
+//     four id registers instead of eight, no address adds (the u16 IS the LDS address: T sits at LDS
+//     address 0, checked once);
+//   * the number of levels of the vertical sums follows the slice: a neighborhood of w members cannot sum
+//     past w, so a wave whose slice is <= 8 / 56 / 248 members wide runs with 4 / 6 / 8 levels instead of 10
+//     (rows are sorted by size: most slices are narrow) -- shorter compare chains, fewer live registers;
+//   * DBG (diagnostics, tools/bits_ablate.py): bit 0 skips the LDS gathers, bit 1 the counter flush,
+//     bit 2 the compare / count step -- wrong results, used to see what the time goes to.
+// --------------------------------------------------------------------------------------
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+
+template <int LV>
+__device__ __forceinline__ uint32_t vadd8_lv(uint32_t (&s)[LV], const uint32_t (&x)[8]) {
+    uint32_t t2a = maj3(s[0], x[0], x[1]);
+    s[0] = xor3(s[0], x[0], x[1]);
+    uint32_t t2b = maj3(s[0], x[2], x[3]);
+    s[0] = xor3(s[0], x[2], x[3]);
+    const uint32_t t4a = maj3(s[1], t2a, t2b);
+    s[1] = xor3(s[1], t2a, t2b);
+    t2a = maj3(s[0], x[4], x[5]);
+    s[0] = xor3(s[0], x[4], x[5]);
+    t2b = maj3(s[0], x[6], x[7]);
+    s[0] = xor3(s[0], x[6], x[7]);
+    const uint32_t t4b = maj3(s[1], t2a, t2b);
+    s[1] = xor3(s[1], t2a, t2b);
+    const uint32_t t8 = maj3(s[2], t4a, t4b);
+    s[2] = xor3(s[2], t4a, t4b);
+    return t8;
+}
+
+template <int LV>
+__device__ __forceinline__ void vripple_lv(uint32_t (&s)[LV], uint32_t t8) {
+#pragma unroll
+    for (int l = 3; l < LV; ++l) {
+        const uint32_t c = s[l] & t8;
+        s[l] ^= t8;
+        t8 = c;
+    }
+}
+
+// ids: this lane's blocks (uint4 = 8 x u16), 64 uint4 apart; SHIFT = 2 turns the resident 2*id list into 8*id
+template <int LV, int SHIFT, bool GATHER>
+__device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
+    // `ids` is the slice's first block, the same for the whole wave (scalar registers); the lane is the offset
+#pragma unroll
+    for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+    u32x4 c = ids[lane];
+    const u32x4 *pc = ids + 64;
+    for (int b = 0; b < nblk; ++b, pc += 64) {
+        uint32_t a[8];
+        a[0] = (c.x & 0xFFFFu) << SHIFT;
+        a[1] = (c.x >> 16) << SHIFT;
+        a[2] = (c.y & 0xFFFFu) << SHIFT;
+        a[3] = (c.y >> 16) << SHIFT;
+        a[4] = (c.z & 0xFFFFu) << SHIFT;
+        a[5] = (c.z >> 16) << SHIFT;
+        a[6] = (c.w & 0xFFFFu) << SHIFT;
+        a[7] = (c.w >> 16) << SHIFT;
+        c = pc[lane];                                                                     // next block (the lists have a tail)
+        uint32_t x0[8], x1[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            if (GATHER) {
+                const u32x2 w = *(lds_u2_ptr)(uintptr_t)(a[u]);
+                x0[u] = w.x;
+                x1[u] = w.y;
+            } else {
+                x0[u] = a[u];
+                x1[u] = a[u] >> 3;
+            }
+        }
+        const uint32_t e0 = vadd8_lv<LV>(s0, x0);
+        const uint32_t e1 = vadd8_lv<LV>(s1, x1);
+        if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+            vripple_lv<LV>(s0, e0);
+            vripple_lv<LV>(s1, e1);
+        }
+    }
+}
+
+// one wave, one task: observed sums, then every permutation of the task's range; counters come back in g / l
+// (levels above CL stay zero), the observed sums in oo (levels above LV zero)
+template <int LV, int CL, int DBG>
+__device__ __forceinline__ void blk_task(const u32x4 *__restrict__ obs_ids, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
+                                         int lane, int nblk, int np, uint32_t (&g0)[CL], uint32_t (&g1)[CL], uint32_t (&l0)[CL],
+                                         uint32_t (&l1)[CL], uint32_t (&oo0)[BT_LV], uint32_t (&oo1)[BT_LV]) {
+    constexpr bool GATHER = !(DBG & 1);
+    uint32_t o0[LV], o1[LV];
+    blk_sum<LV, 2, GATHER>(obs_ids, lane, nblk, o0, o1);
+    uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
+    for (int p = 0; p < np; ++p, perm_ids += perm_stride) {
+        uint32_t s0[LV], s1[LV];
+        blk_sum<LV, 0, GATHER>(perm_ids, lane, nblk, s0, s1);
+        if (DBG & 4) {
+            g0[0] ^= s0[0] ^ s0[LV - 1];
+            g1[0] ^= s1[0] ^ s1[LV - 1];
+            continue;
+        }
+        uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
+#pragma unroll
+        for (int l = 0; l < LV; ++l) {
+            // f(s, o, b) = (s != o) ? o : b  -> 0x8E ;  (s != o) ? s : b -> 0xB2
+            lt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], lt0, 0x8E);
+            gt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], gt0, 0xB2);
+            lt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], lt1, 0x8E);
+            gt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], gt1, 0xB2);
+        }
+        vcount<CL>(g0, gp0, gt0);
+        vcount<CL>(g1, gp1, gt1);
+        vcount<CL>(l0, lp0, lt0);
+        vcount<CL>(l1, lp1, lt1);
+        if ((p & 7) == 7) {
+            vflush<CL>(g0, gp0);
+            vflush<CL>(g1, gp1);
+            vflush<CL>(l0, lp0);
+            vflush<CL>(l1, lp1);
+        }
+    }
+    vflush<CL>(g0, gp0);
+    vflush<CL>(g1, gp1);
+    vflush<CL>(l0, lp0);
+    vflush<CL>(l1, lp1);
+#pragma unroll
+    for (int l = 0; l < BT_LV; ++l) {
+        oo0[l] = l < LV ? o0[l < LV ? l : 0] : 0u;
+        oo1[l] = l < LV ? o1[l < LV ? l : 0] : 0u;
+    }
+}
+
+template <int CL, int DBG>
+__global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
+    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint16_t *__restrict__ sell_col2b, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
+    const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_pad, double *__restrict__ ns_out) {
+    extern __shared__ unsigned int lds[];
+    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
+    uint2 *T = reinterpret_cast<uint2 *>(lds);
+    unsigned int *slot_box = lds + t_words;
+    // the member ids ARE LDS addresses of T rows: T must sit at LDS address 0 (it does: no static LDS in this kernel)
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds) != 0u) __builtin_trap();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+
+    for (;;) {
+        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t slot = *slot_box;
+        __syncthreads();
+        if (slot >= n_tasks) break;
+        const int4 task = tasks[slot];
+        const int wg = task.x, sg = task.y;
+        const int64_t p_begin = p_base + task.z;
+        const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+        if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
+
+        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
+        const bool active = s < n_slices;
+        const int32_t row = active ? sell_row[s * 64 + lane] : -1;
+        const int64_t my_blk = (active ? slice_off[s] : 0) / 8;             // in uint4 units (slice offsets are multiples of 512); wave-uniform
+        const int wdt = __builtin_amdgcn_readfirstlane(active ? slice_width[s] : 0);
+        const int nblk = wdt >> 3;
+        const int np = static_cast<int>(p_end - p_begin);
+        const u32x4 *obs_ids = reinterpret_cast<const u32x4 *>(sell_col2b) + my_blk;
+        const u32x4 *perm_ids = reinterpret_cast<const u32x4 *>(ids_p + (p_begin - p_base) * entries_pad) + my_blk;
+        const int64_t perm_stride = entries_pad / 8;
+        __syncthreads();                                                  // T is complete; waves are independent from here
+
+        uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
+        uint32_t oo0[BT_LV], oo1[BT_LV];                                 // observed sums (safe.py:496-499)
+#pragma unroll
+        for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
+        // a neighborhood of wdt members cannot sum past wdt: levels by slice width (wave-uniform branch)
+        if (wdt <= 8) blk_task<4, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
+        else if (wdt <= 56) blk_task<6, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
+        else if (wdt <= 248) blk_task<8, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
+        else blk_task<BT_LV, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
+
+        const bool live = row >= 0;
+        const int64_t spos = s * 64 + lane;
+        // (observed scores first: their 20 registers are dead before the transposes of the flush need 32)
+        if (ns_out && p_begin == 0 && live) {
+            const int64_t obase = static_cast<int64_t>(row) * mloc;
+#pragma unroll
+            for (int half = 0; half < 2; ++half)
+                for (int bit = 0; bit < 32; ++bit) {
+                    const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                    if (jc >= mloc) break;
+                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(oo1, bit) : vextract<BT_LV>(oo0, bit));
+                }
+        }
+        if (!(DBG & 2)) {
+#pragma unroll
+            for (int half = 0; half < 2; ++half) {
+                uint32_t m[32];
+#pragma unroll
+                for (int l = 0; l < 16; ++l) {
+                    m[l] = l < CL ? (half ? g1[l < CL ? l : 0] : g0[l < CL ? l : 0]) : 0u;
+                    m[16 + l] = l < CL ? (half ? l1[l < CL ? l : 0] : l0[l < CL ? l : 0]) : 0u;
+                }
+                transpose32(m);
+#pragma unroll
+                for (int bit = 0; bit < 32; ++bit) {
+                    const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                    if (jc < mloc && active && m[bit]) atomicAdd(&gl_counts[jc * n_pad + spos], m[bit]);
+                }
+            }
+        } else if (active && (g0[0] | g1[0] | l0[0] | l1[0]) == 0xDEADBEEFu) {
+            gl_counts[spos] = g0[1] ^ l0[1];                              // (keeps the counters alive in the diagnostic build)
+        }
+        __syncthreads();                                                  // before T is overwritten by the next task
+    }
+}
+
 // counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472).
 // The counters are [column][SELL position]; the outputs are [row][column].  A block takes a
 // 64 x 64 tile: coalesced reads along the SELL positions, transpose through LDS, coalesced
@@ -1756,6 +1975,17 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             SAFE_TRY(ctx_scratch(ctx, 4 + b, static_cast<size_t>(span) * entries_pad * sizeof(uint16_t),
                                  reinterpret_cast<void **>(&d_ids[b])));
     const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
+    // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
+    const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
+    const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
+    int dbg = 0;
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 7;
+    const void *blk_fn = dbg == 0   ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
+                         : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
+                         : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>)
+                         : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
+                                    : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
+    if (blk) SAFE_HIP_CHECK(hipFuncSetAttribute(blk_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
     if (pre)
         SAFE_HIP_CHECK(hipFuncSetAttribute(narrow ? reinterpret_cast<const void *>(k_permtest_bits_pre<8>)
                                            : wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
@@ -1766,7 +1996,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<10, false>));
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    ctx->last_kernel.name = pre ? "k_permtest_bits_pre" : "k_permtest_bits";
+    ctx->last_kernel.name = blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
@@ -1785,8 +2015,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         if (pre) {
             hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
                                static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
-                               perms->stride16, nbr->sell_col2, nbr->sell_entries, entries_pad, p_base, p_limit - p_base,
-                               static_cast<uint32_t>(8 * n), d_ids[c & 1]);
+                               perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
+                               p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c & 1]);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD), so the
             // table kernels of the next stage (aux stream) start in this kernel's tail; leaving them CUs
@@ -1795,7 +2025,16 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
-            if (narrow)
+            if (blk) {
+                const uint16_t *ids_c = d_ids[c & 1];
+                void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
+                                (void *)&nbr->slice_width, (void *)&nbr->sell_col2b, (void *)&nbr->n_slices, (void *)&d_bits,
+                                (void *)&n_tasks, (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, nullptr, (void *)&mloc,
+                                (void *)&d_gl, (void *)&n_pad, (void *)&out.ns};
+                unsigned int *queue_c = d_queue + c;
+                args[13] = (void *)&queue_c;
+                SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_pre), dim3(256), args, lds_pre, ks));
+            } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
@@ -2121,7 +2360,7 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
 
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
-    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" ||
+    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" || ctx->last_kernel.name == "k_permtest_bits_blk" ||
         ctx->last_kernel.name == "k_permtest_lds" || ctx->last_kernel.name == "k_permtest_mfma")
         return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;

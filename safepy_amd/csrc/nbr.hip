@@ -205,6 +205,25 @@ __global__ void k_sell_scale16(const int32_t *__restrict__ sell_col, int64_t ent
     if (i < total) out[i] = i < entries ? static_cast<uint16_t>(2 * sell_col[i]) : static_cast<uint16_t>(pad2);
 }
 
+// The same 2*id list in BLOCKED order: inside a slice, block b (8 members) of lane l is the 16 bytes at
+// entry offset (b * 64 + l) * 8 -- a lane fetches a block with ONE 16-byte load (64 lanes: 1 KiB contiguous)
+// instead of eight 2-byte loads (k_permtest_bits_blk).  The order of a lane's members is free: sums commute.
+__global__ void k_sell_blocked16(const int32_t *__restrict__ sell_col, const int64_t *__restrict__ slice_off,
+                                 const int32_t *__restrict__ slice_width, int64_t n_slices, int64_t entries, int64_t total,
+                                 uint32_t pad2, uint16_t *__restrict__ out) {
+    const int64_t s = blockIdx.x;
+    if (s == n_slices) {                                       // the tail one prefetched block may touch
+        for (int64_t i = entries + threadIdx.x; i < total; i += blockDim.x) out[i] = static_cast<uint16_t>(pad2);
+        return;
+    }
+    const int64_t off = slice_off[s];
+    const int64_t cnt = static_cast<int64_t>(slice_width[s]) * 64;
+    for (int64_t i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const int64_t t = i >> 6, lane = i & 63;
+        out[off + ((t >> 3) * 64 + lane) * 8 + (t & 7)] = static_cast<uint16_t>(2 * sell_col[off + i]);
+    }
+}
+
 // --------------------------------------------------------------------------------------
 // K2: bounded all-pairs shortest paths.  One wave per source, label-correcting frontier
 // relaxation to a fixpoint over the CSR adjacency.  cand = dist[v] + w is an f64 add in
@@ -328,6 +347,7 @@ static void nbr_free(safe_nbr *nbr) {
     (void)hipFree(nbr->slice_width);
     (void)hipFree(nbr->sell_col);
     (void)hipFree(nbr->sell_col2);
+    (void)hipFree(nbr->sell_col2b);
     (void)hipFree(nbr->dist);
     (void)hipFree(nbr->at_ptr);
     (void)hipFree(nbr->at_col);
@@ -421,6 +441,10 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
         SAFE_TRY(dev_alloc(&nbr->sell_col2, total));
         hipLaunchKernelGGL(k_sell_scale16, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, nbr->sell_col,
                            nbr->sell_entries, total, static_cast<uint32_t>(2 * n), nbr->sell_col2);
+        SAFE_TRY(dev_alloc(&nbr->sell_col2b, total));
+        hipLaunchKernelGGL(k_sell_blocked16, dim3(nbr->n_slices + 1), dim3(256), 0, ctx->stream, nbr->sell_col, nbr->slice_off,
+                           nbr->slice_width, nbr->n_slices, nbr->sell_entries, total, static_cast<uint32_t>(2 * n),
+                           nbr->sell_col2b);
     }
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host vectors above go out of scope

@@ -96,8 +96,8 @@ def test_config2_ten_thousand_permutations(costanzo):
     sf.compute_pvalues(how='randomization', num_permutations=nperm, verbose=False)
     ctx = amd.Context.default(0)
     assert ctx.last_kernel()[0].startswith('k_permtest_bits')
-    cn, cp = sf.pvalues_neg * nperm, sf.pvalues_pos * nperm
-    assert np.array_equal(cn, np.round(cn)) and np.array_equal(cp, np.round(cp))
+    cn, cp = np.round(sf.pvalues_neg * nperm), np.round(sf.pvalues_pos * nperm)
+    assert np.array_equal(cn / nperm, sf.pvalues_neg) and np.array_equal(cp / nperm, sf.pvalues_pos)      # p = count / P (safe.py:532-533)
     assert cn.min() >= 0 and cn.max() <= nperm and cp.min() >= 0 and cp.max() <= nperm
     assert np.all(cn + cp >= nperm)                              # ties count on both sides (safe_extras.py:65-66)
     assert np.all(cp[sf.ns == 0] == nperm)
@@ -195,8 +195,8 @@ def test_config4_rank_share_20000_by_6250_by_1000_matrix_core():
     sf.load_attributes(attribute_file=b)
     sf.compute_pvalues(num_permutations=nperm)
     assert ctx.last_kernel()[0] == 'k_permtest_mfma'
-    cn, cp = sf.pvalues_neg * nperm, sf.pvalues_pos * nperm
-    assert np.array_equal(cn, np.round(cn)) and np.array_equal(cp, np.round(cp))
+    cn, cp = np.round(sf.pvalues_neg * nperm), np.round(sf.pvalues_pos * nperm)
+    assert np.array_equal(cn / nperm, sf.pvalues_neg) and np.array_equal(cp / nperm, sf.pvalues_pos)
     assert cn.min() >= 0 and cn.max() <= nperm and cp.min() >= 0 and cp.max() <= nperm
     assert np.all(cn + cp >= nperm)
     assert np.array_equal(sf.nes_binary.sum(axis=0), sf.attributes['num_neighborhoods_enriched'].values)

@@ -528,6 +528,37 @@ def test_integer_forms_large_support_and_many_permutations(amd, monkeypatch, pat
     assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
 
 
+@pytest.mark.parametrize('kernel,nperm', [('blk', 40), ('blk', 300), ('pre', 40), ('barrier', 40)])
+def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
+    """The three bit-sliced kernels (blocked member lists = default, pre-permuted lists, permutation row in LDS) on a
+    membership whose SELL slices fall into every width class of the blocked kernel (<= 8, <= 56, <= 248, > 248 members:
+    4 / 6 / 8 / 10 levels of the vertical sums), with columns dense enough that the sums really reach the top
+    levels, an empty neighborhood, a ragged last word group; 300 permutations carry the counters past their low levels."""
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'bits')
+    if kernel == 'pre':
+        monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', 'pre')
+    elif kernel == 'barrier':
+        monkeypatch.setenv('SAFE_HIP_BITS_PRE', '0')
+    rng = np.random.default_rng(77)
+    n, m = 1400, 131
+    sizes = np.r_[rng.integers(600, 1000, 10), rng.integers(100, 248, 150), rng.integers(9, 56, 640), rng.integers(0, 9, 600)]
+    rng.shuffle(sizes)
+    a = np.zeros((n, n), dtype=np.int64)
+    for i, k in enumerate(sizes):
+        a[i, rng.choice(n, k, replace=False)] = 1
+    assert (a.sum(axis=1) == 0).any() and a.sum(axis=1).max() >= 600
+    b = (rng.uniform(size=(n, m)) < np.linspace(0.005, 0.95, m)).astype(np.float32)
+    b[rng.choice(n, 40, replace=False)] = np.nan
+    b = np.asfortranarray(b)
+    cn_want, cp_want = orc.run_permutations(a, b, 'sum', nperm, 13)
+    cn, cp = amd.run_permutations((a, b, 'sum', nperm, 13), verbose=False)
+    name = amd.Context.default(0).last_kernel()[0]
+    assert name == {'blk': 'k_permtest_bits_blk', 'pre': 'k_permtest_bits_pre', 'barrier': 'k_permtest_bits'}[kernel]
+    assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
+    ns = amd.compute_neighborhood_score(a, b, 'sum')
+    assert np.array_equal(ns, orc.compute_neighborhood_score(a, b, 'sum'))
+
+
 # ------------------------------------------------------------ attribute sharding ----------
 
 def test_sharded_columns_equal_unsharded(amd, ctx, golden_enr):
