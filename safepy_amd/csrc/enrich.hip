@@ -1022,12 +1022,17 @@ __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane,
 // one wave, one task: observed sums, then every permutation of the task's range; counters come back in g / l
 // (levels above CL stay zero), the observed sums in oo (levels above LV zero)
 template <int LV, int CL, int DBG>
-__device__ __forceinline__ void blk_task(const u32x4 *__restrict__ obs_ids, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
+__device__ __forceinline__ void blk_task(const uint32_t *__restrict__ obs, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
                                          int lane, int nblk, int np, uint32_t (&g0)[CL], uint32_t (&g1)[CL], uint32_t (&l0)[CL],
-                                         uint32_t (&l1)[CL], uint32_t (&oo0)[BT_LV], uint32_t (&oo1)[BT_LV]) {
+                                         uint32_t (&l1)[CL]) {
     constexpr bool GATHER = !(DBG & 1);
+    // observed sums of this (word group, slice): computed once per call by k_bits_observed, vertical like the permuted sums
     uint32_t o0[LV], o1[LV];
-    blk_sum<LV, 2, GATHER>(obs_ids, lane, nblk, o0, o1);
+#pragma unroll
+    for (int l = 0; l < LV; ++l) {
+        o0[l] = obs[l * 64 + lane];
+        o1[l] = obs[(BT_LV + l) * 64 + lane];
+    }
     uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
     for (int p = 0; p < np; ++p, perm_ids += perm_stride) {
         uint32_t s0[LV], s1[LV];
@@ -1061,10 +1066,86 @@ __device__ __forceinline__ void blk_task(const u32x4 *__restrict__ obs_ids, cons
     vflush<CL>(g1, gp1);
     vflush<CL>(l0, lp0);
     vflush<CL>(l1, lp1);
+}
+
+// Observed neighborhood sums of every (word group, slice), once per call (safe.py:496-499): vertical counters
+// obs[word group][slice][2 x BT_LV levels][64 lanes] for the permutation kernels' compare step, and the scores
+// themselves (`ns`).  One workgroup = one word group x four adjacent slices.
+template <int LV>
+__device__ __forceinline__ void observed_wave(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t *__restrict__ obs,
+                                              uint32_t (&oo0)[BT_LV], uint32_t (&oo1)[BT_LV]) {
+    uint32_t o0[LV], o1[LV];
+    blk_sum<LV, 2, true>(ids, lane, nblk, o0, o1);
 #pragma unroll
     for (int l = 0; l < BT_LV; ++l) {
         oo0[l] = l < LV ? o0[l < LV ? l : 0] : 0u;
         oo1[l] = l < LV ? o1[l < LV ? l : 0] : 0u;
+        obs[l * 64 + lane] = oo0[l];
+        obs[(BT_LV + l) * 64 + lane] = oo1[l];
+    }
+}
+
+__global__ __launch_bounds__(256) void k_bits_observed(int64_t n, const int32_t *__restrict__ sell_row,
+                                                       const int64_t *__restrict__ slice_off,
+                                                       const int32_t *__restrict__ slice_width,
+                                                       const uint16_t *__restrict__ sell_col2b, int64_t n_slices,
+                                                       const uint2 *__restrict__ bbits, int64_t mloc,
+                                                       uint32_t *__restrict__ obs, double *__restrict__ ns_out) {
+    extern __shared__ unsigned int lds[];
+    uint2 *T = reinterpret_cast<uint2 *>(lds);
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds) != 0u) __builtin_trap();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t wg = blockIdx.x, s = static_cast<int64_t>(blockIdx.y) * 4 + wave;
+    for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[wg * (n + 1) + r];
+    __syncthreads();
+    if (s >= n_slices) return;
+    const int wdt = __builtin_amdgcn_readfirstlane(slice_width[s]);
+    const u32x4 *ids = reinterpret_cast<const u32x4 *>(sell_col2b) + slice_off[s] / 8;
+    uint32_t *my_obs = obs + (wg * n_slices + s) * (2 * BT_LV * 64);
+    uint32_t oo0[BT_LV], oo1[BT_LV];
+    if (wdt <= 8) observed_wave<4>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
+    else if (wdt <= 56) observed_wave<6>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
+    else if (wdt <= 248) observed_wave<8>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
+    else observed_wave<BT_LV>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
+    const int32_t row = sell_row[s * 64 + lane];
+    if (ns_out && row >= 0) {
+        const int64_t obase = static_cast<int64_t>(row) * mloc;
+#pragma unroll
+        for (int half = 0; half < 2; ++half)
+            for (int bit = 0; bit < 32; ++bit) {
+                const int64_t jc = wg * 64 + half * 32 + bit;
+                if (jc >= mloc) break;
+                ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(oo1, bit) : vextract<BT_LV>(oo0, bit));
+            }
+    }
+}
+
+// Un-slices the counters of one (wave, work item) -- bit-matrix transpose: rows 0..15 = #greater levels, rows 16..31 =
+// #less levels -> word b = less << 16 | greater of attribute b -- and adds them to the totals [attribute][SELL position]
+// (the 64 lanes of a wave update one contiguous 256-byte run).  The address walks down the attributes in a vector
+// register pair: 64 scalar base addresses held at once do not fit the scalar file.
+template <int CL>
+__device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const uint32_t (&g1)[CL], const uint32_t (&l0)[CL],
+                                               const uint32_t (&l1)[CL], unsigned int *__restrict__ gl_counts, int64_t col0,
+                                               int64_t mloc, int64_t n_pad, int64_t spos, bool active) {
+#pragma unroll
+    for (int half = 0; half < 2; ++half) {
+        uint32_t m[32];
+#pragma unroll
+        for (int l = 0; l < 16; ++l) {
+            m[l] = l < CL ? (half ? g1[l < CL ? l : 0] : g0[l < CL ? l : 0]) : 0u;
+            m[16 + l] = l < CL ? (half ? l1[l < CL ? l : 0] : l0[l < CL ? l : 0]) : 0u;
+        }
+        transpose32(m);
+        const int64_t c_first = col0 + half * 32;
+        const int n_valid = static_cast<int>(mloc - c_first < 32 ? (mloc - c_first > 0 ? mloc - c_first : 0) : 32);
+        unsigned int *pp = gl_counts + c_first * n_pad + spos;
+#pragma unroll
+        for (int bit = 0; bit < 32; ++bit) {
+            asm volatile("" : "+v"(pp));
+            if (bit < n_valid && active && m[bit]) atomicAdd(pp, m[bit]);
+            pp += n_pad;
+        }
     }
 }
 
@@ -1072,9 +1153,9 @@ template <int CL, int DBG>
 __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
-    const uint16_t *__restrict__ sell_col2b, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
+    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
     const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
-    unsigned int *__restrict__ gl_counts, int64_t n_pad, double *__restrict__ ns_out) {
+    unsigned int *__restrict__ gl_counts, int64_t n_pad, const int4 *__restrict__ items) {
     extern __shared__ unsigned int lds[];
     const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
     uint2 *T = reinterpret_cast<uint2 *>(lds);
@@ -1090,67 +1171,141 @@ __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
         __syncthreads();
         if (slot >= n_tasks) break;
         const int4 task = tasks[slot];
-        const int wg = task.x, sg = task.y;
-        const int64_t p_begin = p_base + task.z;
-        const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
-        if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
+        const int wg = task.x;
+        // what this WAVE does in the task: with an item list, four (slice, permutation range) items of about equal cost
+        // (the four waves finish together); else four adjacent slices over the task's permutation range
+        int4 item;
+        if (items) item = items[static_cast<int64_t>(task.y) * 4 + wave];
+        else item = make_int4(task.y * 4 + wave < n_slices ? task.y * 4 + wave : -1, task.z, task.w, 0);
+        const int64_t s = item.x;
+        const bool active = s >= 0;
+        const int64_t p_begin = p_base + item.y;
+        int64_t p_end = p_base + item.z < p_limit ? p_base + item.z : p_limit;
+        if (p_end < p_begin || !active) p_end = p_begin;                  // (nothing to do for this wave; it still joins the barriers)
 
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
-        const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
-        const bool active = s < n_slices;
-        const int32_t row = active ? sell_row[s * 64 + lane] : -1;
         const int64_t my_blk = (active ? slice_off[s] : 0) / 8;             // in uint4 units (slice offsets are multiples of 512); wave-uniform
         const int wdt = __builtin_amdgcn_readfirstlane(active ? slice_width[s] : 0);
         const int nblk = wdt >> 3;
         const int np = static_cast<int>(p_end - p_begin);
-        const u32x4 *obs_ids = reinterpret_cast<const u32x4 *>(sell_col2b) + my_blk;
+        const uint32_t *my_obs = obs + (static_cast<int64_t>(wg) * n_slices + (active ? s : 0)) * (2 * BT_LV * 64);
         const u32x4 *perm_ids = reinterpret_cast<const u32x4 *>(ids_p + (p_begin - p_base) * entries_pad) + my_blk;
         const int64_t perm_stride = entries_pad / 8;
         __syncthreads();                                                  // T is complete; waves are independent from here
 
         uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
-        uint32_t oo0[BT_LV], oo1[BT_LV];                                 // observed sums (safe.py:496-499)
 #pragma unroll
         for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
         // a neighborhood of wdt members cannot sum past wdt: levels by slice width (wave-uniform branch)
-        if (wdt <= 8) blk_task<4, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
-        else if (wdt <= 56) blk_task<6, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
-        else if (wdt <= 248) blk_task<8, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
-        else blk_task<BT_LV, CL, DBG>(obs_ids, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1, oo0, oo1);
+        if (np <= 0) {
+        } else if (wdt <= 8) blk_task<4, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else if (wdt <= 56) blk_task<6, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else if (wdt <= 248) blk_task<8, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else blk_task<BT_LV, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
 
-        const bool live = row >= 0;
         const int64_t spos = s * 64 + lane;
-        // (observed scores first: their 20 registers are dead before the transposes of the flush need 32)
-        if (ns_out && p_begin == 0 && live) {
-            const int64_t obase = static_cast<int64_t>(row) * mloc;
-#pragma unroll
-            for (int half = 0; half < 2; ++half)
-                for (int bit = 0; bit < 32; ++bit) {
-                    const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
-                    if (jc >= mloc) break;
-                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(oo1, bit) : vextract<BT_LV>(oo0, bit));
-                }
-        }
         if (!(DBG & 2)) {
-#pragma unroll
-            for (int half = 0; half < 2; ++half) {
-                uint32_t m[32];
-#pragma unroll
-                for (int l = 0; l < 16; ++l) {
-                    m[l] = l < CL ? (half ? g1[l < CL ? l : 0] : g0[l < CL ? l : 0]) : 0u;
-                    m[16 + l] = l < CL ? (half ? l1[l < CL ? l : 0] : l0[l < CL ? l : 0]) : 0u;
-                }
-                transpose32(m);
-#pragma unroll
-                for (int bit = 0; bit < 32; ++bit) {
-                    const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
-                    if (jc < mloc && active && m[bit]) atomicAdd(&gl_counts[jc * n_pad + spos], m[bit]);
-                }
-            }
+            if (np > 0) flush_counters<CL>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, active);
         } else if (active && (g0[0] | g1[0] | l0[0] | l1[0]) == 0xDEADBEEFu) {
             gl_counts[spos] = g0[1] ^ l0[1];                              // (keeps the counters alive in the diagnostic build)
         }
         __syncthreads();                                                  // before T is overwritten by the next task
+    }
+}
+
+// --------------------------------------------------------------------------------------
+// K5 bit-sliced form, blocked member lists, WAVE-LEVEL work queue (the default).  What a workgroup shares is only
+// the word column T of its 64 attributes; everything after the load of T is per wave.  So:
+//   * a workgroup is persistent and keeps T: it loads the word column of ONE word group and its four waves then pull
+//     work items (slice, permutation range) from that word group's queue independently -- no barrier, no reload of T
+//     between items (the task-per-workgroup form reloaded 32 KB and synchronised ~90 times per word group and launch,
+//     and its four waves waited for the widest of four adjacent slices);
+//   * items have about equal cost: a narrow slice keeps all permutations of the launch in one item (its counters are
+//     un-sliced and flushed once), a wide slice is cut into short permutation ranges;
+//   * a workgroup whose queue has run dry moves to the word group with the most items left (reloading T once).
+// Arithmetic, counters and outputs are those of k_permtest_bits_blk.
+// --------------------------------------------------------------------------------------
+template <int CL, int DBG>
+__global__ __launch_bounds__(256, 4) void k_permtest_bits_wq(
+    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, int n_items,
+    const int4 *__restrict__ items, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queues, int n_wg,
+    int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_pad) {
+    extern __shared__ unsigned int lds[];
+    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
+    uint2 *T = reinterpret_cast<uint2 *>(lds);
+    int *next_box = reinterpret_cast<int *>(lds + t_words);
+    // the member ids ARE LDS addresses of T rows: T must sit at LDS address 0 (it does: no static LDS in this kernel)
+    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds) != 0u) __builtin_trap();
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    const int64_t perm_stride = entries_pad / 8;
+    int wg = static_cast<int>(blockIdx.x % static_cast<unsigned>(n_wg));
+
+    for (;;) {
+        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        __syncthreads();                                                  // T is complete; waves are independent from here
+
+        for (;;) {
+            unsigned int it = 0;
+            if (lane == 0) it = atomicAdd(&queues[wg], 1u);
+            it = __builtin_amdgcn_readfirstlane(it);
+            if (it >= static_cast<unsigned>(n_items)) break;
+            const int4 item = items[it];                                  // (slice, first permutation, end, -) relative to the launch
+            const int64_t s = item.x;
+            const int64_t p_begin = p_base + item.y;
+            const int64_t p_end = p_base + item.z < p_limit ? p_base + item.z : p_limit;
+            if (p_end <= p_begin) continue;                               // a launch shorter than the item grid's span
+            const int64_t my_blk = slice_off[s] / 8;                      // in uint4 units; wave-uniform
+            const int wdt = __builtin_amdgcn_readfirstlane(slice_width[s]);
+            const int nblk = wdt >> 3;
+            const int np = static_cast<int>(p_end - p_begin);
+            const uint32_t *my_obs = obs + (static_cast<int64_t>(wg) * n_slices + s) * (2 * BT_LV * 64);
+            const u32x4 *perm_ids = reinterpret_cast<const u32x4 *>(ids_p + (p_begin - p_base) * entries_pad) + my_blk;
+
+            uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                      // #(S_p > S_obs), #(S_p < S_obs)
+#pragma unroll
+            for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
+            // a neighborhood of wdt members cannot sum past wdt: levels by slice width (wave-uniform branch)
+            if (wdt <= 8) blk_task<4, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+            else if (wdt <= 56) blk_task<6, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+            else if (wdt <= 248) blk_task<8, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+            else blk_task<BT_LV, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+
+            const int64_t spos = s * 64 + lane;
+            if (!(DBG & 2)) {
+                flush_counters<CL>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, true);
+            } else if ((g0[0] | g1[0] | l0[0] | l1[0]) == 0xDEADBEEFu) {
+                gl_counts[spos] = g0[1] ^ l0[1];                          // (keeps the counters alive in the diagnostic build)
+            }
+        }
+
+        // this word group's queue is empty: move to the word group with the most items left, if any
+        __syncthreads();                                                  // nobody reads T any more
+        if (wave == 0) {
+            int best = 0, best_wg = -1;
+            for (int w = lane; w < n_wg; w += 64) {
+                const unsigned int taken = __hip_atomic_load(&queues[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                const int left = n_items - static_cast<int>(taken < static_cast<unsigned>(n_items) ? taken : n_items);
+                if (left > best) {
+                    best = left;
+                    best_wg = w;
+                }
+            }
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) {
+                const int ob = __shfl_xor(best, off), ow = __shfl_xor(best_wg, off);
+                if (ob > best || (ob == best && ow > best_wg)) {
+                    best = ob;
+                    best_wg = ow;
+                }
+            }
+            if (lane == 0) *next_box = best > 0 ? best_wg : -1;
+        }
+        __syncthreads();
+        wg = *next_box;
+        __syncthreads();
+        if (wg < 0) break;
     }
 }
 
@@ -1978,6 +2133,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
+    const bool wq = blk && kern_env && !strcmp(kern_env, "wq");          // wave-level work queue; default: one task per workgroup
     int dbg = 0;
     if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 7;
     const void *blk_fn = dbg == 0   ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
@@ -1986,6 +2142,80 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     if (blk) SAFE_HIP_CHECK(hipFuncSetAttribute(blk_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
+    const void *wq_fn = dbg == 0   ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 0>)
+                        : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 1>)
+                        : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 2>)
+                        : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 4>)
+                                   : reinterpret_cast<const void *>(k_permtest_bits_wq<8, 7>);
+    if (wq) SAFE_HIP_CHECK(hipFuncSetAttribute(wq_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
+    // ---- work items of the blocked kernels: (slice, permutation range) of about equal cost, heaviest first.  Cost of a
+    //      permutation on a slice ~ 60 instructions per block of 8 members + ~100 for the compare / count step; a narrow
+    //      slice keeps the whole launch in one item (one flush of its counters), wide slices are cut.  The wave-queue
+    //      kernel hands items to waves one by one; the task-per-workgroup kernel takes them four at a time (neighbours in
+    //      the cost order: the four waves of a task finish together).
+    std::vector<int4> items, quad_tasks;
+    int4 *d_items = nullptr, *d_quad_tasks = nullptr;
+    unsigned int *d_wq_queues = nullptr;
+    uint32_t *d_obs = nullptr;
+    const int64_t wq_slots = static_cast<int64_t>(ctx->num_cu) * std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre));   // 4: the register file holds 16 waves of these kernels per CU
+    if (blk) {
+        int per_wave = wq ? 4 : 6;                                     // items per wave and launch the plan aims at
+        if (const char *e = getenv("SAFE_HIP_BITS_ITEMS")) per_wave = std::max(1, atoi(e));
+        int64_t min_len = 4;                                           // an item re-reads its observed sums and flushes its counters
+        if (const char *e = getenv("SAFE_HIP_BITS_MINLEN")) min_len = std::max(1, atoi(e));
+        const int64_t waves_per_wg = std::max<int64_t>(1, wq_slots * 4 / n_wg);
+        int64_t total = 0;
+        for (int64_t sl = 0; sl < nbr->n_slices; ++sl) total += (static_cast<int64_t>(nbr->h_slice_width[sl] / 8) * 60 + 100) * span;
+        const int64_t target_cost = std::max<int64_t>(2000, total / (waves_per_wg * per_wave));
+        struct ItemCost { int4 t; int64_t cost; };
+        std::vector<ItemCost> ic;
+        for (int64_t sl = 0; sl < nbr->n_slices; ++sl) {
+            const int64_t c1 = static_cast<int64_t>(nbr->h_slice_width[sl] / 8) * 60 + 100;
+            int64_t len = std::min<int64_t>(std::min<int64_t>(span, 255), std::max<int64_t>(min_len, (target_cost + c1 / 2) / c1));   // <= 255: eight counter levels
+            const int64_t chunks = ceil_div(span, len);
+            len = ceil_div(span, chunks);
+            for (int64_t c = 0; c < chunks; ++c) {
+                const int64_t q0 = c * len, q1 = std::min<int64_t>(span, q0 + len);
+                ic.push_back({make_int4(static_cast<int>(sl), static_cast<int>(q0), static_cast<int>(q1), 0), c1 * (q1 - q0)});
+            }
+        }
+        std::stable_sort(ic.begin(), ic.end(), [](const ItemCost &a, const ItemCost &b) { return a.cost > b.cost; });
+        items.resize(ic.size());
+        for (size_t i = 0; i < ic.size(); ++i) items[i] = ic[i].t;
+        while (items.size() % 4) items.push_back(make_int4(-1, 0, 0, 0));      // (an idle wave in the last task)
+        const char *quad_env = getenv("SAFE_HIP_BITS_QUAD");
+        const bool quad = !wq && quad_env && !strcmp(quad_env, "1");
+        if (!wq && !quad) {                                             // a task = four ADJACENT slices over one permutation range
+            quad_tasks = tasks;
+            items.clear();
+        } else if (!wq) {
+            const int64_t n_quads = static_cast<int64_t>(items.size()) / 4;
+            quad_tasks.reserve(n_quads * n_wg);
+            for (int64_t q = 0; q < n_quads; ++q)                               // heaviest quads first, all word groups of a quad adjacent
+                for (int64_t w = 0; w < n_wg; ++w) quad_tasks.push_back(make_int4(static_cast<int>(w), static_cast<int>(q), 0, 0));
+        }
+        void *ws = nullptr;
+        SAFE_TRY(ctx_scratch(ctx, 6, (items.size() + quad_tasks.size()) * sizeof(int4) +
+                                         static_cast<size_t>(n_launch) * n_wg * sizeof(unsigned int), &ws));
+        d_items = static_cast<int4 *>(ws);
+        d_quad_tasks = d_items + items.size();
+        d_wq_queues = reinterpret_cast<unsigned int *>(d_quad_tasks + quad_tasks.size());
+        if (!items.empty())
+            SAFE_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        else
+            d_items = nullptr;
+        if (!quad_tasks.empty())
+            SAFE_HIP_CHECK(hipMemcpyAsync(d_quad_tasks, quad_tasks.data(), quad_tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+        SAFE_HIP_CHECK(hipMemsetAsync(d_wq_queues, 0, static_cast<size_t>(n_launch) * n_wg * sizeof(unsigned int), ctx->stream));
+        // observed sums of every (word group, slice), once: the compare operand of every item, and `ns`
+        SAFE_TRY(ctx_scratch(ctx, 7, static_cast<size_t>(n_wg) * nbr->n_slices * 2 * BT_LV * 64 * sizeof(uint32_t),
+                             reinterpret_cast<void **>(&d_obs)));
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bits_observed), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds_pre)));
+        hipLaunchKernelGGL(k_bits_observed, dim3(n_wg, ceil_div(nbr->n_slices, 4)), dim3(256), lds_pre, ctx->stream, n, nbr->sell_row,
+                           nbr->slice_off, nbr->slice_width, nbr->sell_col2b, nbr->n_slices, d_bits, mloc, d_obs, out.ns);
+        SAFE_HIP_CHECK(hipGetLastError());
+    }
     if (pre)
         SAFE_HIP_CHECK(hipFuncSetAttribute(narrow ? reinterpret_cast<const void *>(k_permtest_bits_pre<8>)
                                            : wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
@@ -1996,7 +2226,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<10, false>));
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    ctx->last_kernel.name = blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
+    ctx->last_kernel.name = wq ? "k_permtest_bits_wq" : blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
@@ -2025,15 +2255,30 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
-            if (blk) {
+            if (wq) {
                 const uint16_t *ids_c = d_ids[c & 1];
+                int n_items_i = static_cast<int>(items.size()), n_wg_i = static_cast<int>(n_wg);
+                while (n_items_i > 0 && items[n_items_i - 1].x < 0) --n_items_i;          // (padding items are for the quad form)
+                unsigned int *queues_c = d_wq_queues + c * n_wg;
                 void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
-                                (void *)&nbr->slice_width, (void *)&nbr->sell_col2b, (void *)&nbr->n_slices, (void *)&d_bits,
-                                (void *)&n_tasks, (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, nullptr, (void *)&mloc,
-                                (void *)&d_gl, (void *)&n_pad, (void *)&out.ns};
+                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits, (void *)&n_items_i,
+                                (void *)&d_items, (void *)&p_base, (void *)&p_limit, (void *)&queues_c, (void *)&n_wg_i,
+                                (void *)&mloc, (void *)&d_gl, (void *)&n_pad};
+                const int64_t wq_blocks = std::min<int64_t>(std::max<int64_t>(n_wg, 1) * ceil_div(static_cast<int64_t>(n_items_i), 4),
+                                                            static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
+                                                                std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre)));
+                SAFE_HIP_CHECK(hipLaunchKernel(wq_fn, dim3(wq_blocks), dim3(256), args, lds_pre, ks));
+            } else if (blk) {
+                const uint16_t *ids_c = d_ids[c & 1];
+                const int64_t n_quad_tasks = static_cast<int64_t>(quad_tasks.size());
                 unsigned int *queue_c = d_queue + c;
-                args[13] = (void *)&queue_c;
-                SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_pre), dim3(256), args, lds_pre, ks));
+                void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
+                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits,
+                                (void *)&n_quad_tasks, (void *)&d_quad_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c,
+                                (void *)&mloc, (void *)&d_gl, (void *)&n_pad, (void *)&d_items};
+                const int64_t blocks_blk = std::min<int64_t>(n_quad_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
+                                                                               std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre)));
+                SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
             } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
@@ -2360,7 +2605,7 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
 
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
-    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" || ctx->last_kernel.name == "k_permtest_bits_blk" ||
+    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" || ctx->last_kernel.name == "k_permtest_bits_blk" || ctx->last_kernel.name == "k_permtest_bits_wq" ||
         ctx->last_kernel.name == "k_permtest_lds" || ctx->last_kernel.name == "k_permtest_mfma")
         return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;

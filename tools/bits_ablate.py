@@ -36,8 +36,8 @@ def one(P):
         if it and (best is None or dt < best[0]):
             best = (dt, name, ms, launches)
     dt, name, ms, launches = best
-    print('%-22s dbg=%s merge=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
-        name, os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), 1e3 * dt, launches, ms, ms * launches), flush=True)
+    print('%-22s dbg=%s merge=%s items=%s minlen=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
+        name, os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), os.environ.get('SAFE_HIP_BITS_ITEMS', '-'), os.environ.get('SAFE_HIP_BITS_MINLEN', '4'), 1e3 * dt, launches, ms, ms * launches), flush=True)
 
 
 if __name__ == '__main__':
@@ -45,10 +45,11 @@ if __name__ == '__main__':
         one(int(sys.argv[2]))
         sys.exit(0)
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    configs = [{'SAFE_HIP_BITS_KERNEL': 'pre'}, {'SAFE_HIP_BITS_KERNEL': 'blk'},
-               {'SAFE_HIP_BITS_KERNEL': 'blk', 'SAFE_HIP_BITS_DBG': '1'}, {'SAFE_HIP_BITS_KERNEL': 'blk', 'SAFE_HIP_BITS_DBG': '2'},
-               {'SAFE_HIP_BITS_KERNEL': 'blk', 'SAFE_HIP_BITS_DBG': '4'}, {'SAFE_HIP_BITS_KERNEL': 'blk', 'SAFE_HIP_BITS_DBG': '7'},
-               {'SAFE_HIP_BITS_KERNEL': 'blk', 'SAFE_HIP_BITS_MERGE': '2'}, {'SAFE_HIP_BITS_KERNEL': 'blk', 'SAFE_HIP_BITS_MERGE': '8'},
-               {'SAFE_HIP_BITS_KERNEL': 'pre', 'SAFE_HIP_BITS_MERGE': '8'}]
+    K = 'SAFE_HIP_BITS_KERNEL'
+    Q = 'SAFE_HIP_BITS_QUAD'
+    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', Q: '1', 'SAFE_HIP_BITS_ITEMS': '3'}, {K: 'blk', Q: '1', 'SAFE_HIP_BITS_ITEMS': '4'},
+               {K: 'blk', Q: '1', 'SAFE_HIP_BITS_ITEMS': '4', 'SAFE_HIP_BITS_MINLEN': '16'},
+               {K: 'wq', 'SAFE_HIP_BITS_ITEMS': '2'}, {K: 'wq', 'SAFE_HIP_BITS_ITEMS': '3'},
+               {K: 'blk', 'SAFE_HIP_BITS_MERGE': '8'}, {K: 'wq', 'SAFE_HIP_BITS_MERGE': '8'}]
     for cfg in configs:
         subprocess.run([sys.executable, os.path.abspath(__file__), '--one', str(P)], env=dict(os.environ, **cfg))

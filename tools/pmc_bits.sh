@@ -1,8 +1,13 @@
 #!/bin/bash
-# PMC passes for the headline bench step (k_permtest_bits_pre); run on the GPU box through gpurun
-R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pb}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
+# PMC passes for the headline bench step (bit-sliced permutation kernel); run on the GPU box through gpurun.
+# usage: pmc_bits.sh <out tag> [env assignments for the bench, e.g. SAFE_HIP_BITS_KERNEL=pre]
+R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pb}; mkdir -p $O; shift; for kv in "$@"; do export "$kv"; done
+cd /tmp; export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 1 --warmup 1 --cpu-perms 0 --extras 0"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace -d $O/pmc1 -o r -- $CMD > $O/pmc1.log 2>&1
 timeout 300 rocprofv3 --pmc SQ_LDS_IDX_ACTIVE SQ_LDS_BANK_CONFLICT SQ_ACTIVE_INST_LDS SQ_WAIT_INST_LDS SQ_ACTIVE_INST_VALU SQ_INSTS_SALU SQ_WAVES SQ_INSTS_VMEM_WR --kernel-trace -d $O/pmc2 -o r -- $CMD > $O/pmc2.log 2>&1
 timeout 300 rocprofv3 --pmc TCC_HIT_sum TCC_MISS_sum GRBM_GUI_ACTIVE --kernel-trace -d $O/pmc3 -o r -- $CMD > $O/pmc3.log 2>&1
+timeout 300 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $O/pmc4 -o r -- $CMD > $O/pmc4.log 2>&1
+timeout 300 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $O/pmc5 -o r -- $CMD > $O/pmc5.log 2>&1
+for i in 1 2 3 4 5; do python3 $R/tools/rocpd_counters.py $(ls $O/pmc$i/*/*.db $O/pmc$i/*.db 2>/dev/null | head -1) k_perm >> $O/pmc_summary.txt 2>&1; done
 tail -1 $O/pmc3.log
