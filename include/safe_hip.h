@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SAFE_HIP_ABI_VERSION 1
+#define SAFE_HIP_ABI_VERSION 2
 
 #define SAFE_OK 0
 #define SAFE_E_INVALID (-1)   /* bad argument */
@@ -52,6 +52,7 @@ typedef struct safe_ctx safe_ctx;
 typedef struct safe_nbr safe_nbr;       /* neighborhood membership, device resident     */
 typedef struct safe_attr safe_attr;     /* node x attribute matrix, device resident     */
 typedef struct safe_perms safe_perms;   /* composed row-permutation tables, device res. */
+typedef struct safe_comm safe_comm;     /* RCCL communicator of the attribute-sharded path */
 
 /* ------------------------------------------------------------------ context ---- */
 int safe_abi_version(void);
@@ -186,6 +187,14 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host,
 int safe_perms_destroy(safe_perms *perms);
 /* Copy table rows [p0,p1) to host as int32 [p1-p0, n] (tests). */
 int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host);
+/* The same handle from a table the CALLER supplies instead of the legacy stream -- the `perm` of
+ * safepy/safe_extras.py:58 produced elsewhere (an external RNG, a recorded run): perm_idx_host is int32
+ * [num_permutations, n] row-major, COMPOSED like the tables above: row p is the index vector with
+ * permuted_matrix_p = B[perm_idx[p]] (for the reference's cumulative in-place shuffle that is
+ * cur_p = cur_{p-1}[...] of SURVEY A.3, not the single draw).  Every row must be a permutation of
+ * 0..n-1 (SAFE_E_VALUE otherwise). */
+int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutations,
+                                 const int32_t *perm_idx_host, safe_perms **out);
 /* Host-only: the raw stream, for pinning against numpy (no device needed).  Writes
  * count permutations of values[0..n_items) back to back into out[count*n_items]. */
 int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_items,
@@ -264,6 +273,25 @@ int safe_export_packed_counts(safe_ctx *ctx, uint32_t *dst_dev, int64_t capacity
 int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad,
                                 int64_t m, int64_t num_permutations, int sign_mode, const double *nes_table_host,
                                 double *nes_dev);
+
+/* The exchange step of the attribute-sharded path for hosts without their own collective library
+ * (replaces np.concatenate(combined_nes, axis=1), safepy/safe.py:1355, and the process pool around it,
+ * safe.py:1339-1353): a thin wrapper over RCCL (ncclAllGather over xGMI), loaded on first use.
+ * One rank calls safe_comm_unique_id and hands the SAFE_COMM_ID_BYTES bytes to the others by any means (a
+ * file, MPI, a socket); every rank then calls safe_comm_create with its own context (one GPU per rank).
+ * safe_allgather_cols enqueues, on the context's stream, the all-gather of every rank's slab of
+ * bytes_per_rank bytes at local_dev into all_dev (world_size slabs, rank order) -- e.g. the packed counters of
+ * safe_export_packed_counts (attribute-major: a rank's column block IS one slab) or a transposed result
+ * block; it returns without waiting (safe_ctx_sync).  SAFE_E_UNSUPPORTED if RCCL cannot be loaded. */
+#define SAFE_COMM_ID_BYTES 128
+int safe_comm_unique_id(char *id_out, size_t id_len);
+int safe_comm_create(safe_ctx *ctx, int world_size, int rank, const char *id, size_t id_len, safe_comm **out);
+int safe_comm_destroy(safe_comm *comm);
+int safe_allgather_cols(safe_comm *comm, const void *local_dev, size_t bytes_per_rank, void *all_dev);
+
+/* Number of i8 slices the last matrix-core permutation test ran with (2 / 4 / 6: the bits its columns need
+ * on their fixed-point grid; 0 if that kernel has not run) -- for roofline reporting. */
+int safe_last_mfma_slices(safe_ctx *ctx, int *slices);
 
 /* Name and average duration (ms) of the dominant kernel of the last enrichment call,
  * measured with HIP events on the context stream (bench.py's roofline object). */

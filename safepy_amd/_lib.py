@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsafe_hip.so')
 
-ABI_VERSION = 1
+ABI_VERSION = 2
 DTYPE_F32, DTYPE_F64 = 0, 1
 SCORE_SUM, SCORE_ZSCORE = 0, 1
 SIGN_HIGHEST, SIGN_LOWEST, SIGN_BOTH = 0, 1, 2
@@ -45,7 +45,13 @@ def _preload_torch_hip_runtime():
         spec = None
     if spec is None or not spec.submodule_search_locations:
         return None
-    path = os.path.join(list(spec.submodule_search_locations)[0], 'lib', 'libamdhip64.so')
+    libdir = os.path.join(list(spec.submodule_search_locations)[0], 'lib')
+    # the same rule for RCCL, lazily: safe_comm_* (comm.cpp) dlopens RCCL on first use and must pick the copy a later
+    # `import torch` would bring (two RCCL copies in one process corrupt the heap at exit)
+    rccl = os.path.join(libdir, 'librccl.so')
+    if os.path.exists(rccl):
+        os.environ.setdefault('SAFE_HIP_RCCL_PATH', rccl)
+    path = os.path.join(libdir, 'libamdhip64.so')
     if not os.path.exists(path):
         return None
     C.CDLL(path, mode=C.RTLD_GLOBAL)
@@ -117,6 +123,12 @@ PROTOTYPES = {
     'safe_export_packed_counts': (C.c_int, [_vp, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_int)]),
     'safe_nes_from_packed_counts': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _vp, _vp]),
     'safe_last_kernel_stats': (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), _pi64]),
+    'safe_last_mfma_slices': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'safe_perms_create_from_table': (C.c_int, [_vp, _i64, _i64, _vp, _pp]),
+    'safe_comm_unique_id': (C.c_int, [C.c_char_p, C.c_size_t]),
+    'safe_comm_create': (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t, _pp]),
+    'safe_comm_destroy': (C.c_int, [_vp]),
+    'safe_allgather_cols': (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -4,6 +4,7 @@ device-resident handles (membership, attribute matrix, permutation tables).
 Nothing here computes: every method forwards to libsafe_hip.so, and fails loudly if the
 library reports an error (no HIP device, bad arguments, ...).
 """
+import collections
 import ctypes as C
 
 import numpy as np
@@ -53,9 +54,12 @@ def pin_threads_to_device_numa(device=0):
 class DeviceBuffer:
     """A raw device allocation owned by the library allocator (f64/i64 element views).  Freed buffers
     of 1 MiB and more go back to a per-context pool keyed by size: hipMalloc / hipFree of the result
-    matrices (GBs at 20 000 nodes) cost tens of milliseconds per call, more than the kernels."""
+    matrices (GBs at 20 000 nodes) cost tens of milliseconds per call, more than the kernels.
+    The pool is bounded by a share of the device's memory (POOL_FRACTION of ctx.hbm_bytes); when a
+    returned buffer does not fit, the sizes that have gone unused the longest are released first, and an
+    allocation that fails returns the whole pool to the driver and tries once more."""
 
-    POOL_LIMIT = 48 << 30                 # bytes kept for reuse per context (of 288 GB)
+    POOL_FRACTION = 1.0 / 6.0             # of the device memory (48 GB of 288 GB)
 
     def __init__(self, ctx, nbytes):
         self.ctx = ctx
@@ -64,16 +68,32 @@ class DeviceBuffer:
         if pooled:
             self.ptr = pooled.pop()
             ctx._pool_bytes -= self.nbytes
+            if pooled:
+                ctx._pool.move_to_end(self.nbytes)         # most recently used size last
+            else:
+                del ctx._pool[self.nbytes]
             return
         p = C.c_void_p()
-        check(lib.safe_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p)))
+        rc = lib.safe_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p))
+        if rc != 0 and ctx._pool_bytes:                    # out of memory with buffers idling in the pool: release them, retry
+            ctx.trim()
+            rc = lib.safe_dev_alloc(ctx.handle, max(self.nbytes, 1), C.byref(p))
+        check(rc)
         self.ptr = p.value
 
     def free(self):
         if self.ptr:
             ctx = self.ctx
-            if self.nbytes >= (1 << 20) and ctx._pool_bytes + self.nbytes <= self.POOL_LIMIT:
+            limit = int(ctx.hbm_bytes * self.POOL_FRACTION)
+            if (1 << 20) <= self.nbytes <= limit:
+                while ctx._pool and ctx._pool_bytes + self.nbytes > limit:     # evict the least recently used size
+                    size, ptrs = next(iter(ctx._pool.items()))
+                    check(lib.safe_dev_free(ctx.handle, C.c_void_p(ptrs.pop())))
+                    ctx._pool_bytes -= size
+                    if not ptrs:
+                        del ctx._pool[size]
                 ctx._pool.setdefault(self.nbytes, []).append(self.ptr)
+                ctx._pool.move_to_end(self.nbytes)
                 ctx._pool_bytes += self.nbytes
             else:
                 check(lib.safe_dev_free(ctx.handle, C.c_void_p(self.ptr)))
@@ -115,7 +135,7 @@ class Context:
         self.num_cu = ncu.value
         self.hbm_bytes = hbm.value
         self.arch = arch.value.decode()
-        self._pool = {}                   # size -> [device pointers] of released DeviceBuffers
+        self._pool = collections.OrderedDict()     # size -> [device pointers] of released DeviceBuffers, least recently used first
         self._pool_bytes = 0
 
     @classmethod
@@ -373,6 +393,22 @@ class Permutations:
                                     0 if seed is None else seed, C.byref(h)))
         self.handle = h
 
+    @classmethod
+    def from_table(cls, ctx, perm_idx):
+        """Tables supplied by the caller instead of the legacy stream (safe_perms_create_from_table): perm_idx is
+        [P, n], row p the COMPOSED index vector -- permuted matrix p = B[perm_idx[p]] (safe_extras.py:58 applied
+        cumulatively).  Every row must be a permutation of 0..n-1."""
+        perm_idx = np.ascontiguousarray(perm_idx, dtype=np.int32)
+        if perm_idx.ndim != 2:
+            raise ValueError('perm_idx must be [num_permutations, n]')
+        self = cls.__new__(cls)
+        self.ctx = ctx
+        self.count, self.n = int(perm_idx.shape[0]), int(perm_idx.shape[1])
+        h = C.c_void_p()
+        check(lib.safe_perms_create_from_table(ctx.handle, self.n, self.count, _ptr(perm_idx), C.byref(h)))
+        self.handle = h
+        return self
+
     def read(self, p0=0, p1=None):
         p1 = self.count if p1 is None else p1
         out = np.empty((p1 - p0, self.n), dtype=np.int32)
@@ -389,6 +425,50 @@ class Permutations:
             self.close()
         except Exception:
             pass
+
+
+class Comm:
+    """RCCL communicator behind the C ABI (safe_comm_* / safe_allgather_cols): the final exchange of the
+    attribute-sharded path for hosts without torch.distributed.  `Comm.unique_id()` on one rank, the 128 bytes to
+    every rank by any means, then `Comm(ctx, world, rank, uid)` on each (one GPU per rank)."""
+
+    ID_BYTES = 128
+
+    @staticmethod
+    def unique_id():
+        buf = C.create_string_buffer(Comm.ID_BYTES)
+        check(lib.safe_comm_unique_id(buf, Comm.ID_BYTES))
+        return buf.raw
+
+    def __init__(self, ctx, world_size, rank, unique_id):
+        assert len(unique_id) == self.ID_BYTES
+        self.ctx, self.world_size, self.rank = ctx, int(world_size), int(rank)
+        h = C.c_void_p()
+        check(lib.safe_comm_create(ctx.handle, self.world_size, self.rank, unique_id, self.ID_BYTES, C.byref(h)))
+        self.handle = h
+
+    def allgather(self, local_ptr, bytes_per_rank, all_ptr):
+        """Enqueue (context stream) the all-gather of every rank's `bytes_per_rank` bytes at device pointer
+        `local_ptr` into `all_ptr` (world_size slabs in rank order)."""
+        check(lib.safe_allgather_cols(self.handle, C.c_void_p(local_ptr), int(bytes_per_rank), C.c_void_p(all_ptr)))
+
+    def close(self):
+        if self.handle:
+            check(lib.safe_comm_destroy(self.handle))
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+def last_mfma_slices(ctx):
+    """i8 slices the last matrix-core permutation test ran with (2 / 4 / 6; 0 = it has not run)."""
+    v = C.c_int()
+    check(lib.safe_last_mfma_slices(ctx.handle, C.byref(v)))
+    return v.value
 
 
 def rng_permutations_host(seed, values, count):

@@ -68,6 +68,7 @@ struct safe_ctx {
     hipEvent_t t0 = nullptr, t1 = nullptr;      // safe_timer_*
     hipEvent_t k0 = nullptr, k1 = nullptr;      // dominant-kernel timing
     KernelStat last_kernel;
+    int last_slices = 0;                        // i8 slices of the last matrix-core permutation test (2 / 4 / 6)
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
     struct safe_perms *perm_cache = nullptr;    // buffers of the last destroyed permutation handle, reused by the next
     // packed <= / >= counters of the last integer-counter permutation kernel (scratch slot 0):
@@ -255,6 +256,7 @@ struct safe_perms {
     // inverse_t[r * inv_stride + p] = position k with table[p][k] == r; inv_stride = padded count
     uint16_t *inverse_t = nullptr;
     int64_t inv_stride = 0;
+    bool from_table = false;        // rows supplied by the caller (safe_perms_create_from_table): no stream, complete from the start
 };
 
 // launch-geometry helpers

@@ -234,6 +234,12 @@ int safe_timer_stop_ms(safe_ctx *ctx, double *elapsed_ms) {
     return SAFE_OK;
 }
 
+int safe_last_mfma_slices(safe_ctx *ctx, int *slices) {
+    SAFE_REQUIRE(ctx && slices, "safe_last_mfma_slices: NULL argument");
+    *slices = ctx->last_slices;
+    return SAFE_OK;
+}
+
 int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *avg_ms, int64_t *launches) {
     SAFE_REQUIRE(ctx != nullptr, "safe_last_kernel_stats: ctx is NULL");
     if (name && name_len) snprintf(name, name_len, "%s", ctx->last_kernel.name.c_str());

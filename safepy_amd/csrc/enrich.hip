@@ -2679,8 +2679,8 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
     }
     Tiles tiles;
     SAFE_TRY(build_tiles(ctx, attr, col0, col1, z, &tiles));
-    SAFE_TRY(perms_wait(perms, perms->count, ctx->stream));
-    int rc = launch_gather(ctx, nbr, tiles, perms->table, perms->count, col1 - col0, z, out);
+    int rc = perms_wait(perms, perms->count, ctx->stream);          // (rc from here on: the tile buffer is freed on every path)
+    if (rc == SAFE_OK) rc = launch_gather(ctx, nbr, tiles, perms->table, perms->count, col1 - col0, z, out);
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
     (void)hipFree(tiles.bt);
     return rc;
@@ -2837,12 +2837,17 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
         if (rc == SAFE_OK)
             rc = bits ? launch_counts_bits(ctx, nbr, attr, col0, col1, d_hits)
                       : launch_gather(ctx, nbr, tiles, nullptr, 0, mloc, false, out);   // X = A . B0 (safe.py:593-594)
-        if (rc == SAFE_OK) {
-            SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
+        if (rc == SAFE_OK) {                                                // (no early return: the join and the frees below must run)
+            hipError_t e = hipEventRecord(ctx->k0, ctx->stream);
             hipLaunchKernelGGL(k_hypergeom_tail, dim3(ceil_div(mloc, 64), ceil_div(n, 4)), dim3(256), 0, ctx->stream, d_hits,
                                d_size, attr->col_sum, col0, n, mloc, static_cast<double>(pop), d_lf,
                                nes_p_cut(enrichment_threshold), pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr);
-            SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
+            if (e == hipSuccess) e = hipGetLastError();
+            if (e == hipSuccess) e = hipEventRecord(ctx->k1, ctx->stream);
+            if (e != hipSuccess) {
+                safe_set_error("safe_hypergeom: %s", hipGetErrorString(e));
+                rc = SAFE_E_HIP;
+            }
             ctx->last_kernel.name = "k_hypergeom_tail";
         }
         if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // lf is host memory

@@ -42,6 +42,21 @@ constexpr int MF_SHIFT_BITS = 45;     // |q| < 2^46 after scaling: six balanced 
 typedef int v4i __attribute__((ext_vector_type(4)));
 typedef int v16i __attribute__((ext_vector_type(16)));
 
+// 2048 - (exponent of the least significant set bit of x), x finite and non-zero: with the exponent of the column
+// maximum it tells how many bits an EXACT fixed-point image of the column needs (k_mfma_colfinish)
+__device__ __forceinline__ unsigned int neg_lowbit_of(double x) {
+    const unsigned long long b = static_cast<unsigned long long>(__double_as_longlong(x));
+    const int e = static_cast<int>((b >> 52) & 0x7FFull);
+    unsigned long long m = b & ((1ull << 52) - 1ull);
+    int low;
+    if (e == 0) low = -1074 + __ffsll(static_cast<unsigned long long>(m)) - 1;
+    else {
+        m |= 1ull << 52;
+        low = e - 1023 - 52 + __ffsll(static_cast<unsigned long long>(m)) - 1;
+    }
+    return static_cast<unsigned int>(2048 - low);
+}
+
 // ---------------------------------------------------------------------------------------
 // column statistics: max |b|, sum b^2 and count over the non-NaN non-zero entries
 // ---------------------------------------------------------------------------------------
@@ -49,7 +64,7 @@ template <typename T>
 __global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
                                                        int64_t col0, int64_t mloc, int rows_per_block,
                                                        unsigned long long *__restrict__ maxbits, double *__restrict__ sumsq,
-                                                       unsigned int *__restrict__ cnt) {
+                                                       unsigned int *__restrict__ cnt, unsigned int *__restrict__ neg_lowbit) {
     // 32 columns x 8 row lanes; the lane index runs along whichever axis is contiguous
     __shared__ double s_max[8][33], s_sq[8][33];
     __shared__ unsigned int s_cnt[8][33];
@@ -58,7 +73,8 @@ __global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ 
     const int64_t r1 = r0 + rows_per_block < n ? r0 + rows_per_block : n;
     const bool col_major = rs == 1;            // Fortran order: consecutive rows are adjacent
     double mx = 0.0, sq = 0.0;
-    unsigned int ct = 0;
+    unsigned int ct = 0, nl = 0;
+    __shared__ unsigned int s_nl[8][33];
     if (!col_major) {
         const int64_t j = c0 + tx;
         if (j < mloc)
@@ -68,11 +84,13 @@ __global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ 
                     mx = fmax(mx, fabs(x));
                     sq += x * x;
                     ++ct;
+                    if (fabs(x) < __longlong_as_double(0x7FF0000000000000ll)) nl = max(nl, neg_lowbit_of(x));
                 }
             }
         s_max[ty][tx] = mx;
         s_sq[ty][tx] = sq;
         s_cnt[ty][tx] = ct;
+        s_nl[ty][tx] = nl;
     } else {
         // lanes along rows; column = c0 + ty + 8*i
         for (int i = 0; i < 4; ++i) {
@@ -80,6 +98,7 @@ __global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ 
             mx = 0.0;
             sq = 0.0;
             ct = 0;
+            nl = 0;
             if (j < mloc)
                 for (int64_t r = r0 + tx; r < r1; r += 32) {
                     const double x = static_cast<double>(reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs]);
@@ -87,17 +106,20 @@ __global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ 
                         mx = fmax(mx, fabs(x));
                         sq += x * x;
                         ++ct;
+                        if (fabs(x) < __longlong_as_double(0x7FF0000000000000ll)) nl = max(nl, neg_lowbit_of(x));
                     }
                 }
             for (int o = 16; o > 0; o >>= 1) {
                 mx = fmax(mx, __shfl_xor(mx, o, 32));
                 sq += __shfl_xor(sq, o, 32);
                 ct += __shfl_xor(ct, o, 32);
+                nl = max(nl, static_cast<unsigned int>(__shfl_xor(static_cast<int>(nl), o, 32)));
             }
             if (tx == 0 && j < mloc && ct) {
                 atomicMax(&maxbits[j], static_cast<unsigned long long>(__double_as_longlong(mx)));
                 atomicAdd(&sumsq[j], sq);
                 atomicAdd(&cnt[j], ct);
+                atomicMax(&neg_lowbit[j], nl);
             }
         }
         return;
@@ -108,40 +130,62 @@ __global__ __launch_bounds__(256) void k_mfma_colstats(const void *__restrict__ 
             mx = fmax(mx, s_max[k][tx]);
             sq += s_sq[k][tx];
             ct += s_cnt[k][tx];
+            nl = max(nl, s_nl[k][tx]);
         }
         const int64_t j = c0 + tx;
         if (j < mloc && ct) {
             atomicMax(&maxbits[j], static_cast<unsigned long long>(__double_as_longlong(mx)));
             atomicAdd(&sumsq[j], sq);
             atomicAdd(&cnt[j], ct);
+            atomicMax(&neg_lowbit[j], nl);
         }
     }
 }
 
-// per column: the power-of-two scale that maps the column maximum just below 2^46
-__global__ void k_mfma_colfinish(const unsigned long long *__restrict__ maxbits, int64_t mloc, int *__restrict__ shift,
-                                 double *__restrict__ scale, int *__restrict__ bad) {
+// per column: the power-of-two scale of its fixed-point image, and how many bits the image needs.
+//   exact   the column's values all sit on one binary grid that spans <= 46 bits from its lowest set bit to the top bit of
+//           its maximum (integers, f32-valued data of moderate range, ...): scale = 2^-lowbit, q = b * scale EXACTLY;
+//   rounded otherwise (f64 data in general): the maximum is mapped just below 2^46 and q = rint(b * scale), grid step
+//           2^-46 of the column maximum (k_mfma_slice counts what that does to small values, k_mfma_colcheck judges).
+// need[0] = max over columns of the bits needed (47 = rounded): the call runs with 2 / 4 / 6 i8 slices (<= 14 / 30 / 46 bits).
+__global__ void k_mfma_colfinish(const unsigned long long *__restrict__ maxbits, const unsigned int *__restrict__ neg_lowbit,
+                                 int64_t mloc, int *__restrict__ shift, double *__restrict__ scale, int *__restrict__ bad,
+                                 int *__restrict__ need) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (j >= mloc) return;
     const double mx = __longlong_as_double(static_cast<long long>(maxbits[j]));
-    int sh = 0;
-    if (mx > 0.0 && mx < __longlong_as_double(0x7FF0000000000000ll)) sh = MF_SHIFT_BITS - ilogb(mx);
-    else if (mx != 0.0) atomicOr(bad, 1);       // infinities are not representable at all
+    int sh = 0, bits = 1;
+    if (mx > 0.0 && mx < __longlong_as_double(0x7FF0000000000000ll)) {
+        const int top = ilogb(mx), low = 2048 - static_cast<int>(neg_lowbit[j]);
+        const int span = top - low + 1;
+        if (span <= MF_SHIFT_BITS + 1) {
+            sh = -low;                                   // exact: the lowest set bit becomes the unit
+            bits = span;
+        } else {
+            sh = MF_SHIFT_BITS - top;
+            bits = MF_SHIFT_BITS + 2;
+        }
+    } else if (mx != 0.0) {
+        atomicOr(bad, 1);                               // infinities are not representable at all
+    }
     shift[j] = sh;
     scale[j] = ldexp(1.0, -sh);
+    atomicMax(need, bits);
 }
+
+__host__ __device__ __forceinline__ int mfma_slices_for(int need_bits) { return need_bits <= 14 ? 2 : need_bits <= 30 ? 4 : MF_NS; }
 
 // ---------------------------------------------------------------------------------------
 // slices: bs[row][column tile][slice][32 columns] i8, row n = zeros.  q = rint(b * 2^shift)
 // as a 47-bit integer, digits d_t in [-128, 127] with q = sum d_t 256^t.
-// Also counts, per column, the values far below the column maximum (< 2^-6 max) and how many
-// of those had to be rounded: k_mfma_colcheck declines the path when such values are the bulk
-// of a column (an outlier would then set a grid too coarse for the typical sums).
+// Also counts, per column, the values far below the column maximum (< 2^-20 max) that had to be rounded:
+// k_mfma_colcheck declines the path when they are more than a thousandth of a column (the grid, set by the
+// maximum, would be too coarse for sums made of such values).
 // ---------------------------------------------------------------------------------------
 template <typename T>
 __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
                                                     int64_t col0, int64_t mloc, int64_t n_ct, const int *__restrict__ shift,
-                                                    const unsigned long long *__restrict__ maxbits,
+                                                    const unsigned long long *__restrict__ maxbits, const int *__restrict__ need,
                                                     unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
                                                     unsigned int *__restrict__ n_small_rounded) {
     __shared__ double tile[32][33];
@@ -162,8 +206,11 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
     __syncthreads();
     const int64_t j = c0 + tx;
     const int sh = j < mloc ? shift[j] : 0;
-    const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -6) : 0.0;
-    const int64_t row_bytes = n_ct * MF_NS * 32;
+    // "small": more than 2^20 below the column maximum -- held to fewer than 26 significant bits on a rounding grid
+    const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -20) : 0.0;
+    const int ns = mfma_slices_for(*need);
+    const int64_t row_bytes = n_ct * ns * 32;
+    const long long bias = ns == 2 ? 0x8080ll : ns == 4 ? 0x80808080ll : 0x808080808080ll;
     unsigned int k_small = 0, k_rounded = 0;
     for (int i = 0; i < 4; ++i) {
         const int rr = ty + 8 * i;
@@ -178,10 +225,11 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
             ++k_small;
             k_rounded += q != scaled;
         }
-        const unsigned long long u = static_cast<unsigned long long>(static_cast<long long>(q) + 0x808080808080ll);
-        unsigned char *dst = bs + r * row_bytes + ct * (MF_NS * 32) + tx;
+        const unsigned long long u = static_cast<unsigned long long>(static_cast<long long>(q) + bias);
+        unsigned char *dst = bs + r * row_bytes + ct * (ns * 32) + tx;
 #pragma unroll
-        for (int t = 0; t < MF_NS; ++t) dst[t * 32] = static_cast<unsigned char>(((u >> (8 * t)) & 0xFFu) ^ 0x80u);
+        for (int t = 0; t < MF_NS; ++t)
+            if (t < ns) dst[t * 32] = static_cast<unsigned char>(((u >> (8 * t)) & 0xFFu) ^ 0x80u);
     }
     if (k_small) atomicAdd(&s_small[tx], k_small);
     if (k_rounded) atomicAdd(&s_rounded[tx], k_rounded);
@@ -196,7 +244,9 @@ __global__ void k_mfma_colcheck(const unsigned int *__restrict__ cnt, const unsi
                                 const unsigned int *__restrict__ n_small_rounded, int64_t mloc, int *__restrict__ bad) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (j >= mloc) return;
-    if (n_small_rounded[j] > 0 && 2ull * n_small[j] >= cnt[j]) atomicOr(bad, 1);
+    // values that the grid holds to fewer than 26 bits must be a negligible part of the column (< 1 in 1024): sums made of
+    // such values only would be compared at the grid's resolution, not at f64's
+    if (1024ull * n_small_rounded[j] > cnt[j]) atomicOr(bad, 1);
 }
 
 // source-row maps of a span: row 0 = identity (observed score), row 1 + q = permutation p_base + q
@@ -1133,53 +1183,57 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     *declined = false;
     SAFE_TRY(build_blocks(nbr));
     const int64_t n = nbr->n, mloc = col1 - col0, P = perms->count;
-    const int64_t n_ct = ceil_div(mloc, 32), row_bytes = n_ct * MF_NS * 32, n_src = nbr->bs_src;
+    const int64_t n_ct = ceil_div(mloc, 32), n_src = nbr->bs_src;
+    int64_t row_bytes = n_ct * MF_NS * 32;       // (the largest form; the call's slice count is known after the column statistics)
     const int64_t n_padr = nbr->bs_groups * MF_R;
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
 
     // ---- column scales and slices
+    int n_slices = MF_NS;                        // i8 slices of this call: 2 / 4 / 6 by the bits its columns need (k_mfma_colfinish)
     unsigned char *d_bs = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
-    void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale f64 | cnt, small, rounded u32 | shift i32 | bad i32
-    const size_t colbuf_bytes = static_cast<size_t>(mloc) * (8 + 8 + 8 + 4 + 4 + 4 + 4) + 64;
+    void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale f64 | cnt, small, rounded, neg_lowbit u32 | shift i32 | bad, need i32
+    const size_t colbuf_bytes = static_cast<size_t>(mloc) * (8 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + 64;
     SAFE_TRY(ctx_scratch(ctx, 6, colbuf_bytes, &d_colbuf));
     unsigned long long *d_max = static_cast<unsigned long long *>(d_colbuf);
     double *d_sumsq = reinterpret_cast<double *>(d_max + mloc);
     double *d_scale = d_sumsq + mloc;
     unsigned int *d_cnt = reinterpret_cast<unsigned int *>(d_scale + mloc);
-    unsigned int *d_small = d_cnt + mloc, *d_rounded = d_small + mloc;
-    int *d_shift = reinterpret_cast<int *>(d_rounded + mloc);
-    int *d_bad = d_shift + mloc;
+    unsigned int *d_small = d_cnt + mloc, *d_rounded = d_small + mloc, *d_lowbit = d_rounded + mloc;
+    int *d_shift = reinterpret_cast<int *>(d_lowbit + mloc);
+    int *d_bad = d_shift + mloc, *d_need = d_bad + 1;
     SAFE_HIP_CHECK(hipMemsetAsync(d_colbuf, 0, colbuf_bytes, ctx->stream));
     {
         const int rows_per_block = 2048;
         const dim3 grid(ceil_div(mloc, 32), ceil_div(n, rows_per_block));
         if (f32)
             hipLaunchKernelGGL(k_mfma_colstats<float>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, rows_per_block, d_max, d_sumsq, d_cnt);
+                               attr->col_stride, col0, mloc, rows_per_block, d_max, d_sumsq, d_cnt, d_lowbit);
         else
             hipLaunchKernelGGL(k_mfma_colstats<double>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, rows_per_block, d_max, d_sumsq, d_cnt);
-        hipLaunchKernelGGL(k_mfma_colfinish, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_max, mloc, d_shift, d_scale,
-                           d_bad);
+                               attr->col_stride, col0, mloc, rows_per_block, d_max, d_sumsq, d_cnt, d_lowbit);
+        hipLaunchKernelGGL(k_mfma_colfinish, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_max, d_lowbit, mloc, d_shift,
+                           d_scale, d_bad, d_need);
         const dim3 sgrid(n_ct, ceil_div(n + 1, 32));
         if (f32)
             hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_bs, d_small, d_rounded);
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded);
         else
             hipLaunchKernelGGL(k_mfma_slice<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_bs, d_small, d_rounded);
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded);
         hipLaunchKernelGGL(k_mfma_colcheck, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_cnt, d_small, d_rounded, mloc,
                            d_bad);
         SAFE_HIP_CHECK(hipGetLastError());
-        int bad = 0;
-        SAFE_HIP_CHECK(hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
+        int verdict[2] = {0, 0};                   // {bad, bits needed}
+        SAFE_HIP_CHECK(hipMemcpyAsync(verdict, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
         SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
         const char *force = getenv("SAFE_HIP_FORCE_PATH");
-        if (bad && !(force && !strcmp(force, "mfma"))) {
+        if (verdict[0] && !(force && !strcmp(force, "mfma"))) {
             *declined = true;
             return SAFE_OK;
         }
+        n_slices = mfma_slices_for(verdict[1]);
+        row_bytes = n_ct * n_slices * 32;
     }
 
     // ---- tasks: (row group, column tile), one queue per XCD keyed by column tile so the slice
@@ -1214,9 +1268,12 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, (8 * n_launch + 8) * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
 
-    const size_t lds_bytes = 2 * MF_BUF + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds_bytes)));
+    const size_t lds_bytes = 2 * static_cast<size_t>(4 * n_slices * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    const void *kfn = n_slices == 2   ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
+                      : n_slices == 4 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 4>)
+                                      : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
+    SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    ctx->last_slices = n_slices;
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
     ctx->last_kernel.name = "k_permtest_mfma";
     ctx->last_kernel.total_ms = 0.0;
@@ -1234,9 +1291,17 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
                            p_base, d_src[c & 1]);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
-        hipLaunchKernelGGL((k_permtest_mfma<false, MF_NS>), dim3(blocks), dim3(512), lds_bytes, ks, d_bs, row_bytes, d_src[c & 1], n_src,
-                           static_cast<int>(cnt + 1), nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, d_tasks, d_qoff, d_qctr + 8 * c, mloc,
-                           d_counts, n_padr, nbr->bs_rowmap, d_scale, c == 0 ? out.ns : static_cast<double *>(nullptr), HypLookup{});
+        {
+            const int32_t *src_c = d_src[c & 1];
+            int n_q = static_cast<int>(cnt + 1);
+            unsigned int *qctr_c = d_qctr + 8 * c;
+            double *ns_c = c == 0 ? out.ns : static_cast<double *>(nullptr);
+            HypLookup no_lookup{};
+            void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+                            (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
+                            (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup};
+            SAFE_HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(512), args, lds_bytes, ks));
+        }
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
         if (c >= 1) {

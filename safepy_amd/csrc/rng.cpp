@@ -62,6 +62,14 @@ __global__ __launch_bounds__(256) void k_emit_rows(const int32_t *__restrict__ x
     }
 }
 
+// 16-bit copy of a caller-supplied table, rows padded with the padding row's id
+__global__ __launch_bounds__(256) void k_table16(const int32_t *__restrict__ table, int64_t stride, uint16_t *__restrict__ table16,
+                                                  int64_t stride16, int64_t n) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y;
+    if (i < stride16) table16[q * stride16 + i] = static_cast<uint16_t>(i < stride ? table[q * stride + i] : n);
+}
+
 __global__ void k_iota(int32_t *p, int64_t count) {
     const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
     if (i < count) p[i] = static_cast<int32_t>(i);
@@ -483,10 +491,86 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     return SAFE_OK;
 }
 
+int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutations, const int32_t *perm_idx_host,
+                                 safe_perms **out) {
+    SAFE_REQUIRE(ctx && out && (perm_idx_host || num_permutations == 0), "safe_perms_create_from_table: NULL argument");
+    SAFE_REQUIRE(n >= 1 && n < (1ll << 31) - 1, "safe_perms_create_from_table: n out of range");
+    SAFE_REQUIRE(num_permutations >= 0, "safe_perms_create_from_table: negative permutation count");
+    *out = nullptr;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    // every row must be a permutation of 0..n-1 (safe_extras.py:58 moves rows, it never duplicates one)
+    const int64_t stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
+    std::vector<int32_t> staged(static_cast<size_t>(rows) * stride, 0);
+    {
+        std::vector<uint8_t> seen(n);
+        for (int64_t p = 0; p < num_permutations; ++p) {
+            std::fill(seen.begin(), seen.end(), 0);
+            const int32_t *row = perm_idx_host + p * n;
+            for (int64_t i = 0; i < n; ++i) {
+                const int32_t v = row[i];
+                if (v < 0 || v >= n || seen[v]) {
+                    safe_set_error("safe_perms_create_from_table: row %lld is not a permutation of 0..%lld (entry %lld = %d)",
+                                   (long long)p, (long long)(n - 1), (long long)i, v);
+                    return SAFE_E_VALUE;
+                }
+                seen[v] = 1;
+            }
+            memcpy(staged.data() + p * stride, row, n * sizeof(int32_t));
+            staged[p * stride + n] = static_cast<int32_t>(n);           // the padding row maps to itself
+        }
+    }
+    safe_perms *p = new safe_perms();
+    p->ctx = ctx;
+    p->n = n;
+    p->count = num_permutations;
+    p->from_table = true;
+    p->k = n;
+    p->generated = p->swapping = p->enqueued = num_permutations;
+    int rc = SAFE_OK;
+    do {
+        if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
+        hipError_t e = hipMemcpyAsync(p->table, staged.data(), staged.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux_stream);
+        if (e == hipSuccess && n < 65535) {
+            p->stride16 = (stride + 7) / 8 * 8;
+            if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
+            if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
+            hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
+            // table16 from table: the emit kernel with the identity as both composition operands' base
+            const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), rows), block(256);
+            hipLaunchKernelGGL(k_table16, grid, block, 0, ctx->aux_stream, p->table, stride, p->table16, p->stride16, n);
+            e = hipGetLastError();
+        }
+        const int64_t n_chunks = perms_chunk_count(num_permutations);
+        p->chunk_done.assign(std::max<int64_t>(n_chunks, 1), nullptr);
+        for (size_t c = 0; c < p->chunk_done.size() && e == hipSuccess; ++c) {
+            e = hipEventCreateWithFlags(&p->chunk_done[c], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(p->chunk_done[c], ctx->aux_stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->aux_stream);    // `staged` is host memory of this call
+        if (e != hipSuccess) {
+            safe_set_error("safe_perms_create_from_table: %s", hipGetErrorString(e));
+            rc = SAFE_E_HIP;
+        }
+    } while (0);
+    if (rc != SAFE_OK) {
+        perms_free(p);
+        return rc;
+    }
+    *out = p;
+    return SAFE_OK;
+}
+
 int safe_perms_destroy(safe_perms *perms) {
     if (!perms) return SAFE_OK;
     (void)hipSetDevice(perms->ctx->device);
     safe_ctx *ctx = perms->ctx;
+    if (perms->from_table) {                              // no stream, no staging buffers: nothing worth caching
+        (void)hipStreamSynchronize(ctx->aux_stream);
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamSynchronize(ctx->stream);
+        perms_free(perms);
+        return SAFE_OK;
+    }
     drawer_stop(perms);
     SwapPool::get().wait();
     (void)hipStreamSynchronize(ctx->aux_stream);

@@ -113,6 +113,21 @@ def main():
         sf.load_attributes(attribute_file=b.copy())
         sf.compute_pvalues(how='randomization', num_permutations=40, neighborhood_score_type='sum', multiple_testing=False)
         assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+        if backend == 'nccl':
+            # the exchange through the C ABI's own RCCL communicator (safe_comm_* / safe_allgather_cols): the id travels
+            # over the process group here; a non-torch host would use a file or MPI
+            from safepy_amd import backend as be
+            box = [be.Comm.unique_id() if rank == 0 else None]
+            dist.broadcast_object_list(box, src=0)
+            comm = be.Comm(ctx, world, rank, box[0])
+            nbytes = 3 << 20
+            mine, everyone = ctx.alloc(nbytes), ctx.alloc(world * nbytes)
+            mine.upload(np.full(nbytes, 17 + rank, dtype=np.uint8))
+            comm.allgather(mine.ptr, nbytes, everyone.ptr)
+            ctx.sync()
+            got = everyone.download((world, nbytes), dtype=np.uint8)
+            assert all((got[r] == 17 + r).all() for r in range(world))
+            comm.close()
         open(os.path.join(outdir, 'ok%d' % rank), 'w').write('ok')
     finally:
         dist.destroy_process_group()

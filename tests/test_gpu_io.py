@@ -392,3 +392,33 @@ def test_lazy_outputs_equal_eager_and_pickle(amd, golden_nbr, golden_enr):
     h.compute_pvalues()
     assert h.ns is None and h.pvalues_neg is None
     np.testing.assert_array_equal(h.nes_binary, g['hyp_f64_nes_binary'])
+
+
+# ------------------------------------------------------------------ device buffer pool ----
+def test_buffer_pool_is_bounded_reuses_and_evicts_least_recently_used(amd, monkeypatch):
+    """Released result buffers are kept for reuse up to a share of the device memory; beyond it the sizes
+    unused the longest go back to the driver (a run over differently shaped attribute files must not pile up dead sizes)."""
+    from safepy_amd import backend as be
+    ctx = amd.Context.default(0)
+    ctx.trim()
+    assert ctx._pool_bytes == 0
+    monkeypatch.setattr(be.DeviceBuffer, 'POOL_FRACTION', (8 << 20) / ctx.hbm_bytes)
+    a, b = ctx.alloc(3 << 20), ctx.alloc(4 << 20)
+    b_ptr = b.ptr
+    a.free()
+    b.free()
+    assert ctx._pool_bytes == 7 << 20
+    c = ctx.alloc(2 << 20)
+    c.free()                                   # 9 MiB > 8 MiB: the 3 MiB buffer (released first) is evicted
+    assert sorted(ctx._pool) == [2 << 20, 4 << 20] and ctx._pool_bytes == 6 << 20
+    d = ctx.alloc(4 << 20)
+    assert d.ptr == b_ptr and ctx._pool_bytes == 2 << 20      # same size: the pooled buffer comes back
+    d.free()
+    small = ctx.alloc(1 << 10)
+    small.free()                               # below 1 MiB: never pooled
+    assert ctx._pool_bytes == 6 << 20
+    huge = ctx.alloc(9 << 20)
+    huge.free()                                # larger than the whole pool: straight back to the driver
+    assert ctx._pool_bytes == 6 << 20
+    ctx.trim()
+    assert ctx._pool_bytes == 0 and not ctx._pool

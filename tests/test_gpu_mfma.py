@@ -180,6 +180,90 @@ def test_wide_dynamic_range_declines_to_f64_kernels(amd, ctx):
     nbr.close()
 
 
+@pytest.mark.parametrize('kind,want_slices', [('small-int', 2), ('levels-0-1-2', 2), ('int-1e6', 4), ('dyadic', 4), ('f32-normal', 6),
+                                              ('f64-normal', 6), ('int-2e11', 6)])
+def test_slice_count_follows_the_bits_the_columns_need(amd, ctx, monkeypatch, kind, want_slices):
+    """The matrix-core kernel runs with 2 / 4 / 6 i8 slices by the width of the columns' exact fixed-point image
+    (<= 14 / 30 / 46 bits from the lowest set bit of any value to the top bit of the column maximum); data that fits
+    is summed EXACTLY, so counts and observed sums equal the oracle's bit for bit whatever the slice count."""
+    from safepy_amd import backend as be
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'mfma')
+    rng = np.random.default_rng(61)
+    n, m, nperm, seed = 700, 45, 30, 8
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.08)
+    if kind == 'small-int':
+        b = rng.integers(-100, 101, size=(n, m)).astype(np.float64)
+    elif kind == 'levels-0-1-2':
+        b = rng.integers(0, 3, size=(n, m)).astype(np.float32)
+    elif kind == 'int-1e6':
+        b = rng.integers(-10**6, 10**6, size=(n, m)).astype(np.float64)
+    elif kind == 'dyadic':
+        b = rng.integers(-2**20, 2**20, size=(n, m)).astype(np.float64) / 2**12        # multiples of 2^-12 up to 2^8
+    elif kind == 'f32-normal':
+        b = rng.normal(size=(n, m)).astype(np.float32)
+    elif kind == 'f64-normal':
+        b = rng.normal(size=(n, m))
+    else:
+        b = rng.integers(-2 * 10**11, 2 * 10**11, size=(n, m)).astype(np.float64)
+    b[rng.choice(n, 30, replace=False)] = np.nan
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.08))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma' and be.last_mfma_slices(ctx) == want_slices
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    if kind not in ('f32-normal', 'f64-normal'):                 # exact images: the observed sums are exact integers / dyadics
+        np.testing.assert_array_equal(ns, orc.compute_neighborhood_score(a, b, 'sum'))
+    else:
+        np.testing.assert_allclose(ns, orc.compute_neighborhood_score(a, b, 'sum'), rtol=1e-9, atol=1e-12)
+    nbr.close()
+
+
+@pytest.mark.parametrize('kind', ['log-normal-sigma6', 'mixed-1e-8-to-1e3', 'one-in-500-tiny'])
+def test_columns_the_rounding_grid_would_hurt_go_to_the_f64_kernels(amd, ctx, kind):
+    """Real-valued f64 columns are summed on a grid of 2^-46 of the column maximum.  When more than a thousandth of a
+    column lies 2^20 or more below its maximum, sums made of such values would be compared at the grid's resolution
+    rather than f64's: the call declines the matrix cores and the f64 kernels produce the oracle's counts."""
+    rng = np.random.default_rng(71)
+    n, m, nperm, seed = 400, 12, 25, 2
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    if kind == 'log-normal-sigma6':
+        b = np.exp(6.0 * rng.normal(size=(n, m)))
+    elif kind == 'mixed-1e-8-to-1e3':
+        b = np.where(rng.uniform(size=(n, m)) < 0.3, 1e-8, 1e3) * rng.uniform(0.5, 1.5, size=(n, m))
+    else:
+        b = rng.normal(size=(n, m))
+        b[rng.uniform(size=(n, m)) < 1 / 500] *= 1e-9
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name != 'k_permtest_mfma'
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_moderate_dynamic_range_stays_on_the_matrix_cores_and_equals_the_f64_kernel(amd, ctx, monkeypatch):
+    """Log-normal columns of moderate spread (sigma 1.5: three decades) stay on the matrix cores; their <= / >= counts equal
+    the f64 gather kernel's on the same seeded inputs."""
+    rng = np.random.default_rng(73)
+    n, m, nperm, seed = 900, 40, 40, 6
+    xy = rng.uniform(size=(n, 2))
+    b = np.exp(1.5 * rng.normal(size=(n, m))) * np.where(rng.uniform(size=(n, m)) < 0.5, -1.0, 1.0)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.07))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma'
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'gather')
+    ns_g, cn_g, cp_g, name_g = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name_g.startswith('k_permtest_gather')
+    np.testing.assert_array_equal(cn, cn_g)
+    np.testing.assert_array_equal(cp, cp_g)
+    np.testing.assert_allclose(ns, ns_g, rtol=1e-9, atol=1e-9)          # (sums on the 2^-46 grid of the column maximum)
+    nbr.close()
+
+
 @pytest.mark.parametrize('order,m,dtype', [('F', 205, np.float32), ('C', 205, np.float32), ('C', 208, np.float32),
                                            ('C', 205, np.float64), ('C', 206, np.float64), ('F', 206, np.float64)])
 def test_binary_neighborhood_score_on_matrix_cores(amd, ctx, monkeypatch, order, m, dtype):

@@ -192,6 +192,76 @@ def test_permutation_tables_vs_numpy_stream(amd, ctx, golden_enr):
     perms.close()
 
 
+def test_caller_supplied_permutation_tables(amd, ctx, golden_enr):
+    """safe_perms_create_from_table: the `perm` of safe_extras.py:58 produced elsewhere.  (1) NumPy's own composed tables
+    fed back in reproduce the seeded run; (2) tables from another generator give the counts a direct NumPy evaluation
+    of those tables gives; (3) a row that is not a permutation is refused."""
+    from safepy_amd import backend as be
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    n = a.shape[0]
+    nbr = amd.Neighborhoods.from_dense(ctx, a)
+    for b in (g['b_bin'], g['b_q']):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m = b.shape[1]
+        attr = be.Attributes.from_host(ctx, b)
+        for tables in (orc.permutation_index_table(b, 25, 31),
+                       np.stack([np.random.default_rng(s).permutation(n) for s in range(17)])):
+            perms = be.Permutations.from_table(ctx, tables)
+            assert np.array_equal(perms.read().astype(np.int64), tables)
+            neg, pos = ctx.alloc_f64(n, m), ctx.alloc_f64(n, m)
+            be.permtest_counts(ctx, nbr, attr, perms, 'sum', None, neg.ptr, pos.ptr)
+            cn, cp = neg.download((n, m)), pos.download((n, m))
+            perms.close()
+            b0 = np.nan_to_num(b)
+            obs = a @ b0
+            want_n, want_p = np.zeros((n, m)), np.zeros((n, m))
+            for row in tables:
+                sc = a @ b0[row]
+                close = np.abs(sc - obs) <= 1e-9 * np.maximum(1.0, np.abs(obs))      # (real-valued sums: order of summation)
+                want_n += (sc <= obs) | close
+                want_p += (sc >= obs) | close
+            exact = np.array_equal(b0, np.round(b0))
+            if exact:
+                assert np.array_equal(cn, want_n) and np.array_equal(cp, want_p)
+            else:
+                assert np.abs(cn - want_n).max() <= 1 and np.abs(cp - want_p).max() <= 1 and (cn != want_n).mean() < 1e-3
+        attr.close()
+    cn_seeded, cp_seeded = amd.run_permutations((a, g['b_bin'], 'sum', 25, 31), verbose=False)
+    attr = be.Attributes.from_host(ctx, np.ascontiguousarray(g['b_bin'], dtype=np.float64))
+    perms = be.Permutations.from_table(ctx, orc.permutation_index_table(g['b_bin'], 25, 31))
+    m = g['b_bin'].shape[1]
+    neg, pos = ctx.alloc_f64(n, m), ctx.alloc_f64(n, m)
+    be.permtest_counts(ctx, nbr, attr, perms, 'sum', None, neg.ptr, pos.ptr)
+    assert np.array_equal(neg.download((n, m)), cn_seeded) and np.array_equal(pos.download((n, m)), cp_seeded)
+    perms.close()
+    attr.close()
+    bad = np.tile(np.arange(n, dtype=np.int32), (3, 1))
+    bad[1, 5] = bad[1, 6]
+    with pytest.raises(amd.SafeHipError):
+        be.Permutations.from_table(ctx, bad)
+    nbr.close()
+
+
+def test_rccl_all_gather_through_the_c_abi_one_rank(amd, ctx):
+    """safe_comm_* / safe_allgather_cols on a one-rank communicator (the 2-rank form runs in tests/test_gpu_multirank.py
+    when two devices are visible): the slab arrives in the gathered buffer, on the context's stream."""
+    from safepy_amd import backend as be
+    uid = be.Comm.unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = be.Comm(ctx, 1, 0, uid)
+    src, dst = ctx.alloc(1 << 20), ctx.alloc(1 << 20)
+    data = np.random.default_rng(3).integers(0, 255, size=1 << 20, dtype=np.uint8)
+    src.upload(data)
+    dst.zero()
+    comm.allgather(src.ptr, 1 << 20, dst.ptr)
+    ctx.sync()
+    assert np.array_equal(dst.download((1 << 20,), dtype=np.uint8), data)
+    comm.close()
+    src.free()
+    dst.free()
+
+
 # ------------------------------------------------------------------ module functions ----
 
 def test_compute_neighborhood_score_vs_reference(amd, golden_enr):
