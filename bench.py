@@ -224,17 +224,18 @@ MFMA_I8_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: dense i8 MFMA = 2x the 2.5
 
 
 def mfma_kernel(ctx, np, be):
-    """The matrix-core form of the permutation test (BASELINE.json configs[4] per-rank shape,
-    reduced in attributes and permutations so it finishes in well under a second): N = 20 000
-    uniform layout, euclidean r = 0.1, 1024 quantitative f64 attributes x 128 permutations.
-    Algorithmic work = the block-sparse GEMM the kernel runs: stored 256 x 32 membership blocks
-    x 32-column tiles x 6 i8 slices x (permutations + 1 observed pass) x 2 ops per MAC."""
+    """The matrix-core form of the permutation test at ONE RANK'S SHARE of BASELINE.json configs[4], at its own size:
+    N = 20 000 uniform layout, euclidean r = 0.1, 6250 quantitative f64 attributes x 1000 permutations (the whole
+    compute_pvalues_by_randomization call on HBM-resident inputs, measured -- not extrapolated).
+    Algorithmic work = the block-sparse GEMM the kernel runs: stored 256 x 32 membership blocks x 32-column tiles x
+    i8 slices of the call x (permutations + 1 observed pass) x 2 ops per MAC."""
     from safepy_amd import workloads
-    n, m, nperm = 20000, 1024, 128
+    n, m, nperm = 20000, 6250, 1000
     xy = workloads.uniform_layout(4, n)
     nbr = be.Neighborhoods.euclidean(ctx, xy, 0.1 * (xy[:, 0].max() - xy[:, 0].min()))
     b = workloads.quantitative_attributes(3, n, m)
     attr = be.Attributes.from_host(ctx, b)
+    del b
     outs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
     res = None
     for _ in range(2):                                   # first call builds the block structure
@@ -249,16 +250,18 @@ def mfma_kernel(ctx, np, be):
         res = (name, ms, launches, dt)
     name, ms, launches, dt = res
     blocks = be.block_count(nbr)
-    ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * 6 * (nperm + 1)
+    slices = be.last_mfma_slices(ctx)
+    ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
     tops = ops / (ms * launches * 1e-3) / 1e12
-    out = {name: {'bound': 'mfma', 'workload': 'N=%d x M=%d quantitative f64 attributes x %d permutations, %d members per '
-                                              'neighborhood on average (configs[4] per-rank shape, reduced M and P)'
-                                              % (n, m, nperm, int(nbr.nnz / n)),
+    out = {name: {'bound': 'mfma', 'workload': 'configs[4], one rank of 8: N=%d x M=%d quantitative f64 attributes x %d permutations, '
+                                              '%d members per neighborhood on average' % (n, m, nperm, int(nbr.nnz / n)),
                   'kernel_ms': ms * launches, 'call_ms': 1e3 * dt, 'algorithmic_ops': ops, 'achieved': tops,
-                  'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS,
+                  'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS, 'i8_slices': slices,
                   'membership_blocks_256x32': blocks, 'block_fill': nbr.nnz / (blocks * 256.0 * 32.0),
                   'enrichments_per_s': float(n) * m * nperm / dt,
-                  'config5_rank_share_seconds_est': dt * (6250.0 / m) * (1000.0 / nperm)}}
+                  'config5_rank_share_seconds': dt}}
+    for o in outs:
+        o.free()
     attr.close()
     nbr.close()
     return out

@@ -58,47 +58,67 @@ __global__ __launch_bounds__(256) void k_euclid_bits(const double *__restrict__ 
 
 // --------------------------------------------------------------------------------------
 // K1b: the fused all-pairs kernel in the reference's own output layout: int64 [n,n]
-// membership and/or f64 [n,n] distances.  HBM-write bound: each lane produces two
-// adjacent columns (16 B per output per lane, 1 KiB per wave per row), a block walks a
-// strip of rows whose coordinates are wave-uniform (scalar loads).
+// membership and/or f64 [n,n] distances.  HBM-write bound, so the kernel is shaped by what
+// the memory system likes for pure stores (tools/ubench/store_ceiling.hip: 5.5 TB/s for
+// independent 512 x 32 tiles, up to 6.5 TB/s when few waves per CU sweep one compact window --
+// which a kernel with twelve f64 operations per store cannot keep fed): persistent workgroups,
+// four per CU; workgroup b owns the 512-column chunk b % chunks_per_row of the rows
+// b / chunks_per_row, + R, + 2R, ... -- at any moment they write R whole consecutive rows.  A lane keeps its two columns'
+// coordinates in registers for all its rows (16 B per lane and row, 1 KiB per wave); the row's
+// coordinates are wave-uniform (scalar loads).
 // --------------------------------------------------------------------------------------
-#define K1B_ROWS 32
-__global__ __launch_bounds__(256) void k_euclid_dense(const double *__restrict__ xy, int64_t n, double thr_sq,
-                                                      int64_t *__restrict__ mask, double *__restrict__ dist) {
-    const int64_t j = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 2;
-    const int64_t i0 = static_cast<int64_t>(blockIdx.y) * K1B_ROWS;
+#define K1B_BATCH 8
+// MODE bit 0: membership out, bit 1: distances out; VEC: 16-byte pair stores (even n)
+template <int MODE, bool VEC>
+__global__ __launch_bounds__(256) void k_euclid_dense(const double *__restrict__ xy, int64_t n, double thr_sq, int chunks_per_row,
+                                                      int rows_per_sweep, int64_t *__restrict__ mask, double *__restrict__ dist) {
+    const int chunk = blockIdx.x % chunks_per_row;
+    const int64_t j = (static_cast<int64_t>(chunk) * 256 + threadIdx.x) * 2;
     if (j >= n) return;
     const bool two = (j + 1 < n);
     const double xa = xy[2 * j], ya = xy[2 * j + 1];
     const double xb = two ? xy[2 * j + 2] : 0.0, yb = two ? xy[2 * j + 3] : 0.0;
-    const int64_t i1 = i0 + K1B_ROWS < n ? i0 + K1B_ROWS : n;
-    const bool vec_ok = two && ((n & 1) == 0);            // 16-B aligned pair stores need even n
-    for (int64_t i = i0; i < i1; ++i) {
-        const double xi = xy[2 * i], yi = xy[2 * i + 1];  // wave-uniform
-        double dxa = xi - xa, dya = yi - ya;
-        double dxb = xi - xb, dyb = yi - yb;
-        const double sa = dxa * dxa + dya * dya;
+    auto row = [&](int64_t i, double xi, double yi) __attribute__((always_inline)) {
+        const double dxa = xi - xa, dya = yi - ya;
+        const double dxb = xi - xb, dyb = yi - yb;
+        const double sa = dxa * dxa + dya * dya;          // no FMA (-ffp-contract=off)
         const double sb = dxb * dxb + dyb * dyb;
         const int64_t o = i * n + j;
-        if (mask) {
+        if (MODE & 1) {
             const int64_t ma = sa < thr_sq, mb = sb < thr_sq;
-            if (vec_ok) {
+            if (VEC) {
                 *reinterpret_cast<longlong2 *>(mask + o) = make_longlong2(ma, mb);
             } else {
                 mask[o] = ma;
                 if (two) mask[o + 1] = mb;
             }
         }
-        if (dist) {
+        if (MODE & 2) {
             const double da = sqrt(sa), db = sqrt(sb);
-            if (vec_ok) {
+            if (VEC) {
                 *reinterpret_cast<double2 *>(dist + o) = make_double2(da, db);
             } else {
                 dist[o] = da;
                 if (two) dist[o + 1] = db;
             }
         }
+    };
+    // rows in batches of K1B_BATCH: all their (wave-uniform) coordinates are requested before the first is used, so the
+    // scalar-load latency is paid once per batch and the stores of a batch go out back to back
+    const int64_t step = static_cast<int64_t>(K1B_BATCH) * rows_per_sweep;
+    int64_t i0 = blockIdx.x / chunks_per_row;
+    for (; i0 + step - rows_per_sweep < n; i0 += step) {   // whole batches
+        double xi[K1B_BATCH], yi[K1B_BATCH];
+#pragma unroll
+        for (int u = 0; u < K1B_BATCH; ++u) {
+            const int64_t i = i0 + static_cast<int64_t>(u) * rows_per_sweep;
+            xi[u] = xy[2 * i];
+            yi[u] = xy[2 * i + 1];
+        }
+#pragma unroll
+        for (int u = 0; u < K1B_BATCH; ++u) row(i0 + static_cast<int64_t>(u) * rows_per_sweep, xi[u], yi[u]);
     }
+    for (; i0 < n; i0 += rows_per_sweep) row(i0, xy[2 * i0], xy[2 * i0 + 1]);
 }
 
 __global__ void k_edge_lengths(const double *__restrict__ xy, int64_t n_edges, const int32_t *__restrict__ eu,
@@ -530,8 +550,26 @@ int safe_euclidean_dense_dev(safe_ctx *ctx, const double *xy_dev, int64_t n, dou
     SAFE_REQUIRE(ctx && xy_dev && n >= 1, "safe_euclidean_dense_dev: bad argument");
     SAFE_REQUIRE(mask_out_dev || dist_out_dev, "safe_euclidean_dense_dev: no output requested");
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    hipLaunchKernelGGL(k_euclid_dense, dim3(ceil_div(n, 512), ceil_div(n, K1B_ROWS)), dim3(256), 0, ctx->stream,
-                       xy_dev, n, squared_threshold(nr), mask_out_dev, dist_out_dev);
+    int64_t wgs = 4 * static_cast<int64_t>(ctx->num_cu);   // resident workgroups (16 waves per CU hide the scalar-load and f64 latency); they sweep whole rows together
+    if (const char *e = getenv("SAFE_HIP_EUCLID_GRID")) wgs = std::max<int64_t>(1, atoll(e));
+    const int64_t chunks_per_row = ceil_div(n, 512);
+    const int64_t rows_per_sweep = std::max<int64_t>(1, std::min<int64_t>(n, wgs / chunks_per_row));
+    const int mode = (mask_out_dev ? 1 : 0) | (dist_out_dev ? 2 : 0);
+    const bool vec = (n & 1) == 0;                         // 16-byte pair stores need even n (row starts stay 16-byte aligned)
+    const dim3 grid(chunks_per_row * rows_per_sweep), block(256);
+    const double thr_sq = squared_threshold(nr);
+    const int cpr = static_cast<int>(chunks_per_row), rps = static_cast<int>(rows_per_sweep);
+#define LAUNCH_K1B(M, V) hipLaunchKernelGGL((k_euclid_dense<M, V>), grid, block, 0, ctx->stream, xy_dev, n, thr_sq, cpr, rps, mask_out_dev, dist_out_dev)
+    if (vec) {
+        if (mode == 1) LAUNCH_K1B(1, true);
+        else if (mode == 2) LAUNCH_K1B(2, true);
+        else LAUNCH_K1B(3, true);
+    } else {
+        if (mode == 1) LAUNCH_K1B(1, false);
+        else if (mode == 2) LAUNCH_K1B(2, false);
+        else LAUNCH_K1B(3, false);
+    }
+#undef LAUNCH_K1B
     SAFE_HIP_CHECK(hipGetLastError());
     return SAFE_OK;
 }
