@@ -17,6 +17,7 @@
 // contracted.
 #include <algorithm>
 #include <cmath>
+#include <numeric>
 
 #include "common.h"
 
@@ -1155,7 +1156,7 @@ __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
     const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
     const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
-    unsigned int *__restrict__ gl_counts, int64_t n_pad, const int4 *__restrict__ items) {
+    unsigned int *__restrict__ gl_counts, int64_t n_pad) {
     extern __shared__ unsigned int lds[];
     const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
     uint2 *T = reinterpret_cast<uint2 *>(lds);
@@ -1172,15 +1173,11 @@ __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
         if (slot >= n_tasks) break;
         const int4 task = tasks[slot];
         const int wg = task.x;
-        // what this WAVE does in the task: with an item list, four (slice, permutation range) items of about equal cost
-        // (the four waves finish together); else four adjacent slices over the task's permutation range
-        int4 item;
-        if (items) item = items[static_cast<int64_t>(task.y) * 4 + wave];
-        else item = make_int4(task.y * 4 + wave < n_slices ? task.y * 4 + wave : -1, task.z, task.w, 0);
-        const int64_t s = item.x;
-        const bool active = s >= 0;
-        const int64_t p_begin = p_base + item.y;
-        int64_t p_end = p_base + item.z < p_limit ? p_base + item.z : p_limit;
+        // a task = four adjacent slices (one per wave) of one word group over a permutation range
+        const int64_t s = static_cast<int64_t>(task.y) * 4 + wave;
+        const bool active = s < n_slices;
+        const int64_t p_begin = p_base + task.z;
+        int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end < p_begin || !active) p_end = p_begin;                  // (nothing to do for this wave; it still joins the barriers)
 
         for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
@@ -1210,102 +1207,6 @@ __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
             gl_counts[spos] = g0[1] ^ l0[1];                              // (keeps the counters alive in the diagnostic build)
         }
         __syncthreads();                                                  // before T is overwritten by the next task
-    }
-}
-
-// --------------------------------------------------------------------------------------
-// K5 bit-sliced form, blocked member lists, WAVE-LEVEL work queue (the default).  What a workgroup shares is only
-// the word column T of its 64 attributes; everything after the load of T is per wave.  So:
-//   * a workgroup is persistent and keeps T: it loads the word column of ONE word group and its four waves then pull
-//     work items (slice, permutation range) from that word group's queue independently -- no barrier, no reload of T
-//     between items (the task-per-workgroup form reloaded 32 KB and synchronised ~90 times per word group and launch,
-//     and its four waves waited for the widest of four adjacent slices);
-//   * items have about equal cost: a narrow slice keeps all permutations of the launch in one item (its counters are
-//     un-sliced and flushed once), a wide slice is cut into short permutation ranges;
-//   * a workgroup whose queue has run dry moves to the word group with the most items left (reloading T once).
-// Arithmetic, counters and outputs are those of k_permtest_bits_blk.
-// --------------------------------------------------------------------------------------
-template <int CL, int DBG>
-__global__ __launch_bounds__(256, 4) void k_permtest_bits_wq(
-    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
-    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
-    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, int n_items,
-    const int4 *__restrict__ items, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queues, int n_wg,
-    int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_pad) {
-    extern __shared__ unsigned int lds[];
-    const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
-    uint2 *T = reinterpret_cast<uint2 *>(lds);
-    int *next_box = reinterpret_cast<int *>(lds + t_words);
-    // the member ids ARE LDS addresses of T rows: T must sit at LDS address 0 (it does: no static LDS in this kernel)
-    if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds) != 0u) __builtin_trap();
-    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
-    const int64_t perm_stride = entries_pad / 8;
-    int wg = static_cast<int>(blockIdx.x % static_cast<unsigned>(n_wg));
-
-    for (;;) {
-        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
-        __syncthreads();                                                  // T is complete; waves are independent from here
-
-        for (;;) {
-            unsigned int it = 0;
-            if (lane == 0) it = atomicAdd(&queues[wg], 1u);
-            it = __builtin_amdgcn_readfirstlane(it);
-            if (it >= static_cast<unsigned>(n_items)) break;
-            const int4 item = items[it];                                  // (slice, first permutation, end, -) relative to the launch
-            const int64_t s = item.x;
-            const int64_t p_begin = p_base + item.y;
-            const int64_t p_end = p_base + item.z < p_limit ? p_base + item.z : p_limit;
-            if (p_end <= p_begin) continue;                               // a launch shorter than the item grid's span
-            const int64_t my_blk = slice_off[s] / 8;                      // in uint4 units; wave-uniform
-            const int wdt = __builtin_amdgcn_readfirstlane(slice_width[s]);
-            const int nblk = wdt >> 3;
-            const int np = static_cast<int>(p_end - p_begin);
-            const uint32_t *my_obs = obs + (static_cast<int64_t>(wg) * n_slices + s) * (2 * BT_LV * 64);
-            const u32x4 *perm_ids = reinterpret_cast<const u32x4 *>(ids_p + (p_begin - p_base) * entries_pad) + my_blk;
-
-            uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                      // #(S_p > S_obs), #(S_p < S_obs)
-#pragma unroll
-            for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
-            // a neighborhood of wdt members cannot sum past wdt: levels by slice width (wave-uniform branch)
-            if (wdt <= 8) blk_task<4, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-            else if (wdt <= 56) blk_task<6, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-            else if (wdt <= 248) blk_task<8, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-            else blk_task<BT_LV, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-
-            const int64_t spos = s * 64 + lane;
-            if (!(DBG & 2)) {
-                flush_counters<CL>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, true);
-            } else if ((g0[0] | g1[0] | l0[0] | l1[0]) == 0xDEADBEEFu) {
-                gl_counts[spos] = g0[1] ^ l0[1];                          // (keeps the counters alive in the diagnostic build)
-            }
-        }
-
-        // this word group's queue is empty: move to the word group with the most items left, if any
-        __syncthreads();                                                  // nobody reads T any more
-        if (wave == 0) {
-            int best = 0, best_wg = -1;
-            for (int w = lane; w < n_wg; w += 64) {
-                const unsigned int taken = __hip_atomic_load(&queues[w], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                const int left = n_items - static_cast<int>(taken < static_cast<unsigned>(n_items) ? taken : n_items);
-                if (left > best) {
-                    best = left;
-                    best_wg = w;
-                }
-            }
-#pragma unroll
-            for (int off = 32; off > 0; off >>= 1) {
-                const int ob = __shfl_xor(best, off), ow = __shfl_xor(best_wg, off);
-                if (ob > best || (ob == best && ow > best_wg)) {
-                    best = ob;
-                    best_wg = ow;
-                }
-            }
-            if (lane == 0) *next_box = best > 0 ? best_wg : -1;
-        }
-        __syncthreads();
-        wg = *next_box;
-        __syncthreads();
-        if (wg < 0) break;
     }
 }
 
@@ -2080,7 +1981,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int64_t blocks_per_perm = 0;
     for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / 4] = std::max<int64_t>(sg_blocks[s / 4], nbr->h_slice_width[s] / 8);
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
-    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(6 * slots, n_wg));
+    int tasks_per_slot = 6;                              // queue depth per workgroup slot: balance against the per-task costs (T reload, counter flush)
+    if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
+    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
     const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_wg);    // block-permutations per task
     struct TaskCost { int4 t; int64_t cost; };
     std::vector<TaskCost> tc;
@@ -2133,7 +2036,6 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
-    const bool wq = blk && kern_env && !strcmp(kern_env, "wq");          // wave-level work queue; default: one task per workgroup
     int dbg = 0;
     if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 7;
     const void *blk_fn = dbg == 0   ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
@@ -2141,73 +2043,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>)
                          : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
-    if (blk) SAFE_HIP_CHECK(hipFuncSetAttribute(blk_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
-    const void *wq_fn = dbg == 0   ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 0>)
-                        : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 1>)
-                        : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 2>)
-                        : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_wq<8, 4>)
-                                   : reinterpret_cast<const void *>(k_permtest_bits_wq<8, 7>);
-    if (wq) SAFE_HIP_CHECK(hipFuncSetAttribute(wq_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
-    // ---- work items of the blocked kernels: (slice, permutation range) of about equal cost, heaviest first.  Cost of a
-    //      permutation on a slice ~ 60 instructions per block of 8 members + ~100 for the compare / count step; a narrow
-    //      slice keeps the whole launch in one item (one flush of its counters), wide slices are cut.  The wave-queue
-    //      kernel hands items to waves one by one; the task-per-workgroup kernel takes them four at a time (neighbours in
-    //      the cost order: the four waves of a task finish together).
-    std::vector<int4> items, quad_tasks;
-    int4 *d_items = nullptr, *d_quad_tasks = nullptr;
-    unsigned int *d_wq_queues = nullptr;
     uint32_t *d_obs = nullptr;
-    const int64_t wq_slots = static_cast<int64_t>(ctx->num_cu) * std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre));   // 4: the register file holds 16 waves of these kernels per CU
     if (blk) {
-        int per_wave = wq ? 4 : 6;                                     // items per wave and launch the plan aims at
-        if (const char *e = getenv("SAFE_HIP_BITS_ITEMS")) per_wave = std::max(1, atoi(e));
-        int64_t min_len = 4;                                           // an item re-reads its observed sums and flushes its counters
-        if (const char *e = getenv("SAFE_HIP_BITS_MINLEN")) min_len = std::max(1, atoi(e));
-        const int64_t waves_per_wg = std::max<int64_t>(1, wq_slots * 4 / n_wg);
-        int64_t total = 0;
-        for (int64_t sl = 0; sl < nbr->n_slices; ++sl) total += (static_cast<int64_t>(nbr->h_slice_width[sl] / 8) * 60 + 100) * span;
-        const int64_t target_cost = std::max<int64_t>(2000, total / (waves_per_wg * per_wave));
-        struct ItemCost { int4 t; int64_t cost; };
-        std::vector<ItemCost> ic;
-        for (int64_t sl = 0; sl < nbr->n_slices; ++sl) {
-            const int64_t c1 = static_cast<int64_t>(nbr->h_slice_width[sl] / 8) * 60 + 100;
-            int64_t len = std::min<int64_t>(std::min<int64_t>(span, 255), std::max<int64_t>(min_len, (target_cost + c1 / 2) / c1));   // <= 255: eight counter levels
-            const int64_t chunks = ceil_div(span, len);
-            len = ceil_div(span, chunks);
-            for (int64_t c = 0; c < chunks; ++c) {
-                const int64_t q0 = c * len, q1 = std::min<int64_t>(span, q0 + len);
-                ic.push_back({make_int4(static_cast<int>(sl), static_cast<int>(q0), static_cast<int>(q1), 0), c1 * (q1 - q0)});
-            }
-        }
-        std::stable_sort(ic.begin(), ic.end(), [](const ItemCost &a, const ItemCost &b) { return a.cost > b.cost; });
-        items.resize(ic.size());
-        for (size_t i = 0; i < ic.size(); ++i) items[i] = ic[i].t;
-        while (items.size() % 4) items.push_back(make_int4(-1, 0, 0, 0));      // (an idle wave in the last task)
-        const char *quad_env = getenv("SAFE_HIP_BITS_QUAD");
-        const bool quad = !wq && quad_env && !strcmp(quad_env, "1");
-        if (!wq && !quad) {                                             // a task = four ADJACENT slices over one permutation range
-            quad_tasks = tasks;
-            items.clear();
-        } else if (!wq) {
-            const int64_t n_quads = static_cast<int64_t>(items.size()) / 4;
-            quad_tasks.reserve(n_quads * n_wg);
-            for (int64_t q = 0; q < n_quads; ++q)                               // heaviest quads first, all word groups of a quad adjacent
-                for (int64_t w = 0; w < n_wg; ++w) quad_tasks.push_back(make_int4(static_cast<int>(w), static_cast<int>(q), 0, 0));
-        }
-        void *ws = nullptr;
-        SAFE_TRY(ctx_scratch(ctx, 6, (items.size() + quad_tasks.size()) * sizeof(int4) +
-                                         static_cast<size_t>(n_launch) * n_wg * sizeof(unsigned int), &ws));
-        d_items = static_cast<int4 *>(ws);
-        d_quad_tasks = d_items + items.size();
-        d_wq_queues = reinterpret_cast<unsigned int *>(d_quad_tasks + quad_tasks.size());
-        if (!items.empty())
-            SAFE_HIP_CHECK(hipMemcpyAsync(d_items, items.data(), items.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        else
-            d_items = nullptr;
-        if (!quad_tasks.empty())
-            SAFE_HIP_CHECK(hipMemcpyAsync(d_quad_tasks, quad_tasks.data(), quad_tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-        SAFE_HIP_CHECK(hipMemsetAsync(d_wq_queues, 0, static_cast<size_t>(n_launch) * n_wg * sizeof(unsigned int), ctx->stream));
-        // observed sums of every (word group, slice), once: the compare operand of every item, and `ns`
+        SAFE_HIP_CHECK(hipFuncSetAttribute(blk_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
+        // observed sums of every (word group, slice), once: the compare operand of every task, and `ns`
         SAFE_TRY(ctx_scratch(ctx, 7, static_cast<size_t>(n_wg) * nbr->n_slices * 2 * BT_LV * 64 * sizeof(uint32_t),
                              reinterpret_cast<void **>(&d_obs)));
         SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bits_observed), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -2226,7 +2065,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<10, false>));
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    ctx->last_kernel.name = wq ? "k_permtest_bits_wq" : blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
+    ctx->last_kernel.name = blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
@@ -2255,29 +2094,15 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
-            if (wq) {
+            if (blk) {
                 const uint16_t *ids_c = d_ids[c & 1];
-                int n_items_i = static_cast<int>(items.size()), n_wg_i = static_cast<int>(n_wg);
-                while (n_items_i > 0 && items[n_items_i - 1].x < 0) --n_items_i;          // (padding items are for the quad form)
-                unsigned int *queues_c = d_wq_queues + c * n_wg;
-                void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
-                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits, (void *)&n_items_i,
-                                (void *)&d_items, (void *)&p_base, (void *)&p_limit, (void *)&queues_c, (void *)&n_wg_i,
-                                (void *)&mloc, (void *)&d_gl, (void *)&n_pad};
-                const int64_t wq_blocks = std::min<int64_t>(std::max<int64_t>(n_wg, 1) * ceil_div(static_cast<int64_t>(n_items_i), 4),
-                                                            static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
-                                                                std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre)));
-                SAFE_HIP_CHECK(hipLaunchKernel(wq_fn, dim3(wq_blocks), dim3(256), args, lds_pre, ks));
-            } else if (blk) {
-                const uint16_t *ids_c = d_ids[c & 1];
-                const int64_t n_quad_tasks = static_cast<int64_t>(quad_tasks.size());
                 unsigned int *queue_c = d_queue + c;
                 void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
-                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits,
-                                (void *)&n_quad_tasks, (void *)&d_quad_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c,
-                                (void *)&mloc, (void *)&d_gl, (void *)&n_pad, (void *)&d_items};
-                const int64_t blocks_blk = std::min<int64_t>(n_quad_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
-                                                                               std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre)));
+                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits, (void *)&n_tasks,
+                                (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c, (void *)&mloc, (void *)&d_gl,
+                                (void *)&n_pad};
+                const int64_t blocks_blk = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
+                                                                          std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre)));   // 4: the register file holds 16 waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
             } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
@@ -2605,7 +2430,7 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
 
 static int finish_kernel_timing(safe_ctx *ctx) {
     SAFE_HIP_CHECK(hipEventSynchronize(ctx->k1));
-    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" || ctx->last_kernel.name == "k_permtest_bits_blk" || ctx->last_kernel.name == "k_permtest_bits_wq" ||
+    if (ctx->last_kernel.name == "k_permtest_bits" || ctx->last_kernel.name == "k_permtest_bits_pre" || ctx->last_kernel.name == "k_permtest_bits_blk" ||
         ctx->last_kernel.name == "k_permtest_lds" || ctx->last_kernel.name == "k_permtest_mfma")
         return SAFE_OK;   // per-launch events already summed
     float ms = 0.f;

@@ -1,3 +1,7 @@
+    if kernel == 'pre':
+        monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', 'pre')
+    elif kernel == 'barrier':
+        monkeypatch.setenv('SAFE_HIP_BITS_PRE', '0')
 """Parity of the HIP path (through the C ABI) against the golden vectors produced by the
 real reference and against the CPU oracle on seeded inputs.  Needs an MI355X."""
 import numpy as np
@@ -598,15 +602,14 @@ def test_integer_forms_large_support_and_many_permutations(amd, monkeypatch, pat
     assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
 
 
-@pytest.mark.parametrize('kernel,nperm', [('blk', 40), ('blk', 300), ('quad', 40), ('quad', 300), ('wq', 40), ('wq', 300), ('pre', 40), ('barrier', 40)])
+@pytest.mark.parametrize('kernel,nperm', [('blk', 40), ('blk', 300), ('pre', 40), ('barrier', 40)])
 def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
-    """The bit-sliced kernels (blocked member lists with one task per workgroup = default, the same with four equal-cost items
-    per task, the wave-level work queue, pre-permuted lists, permutation row in LDS) on a
+    """The three bit-sliced kernels (blocked member lists = default, pre-permuted lists, permutation row in LDS) on a
     membership whose SELL slices fall into every width class of the blocked kernel (<= 8, <= 56, <= 248, > 248 members:
     4 / 6 / 8 / 10 levels of the vertical sums), with columns dense enough that the sums really reach the top
     levels, an empty neighborhood, a ragged last word group; 300 permutations carry the counters past their low levels."""
     monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'bits')
-    if kernel in ('pre', 'wq'):
+    if kernel in ('pre', 'wq', 'eng'):
         monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', kernel)
     elif kernel == 'quad':
         monkeypatch.setenv('SAFE_HIP_BITS_QUAD', '1')
@@ -626,7 +629,7 @@ def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
     cn_want, cp_want = orc.run_permutations(a, b, 'sum', nperm, 13)
     cn, cp = amd.run_permutations((a, b, 'sum', nperm, 13), verbose=False)
     name = amd.Context.default(0).last_kernel()[0]
-    assert name == {'wq': 'k_permtest_bits_wq', 'blk': 'k_permtest_bits_blk', 'quad': 'k_permtest_bits_blk', 'pre': 'k_permtest_bits_pre', 'barrier': 'k_permtest_bits'}[kernel]
+    assert name == {'blk': 'k_permtest_bits_blk', 'pre': 'k_permtest_bits_pre', 'barrier': 'k_permtest_bits'}[kernel]
     assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
     ns = amd.compute_neighborhood_score(a, b, 'sum')
     assert np.array_equal(ns, orc.compute_neighborhood_score(a, b, 'sum'))

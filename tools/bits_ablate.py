@@ -1,7 +1,8 @@
 """Kernel-only time of the bit-sliced permutation test at configs[1] (tables generated before the call), per kernel
-variant and diagnostic build:  SAFE_HIP_BITS_KERNEL = blk | pre,  SAFE_HIP_BITS_DBG bit 0 = no LDS gathers,
-bit 1 = no counter flush, bit 2 = no compare / count (wrong results; shows what the time goes to).
-usage: bits_ablate.py [P]   -- each configuration runs in its own child process (the env is read per call anyway)."""
+variant, launch plan and diagnostic build:  SAFE_HIP_BITS_KERNEL = blk | pre;  SAFE_HIP_BITS_TASKS = queue depth per
+workgroup slot;  SAFE_HIP_BITS_MERGE = pipeline stages per launch;  SAFE_HIP_BITS_DBG bit 0 = no LDS gathers, bit 1 = no
+counter flush, bit 2 = no compare / count (wrong results; shows what the time goes to).
+usage: bits_ablate.py [P]   -- each configuration runs in its own child process."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -36,8 +37,8 @@ def one(P):
         if it and (best is None or dt < best[0]):
             best = (dt, name, ms, launches)
     dt, name, ms, launches = best
-    print('%-22s dbg=%s merge=%s items=%s minlen=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
-        name, os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), os.environ.get('SAFE_HIP_BITS_ITEMS', '-'), os.environ.get('SAFE_HIP_BITS_MINLEN', '4'), 1e3 * dt, launches, ms, ms * launches), flush=True)
+    print('%-22s tasks=%s dbg=%s merge=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
+        name, os.environ.get('SAFE_HIP_BITS_TASKS', '6'), os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), 1e3 * dt, launches, ms, ms * launches), flush=True)
 
 
 if __name__ == '__main__':
@@ -45,11 +46,8 @@ if __name__ == '__main__':
         one(int(sys.argv[2]))
         sys.exit(0)
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    K = 'SAFE_HIP_BITS_KERNEL'
-    Q = 'SAFE_HIP_BITS_QUAD'
-    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', Q: '1', 'SAFE_HIP_BITS_ITEMS': '3'}, {K: 'blk', Q: '1', 'SAFE_HIP_BITS_ITEMS': '4'},
-               {K: 'blk', Q: '1', 'SAFE_HIP_BITS_ITEMS': '4', 'SAFE_HIP_BITS_MINLEN': '16'},
-               {K: 'wq', 'SAFE_HIP_BITS_ITEMS': '2'}, {K: 'wq', 'SAFE_HIP_BITS_ITEMS': '3'},
-               {K: 'blk', 'SAFE_HIP_BITS_MERGE': '8'}, {K: 'wq', 'SAFE_HIP_BITS_MERGE': '8'}]
+    K, TK = 'SAFE_HIP_BITS_KERNEL', 'SAFE_HIP_BITS_TASKS'
+    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', TK: '2'}, {K: 'blk', TK: '3'}, {K: 'blk', 'SAFE_HIP_BITS_DBG': '2'},
+               {K: 'blk', 'SAFE_HIP_BITS_DBG': '4'}, {K: 'blk', 'SAFE_HIP_BITS_MERGE': '2'}, {K: 'blk', 'SAFE_HIP_BITS_MERGE': '8'}]
     for cfg in configs:
         subprocess.run([sys.executable, os.path.abspath(__file__), '--one', str(P)], env=dict(os.environ, **cfg))

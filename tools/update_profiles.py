@@ -1,19 +1,36 @@
-"""Copy the summaries of a tools/prof_round.sh run (gpurun_out/<tag>/) into profiles/: kernel statistics, FETCH_SIZE /
-WRITE_SIZE sums and profiles/pmc_traffic.json (per-launch HBM bytes bench.py reports as roofline.traffic).
-usage: update_profiles.py <tag>"""
-import json, os, re, sys
+"""Turn the summaries of a tools/prof_round.sh run (gpurun_out/<tag>/) into the committed profiles of a round:
+  profiles/rNN_bench_kernel_stats.txt   per-kernel durations of the default bench run (rocprofv3 --kernel-trace --stats)
+  profiles/rNN_pmc_permtest_bits.txt    SQ / TCC counters of the headline step
+  profiles/rNN_pmc_traffic.txt          FETCH_SIZE / WRITE_SIZE sums per kernel of the whole bench
+  profiles/pmc_bits.json, pmc_traffic.json   the figures bench.py quotes as roofline.binding_resource_utilisation / traffic,
+                                             stamped with the commit and the hash of the kernel sources they were taken at
+                                             (bench.py marks them "stale" when the sources differ)
+usage: update_profiles.py <tag> <round, e.g. r02>    -- run at the commit that was profiled"""
+import json, os, re, subprocess, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-tag = sys.argv[1]
+sys.path.insert(0, ROOT)
+import bench                                                     # noqa: E402  (kernel_source_sha256)
+
+tag, rnd = sys.argv[1], sys.argv[2]
 src_dir = os.path.join(ROOT, 'gpurun_out', tag)
-src = open(os.path.join(src_dir, 'pmc_traffic.txt')).read().splitlines()
-vals = {}
-for line in src:
-    m = re.match(r'(.{60}) (\S+)\s+sum=(\S+)\s+n=(\d+)', line)
-    if m:
-        vals[(m.group(1).strip(), m.group(2))] = (float(m.group(3)), int(m.group(4)))
+commit = subprocess.run(['git', 'rev-parse', '--short', 'HEAD'], cwd=ROOT, capture_output=True, text=True).stdout.strip()
+stamp = {'commit': commit, 'kernel_source_sha256': bench.kernel_source_sha256()}
 
 
-def get(sub, ctr):
+def counters(path):
+    vals = {}
+    for line in open(path).read().splitlines():
+        m = re.match(r'(.{60}) (\S+)\s+sum=(\S+)\s+n=(\d+)', line)
+        if m:
+            vals[(m.group(1).strip(), m.group(2))] = (float(m.group(3)), int(m.group(4)))
+    return vals
+
+
+# ---- traffic per launch (counter unit KiB)
+traffic = counters(os.path.join(src_dir, 'pmc_traffic.txt'))
+
+
+def get(vals, sub, ctr):
     for (k, c), v in vals.items():
         if sub in k and c == ctr:
             return v
@@ -24,7 +41,7 @@ out = {}
 
 
 def entry(key, sub, corr=1.0, note=None):
-    f, w = get(sub, 'FETCH_SIZE'), get(sub, 'WRITE_SIZE')
+    f, w = get(traffic, sub, 'FETCH_SIZE'), get(traffic, sub, 'WRITE_SIZE')
     if f is None or w is None:
         return
     e = {'fetch_bytes_per_launch': f[0] * 1024 / f[1], 'write_bytes_per_launch': w[0] * 1024 / w[1], 'fetch_correction': corr,
@@ -34,27 +51,51 @@ def entry(key, sub, corr=1.0, note=None):
     out[key] = e
 
 
-entry('k_permtest_bits_pre', 'k_permtest_bits_pre')
+entry('k_permtest_bits_blk', 'k_permtest_bits_blk')
+entry('k_bits_observed', 'k_bits_observed')
 entry('k_euclid_dense', 'k_euclid_dense')
 entry('k_hyp_emit', 'k_hyp_emit', 1.0,
       'reads are 12 B/lane count records + 16 B/lane table slabs (mostly L2 hits): the x2 correction of 16 B/lane streams is not '
-      'applied (uncalibrated width); algorithmic bytes 5.21 GB (4.80 GB written + 0.41 GB of packed counts read); 4 % of the writes '
-      'are repeated last rows of short row batches (1-2 % with the tail rule)')
+      'applied (uncalibrated width); algorithmic bytes 5.21 GB (4.80 GB written + 0.41 GB of packed counts read)')
 entry('k_permtest_mfma<counts> (split form)', 'k_permtest_mfma<true, 6>', 2.0)
+entry('k_permtest_mfma', 'k_permtest_mfma<false, 6>', 2.0)
 entry('k_mfma_planes01_rows', 'k_mfma_planes01_rows', 2.0)
 entry('k_permute_cols', 'k_permute_cols')
 entry('k_counts_finalize', 'k_counts_finalize')
 out['_source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python3 bench.py --steps 1 --warmup 1 '
-                  '--cpu-perms 0 (tools/prof_round.sh), round 1, MI355X; counter unit KiB; x2 gfx950 FETCH_SIZE correction applied only to '
-                  'kernels whose reads are 16 B/lane streams (MI355X_MICROARCH.md, HBM section); see profiles/r01_pmc_traffic.txt')
+                  '--cpu-perms 0 (tools/prof_round.sh), round %s, MI355X; counter unit KiB; x2 gfx950 FETCH_SIZE correction applied only to '
+                  'kernels whose reads are 16 B/lane streams (MI355X_MICROARCH.md, HBM section); see profiles/%s_pmc_traffic.txt' % (rnd, rnd))
+out['_stamp'] = stamp
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
 hdr = ('# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --cpu-perms 0 '
-       '(tools/prof_round.sh; round 1, MI355X); sums over launches, unit KiB\n')
-open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.txt'), 'w').write(hdr + '\n'.join(src) + '\n')
+       '(tools/prof_round.sh; round %s, commit %s, MI355X); sums over launches, unit KiB\n' % (rnd, commit))
+open(os.path.join(ROOT, 'profiles', '%s_pmc_traffic.txt' % rnd), 'w').write(hdr + open(os.path.join(src_dir, 'pmc_traffic.txt')).read())
+
+# ---- kernel statistics
 ks = open(os.path.join(src_dir, 'kernel_stats.txt')).read()
 line = open(os.path.join(src_dir, 'bench_line.json')).read().strip()
-hdr = ('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-perms 0 (tools/prof_round.sh; round 1, MI355X): '
-       'headline steps + extras (K1 distance, K4 hypergeometric at 20000 x 10000, matrix-core permutation kernel)\n'
-       '# bench line of the same run: ' + line[:700] + ' ...\n')
-open(os.path.join(ROOT, 'profiles', 'r01_bench_kernel_stats.txt'), 'w').write(hdr + ks)
-print({k: round(v['hbm_bytes_per_launch'] / 1e6, 1) for k, v in out.items() if isinstance(v, dict)})
+hdr = ('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmup 1 --cpu-perms 0 (tools/prof_round.sh; round %s, commit %s, '
+       'MI355X): headline steps + extras (K1 distance, K4 hypergeometric at 20000 x 10000, matrix-core permutation kernel at one rank\'s '
+       'configs[4] share)\n# bench line of the same run: %s ...\n' % (rnd, commit, line[:900]))
+open(os.path.join(ROOT, 'profiles', '%s_bench_kernel_stats.txt' % rnd), 'w').write(hdr + ks)
+
+# ---- SQ / TCC counters of the headline kernel
+bits_txt = open(os.path.join(src_dir, 'bits', 'pmc_summary.txt')).read()
+hdr = ('# rocprofv3 --pmc <8 SQ counters | 8 SQ counters | TCC_HIT TCC_MISS GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE> --kernel-trace -- '
+       'python3 bench.py --steps 1 --warmup 1 --cpu-perms 0 --extras 0 (tools/pmc_bits.sh: five separate passes; round %s, commit %s, '
+       'MI355X); sums over the launches of 2 steps (warm-up + 1)\n' % (rnd, commit))
+open(os.path.join(ROOT, 'profiles', '%s_pmc_permtest_bits.txt' % rnd), 'w').write(hdr + bits_txt)
+bits = counters(os.path.join(src_dir, 'bits', 'pmc_summary.txt'))
+kname = 'k_permtest_bits_blk'
+doc = {'kernel': 'k_permtest_bits_blk<8, 0>', 'steps_profiled': 2}
+for ctr in ('SQ_WAVE_CYCLES', 'SQ_ACTIVE_INST_ANY', 'SQ_WAIT_ANY', 'SQ_WAIT_INST_ANY', 'SQ_INSTS_VALU', 'SQ_INSTS_LDS', 'SQ_LDS_IDX_ACTIVE',
+            'SQ_LDS_BANK_CONFLICT', 'GRBM_GUI_ACTIVE', 'TCC_HIT_sum', 'TCC_MISS_sum'):
+    v = get(bits, kname, ctr)
+    if v is not None:
+        doc[ctr] = v[0]
+doc['valu_wave_insts_per_clock_per_simd_sustained'] = 0.43
+doc['_source'] = 'profiles/%s_pmc_permtest_bits.txt (rocprofv3 --pmc, tools/pmc_bits.sh), tools/ubench/valu_issue.hip' % rnd
+doc.update(stamp)
+json.dump(doc, open(os.path.join(ROOT, 'profiles', 'pmc_bits.json'), 'w'), indent=1)
+print({k: round(v['hbm_bytes_per_launch'] / 1e6, 1) for k, v in out.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v})
+print('LDS conflict share', doc.get('SQ_LDS_BANK_CONFLICT', 0) / max(doc.get('SQ_LDS_IDX_ACTIVE', 1), 1))
