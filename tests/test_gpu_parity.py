@@ -1,7 +1,3 @@
-    if kernel == 'pre':
-        monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', 'pre')
-    elif kernel == 'barrier':
-        monkeypatch.setenv('SAFE_HIP_BITS_PRE', '0')
 """Parity of the HIP path (through the C ABI) against the golden vectors produced by the
 real reference and against the CPU oracle on seeded inputs.  Needs an MI355X."""
 import numpy as np
@@ -609,10 +605,8 @@ def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
     4 / 6 / 8 / 10 levels of the vertical sums), with columns dense enough that the sums really reach the top
     levels, an empty neighborhood, a ragged last word group; 300 permutations carry the counters past their low levels."""
     monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'bits')
-    if kernel in ('pre', 'wq', 'eng'):
-        monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', kernel)
-    elif kernel == 'quad':
-        monkeypatch.setenv('SAFE_HIP_BITS_QUAD', '1')
+    if kernel == 'pre':
+        monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', 'pre')
     elif kernel == 'barrier':
         monkeypatch.setenv('SAFE_HIP_BITS_PRE', '0')
     rng = np.random.default_rng(77)

@@ -40,6 +40,26 @@ __global__ __launch_bounds__(256) void k_tiles(long long *__restrict__ out, long
     }
 }
 
+// K4-like row sweep: a workgroup writes one whole row (m f64 columns) of three arrays, then the row `gridDim.x` further on;
+// 8 B per lane, a wave covers 512 contiguous bytes per instruction (the emit kernel's lane layout)
+template <bool NT>
+__global__ __launch_bounds__(256) void k_rows3(double *__restrict__ a, double *__restrict__ b, double *__restrict__ c, long long n, long long m) {
+    for (long long r = blockIdx.x; r < n; r += gridDim.x) {
+        for (long long j = threadIdx.x; j < m; j += 256) {
+            const long long o = r * m + j;
+            if (NT) {
+                __builtin_nontemporal_store(1.0, a + o);
+                __builtin_nontemporal_store(2.0, b + o);
+                __builtin_nontemporal_store(3.0, c + o);
+            } else {
+                a[o] = 1.0;
+                b[o] = 2.0;
+                c[o] = 3.0;
+            }
+        }
+    }
+}
+
 template <typename F>
 static double time_ms(F f) {
     hipEvent_t a, b;
@@ -72,6 +92,13 @@ int main() {
         printf("3 x 1.6 GB, 16 B/lane, nt     , grid %5d: %.3f ms = %.2f TB/s\n", grid, t, 3.0 * each / t / 1e9);
         t = time_ms([&] { hipLaunchKernelGGL((k_fill<8, true>), dim3(grid), dim3(256), 0, 0, p0, p1, p2, each, 3); });
         printf("3 x 1.6 GB,  8 B/lane, nt     , grid %5d: %.3f ms = %.2f TB/s\n", grid, t, 3.0 * each / t / 1e9);
+    }
+    for (int grid : {256, 512, 1024, 2048}) {
+        const long long rn = 20000, rm = 10000;
+        double tr = time_ms([&] { hipLaunchKernelGGL((k_rows3<true>), dim3(grid), dim3(256), 0, 0, (double *)p0, (double *)p1, (double *)p2, rn, rm); });
+        printf("rows x 3 arrays (20000 x 10000 f64), 8 B/lane nt, grid %5d: %.3f ms = %.2f TB/s\n", grid, tr, 3.0 * 8 * rn * rm / tr / 1e9);
+        tr = time_ms([&] { hipLaunchKernelGGL((k_rows3<false>), dim3(grid), dim3(256), 0, 0, (double *)p0, (double *)p1, (double *)p2, rn, rm); });
+        printf("rows x 3 arrays (20000 x 10000 f64), 8 B/lane   , grid %5d: %.3f ms = %.2f TB/s\n", grid, tr, 3.0 * 8 * rn * rm / tr / 1e9);
     }
     const long long n = 20000;
     double t = time_ms([&] { hipLaunchKernelGGL((k_tiles<32, false>), dim3((n + 511) / 512, (n + 31) / 32), dim3(256), 0, 0, (long long *)p0, n); });
