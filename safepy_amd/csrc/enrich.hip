@@ -2087,10 +2087,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
                                p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c & 1]);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
-            // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD), so the
-            // table kernels of the next stage (aux stream) start in this kernel's tail; leaving them CUs
-            // (SAFE_HIP_BITS_SPARE) changes nothing measurable: the stage is not ready earlier (host draws)
-            int spare = 0;
+            // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
+            // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
+            // workgroup to finish.  A few CUs are therefore left out of the grid (SAFE_HIP_BITS_SPARE, default 8 of 256):
+            // the median step shrinks by ~3 % at 1000 permutations, ~6 % at 10 000 (tools/step_sweep.sh)
+            int spare = std::min(8, ctx->num_cu / 8);
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
