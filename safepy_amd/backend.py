@@ -435,13 +435,25 @@ class Comm:
     ID_BYTES = 128
 
     @staticmethod
+    def _framework_first():
+        """When PyTorch-ROCm is installed its bundled RCCL must be the process's RCCL, loaded the way torch loads it:
+        dlopen-ing that file ahead of `import torch` (or a second copy beside it) ends in a heap corruption at interpreter
+        exit.  A host without torch uses the system's librccl (comm.cpp)."""
+        try:
+            import torch  # noqa: F401
+        except ImportError:
+            pass
+
+    @staticmethod
     def unique_id():
+        Comm._framework_first()
         buf = C.create_string_buffer(Comm.ID_BYTES)
         check(lib.safe_comm_unique_id(buf, Comm.ID_BYTES))
         return buf.raw
 
     def __init__(self, ctx, world_size, rank, unique_id):
         assert len(unique_id) == self.ID_BYTES
+        self._framework_first()
         self.ctx, self.world_size, self.rank = ctx, int(world_size), int(rank)
         h = C.c_void_p()
         check(lib.safe_comm_create(ctx.handle, self.world_size, self.rank, unique_id, self.ID_BYTES, C.byref(h)))

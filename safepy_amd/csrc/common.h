@@ -232,6 +232,7 @@ struct safe_perms {
     DrawStream *stream = nullptr;
     // pipeline positions (in permutations): drawn >= handed to the swap workers >= enqueued on the GPU
     int64_t generated = 0, swapping = 0, enqueued = 0;
+    std::vector<int64_t> stages;                   // pipeline stage boundaries of this handle (perms_stage_plan(count))
     std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each enqueued chunk
     std::vector<uint32_t> h_targets[2];            // swap targets of a chunk (draw thread -> workers)
     std::vector<uint32_t> h_local;                 // the draw thread's private chunk buffer
@@ -268,10 +269,9 @@ int nbr_build_transpose(safe_nbr *nbr);      // at_ptr / at_col (nbr.hip)
 int attr_build_support(safe_attr *attr);     // sup_ptr / sup_row of a binary matrix (attr.hip)
 int perms_build_inverse(safe_perms *perms);  // inverse tables (rng.cpp)
 int perms_generate_until(safe_perms *perms, int64_t upto);   // enqueue table rows [generated, upto) on aux_stream (rng.cpp)
-// host/GPU pipeline stages of the permutation stream: stage ci covers permutations
-// [perms_chunk_begin(ci), perms_chunk_begin(ci + 1)) -- a short first stage, then 128 each
-int64_t perms_chunk_begin(int64_t ci);
-int64_t perms_chunk_count(int64_t count);
+// host/GPU pipeline stages of the permutation stream for `count` permutations: boundaries b[0] = 0 < b[1] < ... < b.back() = count
+// (a short first stage, 128 each, short last stages -- rng.cpp)
+std::vector<int64_t> perms_stage_plan(int64_t count);
 // launch boundaries of the permutation kernels: starts[c] .. starts[c+1]; the default follows the
 // stream's pipeline stages (so the first launch can start after 32 permutations have been drawn),
 // SAFE_HIP_BITS_SPAN=<n> forces uniform spans.  *span = the longest launch.
@@ -284,9 +284,10 @@ static inline std::vector<int64_t> perm_launch_starts(int64_t P, int64_t *span, 
     if (uniform > 0) {
         for (int64_t p = 0; p < P; p += uniform) starts.push_back(p);
     } else {
-        const int64_t nc = perms_chunk_count(P);
+        const std::vector<int64_t> plan = perms_stage_plan(P);
+        const int64_t nc = static_cast<int64_t>(plan.size()) - 1;
         for (int64_t c = 0; c < nc; ++c)
-            if (c < 3 || merge <= 1 || (c - 3) % merge == 0) starts.push_back(perms_chunk_begin(c));
+            if (c < 3 || merge <= 1 || (c - 3) % merge == 0) starts.push_back(plan[c]);
     }
     if (starts.empty()) starts.push_back(0);
     starts.push_back(std::max<int64_t>(P, 0));

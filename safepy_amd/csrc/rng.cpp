@@ -89,11 +89,27 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
 static const int64_t kFirst = 32;       // the first stage is short so that the first kernel starts early
 
-// stage boundaries: [0, kFirst), [kFirst, kChunk), [kChunk, 2 kChunk), ...
-int64_t perms_chunk_begin(int64_t ci) { return ci == 0 ? 0 : ci == 1 ? kFirst : (ci - 1) * kChunk; }
-int64_t perms_chunk_count(int64_t count) { return count <= kFirst ? (count > 0 ? 1 : 0) : 1 + ceil_div(count, kChunk); }
-static int64_t chunk_of(int64_t perm) { return perm < kFirst ? 0 : 1 + perm / kChunk; }
-static int64_t chunk_end(int64_t ci, int64_t count) { return std::min<int64_t>(count, perms_chunk_begin(ci + 1)); }
+// Stage boundaries of the host / GPU pipeline for `count` permutations: [0, 32), [32, 128), [128, 256), ... and a SHORT last
+// stage.  The draw thread is what the pipeline waits for (128 permutations per ~0.4 ms, the kernels keep up), so whatever
+// the last stage holds is processed after the draws have ended: the final stages are cut to <= 72 and 32 permutations
+// (0.25 ms less tail per call than a last stage of ~100).
+std::vector<int64_t> perms_stage_plan(int64_t count) {
+    std::vector<int64_t> b;
+    b.push_back(0);
+    if (count <= 0) return b;
+    if (count > kFirst) b.push_back(kFirst);
+    for (int64_t q = kChunk; q < count; q += kChunk) b.push_back(q);
+    const int64_t last = b.back();
+    if (count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
+    b.push_back(count);
+    return b;
+}
+static int64_t stage_begin(const safe_perms *p, int64_t ci) { return p->stages[std::min<size_t>(ci, p->stages.size() - 1)]; }
+static int64_t stage_count(const safe_perms *p) { return static_cast<int64_t>(p->stages.size()) - 1; }
+static int64_t chunk_of(const safe_perms *p, int64_t perm) {
+    return static_cast<int64_t>(std::upper_bound(p->stages.begin(), p->stages.end(), perm) - p->stages.begin()) - 1;
+}
+static int64_t chunk_end(const safe_perms *p, int64_t ci) { return stage_begin(p, ci + 1); }
 
 // A small process-wide pool of swap workers (creating threads per chunk costs more than the
 // chunk's draws).  One job at a time: parallel-for over the permutations of a chunk.
@@ -222,7 +238,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     safe_ctx *ctx = p->ctx;
     hipStream_t gs = ctx->aux_stream;
     const int64_t n = p->n, stride = n + 1;
-    const int64_t q0 = perms_chunk_begin(ci), q1 = chunk_end(ci, p->count), cnt = q1 - q0;
+    const int64_t q0 = stage_begin(p, ci), q1 = chunk_end(p, ci), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
     SwapPool::get().wait();
     {
@@ -255,7 +271,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
 
 static void drawer_main(safe_perms *p) {
     const int64_t k = p->k, width = std::max<int64_t>(k, 1);
-    const int64_t n_chunks = perms_chunk_count(p->count);
+    const int64_t n_chunks = stage_count(p);
     for (int64_t c = 0; c < n_chunks; ++c) {
         {
             std::unique_lock<std::mutex> lk(p->draw_mu);
@@ -263,7 +279,7 @@ static void drawer_main(safe_perms *p) {
             if (p->draw_stop) return;
         }
         safe_trace("    drawer: buffer free, drawing");
-        const int64_t q0 = perms_chunk_begin(c), cnt = chunk_end(c, p->count) - q0;
+        const int64_t q0 = stage_begin(p, c), cnt = chunk_end(p, c) - q0;
         // draw into a buffer only this thread touches, then stream the chunk to the shared one
         uint32_t *h = p->h_local.data();
         for (int64_t q = 0; q < cnt; ++q) {
@@ -304,7 +320,7 @@ static void drawer_stop(safe_perms *p) {
 // On return every row < upto has been enqueued on ctx->aux_stream.
 // hands chunk ci (already drawn) to the swap workers
 static int submit_swaps(safe_perms *p, int64_t ci) {
-    const int64_t q0 = perms_chunk_begin(ci), q1 = chunk_end(ci, p->count), cnt = q1 - q0;
+    const int64_t q0 = stage_begin(p, ci), q1 = chunk_end(p, ci), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
     // the pinned map buffer of two chunks ago must have been uploaded
     if (ci >= 2) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
@@ -320,14 +336,14 @@ static int submit_swaps(safe_perms *p, int64_t ci) {
 // moves chunks along (drawn -> swap workers -> GPU); the draws themselves run on p->drawer.
 int perms_generate_until(safe_perms *p, int64_t upto) {
     upto = std::min<int64_t>(upto, p->count);
-    const int64_t n_chunks = perms_chunk_count(p->count);
+    const int64_t n_chunks = stage_count(p);
     while (p->enqueued < upto) {
-        const int64_t ci = chunk_of(p->enqueued);
-        if (p->swapping <= perms_chunk_begin(ci)) {          // its swaps have not been started yet
+        const int64_t ci = chunk_of(p, p->enqueued);
+        if (p->swapping <= stage_begin(p, ci)) {          // its swaps have not been started yet
             {
                 std::unique_lock<std::mutex> lk(p->draw_mu);
                 p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
-                p->generated = chunk_end(p->drawn_chunks - 1, p->count);
+                p->generated = chunk_end(p, p->drawn_chunks - 1);
             }
             safe_trace("  gen: chunk drawn");
             SAFE_TRY(submit_swaps(p, ci));
@@ -350,7 +366,7 @@ int perms_wait(safe_perms *p, int64_t upto, hipStream_t s) {
     SAFE_TRY(perms_generate_until(p, upto));
     upto = std::min<int64_t>(upto, p->count);
     if (upto <= 0) return SAFE_OK;
-    const int64_t ci = chunk_of(upto - 1);
+    const int64_t ci = chunk_of(p, upto - 1);
     SAFE_HIP_CHECK(hipStreamWaitEvent(s, p->chunk_done[ci], 0));
     return SAFE_OK;
 }
@@ -443,6 +459,7 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     p->k = static_cast<int64_t>(p->h_movable.size());
     p->stream = draw_stream_new(has_seed ? seed : entropy_seed());
     p->generated = p->swapping = p->enqueued = 0;
+    p->stages = perms_stage_plan(num_permutations);
     if (reused) {
         const int64_t stride = n + 1;
         for (int b = 0; b < 2; ++b) p->h_targets[b].resize(kChunk * std::max<int64_t>(p->k, 1) + 16);
@@ -540,7 +557,8 @@ int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutati
             hipLaunchKernelGGL(k_table16, grid, block, 0, ctx->aux_stream, p->table, stride, p->table16, p->stride16, n);
             e = hipGetLastError();
         }
-        const int64_t n_chunks = perms_chunk_count(num_permutations);
+        p->stages = perms_stage_plan(num_permutations);
+        const int64_t n_chunks = stage_count(p);
         p->chunk_done.assign(std::max<int64_t>(n_chunks, 1), nullptr);
         for (size_t c = 0; c < p->chunk_done.size() && e == hipSuccess; ++c) {
             e = hipEventCreateWithFlags(&p->chunk_done[c], hipEventDisableTiming);
