@@ -260,6 +260,21 @@ def mfma_kernel(ctx, np, be):
                   'membership_blocks_256x32': blocks, 'block_fill': nbr.nnz / (blocks * 256.0 * 32.0),
                   'enrichments_per_s': float(n) * m * nperm / dt,
                   'config5_rank_share_seconds': dt}}
+    # the same share with neighborhood_score_type='z-score' (safe_extras.py:19-31): 16-column tiles carrying value digits,
+    # square digits and the not-NaN slice (7 i8 slices), f64 score evaluation on the exact sums in the epilogue
+    perms = be.Permutations(ctx, n, attr.row_flags(), nperm, 0)
+    ctx.sync()
+    t0 = time.perf_counter()
+    be.randomization(ctx, nbr, attr, perms, 'z-score', 'both', 0.05, [o.ptr for o in outs])
+    ctx.sync()
+    dtz = time.perf_counter() - t0
+    perms.close()
+    zname, zms, zlaunches = ctx.last_kernel()
+    zops = 2.0 * blocks * 256 * 32 * (32 * ((m + 15) // 16)) * 7 * (nperm + 1)
+    out[zname + '<z-score>'] = {'bound': 'mfma', 'workload': 'the same share, z-scores', 'kernel_ms': zms * zlaunches, 'call_ms': 1e3 * dtz,
+                                'algorithmic_ops': zops, 'achieved': zops / (zms * zlaunches * 1e-3) / 1e12, 'peak': MFMA_I8_PEAK_TOPS,
+                                'unit': 'TOP/s', 'frac': zops / (zms * zlaunches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 'i8_slices': 7,
+                                'enrichments_per_s': float(n) * m * nperm / dtz}
     for o in outs:
         o.free()
     attr.close()

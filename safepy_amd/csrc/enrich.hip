@@ -2421,10 +2421,15 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     return SAFE_OK;
 }
 
+// ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
-                           int64_t n_perm, const PermOut &out) {
-    hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, counts, n_pad,
-                       rowmap, static_cast<const double *>(nullptr), mloc, n_perm, out);
+                           int64_t n_perm, const PermOut &out, const double *ns_direct) {
+    if (ns_direct)
+        hipLaunchKernelGGL(k_counts_finalize<true>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, counts, n_pad,
+                           rowmap, ns_direct, mloc, n_perm, out);
+    else
+        hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, counts, n_pad,
+                           rowmap, static_cast<const double *>(nullptr), mloc, n_perm, out);
     SAFE_HIP_CHECK(hipGetLastError());
     return SAFE_OK;
 }
@@ -2496,7 +2501,7 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
     }
     if (mfma_applicable(ctx, nbr, attr, perms, z)) {
         bool declined = false;
-        SAFE_TRY(launch_mfma(ctx, nbr, attr, perms, col0, col1, out, &declined));
+        SAFE_TRY(launch_mfma(ctx, nbr, attr, perms, col0, col1, z, out, &declined));
         if (!declined) return finish_kernel_timing(ctx);
     }
     if (lds_f64_applicable(nbr, perms)) {
@@ -2570,7 +2575,7 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         out.mode = 2;
         if (mfma) {
             bool declined = false;
-            rc = launch_mfma(ctx, nbr, attr, perms, col0, col1, out, &declined);
+            rc = launch_mfma(ctx, nbr, attr, perms, col0, col1, z, out, &declined);
             if (declined) mfma = false;
         }
         if (rc == SAFE_OK && !mfma) {
@@ -2735,7 +2740,7 @@ int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *co
     out.nes_table = d_tab;
     out.sign_mode = sign_mode;
     out.mode = 3;
-    int rc = enrich_finalize_counts(ctx, counts_dev, n_pad, rowmap, m, P, out);
+    int rc = enrich_finalize_counts(ctx, counts_dev, n_pad, rowmap, m, P, out, nullptr);
     if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab is a host vector
     return rc;
 }

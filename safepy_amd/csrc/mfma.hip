@@ -240,10 +240,112 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
     }
 }
 
-__global__ void k_mfma_colcheck(const unsigned int *__restrict__ cnt, const unsigned int *__restrict__ n_small,
-                                const unsigned int *__restrict__ n_small_rounded, int64_t mloc, int *__restrict__ bad) {
+// z-scores: the scale of the SQUARES of a column (always the rounding regime: b*b is itself a rounded f64 product,
+// as in the reference's np.power(B0, 2)): max^2 sits just below 2^46.  scale2[j] = 2^-shift2[j].
+// inexact[j] = 1 unless both the values and their squares are held exactly (values on one binary grid spanning <= 22 bits).
+__global__ void k_mfma_colfinish_sq(const unsigned long long *__restrict__ maxbits, const unsigned int *__restrict__ neg_lowbit,
+                                    int64_t mloc, int *__restrict__ shift2, double *__restrict__ scale2,
+                                    unsigned int *__restrict__ inexact, int *__restrict__ bad) {
     const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (j >= mloc) return;
+    const double mx = __longlong_as_double(static_cast<long long>(maxbits[j]));
+    const double m2 = mx * mx;
+    int sh = 0;
+    unsigned int rounded = 0;
+    if (mx != 0.0) {
+        if (m2 < __longlong_as_double(0x7FF0000000000000ll) && m2 >= __longlong_as_double(0x0010000000000000ll)) {
+            sh = MF_SHIFT_BITS - ilogb(m2);
+            const int span = ilogb(mx) - (2048 - static_cast<int>(neg_lowbit[j])) + 1;
+            rounded = 2 * span > MF_SHIFT_BITS;
+        } else {
+            atomicOr(bad, 1);                           // squares overflow or leave the normal range
+        }
+    }
+    shift2[j] = sh;
+    scale2[j] = ldexp(1.0, -sh);
+    inexact[j] = rounded;
+}
+
+// z-score slices: bs[row][16-column tile][7 slices][32 bytes]; bytes 0-15 of slice t = digit t of q1 = fixed-point B0 of
+// the tile's columns, bytes 16-31 = digit t of q2 = rint(B0*B0 * 2^shift2); slice 6 = the not-NaN flags (bytes 0-15).
+// Row n = zeros (and not counted).  Counts the small rounded values of B0 like k_mfma_slice.
+template <typename T>
+__global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ raw, int64_t n, int64_t rs, int64_t cs,
+                                                      int64_t col0, int64_t mloc, int64_t n_ct, const int *__restrict__ shift,
+                                                      const int *__restrict__ shift2, const unsigned long long *__restrict__ maxbits,
+                                                      unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
+                                                      unsigned int *__restrict__ n_small_rounded, unsigned int *__restrict__ n_zero) {
+    __shared__ double tile[32][17];
+    __shared__ unsigned int s_small[16], s_rounded[16], s_zero[16];
+    const int64_t ct = blockIdx.x, r0 = static_cast<int64_t>(blockIdx.y) * 32, c0 = ct * 16;
+    const bool col_major = rs == 1;
+    if (threadIdx.x < 16) s_small[threadIdx.x] = s_rounded[threadIdx.x] = s_zero[threadIdx.x] = 0;
+    for (int i = 0; i < 2; ++i) {
+        // the fast thread index runs along whichever axis is contiguous in memory
+        const int rr = col_major ? (threadIdx.x & 31) : (threadIdx.x >> 4) + 16 * i;
+        const int cc = col_major ? (threadIdx.x >> 5) + 8 * i : (threadIdx.x & 15);
+        const int64_t r = r0 + rr, j = c0 + cc;
+        double x = __longlong_as_double(0x7FF8000000000000ll);
+        if (r < n && j < mloc) x = static_cast<double>(reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs]);
+        tile[rr][cc] = x;
+    }
+    __syncthreads();
+    const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+    const int64_t j = c0 + tx;
+    const int sh = j < mloc ? shift[j] : 0, sh2 = j < mloc ? shift2[j] : 0;
+    const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -20) : 0.0;
+    const int64_t row_bytes = n_ct * (MF_NS + 1) * 32;
+    const long long bias = 0x808080808080ll;
+    unsigned int k_small = 0, k_rounded = 0, k_zero = 0;
+    for (int i = 0; i < 2; ++i) {
+        const int rr = ty + 16 * i;
+        const int64_t r = r0 + rr;
+        if (r > n) continue;
+        double x = tile[rr][tx];
+        const bool present = (x == x) && r < n && j < mloc;            // safe_extras.py:19 (~isnan)
+        k_zero += present && x == 0.0;
+        if (!present) x = 0.0;                                          // NaN -> 0 (safe_extras.py:10)
+        if (!(fabs(x) < __longlong_as_double(0x7FF0000000000000ll))) x = 0.0;   // +-inf: the path is declined anyway
+        const double scaled = ldexp(x, sh);
+        const double q1 = rint(scaled);
+        const T xt = static_cast<T>(x);
+        const double q2 = rint(ldexp(static_cast<double>(static_cast<T>(xt * xt)), sh2));   // np.power(B0, 2) rounds in B's own type
+        if (x != 0.0 && fabs(x) < small_below) {
+            ++k_small;
+            k_rounded += q1 != scaled;
+        }
+        const unsigned long long u1 = static_cast<unsigned long long>(static_cast<long long>(q1) + bias);
+        const unsigned long long u2 = static_cast<unsigned long long>(static_cast<long long>(q2) + bias);
+        unsigned char *dst = bs + r * row_bytes + ct * ((MF_NS + 1) * 32) + tx;
+#pragma unroll
+        for (int t = 0; t < MF_NS; ++t) {
+            dst[t * 32] = static_cast<unsigned char>(((u1 >> (8 * t)) & 0xFFu) ^ 0x80u);
+            dst[t * 32 + 16] = static_cast<unsigned char>(((u2 >> (8 * t)) & 0xFFu) ^ 0x80u);
+        }
+        dst[MF_NS * 32] = present ? 1 : 0;
+        dst[MF_NS * 32 + 16] = 0;
+    }
+    if (k_small) atomicAdd(&s_small[tx], k_small);
+    if (k_rounded) atomicAdd(&s_rounded[tx], k_rounded);
+    if (k_zero) atomicAdd(&s_zero[tx], k_zero);
+    __syncthreads();
+    if (threadIdx.x < 16 && c0 + threadIdx.x < mloc) {
+        if (s_small[threadIdx.x]) atomicAdd(&n_small[c0 + threadIdx.x], s_small[threadIdx.x]);
+        if (s_rounded[threadIdx.x]) atomicAdd(&n_small_rounded[c0 + threadIdx.x], s_rounded[threadIdx.x]);
+        if (s_zero[threadIdx.x]) atomicAdd(&n_zero[c0 + threadIdx.x], s_zero[threadIdx.x]);
+    }
+}
+
+// z-scores (n_zero != NULL) also decline a column that is BOTH held inexactly and has exact zeros: a z-score does not change
+// when its values are scaled, so neighborhoods whose non-zero members are one value each (sparse columns) give mathematically
+// EQUAL scores from different values, the reference decides such comparisons by the rounding of its f64 operations, and only
+// the very same operands reproduce that (the f64 kernels do; a rounded fixed-point image cannot).
+__global__ void k_mfma_colcheck(const unsigned int *__restrict__ cnt, const unsigned int *__restrict__ n_small,
+                                const unsigned int *__restrict__ n_small_rounded, const unsigned int *__restrict__ n_zero,
+                                const unsigned int *__restrict__ inexact, int64_t mloc, int *__restrict__ bad) {
+    const int64_t j = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (j >= mloc) return;
+    if (n_zero && n_zero[j] && inexact[j]) atomicOr(bad, 1);
     // values that the grid holds to fewer than 26 bits must be a negligible part of the column (< 1 in 1024): sums made of
     // such values only would be compared at the grid's resolution, not at f64's
     if (1024ull * n_small_rounded[j] > cnt[j]) atomicOr(bad, 1);
@@ -284,13 +386,21 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
 // COUNTS = true : observed counts only, for 0/1 attributes (hypergeometric path, 'sum' scores): the six
 //                 planes of a task are six adjacent 32-column TILES with one plane each, n_q = 1, and
 //                 the epilogue writes through `hl` (table lookup or plain counts).
-template <bool COUNTS, int NS>
+// Z = true   : z-scores (safe_extras.py:19-31).  A task is a tile of SIXTEEN attribute columns: bytes 0-15 of a slice row
+//                are the digits of B0, bytes 16-31 the digits of B0^2 (both six slices), and a seventh slice carries the
+//                not-NaN flags -- so the same 32-column MFMA tile accumulates sum, sum of squares and count at once.  The
+//                lane that owns column a of a row and the lane that owns column 16 + a differ in lane bit 2: when a score
+//                completes the square sums cross over with one shuffle and the owner of column a evaluates
+//                mean / sqrt(EXX - mean^2) in f64, in the reference's order of operations, on the EXACT integer sums.
+//                Counters then hold (#>= << 16 | #<=) like the f64 kernels' (NaN scores compare false).
+template <bool COUNTS, int NS, bool Z = false>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
     const unsigned char *__restrict__ bs, int64_t row_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
     const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
     const double *__restrict__ col_scale, double *__restrict__ ns_out, HypLookup hl) {
+    static_assert(!Z || (NS == MF_NS + 1 && !COUNTS), "z-scores: six value slices + the not-NaN slice");
     constexpr int KS = NS * MF_SS, BUF = 4 * KS;                            // LDS bytes per k-step / per super-step buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] + kb list
     __shared__ int slot_box;
@@ -333,6 +443,14 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * (NS * 32) + chunk * 16;
             const uint32_t *bits_w = blk_bits + static_cast<int64_t>(b0) * MF_R + wave * 32 + lam;
             const int total = n_q * S;
+
+            // z-scores: this lane's attribute column and the power-of-two scales of its sum / sum of squares
+            const int64_t colz = static_cast<int64_t>(ct) * 16 + (col_in_tile & 15);
+            double sc1 = 1.0, sc2 = 1.0;
+            if (Z && colz < mloc) {
+                sc1 = col_scale[colz];
+                sc2 = col_scale[mloc + colz];
+            }
 
             v16i acc[NS];
 #pragma unroll
@@ -423,10 +541,14 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (k < 3) {
-#pragma unroll
+                    if (k < 3 && !Z) {                               // (z-scores: seven slices -- no room for a second operand set,
+#pragma unroll                                                       //  the other wave of the SIMD covers the LDS latency)
                         for (int s = 0; s < NS; ++s)
                             b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
+                    }
+                    if (Z && k > 0) {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
                     }
                     __builtin_amdgcn_sched_barrier(0);               // keep the LDS reads ahead of this k-step's MFMAs
                     v4i a;
@@ -439,8 +561,10 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     // a quarter of the next super-step's tile goes to the other buffer while the
                     // matrix pipe works through this k-step
                     if (gth && more1) store_quarter(L_store, k, buf ^ 1);
+                    if (!Z) {
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
+                        for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
+                    }
                 }
 
                 if constexpr (COUNTS) {
@@ -448,10 +572,28 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 } else if (t == S - 1) {                             // a score is complete
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        long long v = static_cast<long long>(acc[NS - 1][r]);
+                        constexpr int NV = Z ? MF_NS : NS;                  // value slices
+                        long long v = static_cast<long long>(acc[NV - 1][r]);
 #pragma unroll
-                        for (int s = NS - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
-                        if (q == 0) {
+                        for (int s = NV - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
+                        if constexpr (Z) {
+                            // columns 0-15 of the tile: sum (and count, slice 6); columns 16-31: sum of squares, one lane-bit away
+                            const int lo_sq = __shfl_xor(static_cast<int>(v), 4), hi_sq = __shfl_xor(static_cast<int>(v >> 32), 4);
+                            const long long w = (static_cast<long long>(hi_sq) << 32) | static_cast<long long>(static_cast<uint32_t>(lo_sq));
+                            const double members = static_cast<double>(acc[NS - 1][r]);
+                            const double mean = (static_cast<double>(v) * sc1) / members;          // safe_extras.py:21-23
+                            const double exx = (static_cast<double>(w) * sc2) / members;           // safe_extras.py:25-26
+                            const double sd = sqrt(exx - mean * mean);                            // safe_extras.py:27
+                            double zs = mean / sd;                                                // safe_extras.py:28
+                            if (sd == 0.0) zs = __longlong_as_double(0x7FF8000000000000ll);       // safe_extras.py:29
+                            if (members < 3.0) zs = __longlong_as_double(0x7FF8000000000000ll);   // safe_extras.py:30
+                            if (q == 0) {
+                                obs[r * 512] = __double_as_longlong(zs);
+                            } else {
+                                const double o = __longlong_as_double(obs[r * 512]);
+                                cnt[r] += (static_cast<uint32_t>(zs >= o) << 16) | static_cast<uint32_t>(zs <= o);
+                            }
+                        } else if (q == 0) {
                             obs[r * 512] = v;
                         } else {
                             const long long o = obs[r * 512];
@@ -575,16 +717,18 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 }
             }
             // ---- task epilogue: observed scores (first span only) and the counters
-            const int64_t col = static_cast<int64_t>(ct) * 32 + col_in_tile;
-            if (!COUNTS && col < mloc) {
-                const double sc = ns_out ? col_scale[col] : 0.0;
+            const int64_t col = Z ? colz : static_cast<int64_t>(ct) * 32 + col_in_tile;
+            if (!COUNTS && col < mloc && !(Z && (col_in_tile & 16))) {
+                const double sc = (ns_out && !Z) ? col_scale[col] : 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (cnt[r]) atomicAdd(&gl_counts[col * n_padr + u], cnt[r]);
                     if (ns_out) {
                         const int32_t node = rowmap[u];
-                        if (node >= 0) ns_out[static_cast<int64_t>(node) * mloc + col] = static_cast<double>(obs[r * 512]) * sc;
+                        if (node >= 0)
+                            ns_out[static_cast<int64_t>(node) * mloc + col] =
+                                Z ? __longlong_as_double(obs[r * 512]) : static_cast<double>(obs[r * 512]) * sc;
                     }
                 }
             }
@@ -1169,7 +1313,9 @@ bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *
     (void)attr;
     const char *force = getenv("SAFE_HIP_FORCE_PATH");
     if (force && (!strcmp(force, "gather") || !strcmp(force, "lds"))) return false;
-    if (z || perms->count < 1 || perms->count > 65535) return false;
+    const char *z_env = getenv("SAFE_HIP_MFMA_Z");                       // =0: z-scores stay on the f64 kernels
+    if (z && z_env && !strcmp(z_env, "0")) return false;
+    if (perms->count < 1 || perms->count > 65535) return false;
     if (nbr->n > (1ll << 30) / 32 || nbr->max_count >= (1 << 23)) return false;
     if (force && !strcmp(force, "mfma")) return true;
     return nbr->n >= 256;                       // below one row group the LDS-resident f64 kernel is the better fit
@@ -1178,13 +1324,15 @@ bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *
 // Runs the permutation test of columns [col0, col1) on the MFMA path.  *declined = true (and
 // SAFE_OK) when the attribute values cannot be represented on the fixed-point grid without a
 // rounding that could matter; the caller then uses the f64 kernels.
-int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
-                const PermOut &out, bool *declined) {
+int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1, bool z,
+                const PermOut &out_in, bool *declined) {
     *declined = false;
     SAFE_TRY(build_blocks(nbr));
+    PermOut out = out_in;
     const int64_t n = nbr->n, mloc = col1 - col0, P = perms->count;
-    const int64_t n_ct = ceil_div(mloc, 32), n_src = nbr->bs_src;
-    int64_t row_bytes = n_ct * MF_NS * 32;       // (the largest form; the call's slice count is known after the column statistics)
+    // z-scores: tiles of 16 columns (value digits | square digits) and a seventh slice of not-NaN flags
+    const int64_t n_ct = ceil_div(mloc, z ? 16 : 32), n_src = nbr->bs_src;
+    int64_t row_bytes = n_ct * (z ? MF_NS + 1 : MF_NS) * 32;   // (the largest form; the call's slice count is known after the column statistics)
     const int64_t n_padr = nbr->bs_groups * MF_R;
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
 
@@ -1192,16 +1340,17 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     int n_slices = MF_NS;                        // i8 slices of this call: 2 / 4 / 6 by the bits its columns need (k_mfma_colfinish)
     unsigned char *d_bs = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
-    void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale f64 | cnt, small, rounded, neg_lowbit u32 | shift i32 | bad, need i32
-    const size_t colbuf_bytes = static_cast<size_t>(mloc) * (8 + 8 + 8 + 4 + 4 + 4 + 4 + 4) + 64;
+    void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale, scale2 f64 | cnt, small, rounded, neg_lowbit u32 | shift, shift2 i32 | bad, need i32
+    const size_t colbuf_bytes = static_cast<size_t>(mloc) * (8 + 8 + 16 + 4 + 4 + 4 + 4 + 4 + 4 + 8) + 64;   // (+ zeros, inexact u32)
     SAFE_TRY(ctx_scratch(ctx, 6, colbuf_bytes, &d_colbuf));
     unsigned long long *d_max = static_cast<unsigned long long *>(d_colbuf);
     double *d_sumsq = reinterpret_cast<double *>(d_max + mloc);
     double *d_scale = d_sumsq + mloc;
-    unsigned int *d_cnt = reinterpret_cast<unsigned int *>(d_scale + mloc);
+    unsigned int *d_cnt = reinterpret_cast<unsigned int *>(d_scale + 2 * mloc);
     unsigned int *d_small = d_cnt + mloc, *d_rounded = d_small + mloc, *d_lowbit = d_rounded + mloc;
-    int *d_shift = reinterpret_cast<int *>(d_lowbit + mloc);
-    int *d_bad = d_shift + mloc, *d_need = d_bad + 1;
+    unsigned int *d_zero = d_lowbit + mloc, *d_inexact = d_zero + mloc;
+    int *d_shift = reinterpret_cast<int *>(d_inexact + mloc);
+    int *d_bad = d_shift + 2 * mloc, *d_need = d_bad + 1;
     SAFE_HIP_CHECK(hipMemsetAsync(d_colbuf, 0, colbuf_bytes, ctx->stream));
     {
         const int rows_per_block = 2048;
@@ -1215,14 +1364,23 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         hipLaunchKernelGGL(k_mfma_colfinish, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_max, d_lowbit, mloc, d_shift,
                            d_scale, d_bad, d_need);
         const dim3 sgrid(n_ct, ceil_div(n + 1, 32));
-        if (f32)
+        if (z) {
+            hipLaunchKernelGGL(k_mfma_colfinish_sq, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_max, d_lowbit, mloc, d_shift + mloc,
+                               d_scale + mloc, d_inexact, d_bad);
+            if (f32)
+                hipLaunchKernelGGL(k_mfma_slice_z<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero);
+            else
+                hipLaunchKernelGGL(k_mfma_slice_z<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
+                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero);
+        } else if (f32)
             hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded);
         else
             hipLaunchKernelGGL(k_mfma_slice<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded);
-        hipLaunchKernelGGL(k_mfma_colcheck, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_cnt, d_small, d_rounded, mloc,
-                           d_bad);
+        hipLaunchKernelGGL(k_mfma_colcheck, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_cnt, d_small, d_rounded,
+                           z ? d_zero : static_cast<unsigned int *>(nullptr), d_inexact, mloc, d_bad);
         SAFE_HIP_CHECK(hipGetLastError());
         int verdict[2] = {0, 0};                   // {bad, bits needed}
         SAFE_HIP_CHECK(hipMemcpyAsync(verdict, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
@@ -1232,7 +1390,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             *declined = true;
             return SAFE_OK;
         }
-        n_slices = mfma_slices_for(verdict[1]);
+        n_slices = z ? MF_NS + 1 : mfma_slices_for(verdict[1]);
         row_bytes = n_ct * n_slices * 32;
     }
 
@@ -1269,12 +1427,15 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
 
     const size_t lds_bytes = 2 * static_cast<size_t>(4 * n_slices * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
-    const void *kfn = n_slices == 2   ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
+    const void *kfn = z               ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>)
+                      : n_slices == 2 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
                       : n_slices == 4 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 4>)
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     ctx->last_slices = n_slices;
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    // z-scores: the counters compare against the observed score itself, which may be NaN (k_counts_finalize<true> reads it)
+    if (z && !out.ns) SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&out.ns)));
     ctx->last_kernel.name = "k_permtest_mfma";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.launches = 0;
@@ -1310,12 +1471,14 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_padr, nbr->bs_rowmap, mloc, P, out));
-    ctx->packed_counts = d_counts;
-    ctx->packed_n_pad = n_padr;
-    ctx->packed_m = mloc;
-    ctx->packed_perms = P;
-    ctx->packed_layout = 1;
+    SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_padr, nbr->bs_rowmap, mloc, P, out, z ? out.ns : nullptr));
+    if (!z) {                                                 // (z-score counters depend on NaN observed scores: not exported)
+        ctx->packed_counts = d_counts;
+        ctx->packed_n_pad = n_padr;
+        ctx->packed_m = mloc;
+        ctx->packed_perms = P;
+        ctx->packed_layout = 1;
+    }
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));

@@ -30,7 +30,7 @@ def _quant(rng, n, m, dtype=np.float64, order='C', nan_rows=0, nan_frac=0.0):
     return np.asfortranarray(b) if order == 'F' else np.ascontiguousarray(b)
 
 
-def _counts(amd, ctx, nbr, b, nperm, seed, col0=0, col1=None, flags=None):
+def _counts(amd, ctx, nbr, b, nperm, seed, col0=0, col1=None, flags=None, score='sum'):
     from safepy_amd import backend as be
     attr = be.Attributes.from_host(ctx, b)
     if flags is not None:
@@ -39,7 +39,7 @@ def _counts(amd, ctx, nbr, b, nperm, seed, col0=0, col1=None, flags=None):
     col1 = m if col1 is None else col1
     perms = be.Permutations(ctx, n, attr.row_flags() if flags is None else flags, nperm, seed)
     ns, neg, pos = (ctx.alloc_f64(n, col1 - col0) for _ in range(3))
-    be.permtest_counts(ctx, nbr, attr, perms, 'sum', ns.ptr, neg.ptr, pos.ptr, col0, col1)
+    be.permtest_counts(ctx, nbr, attr, perms, score, ns.ptr, neg.ptr, pos.ptr, col0, col1)
     name = ctx.last_kernel()[0]
     out = (ns.download((n, col1 - col0)), neg.download((n, col1 - col0)), pos.download((n, col1 - col0)), name)
     perms.close()
@@ -284,3 +284,123 @@ def test_binary_neighborhood_score_on_matrix_cores(amd, ctx, monkeypatch, order,
     got = amd.compute_neighborhood_score(sf.neighborhoods, np.asfortranarray(b) if order == 'F' else np.ascontiguousarray(b), 'sum')
     assert ctx.last_kernel()[0] == 'k_permtest_mfma<counts>'
     np.testing.assert_array_equal(got, orc.compute_neighborhood_score(a, b, 'sum'))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# z-scores on the matrix cores (safe_extras.py:19-31): sum, sum of squares and count of a neighborhood ride in one
+# 32-column MFMA tile (16 attribute columns: value digits | square digits, + the not-NaN slice)
+# ---------------------------------------------------------------------------------------------------------------------
+def _zdata(rng, n, m, kind, dtype, order):
+    if kind == 'dyadic':                  # multiples of 1/8: sums, squares and their sums are exact in f64 AND on the fixed-point grid
+        b = (rng.integers(-40, 41, size=(n, m)) / 8.0).astype(dtype)
+    else:
+        b = rng.normal(size=(n, m)).astype(dtype)
+    b[rng.uniform(size=(n, m)) < 0.02] = np.nan
+    b[rng.choice(n, n // 25, replace=False)] = np.nan
+    if m > 4:
+        b[:, 1] = np.nan                                          # nothing to score at all
+        b[:, 2] = 2.5                                             # zero variance everywhere: std == 0 -> NaN (safe_extras.py:29)
+        keep = rng.choice(n, max(3, n // 40), replace=False)      # a column so sparse that most neighborhoods see < 3 values (:30)
+        col = np.full(n, np.nan)
+        col[keep] = b[keep, 3]
+        b[:, 3] = col
+    return np.asfortranarray(b) if order == 'F' else np.ascontiguousarray(b)
+
+
+@pytest.mark.parametrize('n,m,dtype,order,kind', [(600, 37, np.float64, 'C', 'normal'), (1000, 16, np.float32, 'F', 'normal'),
+                                                  (257, 5, np.float64, 'F', 'dyadic'), (1300, 50, np.float64, 'C', 'dyadic'),
+                                                  (900, 17, np.float32, 'C', 'dyadic')])
+def test_zscore_counts_on_matrix_cores_vs_oracle(amd, ctx, n, m, dtype, order, kind):
+    rng = np.random.default_rng(3 * n + m)
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.09)
+    b = _zdata(rng, n, m, kind, dtype, order)
+    nperm, seed = 40, 11
+    ns_w = orc.compute_neighborhood_score(a, b, 'z-score')
+    cn_w, cp_w = orc.run_permutations(a, b, 'z-score', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.09))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name == 'k_permtest_mfma'
+    assert np.array_equal(np.isnan(ns), np.isnan(ns_w))               # < 3 values, zero variance, empty: NaN in the same places
+    if kind == 'dyadic':
+        np.testing.assert_array_equal(ns, ns_w)                       # exact sums in, the reference's operations in its order: same bits
+    else:
+        np.testing.assert_allclose(ns, ns_w, rtol=1e-9, atol=1e-12)   # north-star tolerance: 1e-6 relative
+    np.testing.assert_array_equal(cn, cn_w)                           # every <= / >= decision identical
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_zscore_matrix_cores_agree_with_the_f64_kernels(amd, ctx, monkeypatch):
+    """Same inputs through the matrix-core form and (SAFE_HIP_MFMA_Z=0) through the f64 kernels, column shards included."""
+    rng = np.random.default_rng(77)
+    n, m, nperm, seed = 1500, 41, 50, 5
+    xy = rng.uniform(size=(n, 2))
+    b = _zdata(rng, n, m, 'normal', np.float64, 'C')
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.07))
+    flags = (~np.isnan(b)).any(axis=1).astype(np.uint8)
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name == 'k_permtest_mfma'
+    for c0, c1 in ((0, 16), (16, 17), (17, 41)):                      # tiles of 16 columns: aligned, single, ragged
+        ns_s, cn_s, cp_s, name_s = _counts(amd, ctx, nbr, b, nperm, seed, c0, c1, flags=flags, score='z-score')
+        assert name_s == 'k_permtest_mfma'
+        np.testing.assert_array_equal(ns_s, ns[:, c0:c1])
+        np.testing.assert_array_equal(cn_s, cn[:, c0:c1])
+        np.testing.assert_array_equal(cp_s, cp[:, c0:c1])
+    monkeypatch.setenv('SAFE_HIP_MFMA_Z', '0')
+    ns_f, cn_f, cp_f, name_f = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name_f != 'k_permtest_mfma'
+    np.testing.assert_allclose(ns, ns_f, rtol=1e-9, atol=1e-12, equal_nan=True)
+    np.testing.assert_array_equal(cn, cn_f)
+    np.testing.assert_array_equal(cp, cp_f)
+    nbr.close()
+
+
+def test_full_pipeline_zscore_vs_oracle(amd):
+    """SAFE.compute_pvalues(neighborhood_score_type='z-score') on a network too large for the LDS-resident f64 kernel's
+    comfort runs on the matrix cores; p-values, NES and the binarised map equal the oracle's."""
+    rng = np.random.default_rng(8)
+    n, m, nperm = 1100, 24, 50
+    xy = rng.uniform(size=(n, 2))
+    b = _zdata(rng, n, m, 'normal', np.float64, 'C')
+    a = orc.neighborhoods_euclidean(xy, 0.08)
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=4,
+                               neighborhood_score_type='z-score')
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(xy)
+    sf.random_seed = 4
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.08)
+    sf.load_attributes(attribute_file=b.copy())
+    sf.compute_pvalues(num_permutations=nperm, neighborhood_score_type='z-score', verbose=False)
+    assert amd.Context.default(0).last_kernel()[0] == 'k_permtest_mfma'
+    np.testing.assert_allclose(sf.ns, want['ns'], rtol=1e-9, atol=1e-12, equal_nan=True)
+    for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        np.testing.assert_array_equal(getattr(sf, key), want[key])
+
+
+def test_zscore_sparse_inexact_column_is_left_to_the_f64_kernels(amd, ctx):
+    """A z-score is scale-free: with one non-zero value among a neighborhood's members it is +-1/sqrt(n - 1) whatever the value,
+    so a sparse column produces mathematically equal scores that the reference orders by f64 rounding.  Only the same f64
+    operands reproduce that -- the matrix-core form declines such a call (exact zeros in a column it cannot hold exactly)."""
+    rng = np.random.default_rng(31)
+    n, m, nperm, seed = 800, 20, 40, 3
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.06)
+    b = rng.normal(size=(n, m))
+    b[:, 5] = np.where(rng.uniform(size=n) < 0.9, 0.0, b[:, 5])
+    cn_w, cp_w = orc.run_permutations(a, b, 'z-score', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.06))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name != 'k_permtest_mfma'
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    # the same column on a grid the fixed-point image holds exactly (small integers): the matrix cores take it, same decisions
+    b[:, 5] = np.where(b[:, 5] == 0.0, 0.0, np.rint(4 * b[:, 5]))
+    others = [j for j in range(m) if j != 5]
+    b[:, others] = np.rint(64 * b[:, others]) / 8.0
+    cn_w, cp_w = orc.run_permutations(a, b, 'z-score', nperm, seed)
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name == 'k_permtest_mfma'
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
