@@ -195,6 +195,11 @@ int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host
  * 0..n-1 (SAFE_E_VALUE otherwise). */
 int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutations,
                                  const int32_t *perm_idx_host, safe_perms **out);
+/* Permutations [p0, p1) of an existing handle as a handle of their own (device-to-device copy).  The permutation-axis
+ * split of safepy/safe.py:489-519 (the reference hands each worker process num_permutations / processes permutations;
+ * its workers reseed identically, so they repeat one another -- here every rank draws the ONE cumulative stream of
+ * safe_extras.py:46-58 and tests its own range of it, and the ranks' counts add up to the single-process counts). */
+int safe_perms_slice(safe_perms *perms, int64_t p0, int64_t p1, safe_perms **out);
 /* Host-only: the raw stream, for pinning against numpy (no device needed).  Writes
  * count permutations of values[0..n_items) back to back into out[count*n_items]. */
 int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_items,
@@ -258,6 +263,14 @@ int safe_enriched_components(safe_ctx *ctx, int64_t n, int64_t n_edges, const in
  * condensed order; 0 where both profiles are empty. */
 int safe_jaccard_condensed(safe_ctx *ctx, int64_t m_top, int64_t n, const double *x_host, double *out_host);
 
+/* Counts of a whole call -> outputs (safepy/safe.py:528-554 and 468-472): counts_neg / counts_pos are #(S_p <= S_obs) /
+ * #(S_p >= S_obs) as f64 [n, m] on the device (e.g. safe_permtest_counts results summed over the ranks of a
+ * permutation-axis split), ns_dev the observed scores (NaN = no test; may be NULL).  Writes p-values, NES
+ * (nes_table_host as in safe_randomization), nes_binary [n, m] and num_enriched [m]. */
+int safe_outputs_from_counts(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutations, int sign_mode,
+                             double enrichment_threshold, const double *nes_table_host, const double *counts_neg_dev,
+                             const double *counts_pos_dev, const double *ns_dev, double *pvalues_neg_dev, double *pvalues_pos_dev,
+                             double *nes_dev, double *nes_binary_dev, double *num_enriched_dev);
 /* Multi-GPU exchange in integers (replaces gathering f64 NES blocks for the np.concatenate of
  * safepy/safe.py:1355): after safe_randomization / safe_permtest_counts on the bit-sliced or
  * matrix-core kernel, the raw counters of the call are still resident as

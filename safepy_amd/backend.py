@@ -409,6 +409,15 @@ class Permutations:
         self.handle = h
         return self
 
+    def slice(self, p0, p1):
+        """Permutations [p0, p1) as a handle of their own (safe_perms_slice): one rank's range of a permutation-axis split."""
+        other = Permutations.__new__(Permutations)
+        other.ctx, other.n, other.count = self.ctx, self.n, int(p1) - int(p0)
+        h = C.c_void_p()
+        check(lib.safe_perms_slice(self.handle, int(p0), int(p1), C.byref(h)))
+        other.handle = h
+        return other
+
     def read(self, p0=0, p1=None):
         p1 = self.count if p1 is None else p1
         out = np.empty((p1 - p0, self.n), dtype=np.int32)
@@ -523,6 +532,19 @@ def randomization(ctx, nbr, attr, perms, score_type, attribute_sign, enrichment_
                                  _SIGN[attribute_sign], float(enrichment_threshold), _ptr(table), col0, col1,
                                  C.c_void_p(ns) if ns else None, C.c_void_p(pn), C.c_void_p(pp), C.c_void_p(nes),
                                  C.c_void_p(nb), C.c_void_p(ne)))
+
+
+def outputs_from_counts(ctx, n, m, num_permutations, attribute_sign, enrichment_threshold, counts_neg_ptr, counts_pos_ptr, ns_ptr,
+                        out_ptrs, table=None):
+    """#<= / #>= counts of a whole call (f64 [n, m] on the device) -> out_ptrs = (pvalues_neg, pvalues_pos, nes, nes_binary,
+    num_enriched) device pointers (safe_outputs_from_counts; safe.py:528-554, 468-472)."""
+    if table is None:
+        table = nes_table(num_permutations)
+    pn, pp, nes, nb, ne = out_ptrs
+    check(lib.safe_outputs_from_counts(ctx.handle, int(n), int(m), int(num_permutations), _SIGN[attribute_sign],
+                                       float(enrichment_threshold), _ptr(table), C.c_void_p(counts_neg_ptr), C.c_void_p(counts_pos_ptr),
+                                       C.c_void_p(ns_ptr) if ns_ptr else None, C.c_void_p(pn), C.c_void_p(pp), C.c_void_p(nes),
+                                       C.c_void_p(nb), C.c_void_p(ne)))
 
 
 def hypergeom(ctx, nbr, attr, enrichment_threshold, out_ptrs, col0=0, col1=None):

@@ -2421,6 +2421,28 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     return SAFE_OK;
 }
 
+// counts of a whole call (#<=, #>= as f64 [N, M], e.g. summed over the ranks of a permutation-axis split) ->
+// p-values, NES, nes_binary, enriched counts (safe.py:528-554, 468-472); an element whose observed score is NaN has no test
+__global__ __launch_bounds__(256) void k_counts_to_outputs(const double *__restrict__ counts_neg, const double *__restrict__ counts_pos,
+                                                           const double *__restrict__ ns, int64_t total, int64_t m, int64_t n_perm,
+                                                           PermOut out) {
+    const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= total) return;
+    const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+    const bool obs_nan = ns && ns[idx] != ns[idx];
+    const unsigned int kn = static_cast<unsigned int>(counts_neg[idx]), kp = static_cast<unsigned int>(counts_pos[idx]);
+    const double en = obs_nan ? qnan : out.nes_table[kn], ep = obs_nan ? qnan : out.nes_table[kp];
+    double nes = ep - en;
+    if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+    if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+    const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+    out.pvalues_neg[idx] = obs_nan ? qnan : static_cast<double>(kn) / static_cast<double>(n_perm);
+    out.pvalues_pos[idx] = obs_nan ? qnan : static_cast<double>(kp) / static_cast<double>(n_perm);
+    out.nes[idx] = nes;
+    out.nes_binary[idx] = hit ? 1.0 : 0.0;
+    if (hit) atomicAdd(&out.enriched[idx % m], 1u);
+}
+
 // ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
                            int64_t n_perm, const PermOut &out, const double *ns_direct) {
@@ -2695,6 +2717,49 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     (void)hipFree(d_lf);
     (void)hipFree(tiles.bt);
     return rc;
+}
+
+int safe_outputs_from_counts(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutations, int sign_mode,
+                             double enrichment_threshold, const double *nes_table_host, const double *counts_neg_dev,
+                             const double *counts_pos_dev, const double *ns_dev, double *pvalues_neg_dev, double *pvalues_pos_dev,
+                             double *nes_dev, double *nes_binary_dev, double *num_enriched_dev) {
+    SAFE_REQUIRE(ctx && counts_neg_dev && counts_pos_dev && pvalues_neg_dev && pvalues_pos_dev && nes_dev && nes_binary_dev &&
+                     num_enriched_dev,
+                 "safe_outputs_from_counts: NULL argument");
+    SAFE_REQUIRE(n >= 1 && m >= 1 && num_permutations >= 1, "safe_outputs_from_counts: bad sizes");
+    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_outputs_from_counts: bad sign_mode %d", sign_mode);
+    SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_outputs_from_counts: enrichment_threshold must be in (0,1)");
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    const int64_t P = num_permutations;
+    std::vector<double> tab(P + 1);
+    if (nes_table_host) {
+        std::copy(nes_table_host, nes_table_host + P + 1, tab.begin());
+    } else {
+        tab[0] = -std::log10(1.0 / static_cast<double>(P));
+        for (int64_t k = 1; k <= P; ++k) tab[k] = -std::log10(static_cast<double>(k) / static_cast<double>(P));
+    }
+    void *small = nullptr;                           // NES table f64 [P + 1] | enriched counters u32 [m + 16]
+    SAFE_TRY(ctx_scratch(ctx, 10, static_cast<size_t>(P + 1) * sizeof(double) + static_cast<size_t>(m + 16) * sizeof(unsigned int), &small));
+    double *d_tab = static_cast<double *>(small);
+    unsigned int *d_enr = reinterpret_cast<unsigned int *>(d_tab + P + 1);
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_enr, 0, (m + 16) * sizeof(unsigned int), ctx->stream));
+    PermOut out{};
+    out.pvalues_neg = pvalues_neg_dev;
+    out.pvalues_pos = pvalues_pos_dev;
+    out.nes = nes_dev;
+    out.nes_binary = nes_binary_dev;
+    out.enriched = d_enr;
+    out.nes_table = d_tab;
+    out.nes_threshold = -std::log10(enrichment_threshold);
+    out.sign_mode = sign_mode;
+    out.mode = 2;
+    hipLaunchKernelGGL(k_counts_to_outputs, dim3(ceil_div(n * m, 256)), dim3(256), 0, ctx->stream, counts_neg_dev, counts_pos_dev, ns_dev,
+                       n * m, m, P, out);
+    hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, m);
+    SAFE_HIP_CHECK(hipGetLastError());
+    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // tab is a host vector
+    return SAFE_OK;
 }
 
 int safe_export_packed_counts(safe_ctx *ctx, uint32_t *dst_dev, int64_t capacity, int64_t *n_pad, int64_t *m,

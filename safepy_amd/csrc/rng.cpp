@@ -508,6 +508,53 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     return SAFE_OK;
 }
 
+// A handle over finished tables: `count` composed rows of n + 1 entries at `src` (host memory, or device memory that is
+// complete on the aux stream when this is called).  No draw stream, no pipeline: every stage is done at once.
+static int perms_table_handle(safe_ctx *ctx, int64_t n, int64_t count, const int32_t *src, hipMemcpyKind kind, const char *who,
+                              safe_perms **out) {
+    const int64_t stride = n + 1, rows = std::max<int64_t>(count, 1);
+    safe_perms *p = new safe_perms();
+    p->ctx = ctx;
+    p->n = n;
+    p->count = count;
+    p->from_table = true;
+    p->k = n;
+    p->generated = p->swapping = p->enqueued = count;
+    int rc = SAFE_OK;
+    do {
+        if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
+        hipError_t e = count ? hipMemcpyAsync(p->table, src, static_cast<size_t>(count) * stride * sizeof(int32_t), kind, ctx->aux_stream)
+                             : hipMemsetAsync(p->table, 0, static_cast<size_t>(rows) * stride * sizeof(int32_t), ctx->aux_stream);
+        if (e == hipSuccess && n < 65535) {
+            p->stride16 = (stride + 7) / 8 * 8;
+            if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
+            if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
+            hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
+            const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), rows), block(256);
+            hipLaunchKernelGGL(k_table16, grid, block, 0, ctx->aux_stream, p->table, stride, p->table16, p->stride16, n);
+            e = hipGetLastError();
+        }
+        p->stages = perms_stage_plan(count);
+        const int64_t n_chunks = stage_count(p);
+        p->chunk_done.assign(std::max<int64_t>(n_chunks, 1), nullptr);
+        for (size_t c = 0; c < p->chunk_done.size() && e == hipSuccess; ++c) {
+            e = hipEventCreateWithFlags(&p->chunk_done[c], hipEventDisableTiming);
+            if (e == hipSuccess) e = hipEventRecord(p->chunk_done[c], ctx->aux_stream);
+        }
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->aux_stream);    // `src` may be host memory of the caller's call
+        if (e != hipSuccess) {
+            safe_set_error("%s: %s", who, hipGetErrorString(e));
+            rc = SAFE_E_HIP;
+        }
+    } while (0);
+    if (rc != SAFE_OK) {
+        perms_free(p);
+        return rc;
+    }
+    *out = p;
+    return SAFE_OK;
+}
+
 int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutations, const int32_t *perm_idx_host,
                                  safe_perms **out) {
     SAFE_REQUIRE(ctx && out && (perm_idx_host || num_permutations == 0), "safe_perms_create_from_table: NULL argument");
@@ -536,46 +583,21 @@ int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutati
             staged[p * stride + n] = static_cast<int32_t>(n);           // the padding row maps to itself
         }
     }
-    safe_perms *p = new safe_perms();
-    p->ctx = ctx;
-    p->n = n;
-    p->count = num_permutations;
-    p->from_table = true;
-    p->k = n;
-    p->generated = p->swapping = p->enqueued = num_permutations;
-    int rc = SAFE_OK;
-    do {
-        if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
-        hipError_t e = hipMemcpyAsync(p->table, staged.data(), staged.size() * sizeof(int32_t), hipMemcpyHostToDevice, ctx->aux_stream);
-        if (e == hipSuccess && n < 65535) {
-            p->stride16 = (stride + 7) / 8 * 8;
-            if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
-            if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
-            hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
-            // table16 from table: the emit kernel with the identity as both composition operands' base
-            const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), rows), block(256);
-            hipLaunchKernelGGL(k_table16, grid, block, 0, ctx->aux_stream, p->table, stride, p->table16, p->stride16, n);
-            e = hipGetLastError();
-        }
-        p->stages = perms_stage_plan(num_permutations);
-        const int64_t n_chunks = stage_count(p);
-        p->chunk_done.assign(std::max<int64_t>(n_chunks, 1), nullptr);
-        for (size_t c = 0; c < p->chunk_done.size() && e == hipSuccess; ++c) {
-            e = hipEventCreateWithFlags(&p->chunk_done[c], hipEventDisableTiming);
-            if (e == hipSuccess) e = hipEventRecord(p->chunk_done[c], ctx->aux_stream);
-        }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->aux_stream);    // `staged` is host memory of this call
-        if (e != hipSuccess) {
-            safe_set_error("safe_perms_create_from_table: %s", hipGetErrorString(e));
-            rc = SAFE_E_HIP;
-        }
-    } while (0);
-    if (rc != SAFE_OK) {
-        perms_free(p);
-        return rc;
-    }
-    *out = p;
-    return SAFE_OK;
+    return perms_table_handle(ctx, n, num_permutations, staged.data(), hipMemcpyHostToDevice, "safe_perms_create_from_table", out);
+}
+
+// Permutations [p0, p1) of an existing handle as a handle of their own (device-to-device copy of the finished rows): the
+// permutation-axis split -- every rank draws the ONE stream of the call (safe_extras.py:46, 58: the permutations are
+// cumulative, so each rank needs all of its predecessors' draws anyway) and tests its own range of it.
+int safe_perms_slice(safe_perms *perms, int64_t p0, int64_t p1, safe_perms **out) {
+    SAFE_REQUIRE(perms && out, "safe_perms_slice: NULL argument");
+    SAFE_REQUIRE(0 <= p0 && p0 <= p1 && p1 <= perms->count, "safe_perms_slice: range [%lld,%lld) outside [0,%lld)", (long long)p0,
+                 (long long)p1, (long long)perms->count);
+    *out = nullptr;
+    safe_ctx *ctx = perms->ctx;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_TRY(perms_wait(perms, p1, ctx->aux_stream));
+    return perms_table_handle(ctx, perms->n, p1 - p0, perms->table + p0 * (perms->n + 1), hipMemcpyDeviceToDevice, "safe_perms_slice", out);
 }
 
 int safe_perms_destroy(safe_perms *perms) {

@@ -306,6 +306,75 @@ def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, 
         attr.close()
 
 
+def permutation_split_randomization(ctx, nbr, attr_host, num_permutations, random_seed, neighborhood_score_type='sum',
+                                    attribute_sign='both', enrichment_threshold=0.05, group=None, multiple_testing=False):
+    """compute_pvalues_by_randomization split along the PERMUTATION axis -- for matrices with fewer attributes than
+    ranks (one scatter-plot column, BASELINE configs[0]), where column shards leave GPUs idle.  The reference sketches
+    this split for its worker processes (safe.py:489-519: num_permutations / processes each, counts added up); there
+    every worker reseeds identically and repeats the others' permutations.  Here EVERY rank passes the whole [N, M]
+    matrix and draws the one cumulative stream of the call (safe_extras.py:46-58 -- a permutation depends on all earlier
+    ones, so the host draws cannot be skipped), tests only its own range of it (safe_perms_slice) and the integer
+    counts are summed over the ranks (one all-reduce: the path's real exchange step).  The sum equals the
+    single-process counts, so p-values / NES / nes_binary are those of the unsplit call, on every rank.
+    Returns the same dict as sharded_randomization with every 'full_<name>' equal to the local matrix."""
+    import torch
+    from . import backend as be
+    dist = _dist()
+    alone = not dist.is_initialized()
+    world = 1 if alone else dist.get_world_size(group)
+    rank = 0 if alone else dist.get_rank(group)
+    total = int(num_permutations)
+    attr = be.Attributes.from_host(ctx, attr_host)
+    try:
+        seed = random_seed if alone else agree_on_seed(random_seed, group)
+        n, m = attr.n, attr.m
+        dev = torch.device('cuda', ctx.device)
+        ns, neg, pos = (torch.zeros((n, m), dtype=torch.float64, device=dev) for _ in range(3))
+        torch.cuda.current_stream().synchronize()
+        p0, p1 = column_shards(total, world)[rank]
+        whole = be.Permutations(ctx, n, attr.row_flags(), total, seed)
+        try:
+            if p1 > p0:
+                mine = whole.slice(p0, p1)
+                try:
+                    be.permtest_counts(ctx, nbr, attr, mine, neighborhood_score_type, ns.data_ptr(), neg.data_ptr(), pos.data_ptr())
+                finally:
+                    mine.close()
+            else:                                           # more ranks than permutations: nothing to test, the scores only
+                be.score(ctx, nbr, attr, neighborhood_score_type, ns.data_ptr())
+            ctx.sync()
+        finally:
+            whole.close()
+        counts = torch.stack([neg, pos]).to(torch.int64)   # exact: counts are whole numbers <= num_permutations
+        if not alone:
+            if dist.get_backend(group) == 'gloo':
+                host = counts.cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM, group=group)
+                counts = host.to(dev)
+            else:
+                dist.all_reduce(counts, op=dist.ReduceOp.SUM, group=group)
+        neg, pos = counts[0].to(torch.float64).contiguous(), counts[1].to(torch.float64).contiguous()
+        bufs, enriched = _alloc_outputs(ctx, n, m, ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'))
+        torch.cuda.current_stream().synchronize()
+        be.outputs_from_counts(ctx, n, m, total, attribute_sign, enrichment_threshold, neg.data_ptr(), pos.data_ptr(), ns.data_ptr(),
+                               [bufs[k].data_ptr() for k in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')] + [enriched.data_ptr()])
+        if multiple_testing:                               # whole rows are here already (safe.py:536-542)
+            be.fdr_adjust(ctx, n, m, total, attribute_sign, enrichment_threshold,
+                          [bufs['pvalues_neg'].data_ptr(), bufs['pvalues_pos'].data_ptr(), bufs['nes'].data_ptr(),
+                           bufs['nes_binary'].data_ptr(), enriched.data_ptr()])
+        ctx.sync()
+        out = {k: v.cpu().numpy() for k, v in bufs.items()}
+        out['ns'] = ns.cpu().numpy()
+        out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
+        for k in RANDOMIZATION_OUTPUTS:
+            out['full_' + k] = out[k]
+        out['stats'] = {'random_seed': seed, 'permutation_range': (p0, p1)}
+        out['how'] = 'randomization'
+        return out
+    finally:
+        attr.close()
+
+
 def _hypergeom_host(ctx, nbr, attr, m_total, flags, enrichment_threshold, group, gather, multiple_testing, attribute_sign):
     import torch
     from . import backend as be

@@ -113,6 +113,37 @@ def main():
         sf.load_attributes(attribute_file=b.copy())
         sf.compute_pvalues(how='randomization', num_permutations=40, neighborhood_score_type='sum', multiple_testing=False)
         assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+        # permutation-axis split (fewer attributes than ranks -- BASELINE configs[0] is ONE column): every rank passes the
+        # whole matrix, tests its range of the one stream, the counts are all-reduced; the result on every rank is the
+        # single-process result
+        one = rng.normal(size=(n, 1))
+        one[rng.choice(n, 200, replace=False)] = np.nan
+        one[3, 0] = 0.0
+        two = (rng.uniform(size=(n, 2)) < 0.05).astype(np.float64)
+        for name, b, kw in (('one-column-sum', one, dict(num_permutations=53)),
+                            ('one-column-zscore', one, dict(num_permutations=31, neighborhood_score_type='z-score')),
+                            ('two-binary-columns', two, dict(num_permutations=40)),
+                            ('one-column-fdr', one, dict(num_permutations=30, multiple_testing=True)),
+                            ('fewer-permutations-than-ranks', one, dict(num_permutations=world - 1))):
+            score = kw.get('neighborhood_score_type', 'sum')
+            fdr = kw.get('multiple_testing', False)
+            out = sharding.permutation_split_randomization(ctx, nbr, b, kw['num_permutations'], 9, neighborhood_score_type=score,
+                                                           multiple_testing=fdr)
+            p0, p1 = out['stats']['permutation_range']
+            assert (p0, p1) == sharding.column_shards(kw['num_permutations'], world)[rank], name
+            if kw['num_permutations'] >= 10:            # (SAFE itself refuses fewer, like the reference: safe.py validate_config)
+                sf.random_seed = 9
+                sf.load_attributes(attribute_file=b.copy())
+                sf.compute_pvalues(how='randomization', num_permutations=kw['num_permutations'], neighborhood_score_type=score,
+                                   multiple_testing=fdr)
+                for key in ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+                    assert np.array_equal(out[key], getattr(sf, key), equal_nan=True), (name, key, rank)
+                assert np.array_equal(out['num_neighborhoods_enriched'], sf.attributes['num_neighborhoods_enriched'].values), name
+            if not fdr:
+                want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=kw['num_permutations'],
+                                           random_seed=9, neighborhood_score_type=score)
+                for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+                    assert np.array_equal(out[key], want[key], equal_nan=True), (name, key, rank)
         if backend == 'nccl':
             # the exchange through the C ABI's own RCCL communicator (safe_comm_* / safe_allgather_cols): the id travels
             # over the process group here; a non-torch host would use a file or MPI

@@ -192,6 +192,53 @@ def test_permutation_tables_vs_numpy_stream(amd, ctx, golden_enr):
     perms.close()
 
 
+def test_permutation_ranges_add_up_to_the_whole_call(amd, ctx, golden_enr):
+    """safe_perms_slice + safe_outputs_from_counts (the permutation-axis split, safe.py:489-519): the counts of the ranges
+    [0,7), [7,7), [7,19), [19,25) of one seeded stream add up to the counts of the 25-permutation call, every kernel family,
+    and the outputs rebuilt from the summed counts are the outputs of the whole call."""
+    from safepy_amd import backend as be
+    from safepy_amd import sharding
+    g = golden_enr
+    a = g['A'].astype(np.int64)
+    n = a.shape[0]
+    nbr = amd.Neighborhoods.from_dense(ctx, a)
+    for b, score in ((g['b_bin'], 'sum'), (g['b_q'], 'sum'), (g['b_q'], 'z-score')):
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        m = b.shape[1]
+        attr = be.Attributes.from_host(ctx, b)
+        whole = be.Permutations(ctx, n, attr.row_flags(), 25, 31)
+        ns, neg, pos = (ctx.alloc_f64(n, m) for _ in range(3))
+        be.permtest_counts(ctx, nbr, attr, whole, score, ns.ptr, neg.ptr, pos.ptr)
+        want_n, want_p, want_ns = neg.download((n, m)), pos.download((n, m)), ns.download((n, m))
+        tables = whole.read()
+        sum_n, sum_p = np.zeros((n, m)), np.zeros((n, m))
+        for p0, p1 in ((0, 7), (7, 7), (7, 19), (19, 25)):
+            part = whole.slice(p0, p1)
+            assert part.count == p1 - p0 and np.array_equal(part.read(), tables[p0:p1])
+            if p1 > p0:
+                be.permtest_counts(ctx, nbr, attr, part, score, ns.ptr, neg.ptr, pos.ptr)
+                sum_n += neg.download((n, m))
+                sum_p += pos.download((n, m))
+                assert np.array_equal(ns.download((n, m)), want_ns, equal_nan=True)
+            part.close()
+        assert np.array_equal(sum_n, want_n) and np.array_equal(sum_p, want_p)
+        whole.close()
+        # outputs from the summed counts == the whole call's outputs (one process, no process group)
+        out = sharding.permutation_split_randomization(ctx, nbr, b, 25, 31, neighborhood_score_type=score)
+        perms = be.Permutations(ctx, n, attr.row_flags(), 25, 31)
+        bufs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
+        be.randomization(ctx, nbr, attr, perms, score, 'both', 0.05, [x.ptr for x in bufs])
+        ctx.sync()
+        for key, buf in zip(('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'), bufs):
+            assert np.array_equal(out[key], buf.download((n, m)), equal_nan=True), (score, key)
+        assert np.array_equal(out['num_neighborhoods_enriched'], bufs[5].download((m,)))
+        perms.close()
+        attr.close()
+    with pytest.raises(Exception):
+        be.Permutations(ctx, n, np.ones(n, dtype=np.uint8), 5, 1).slice(3, 9)
+    nbr.close()
+
+
 def test_caller_supplied_permutation_tables(amd, ctx, golden_enr):
     """safe_perms_create_from_table: the `perm` of safe_extras.py:58 produced elsewhere.  (1) NumPy's own composed tables
     fed back in reproduce the seeded run; (2) tables from another generator give the counts a direct NumPy evaluation
