@@ -1981,7 +1981,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int64_t blocks_per_perm = 0;
     for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / 4] = std::max<int64_t>(sg_blocks[s / 4], nbr->h_slice_width[s] / 8);
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
-    int tasks_per_slot = 6;                              // queue depth per workgroup slot: balance against the per-task costs (T reload, counter flush)
+    int tasks_per_slot = 2;                              // queue depth per workgroup slot: balance against the per-task costs (T reload, counter flush);
+                                                         // 2 measured best of 1..6 once the host stream stopped being the bottleneck (tools/step_sweep2.sh)
     if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
     const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
     const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_wg);    // block-permutations per task
