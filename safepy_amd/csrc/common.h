@@ -127,7 +127,7 @@ struct safe_nbr {
     int32_t *slice_width = nullptr; // [n_slices]
     int32_t *sell_col = nullptr;    // [slice_off[n_slices]] column id, n = padding (zero row)
     int64_t sell_entries = 0;
-    uint16_t *sell_col2 = nullptr;  // [sell_entries + 512] 2*column id as u16 (n < 32768 only): LDS byte offsets of a u16 table
+    uint16_t *sell_col2 = nullptr;  // [sell_entries + 1024] 2*column id as u16 (n < 32768 only): LDS byte offsets of a u16 table
     uint16_t *sell_col2b = nullptr; // the same list in blocked order: 8 members of a lane adjacent (one 16-byte load per lane and block)
     std::vector<int32_t> h_slice_width;
     std::vector<int64_t> h_slice_off;

@@ -980,44 +980,55 @@ __device__ __forceinline__ void vripple_lv(uint32_t (&s)[LV], uint32_t t8) {
     }
 }
 
-// ids: this lane's blocks (uint4 = 8 x u16), 64 uint4 apart; SHIFT = 2 turns the resident 2*id list into 8*id
+// ids: this lane's blocks (uint4 = 8 x u16), 64 uint4 apart; SHIFT = 2 turns the resident 2*id list into 8*id.
+// The id words are fetched TWO blocks ahead into two register quads that swap roles (no copies): a block's adds take
+// 100-200 cycles, a load from L2 / MALL several hundred -- one block of look-ahead left every wave waiting at vmcnt(0)
+// at the top of each block (the lists have a tail of two blocks, so the look-ahead never leaves the buffer).
+template <int LV, int SHIFT, bool GATHER>
+__device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ refill, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
+    uint32_t a[8];
+    a[0] = (c.x & 0xFFFFu) << SHIFT;
+    a[1] = (c.x >> 16) << SHIFT;
+    a[2] = (c.y & 0xFFFFu) << SHIFT;
+    a[3] = (c.y >> 16) << SHIFT;
+    a[4] = (c.z & 0xFFFFu) << SHIFT;
+    a[5] = (c.z >> 16) << SHIFT;
+    a[6] = (c.w & 0xFFFFu) << SHIFT;
+    a[7] = (c.w >> 16) << SHIFT;
+    c = *refill;                                                                          // the block after next
+    uint32_t x0[8], x1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (GATHER) {
+            const u32x2 w = *(lds_u2_ptr)(uintptr_t)(a[u]);
+            x0[u] = w.x;
+            x1[u] = w.y;
+        } else {
+            x0[u] = a[u];
+            x1[u] = a[u] >> 3;
+        }
+    }
+    const uint32_t e0 = vadd8_lv<LV>(s0, x0);
+    const uint32_t e1 = vadd8_lv<LV>(s1, x1);
+    if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+        vripple_lv<LV>(s0, e0);
+        vripple_lv<LV>(s1, e1);
+    }
+}
+
 template <int LV, int SHIFT, bool GATHER>
 __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     // `ids` is the slice's first block, the same for the whole wave (scalar registers); the lane is the offset
 #pragma unroll
     for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
-    u32x4 c = ids[lane];
-    const u32x4 *pc = ids + 64;
-    for (int b = 0; b < nblk; ++b, pc += 64) {
-        uint32_t a[8];
-        a[0] = (c.x & 0xFFFFu) << SHIFT;
-        a[1] = (c.x >> 16) << SHIFT;
-        a[2] = (c.y & 0xFFFFu) << SHIFT;
-        a[3] = (c.y >> 16) << SHIFT;
-        a[4] = (c.z & 0xFFFFu) << SHIFT;
-        a[5] = (c.z >> 16) << SHIFT;
-        a[6] = (c.w & 0xFFFFu) << SHIFT;
-        a[7] = (c.w >> 16) << SHIFT;
-        c = pc[lane];                                                                     // next block (the lists have a tail)
-        uint32_t x0[8], x1[8];
-#pragma unroll
-        for (int u = 0; u < 8; ++u) {
-            if (GATHER) {
-                const u32x2 w = *(lds_u2_ptr)(uintptr_t)(a[u]);
-                x0[u] = w.x;
-                x1[u] = w.y;
-            } else {
-                x0[u] = a[u];
-                x1[u] = a[u] >> 3;
-            }
-        }
-        const uint32_t e0 = vadd8_lv<LV>(s0, x0);
-        const uint32_t e1 = vadd8_lv<LV>(s1, x1);
-        if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
-            vripple_lv<LV>(s0, e0);
-            vripple_lv<LV>(s1, e1);
-        }
+    u32x4 ca = ids[lane], cb = ids[64 + lane];
+    const u32x4 *pc = ids + 128 + lane;
+    int b = 0;
+    for (; b + 1 < nblk; b += 2, pc += 128) {
+        blk_add8<LV, SHIFT, GATHER>(ca, pc, s0, s1);
+        blk_add8<LV, SHIFT, GATHER>(cb, pc + 64, s0, s1);
     }
+    if (b < nblk) blk_add8<LV, SHIFT, GATHER>(ca, pc, s0, s1);
 }
 
 // one wave, one task: observed sums, then every permutation of the task's range; counters come back in g / l
@@ -1107,6 +1118,7 @@ __global__ __launch_bounds__(256) void k_bits_observed(int64_t n, const int32_t 
     if (wdt <= 8) observed_wave<4>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
     else if (wdt <= 56) observed_wave<6>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
     else if (wdt <= 248) observed_wave<8>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
+    else if (wdt <= 504) observed_wave<9>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
     else observed_wave<BT_LV>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
     const int32_t row = sell_row[s * 64 + lane];
     if (ns_out && row >= 0) {
@@ -1198,6 +1210,7 @@ __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
         } else if (wdt <= 8) blk_task<4, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         else if (wdt <= 56) blk_task<6, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         else if (wdt <= 248) blk_task<8, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else if (wdt <= 504) blk_task<9, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         else blk_task<BT_LV, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
 
         const int64_t spos = s * 64 + lane;
@@ -2027,7 +2040,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const bool scaled = (n + 1) * 8 < 65536;
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
     const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
-    const int64_t entries_pad = (nbr->sell_entries + 512 + 255) / 256 * 256;
+    const int64_t entries_pad = (nbr->sell_entries + 1024 + 255) / 256 * 256;    // tail: the kernels fetch ids two blocks (2 x 512) ahead
     uint16_t *d_ids[2] = {nullptr, nullptr};
     if (pre)
         for (int b = 0; b < 2; ++b)

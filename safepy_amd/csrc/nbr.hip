@@ -457,7 +457,7 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
                        nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->n_slices, static_cast<int32_t>(n),
                        nbr->sell_col);
     if (n < 32768) {
-        const int64_t total = nbr->sell_entries + 512;          // tail: one block of 8 x 64 may be prefetched past the end
+        const int64_t total = nbr->sell_entries + 1024;         // tail: two blocks of 8 x 64 may be prefetched past the end
         SAFE_TRY(dev_alloc(&nbr->sell_col2, total));
         hipLaunchKernelGGL(k_sell_scale16, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, nbr->sell_col,
                            nbr->sell_entries, total, static_cast<uint32_t>(2 * n), nbr->sell_col2);

@@ -38,7 +38,7 @@ def one(P):
             best = (dt, name, ms, launches)
     dt, name, ms, launches = best
     print('%-22s tasks=%s dbg=%s merge=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
-        name, os.environ.get('SAFE_HIP_BITS_TASKS', '6'), os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), 1e3 * dt, launches, ms, ms * launches), flush=True)
+        name, os.environ.get('SAFE_HIP_BITS_TASKS', '2'), os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), 1e3 * dt, launches, ms, ms * launches), flush=True)
 
 
 if __name__ == '__main__':
@@ -47,7 +47,8 @@ if __name__ == '__main__':
         sys.exit(0)
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
     K, TK = 'SAFE_HIP_BITS_KERNEL', 'SAFE_HIP_BITS_TASKS'
-    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', TK: '2'}, {K: 'blk', TK: '3'}, {K: 'blk', 'SAFE_HIP_BITS_DBG': '2'},
-               {K: 'blk', 'SAFE_HIP_BITS_DBG': '4'}, {K: 'blk', 'SAFE_HIP_BITS_MERGE': '2'}, {K: 'blk', 'SAFE_HIP_BITS_MERGE': '8'}]
+    D = 'SAFE_HIP_BITS_DBG'
+    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', TK: '1'}, {K: 'blk', TK: '3'}, {K: 'blk', D: '1'}, {K: 'blk', D: '2'}, {K: 'blk', D: '4'},
+               {K: 'blk', D: '7'}, {K: 'blk', 'SAFE_HIP_BITS_MERGE': '2'}]
     for cfg in configs:
         subprocess.run([sys.executable, os.path.abspath(__file__), '--one', str(P)], env=dict(os.environ, **cfg))
