@@ -311,12 +311,12 @@ def main():
 
     import numpy as np
     import torch
-    # host threads of the permutation stream per rank: the draw thread, its raw-word helper and the swap
+    # host threads of the permutation stream per rank: the draw thread and the swap
     # workers.  Ranks of one node share the host: keep the swap pool within this rank's share of the CPUs
     # the container may use (4 workers keep pace with the draw thread; fewer only when the host is short).
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
     if 'SAFE_HIP_SWAP_THREADS' not in os.environ:
-        os.environ['SAFE_HIP_SWAP_THREADS'] = str(max(1, min(4, effective_cores() // max(1, local_world) - 2)))
+        os.environ['SAFE_HIP_SWAP_THREADS'] = str(max(1, min(4, effective_cores() // max(1, local_world) - 1)))
     import safepy_amd
     from safepy_amd import backend as be
     from safepy_amd import workloads, sharding

@@ -21,7 +21,7 @@ def _ptr(a):
 
 
 def pin_threads_to_device_numa(device=0):
-    """Keep every thread this process has -- and those it starts later: the draw thread, its raw-word helper, the
+    """Keep every thread this process has -- and those it starts later: the draw thread, the
     swap workers -- on the CPUs of the NUMA node the GPU hangs off.  A container may be scheduled on any CPU of a
     two-socket host; with the draw thread on the far socket a whole run is ~15-20 % slower (5.2 vs 5.4-6.2
     ms/step at configs[1]).  Returns the node, or None when the topology cannot be read (nothing is changed
