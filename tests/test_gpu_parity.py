@@ -648,8 +648,8 @@ def test_integer_forms_large_support_and_many_permutations(amd, monkeypatch, pat
 @pytest.mark.parametrize('kernel,nperm', [('blk', 40), ('blk', 300), ('pre', 40), ('barrier', 40)])
 def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
     """The three bit-sliced kernels (blocked member lists = default, pre-permuted lists, permutation row in LDS) on a
-    membership whose SELL slices fall into every width class of the blocked kernel (<= 8, <= 56, <= 248, > 248 members:
-    4 / 6 / 8 / 10 levels of the vertical sums), with columns dense enough that the sums really reach the top
+    membership whose SELL slices fall into every width class of the blocked kernel (<= 8, <= 56, <= 248, <= 504, > 504 members:
+    4 / 6 / 8 / 9 / 10 levels of the vertical sums), with columns dense enough that the sums really reach the top
     levels, an empty neighborhood, a ragged last word group; 300 permutations carry the counters past their low levels."""
     monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'bits')
     if kernel == 'pre':
@@ -658,7 +658,8 @@ def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
         monkeypatch.setenv('SAFE_HIP_BITS_PRE', '0')
     rng = np.random.default_rng(77)
     n, m = 1400, 131
-    sizes = np.r_[rng.integers(600, 1000, 10), rng.integers(100, 248, 150), rng.integers(9, 56, 640), rng.integers(0, 9, 600)]
+    sizes = np.r_[rng.integers(600, 1000, 10), rng.integers(260, 500, 70), rng.integers(100, 248, 150), rng.integers(9, 56, 640),
+                  rng.integers(0, 9, 530)]
     rng.shuffle(sizes)
     a = np.zeros((n, n), dtype=np.int64)
     for i, k in enumerate(sizes):
