@@ -42,7 +42,9 @@ def test_host_only_rng_stream_matches_numpy(golden_rng):
             for suffix in ('a', 'b'):
                 assert np.array_equal(np.random.permutation(base), golden_rng['s%d_n%d_%s' % (seed, n_items, suffix)])
         # the library call restarts the stream: compare each size with a fresh NumPy stream
-        for n_items in (1, 2, 3, 17, 64, 257, 3971, 20000):
+        # (sizes on both sides of every power of two: the acceptance mask changes there and the vector loop cuts its batch)
+        for n_items in (1, 2, 3, 15, 16, 17, 31, 32, 33, 63, 64, 65, 127, 128, 129, 255, 256, 257, 511, 512, 513, 1023, 1024, 1025,
+                        2047, 2048, 2049, 3971, 4095, 4096, 4097, 20000):
             base = np.arange(n_items) * 3 + 1
             np.random.seed(seed)
             want = np.stack([np.random.permutation(base) for _ in range(3)])
