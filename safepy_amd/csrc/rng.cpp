@@ -90,9 +90,10 @@ static const int64_t kChunk = 128;      // permutations per host/GPU pipeline st
 static const int64_t kFirst = 32;       // the first stage is short so that the first kernel starts early
 
 // Stage boundaries of the host / GPU pipeline for `count` permutations: [0, 32), [32, 128), [128, 256), ... and a SHORT last
-// stage.  The draw thread is what the pipeline waits for (128 permutations per ~0.4 ms, the kernels keep up), so whatever
-// the last stage holds is processed after the draws have ended: the final stages are cut to <= 72 and 32 permutations
-// (0.25 ms less tail per call than a last stage of ~100).
+// stage: the final stages are cut to <= 72 and 32 permutations.  That rule dates from the host-bound pipeline (draw thread:
+// 128 permutations per ~0.4 ms; whatever the last stage held ran after the draws had ended, 0.25 ms more tail with a last
+// stage of ~100).  With the faster draw loop the kernels bound the step and a first stage of 16 ... 96 or an uncut tail
+// measure the same within run-to-run noise (4.0-4.4 ms), so the plan stayed.
 std::vector<int64_t> perms_stage_plan(int64_t count) {
     std::vector<int64_t> b;
     b.push_back(0);
