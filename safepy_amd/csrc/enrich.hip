@@ -1998,25 +1998,46 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                          // 2 measured best of 1..6 once the host stream stopped being the bottleneck (tools/step_sweep2.sh)
     if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
     const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
-    const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_wg);    // block-permutations per task
+    // One task list per DISTINCT launch size: the stream's stages are 32, 96, 128 ... and short last ones, and a list cut for 128
+    // permutations leaves a 32-permutation launch with half-empty and empty tasks (each still reloads T): a 32-permutation launch
+    // took 207 us, 6.5 us per permutation against 3.2 in the long launches.
     struct TaskCost { int4 t; int64_t cost; };
-    std::vector<TaskCost> tc;
-    for (int64_t g = 0; g < n_sg; ++g) {
-        const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
-        int64_t ppt = std::min<int64_t>(std::min<int64_t>(span, 255), std::max<int64_t>(16, target / bl));   // <= 255: eight counter levels
-        const int64_t chunks = ceil_div(span, ppt);
-        ppt = ceil_div(span, chunks);
-        for (int64_t c = 0; c < chunks; ++c) {
-            const int64_t p0 = c * ppt, p1 = std::min<int64_t>(span, p0 + ppt);
-            for (int64_t w = 0; w < n_wg; ++w)
-                tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
-                              bl * (p1 - p0)});
+    auto build_tasks = [&](int64_t span_c) {
+        const int64_t target = std::max<int64_t>(256, blocks_per_perm * span_c / tasks_per_wg);    // block-permutations per task
+        std::vector<TaskCost> tc;
+        for (int64_t g = 0; g < n_sg; ++g) {
+            const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
+            int64_t ppt = std::min<int64_t>(std::min<int64_t>(span_c, 255), std::max<int64_t>(16, target / bl));   // <= 255: eight counter levels
+            const int64_t chunks = ceil_div(span_c, ppt);
+            ppt = ceil_div(span_c, chunks);
+            for (int64_t c = 0; c < chunks; ++c) {
+                const int64_t p0 = c * ppt, p1 = std::min<int64_t>(span_c, p0 + ppt);
+                for (int64_t w = 0; w < n_wg; ++w)
+                    tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
+                                  bl * (p1 - p0)});
+            }
         }
-    }
-    std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
-    std::vector<int4> tasks(tc.size());
-    for (size_t i = 0; i < tc.size(); ++i) tasks[i] = tc[i].t;
+        std::stable_sort(tc.begin(), tc.end(), [](const TaskCost &a, const TaskCost &b) { return a.cost > b.cost; });
+        std::vector<int4> out(tc.size());
+        for (size_t i = 0; i < tc.size(); ++i) out[i] = tc[i].t;
+        return out;
+    };
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
+    std::vector<int4> tasks;                             // the lists back to back
+    std::vector<int64_t> list_span, list_first, list_count, launch_list(std::max<int64_t>(n_launch, 1), 0);
+    for (int64_t c = 0; c < n_launch; ++c) {
+        const int64_t span_c = starts[c + 1] - starts[c];
+        size_t k = 0;
+        while (k < list_span.size() && list_span[k] != span_c) ++k;
+        if (k == list_span.size()) {
+            const std::vector<int4> one = build_tasks(span_c);
+            list_span.push_back(span_c);
+            list_first.push_back(static_cast<int64_t>(tasks.size()));
+            list_count.push_back(static_cast<int64_t>(one.size()));
+            tasks.insert(tasks.end(), one.begin(), one.end());
+        }
+        launch_list[c] = static_cast<int64_t>(k);
+    }
     safe_trace("launch_bits: tasks built");
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
@@ -2033,8 +2054,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, n_launch * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), ctx->stream));
     safe_trace("launch_bits: buffers ready");
-    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), slots);
-    const int64_t n_tasks = static_cast<int64_t>(tasks.size());
+    int4 *const d_task_lists = d_tasks;
     const bool wide = P >= 1024;
     const bool narrow = true;                         // a task counts at most 255 permutations (ppt above): 8 counter levels do
     const bool scaled = (n + 1) * 8 < 65536;
@@ -2092,6 +2112,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
         const int64_t p_base = starts[c], p_limit = starts[c + 1];
+        const int64_t n_tasks = list_count[launch_list[c]];                 // this launch size's task list
+        const int4 *d_tasks = d_task_lists + list_first[launch_list[c]];
+        const int64_t blocks = std::min<int64_t>(n_tasks, slots);
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
         safe_trace("launch_bits: span tables enqueued");

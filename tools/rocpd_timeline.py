@@ -1,15 +1,30 @@
 #!/usr/bin/env python3
-"""Print the kernel/copy timeline (ms, relative) of a rocprofv3 rocpd database."""
-import sqlite3, sys
-con = sqlite3.connect(sys.argv[1])
-skip = int(sys.argv[2]) if len(sys.argv) > 2 else 0
-rows = con.execute("select name, start, end from kernels order by start").fetchall()
-try:
-    cp = con.execute("select name, start, end from memory_copies order by start").fetchall()
-except Exception:
-    cp = []
-ev = sorted([(s, e, n[:48]) for n, s, e in rows] + [(s, e, 'COPY ' + str(n)[:40]) for n, s, e in cp])
-ev = ev[skip:]
-t0 = ev[0][0]
-for s, e, n in ev:
-    print('%9.3f %9.3f  %7.3f  %s' % ((s - t0) / 1e6, (e - t0) / 1e6, (e - s) / 1e6, n))
+"""GPU timeline of the LAST headline step in a rocprofv3 kernel trace (rocpd database): every kernel between the last
+k_attr_stats-like start of a step and its k_counts_finalize, start / end relative to the step's first kernel, in microseconds.
+usage: rocpd_timeline.py <results.db> [first-kernel-substring]"""
+import sqlite3
+import sys
+
+
+def main(path, first='k_bits_prep'):
+    con = sqlite3.connect(path)
+    cols = [r[1] for r in con.execute("pragma table_info(kernels)")]
+    name_col = 'name' if 'name' in cols else 'kernel_name'
+    rows = con.execute("select %s, start, end from kernels order by start" % name_col).fetchall()
+    starts = [i for i, r in enumerate(rows) if first in r[0]]
+    if not starts:
+        print('no kernel matching', first)
+        return
+    i0 = starts[-1]
+    t0 = rows[i0][1]
+    busy_end = t0
+    for name, s, e in rows[i0:]:
+        gap = (s - busy_end) / 1e3
+        print('%9.1f %9.1f  %8.1f us  gap %7.1f  %s' % ((s - t0) / 1e3, (e - t0) / 1e3, (e - s) / 1e3, gap, name[:70]))
+        busy_end = max(busy_end, e)
+        if 'k_counts_finalize' in name:
+            break
+
+
+if __name__ == '__main__':
+    main(*sys.argv[1:])
