@@ -1433,7 +1433,14 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     ctx->last_slices = n_slices;
+    // The kernel is persistent and takes a CU whole (256 VGPRs x 2 waves per SIMD): table kernels of the next span that are
+    // queued while it runs (aux stream: scan rounds, row emission) get a CU only as its workgroups retire and trickle through
+    // the whole tail of the launch -- harmless for the result, but they then show launch-long durations in a kernel trace
+    // (half of the "GPU time" of a profile).  Leaving CUs free does not help unless every XCD has one (workgroups are dealt to
+    // XCDs round-robin), which costs 3 % of the matrix-core throughput.  Long launches therefore make the table stream wait for
+    // their predecessor instead (below): the tables of a span are needed only when that launch has ended.
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    const bool long_launches = static_cast<double>(n) * static_cast<double>(mloc) * static_cast<double>(span) >= 2e9;   // >~ 20 ms each
     // z-scores: the counters compare against the observed score itself, which may be NaN (k_counts_finalize<true> reads it)
     if (z && !out.ns) SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&out.ns)));
     ctx->last_kernel.name = "k_permtest_mfma";
@@ -1448,6 +1455,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     for (int64_t c = 0; c < n_launch; ++c) {
         const int64_t p_base = starts[c], p_limit = starts[c + 1], cnt = p_limit - p_base;
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
+        if (long_launches && c >= 1) SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev[2 * (c - 1) + 1], 0));
         SAFE_TRY(perms_wait(perms, p_limit, ks));
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
                            p_base, d_src[c & 1]);
