@@ -176,7 +176,8 @@ __global__ void k_mfma_colfinish(const unsigned long long *__restrict__ maxbits,
 __host__ __device__ __forceinline__ int mfma_slices_for(int need_bits) { return need_bits <= 14 ? 2 : need_bits <= 30 ? 4 : MF_NS; }
 
 // ---------------------------------------------------------------------------------------
-// slices: bs[row][column tile][slice][32 columns] i8, row n = zeros.  q = rint(b * 2^shift)
+// slices: bs[column tile][row][slice][32 columns] i8 (tile-major: the rows one XCD gathers for its tile are packed, not
+// interleaved with the neighbouring tiles' bytes in the same cache lines), row n = zeros.  q = rint(b * 2^shift)
 // as a 47-bit integer, digits d_t in [-128, 127] with q = sum d_t 256^t.
 // Also counts, per column, the values far below the column maximum (< 2^-20 max) that had to be rounded:
 // k_mfma_colcheck declines the path when they are more than a thousandth of a column (the grid, set by the
@@ -209,7 +210,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
     // "small": more than 2^20 below the column maximum -- held to fewer than 26 significant bits on a rounding grid
     const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -20) : 0.0;
     const int ns = mfma_slices_for(*need);
-    const int64_t row_bytes = n_ct * ns * 32;
+    const int64_t row_bytes = ns * 32, tile_bytes = (n + 1) * row_bytes;         // tile-major: bs[column tile][row][slice][32]
     const long long bias = ns == 2 ? 0x8080ll : ns == 4 ? 0x80808080ll : 0x808080808080ll;
     unsigned int k_small = 0, k_rounded = 0;
     for (int i = 0; i < 4; ++i) {
@@ -226,7 +227,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
             k_rounded += q != scaled;
         }
         const unsigned long long u = static_cast<unsigned long long>(static_cast<long long>(q) + bias);
-        unsigned char *dst = bs + r * row_bytes + ct * (ns * 32) + tx;
+        unsigned char *dst = bs + ct * tile_bytes + r * row_bytes + tx;
 #pragma unroll
         for (int t = 0; t < MF_NS; ++t)
             if (t < ns) dst[t * 32] = static_cast<unsigned char>(((u >> (8 * t)) & 0xFFu) ^ 0x80u);
@@ -266,7 +267,7 @@ __global__ void k_mfma_colfinish_sq(const unsigned long long *__restrict__ maxbi
     inexact[j] = rounded;
 }
 
-// z-score slices: bs[row][16-column tile][7 slices][32 bytes]; bytes 0-15 of slice t = digit t of q1 = fixed-point B0 of
+// z-score slices: bs[16-column tile][row][7 slices][32 bytes]; bytes 0-15 of slice t = digit t of q1 = fixed-point B0 of
 // the tile's columns, bytes 16-31 = digit t of q2 = rint(B0*B0 * 2^shift2); slice 6 = the not-NaN flags (bytes 0-15).
 // Row n = zeros (and not counted).  Counts the small rounded values of B0 like k_mfma_slice.
 template <typename T>
@@ -294,7 +295,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
     const int64_t j = c0 + tx;
     const int sh = j < mloc ? shift[j] : 0, sh2 = j < mloc ? shift2[j] : 0;
     const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -20) : 0.0;
-    const int64_t row_bytes = n_ct * (MF_NS + 1) * 32;
+    const int64_t row_bytes = (MF_NS + 1) * 32, tile_bytes = (n + 1) * row_bytes; // tile-major: bs[16-column tile][row][slice][32]
     const long long bias = 0x808080808080ll;
     unsigned int k_small = 0, k_rounded = 0, k_zero = 0;
     for (int i = 0; i < 2; ++i) {
@@ -316,7 +317,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
         }
         const unsigned long long u1 = static_cast<unsigned long long>(static_cast<long long>(q1) + bias);
         const unsigned long long u2 = static_cast<unsigned long long>(static_cast<long long>(q2) + bias);
-        unsigned char *dst = bs + r * row_bytes + ct * ((MF_NS + 1) * 32) + tx;
+        unsigned char *dst = bs + ct * tile_bytes + r * row_bytes + tx;
 #pragma unroll
         for (int t = 0; t < MF_NS; ++t) {
             dst[t * 32] = static_cast<unsigned char>(((u1 >> (8 * t)) & 0xFFu) ^ 0x80u);
@@ -395,7 +396,7 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
 //                Counters then hold (#>= << 16 | #<=) like the f64 kernels' (NaN scores compare false).
 template <bool COUNTS, int NS, bool Z = false>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
-    const unsigned char *__restrict__ bs, int64_t row_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
+    const unsigned char *__restrict__ bs, int64_t row_bytes, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
     const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
@@ -440,7 +441,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             for (int i = tid; i < nb; i += 512) kb_list[i] = blk_kb[b0 + i];
             __syncthreads();
 
-            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * (NS * 32) + chunk * 16;
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + chunk * 16;
             const uint32_t *bits_w = blk_bits + static_cast<int64_t>(b0) * MF_R + wave * 32 + lam;
             const int total = n_q * S;
 
@@ -1175,7 +1176,8 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
 void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl, int spare_cus = 0) {
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks.size()), std::max(1, ctx->num_cu - spare_cus));
-    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs, cs.row_bytes, cs.d_src,
+    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs, cs.row_bytes,
+                       static_cast<int64_t>(MF_CN * 32), cs.d_src,
                        cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, cs.d_tasks, cs.d_qoff, cs.d_qctr, cs.mloc,
                        static_cast<unsigned int *>(nullptr), nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr),
                        static_cast<double *>(nullptr), hl);
@@ -1391,7 +1393,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             return SAFE_OK;
         }
         n_slices = z ? MF_NS + 1 : mfma_slices_for(verdict[1]);
-        row_bytes = n_ct * n_slices * 32;
+        row_bytes = static_cast<int64_t>(n_slices) * 32;          // tile-major: a row of a tile is n_slices x 32 bytes, tiles (n + 1) rows apart
     }
 
     // ---- tasks: (row group, column tile), one queue per XCD keyed by column tile so the slice
@@ -1440,6 +1442,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     // XCDs round-robin), which costs 3 % of the matrix-core throughput.  Long launches therefore make the table stream wait for
     // their predecessor instead (below): the tables of a span are needed only when that launch has ended.
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    const int64_t tile_bytes = (n + 1) * row_bytes;
     const bool long_launches = static_cast<double>(n) * static_cast<double>(mloc) * static_cast<double>(span) >= 2e9;   // >~ 20 ms each
     // z-scores: the counters compare against the observed score itself, which may be NaN (k_counts_finalize<true> reads it)
     if (z && !out.ns) SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&out.ns)));
@@ -1466,7 +1469,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             unsigned int *qctr_c = d_qctr + 8 * c;
             double *ns_c = c == 0 ? out.ns : static_cast<double *>(nullptr);
             HypLookup no_lookup{};
-            void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+            void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
                             (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup};
             SAFE_HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(512), args, lds_bytes, ks));
