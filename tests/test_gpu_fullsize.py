@@ -188,3 +188,40 @@ def test_config5_shape_quantitative_permutation_test_sampled_rows():
     perms.close()
     attr.close()
     nbr.close()
+
+
+@pytest.mark.parametrize('n,expect', [(8300, 'k_permtest_bits'), (20000, 'k_permtest_mfma')])
+def test_binary_randomization_beyond_the_16_bit_address_range(n, expect):
+    """0/1 attributes under how='randomization' on networks too large for the blocked bit-sliced kernel (member ids as
+    16-bit LDS addresses need 8 (N + 1) < 65536): N = 8300 runs the bit-sliced kernel with the permutation row staged in
+    LDS and 32-bit ids, N = 20 000 the matrix-core kernel in its exact two-slice regime.  Sampled neighborhoods against a
+    direct NumPy evaluation over the device's own permutation tables: integer sums, every count identical."""
+    import safepy_amd
+    from safepy_amd import backend as be, workloads
+    ctx = safepy_amd.Context.default(0)
+    m, nperm, seed = 70, 24, 3
+    xy = workloads.uniform_layout(9, n)
+    rng = np.random.default_rng(n)
+    b = (rng.uniform(size=(n, m)) < np.linspace(0.002, 0.3, m)).astype(np.float32)
+    b[rng.choice(n, n // 50, replace=False)] = np.nan
+    nr = 0.03 * (xy[:, 0].max() - xy[:, 0].min())
+    nbr = be.Neighborhoods.euclidean(ctx, xy, nr)
+    attr = be.Attributes.from_host(ctx, b)
+    perms = be.Permutations(ctx, n, attr.row_flags(), nperm, seed)
+    ns, neg, pos = (ctx.alloc_f64(n, m) for _ in range(3))
+    be.permtest_counts(ctx, nbr, attr, perms, 'sum', ns.ptr, neg.ptr, pos.ptr)
+    assert ctx.last_kernel()[0] == expect
+    ns, neg, pos = ns.download((n, m)), neg.download((n, m)), pos.download((n, m))
+    table = perms.read()
+    assert np.all(neg + pos >= nperm) and np.all((neg <= nperm) & (pos <= nperm))
+    rp, col = nbr.csr()
+    b0 = np.nan_to_num(b).astype(np.float64)
+    for i in np.random.default_rng(1).choice(n, 40, replace=False):
+        members = col[rp[i]:rp[i + 1]]
+        obs = b0[members].sum(axis=0)
+        assert np.array_equal(ns[i], obs)
+        s = b0[table[:, members]].sum(axis=1)                    # [P, m], whole numbers
+        assert np.array_equal(neg[i], (s <= obs).sum(axis=0)) and np.array_equal(pos[i], (s >= obs).sum(axis=0))
+    perms.close()
+    attr.close()
+    nbr.close()
