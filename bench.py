@@ -309,6 +309,10 @@ def main():
     if world != args.gpus:
         args.gpus = world                          # under a launcher the launcher's world size is the truth
 
+    # RCCL brings its own HIP streams: with the runtime's default of four hardware queues the context's two kernel streams and
+    # its table stream end up sharing queues with them -- a one-rank RCCL group measured 5.1-5.3 ms per step against 4.4-4.6 with
+    # eight queues (or with the context created before the group: both are done here)
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     import numpy as np
     import torch
     # host threads of the permutation stream per rank: the draw thread and the swap
@@ -324,6 +328,7 @@ def main():
     torch.cuda.set_device(local_rank)
     numa_node = None if os.environ.get('SAFE_BENCH_NO_PIN') == '1' else be.pin_threads_to_device_numa(local_rank)
     torch.set_num_threads(1)      # no OpenMP spinning next to the host draw/swap threads (container CPU quotas throttle it)
+    ctx = be.Context.default(local_rank)          # (before the process group: see GPU_MAX_HW_QUEUES above)
     dist = None
     force_dist = os.environ.get('SAFE_BENCH_FORCE_DIST') == '1'      # exercise the collectives with a single rank
     if world > 1 or force_dist:
@@ -341,7 +346,6 @@ def main():
     if rank > 0:                                   # weak scaling: every rank its own attribute shard
         data['attributes'] = workloads.go_like_binary(np.random.default_rng(1000 + rank), args.nodes, args.attrs,
                                                       int(182 * args.nodes / 3971))
-    ctx = be.Context.default(local_rank)
     ctx.set_stream(torch.cuda.current_stream().cuda_stream)
     sf = safepy_amd.SAFE(verbose=False, device=local_rank)
     sf.graph = safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length'])
@@ -481,10 +485,17 @@ def main():
         if args.extras and world == 1:
             line['hbm_bound_kernels'] = hbm_kernels(ctx, torch, np, be)
             line['mfma_bound_kernels'] = mfma_kernel(ctx, np, be)
-        print(json.dumps(line))
+    # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe): tear the group down and flush every
+    # rank's C buffers first, so that rank 0's JSON line is the LAST line of the job's output
     if dist is not None:
         dist.barrier()
         dist.destroy_process_group()
+        import ctypes
+        ctypes.CDLL(None).fflush(None)
+        if rank == 0 and world > 1:
+            time.sleep(0.3)                                     # (the other ranks flush and leave)
+    if rank == 0:
+        print(json.dumps(line), flush=True)
 
 
 if __name__ == '__main__':

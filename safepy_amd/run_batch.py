@@ -43,14 +43,17 @@ def main(argv=None):
     world = int(os.environ.get('WORLD_SIZE', '1'))
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    # RCCL brings its own HIP streams: with the runtime's default of four hardware queues the context's kernel / table streams
+    # end up sharing queues with them (measured: +0.8 ms on a 4.2 ms permutation step).  More queues, and the context first.
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
+    import safepy_amd
+    from safepy_amd import sharding, backend
     if world > 1:
         import torch
         import torch.distributed as dist
         torch.cuda.set_device(local_rank)
+        backend.Context.default(local_rank)              # (its streams exist before the process group's)
         dist.init_process_group('nccl')
-
-    import safepy_amd
-    from safepy_amd import sharding, backend
     backend.pin_threads_to_device_numa(local_rank)       # this rank's host threads next to its GPU
     sf = safepy_amd.SAFE(verbose=(rank == 0), device=local_rank)
     if args.seed is not None:
