@@ -6,7 +6,8 @@ the *checker* for the HIP path: only ``tests/``, ``__graft_entry__.smoke()`` and
 ``bench.py``'s ``cpu_baseline`` leg may import it.  Nothing under ``safepy_amd/``
 imports it, and the product path has no CPU fallback.
 
-Parity status: PINNED.  ``tests/golden/make_golden.py`` imports the real
+Parity status: PINNED, every branch (``multiple_testing=True`` included, see
+``fdrcorrection``).  ``tests/golden/make_golden.py`` imports the real
 reference from ``/root/reference`` (in the build container only), runs it on
 seeded synthetic inputs and commits the input/output vectors under
 ``tests/golden/*.npz``; ``tests/test_oracle_golden.py`` checks every function
@@ -186,12 +187,16 @@ def fdrcorrection(pvals):
     ``statsmodels.stats.multitest.fdrcorrection(pvals)[1]`` (alpha=0.05, method='indep',
     is_sorted=False), called row by row at safe.py:536-542 and 599-605.
 
-    statsmodels (pinned 0.14.4 in extras/requirements.txt) is NOT in this image and there is no
-    wheel for it, so this branch is restated from the published algorithm, operation by
-    operation -- argsort; ecdf = arange(1, n+1) / float(n); sorted / ecdf;
-    np.minimum.accumulate from the right; clip at 1; scatter back -- and PARITY IS UNPINNED
-    against statsmodels itself.  It is cross-checked against SciPy's independent implementation
-    (scipy.stats.false_discovery_control, method 'bh') in tests/test_oracle_golden.py.
+    PINNED: ``tests/golden/fdr.npz`` holds outputs of the real ``fdrcorrection`` (statsmodels 0.12.2,
+    the copy under /opt/conda in the build image, reached by appending that directory to sys.path;
+    the reference pins 0.14.4 in extras/requirements.txt -- version skew, stated, the function's
+    arithmetic is the same seven NumPy calls in both) on rows of length 1 ... 4373 with ties,
+    zeros, ones and NaN, and of the UNSTUBBED reference run with ``multiple_testing=True``
+    (randomization x {sum, z-score} x three attribute signs, hypergeometric with a NaN column,
+    1 / 2 / 129 attributes per row); ``tests/test_oracle_golden.py`` checks this function and
+    ``compute_pvalues(..., multiple_testing=True)`` against them bit for bit.  The restatement
+    follows the published algorithm operation by operation -- argsort; ecdf = arange(1, n+1) /
+    float(n); sorted / ecdf; np.minimum.accumulate from the right; clip at 1; scatter back.
     NaN p-values sort last and np.minimum propagates them through the whole accumulated row,
     exactly as the NumPy calls above would."""
     pvals = np.asarray(pvals, dtype=np.float64)

@@ -5,12 +5,23 @@ Run in the build container only (needs /root/reference, networkx, pandas):
 
     python tests/golden/make_golden.py
 
-It imports baryshnikova-lab/safepy from /root/reference (statsmodels, which the
-image lacks and the hot path never calls with multiple_testing=False, is stubbed
-in sys.modules), pushes seeded synthetic inputs through
-``SAFE.define_neighborhoods`` / ``SAFE.compute_pvalues`` /
+It imports baryshnikova-lab/safepy from /root/reference, pushes seeded synthetic inputs
+through ``SAFE.define_neighborhoods`` / ``SAFE.compute_pvalues`` /
 ``safe_extras.run_permutations`` and stores inputs + outputs as small ``.npz``
 files next to this script.  Only data is written: no reference source travels.
+
+statsmodels (the reference imports ``fdrcorrection`` from it, safe.py:30) is not installed
+for the system interpreter, but a pure-Python-on-this-path copy (0.12.2) sits in the image at
+/opt/conda/lib/python3.9/site-packages: that directory is APPENDED to sys.path, so numpy /
+scipy / pandas stay the system ones and only statsmodels (+ patsy) resolve there.  The
+reference pins 0.14.4 (extras/requirements.txt); the version actually used is recorded in
+``fdr.npz`` (``statsmodels_version``).  Only if that import fails is a raising stub installed
+(then ``fdr`` cannot be generated).
+
+    python tests/golden/make_golden.py          # everything
+    python tests/golden/make_golden.py fdr      # only fdr.npz  (multiple_testing=True)
+    python tests/golden/make_golden.py big      # only big.npz  (N = 1200, 300 permutations)
+    python tests/golden/make_golden.py io       # only io.npz
 """
 import os
 import sys
@@ -22,19 +33,27 @@ HERE = os.path.dirname(os.path.abspath(__file__))
 REF = '/root/reference'
 
 
-def import_reference():
-    sm = types.ModuleType('statsmodels')
-    sms = types.ModuleType('statsmodels.stats')
-    smm = types.ModuleType('statsmodels.stats.multitest')
+STATSMODELS_SITE = '/opt/conda/lib/python3.9/site-packages'
 
-    def fdrcorrection(*a, **k):
-        raise RuntimeError('statsmodels is stubbed; multiple_testing is out of scope')
-    smm.fdrcorrection = fdrcorrection
-    sm.stats = sms
-    sms.multitest = smm
-    sys.modules.setdefault('statsmodels', sm)
-    sys.modules.setdefault('statsmodels.stats', sms)
-    sys.modules.setdefault('statsmodels.stats.multitest', smm)
+
+def import_reference():
+    if STATSMODELS_SITE not in sys.path:
+        sys.path.append(STATSMODELS_SITE)      # append: numpy / scipy / pandas stay the system ones
+    try:
+        import statsmodels.stats.multitest     # noqa: F401  the real one (0.12.2 in this image)
+    except Exception:                          # no statsmodels anywhere: multiple_testing=False only
+        sm = types.ModuleType('statsmodels')
+        sms = types.ModuleType('statsmodels.stats')
+        smm = types.ModuleType('statsmodels.stats.multitest')
+
+        def fdrcorrection(*a, **k):
+            raise RuntimeError('statsmodels is stubbed; multiple_testing=True cannot be generated')
+        smm.fdrcorrection = fdrcorrection
+        sm.stats = sms
+        sms.multitest = smm
+        sys.modules['statsmodels'] = sm
+        sys.modules['statsmodels.stats'] = sms
+        sys.modules['statsmodels.stats.multitest'] = smm
     sys.path.insert(0, REF)
     sys.path.insert(0, os.path.join(REF, 'safepy'))
     import logging
@@ -292,6 +311,185 @@ def make_io(safe, safe_io, nx, pd):
     np.savez_compressed(os.path.join(HERE, 'io.npz'), **out)
 
 
+def _run_reference(safe, pd, g, A, mat, **kw):
+    """One compute_pvalues call of the real reference on a prepared network; returns its outputs."""
+    import time
+    attrs = {k: kw.pop(k) for k in ('attribute_sign', 'random_seed') if k in kw}
+    sf = new_safe(safe, g, **attrs)
+    sf.neighborhoods = A
+    set_attributes(pd, sf, mat)
+    real_sleep = time.sleep
+    time.sleep = lambda s: None            # skip the fixed 1 s pause (safe.py:484)
+    try:
+        sf.compute_pvalues(verbose=False, **kw)
+    finally:
+        time.sleep = real_sleep
+    out = {'pvalues_pos': sf.pvalues_pos, 'nes': sf.nes, 'nes_binary': sf.nes_binary,
+           'num_enriched': sf.attributes['num_neighborhoods_enriched'].values.astype(np.float64)}
+    if sf.pvalues_neg is not None:
+        out['pvalues_neg'] = sf.pvalues_neg
+        out['ns'] = sf.ns
+    return out
+
+
+def make_fdr(safe, safe_io, nx, pd):
+    """multiple_testing=True through the UNSTUBBED reference (safe.py:30, 536-542, 599-605) with the real
+    statsmodels.stats.multitest.fdrcorrection, plus fdrcorrection itself on tie-heavy rows."""
+    import warnings
+    import statsmodels
+    from statsmodels.stats.multitest import fdrcorrection
+    assert getattr(statsmodels, '__file__', None), 'statsmodels is stubbed: fdr.npz cannot be generated'
+    warnings.simplefilter('ignore')
+    rng = np.random.default_rng(31337)
+    out = {'statsmodels_version': np.array(statsmodels.__version__)}
+
+    # ---- fdrcorrection on rows of every interesting length: ties, zeros, ones, multiples of 1/P --------
+    lengths = (1, 2, 3, 7, 64, 129, 1000, 4373)
+    out['row_lengths'] = np.array(lengths, dtype=np.int64)
+    for n in lengths:
+        rows = [rng.uniform(size=n),                                        # distinct values
+                rng.integers(0, 41, size=n) / 40.0,                         # counts / P: heavy ties, 0 and 1 present
+                np.where(rng.uniform(size=n) < 0.7, 1.0, rng.uniform(size=n) ** 4),   # mostly 1 (hypergeometric shape)
+                np.full(n, 0.02)]                                           # one value
+        rows.append(rows[0].copy())
+        rows[-1][rng.integers(n)] = np.nan                                  # a NaN poisons the whole row
+        p = np.stack(rows)
+        out['rows_n%d_p' % n] = p
+        out['rows_n%d_adj' % n] = np.stack([fdrcorrection(r)[1] for r in p])
+
+    # ---- the whole call: a small clustered network, default metric -----------------------------------
+    n = 150
+    xy = clustered_layout(rng, n, n_blobs=4)
+    eu, ev = radius_graph_edges(xy, 0.09, rng)
+    g = make_graph(nx, xy, eu, ev)
+    g = safe_io.calculate_edge_lengths(g, verbose=False)
+    out.update({'xy': xy, 'edge_u': eu, 'edge_v': ev})
+    sf = new_safe(safe, g)
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.2)
+    A = sf.neighborhoods.copy()
+    out['A'] = A.astype(np.int8)
+
+    nan_rows = rng.choice(n, size=11, replace=False)
+
+    def binary(m):
+        b = (rng.uniform(size=(n, m)) < rng.uniform(0.03, 0.3, size=m)).astype(np.float64)
+        b[nan_rows] = np.nan
+        return b
+
+    def quantitative(m):
+        b = rng.normal(size=(n, m))
+        b[nan_rows] = np.nan
+        b[rng.uniform(size=(n, m)) < 0.03] = np.nan
+        return b
+
+    cases = []
+    m = 21
+    b_q = quantitative(m)
+    b_qz = b_q.copy()
+    b_qz[:, 4] = np.nan                              # an all-NaN column: z-score NaN -> NaN p-values -> whole rows NaN
+    b_bin = binary(m)
+    b_bin_nan = b_bin.copy()
+    b_bin_nan[~np.isnan(b_bin_nan[:, 7]), 7] *= 0.5  # halves: hypergeom.sf is NaN where the hit count is not an integer
+    b_bin_nan_all = b_bin_nan.copy()
+    b_bin_nan_all[np.flatnonzero(b_bin_nan_all[:, 3] == 1)[0], 3] = 0.25   # a non-integer column total: NaN in every row
+    assert np.nansum(b_bin_nan_all[:, 3]) % 1 != 0
+    out.update({'b_q': b_q, 'b_qz': b_qz, 'b_bin': b_bin, 'b_bin_nan': b_bin_nan, 'b_bin_nan_all': b_bin_nan_all})
+    seed = 100
+    for sign in ('both', 'highest', 'lowest'):
+        cases.append(('rnd_sum_' + sign, 'b_q', dict(how='randomization', neighborhood_score_type='sum', attribute_sign=sign,
+                                                     num_permutations=40, random_seed=seed)))
+        cases.append(('rnd_z_' + sign, 'b_qz', dict(how='randomization', neighborhood_score_type='z-score', attribute_sign=sign,
+                                                    num_permutations=30, random_seed=seed + 1)))
+        seed += 2
+    cases.append(('rnd_bin', 'b_bin', dict(how='randomization', neighborhood_score_type='sum', num_permutations=50, random_seed=9)))
+    cases.append(('rnd_net', 'b_q', dict(how='randomization', neighborhood_score_type='sum', background='network',
+                                         num_permutations=30, random_seed=10)))
+    cases.append(('hyp', 'b_bin', dict()))
+    cases.append(('hyp_net', 'b_bin', dict(background='network')))
+    cases.append(('hyp_nan', 'b_bin_nan', dict(how='hypergeometric')))
+    cases.append(('hyp_nan_all', 'b_bin_nan_all', dict(how='hypergeometric')))
+    for width in (1, 2, 129):                        # rows of length 1 / 2 / 129 attributes
+        out['b_q_m%d' % width] = quantitative(width)
+        out['b_bin_m%d' % width] = binary(width)
+        cases.append(('rnd_m%d' % width, 'b_q_m%d' % width, dict(how='randomization', neighborhood_score_type='sum',
+                                                                   num_permutations=25, random_seed=200 + width)))
+        cases.append(('hyp_m%d' % width, 'b_bin_m%d' % width, dict()))
+    names = []
+    for tag, key, kw in cases:
+        res = _run_reference(safe, pd, g, A, out[key].copy(), multiple_testing=True, **dict(kw))
+        names.append(tag)
+        out[tag + '_input'] = np.array(key)
+        out[tag + '_kwargs'] = np.array(repr(kw))
+        for k, v in res.items():
+            out[tag + '_' + k] = v
+    out['cases'] = np.array(names)
+    np.savez_compressed(os.path.join(HERE, 'fdr.npz'), **out)
+
+
+def make_big(safe, safe_io, nx, pd):
+    """A second size (all other vectors are N = 257, P <= 40): N = 1200 ragged clustered layout, default metric,
+    300 permutations (> 255: counter carries past a byte; several 256-row groups for the matrix-core kernel;
+    multi-level width classes of the blocked bit-sliced kernel).  Quantitative f64 (sum and z-score) and binary
+    attributes through SAFE.compute_pvalues of the real reference (safe.py:432-554, safe_extras.py:36-70)."""
+    import warnings
+    warnings.simplefilter('ignore')
+    rng = np.random.default_rng(1200)
+    n = 1200
+    xy = clustered_layout(rng, n, n_blobs=9, spread=0.05)
+    eu, ev = radius_graph_edges(xy, 0.035, rng, keep=0.7)
+    g = make_graph(nx, xy, eu, ev)
+    g = safe_io.calculate_edge_lengths(g, verbose=False)
+    el = np.array([g.edges[int(u), int(v)]['length'] for u, v in zip(eu, ev)], dtype=np.float64)
+    out = {'xy': xy, 'edge_u': eu.astype(np.int32), 'edge_v': ev.astype(np.int32), 'edge_length': el}
+    sf = new_safe(safe, g)
+    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.15)
+    A = sf.neighborhoods.copy()
+    out['A_bits'] = np.packbits(A.astype(np.uint8), axis=1)
+    out['A_row_counts'] = A.sum(axis=1).astype(np.int64)
+
+    nan_rows = rng.choice(n, size=57, replace=False)
+    mb = 160                                                     # 2.5 64-attribute word groups
+    sizes = np.exp(rng.uniform(np.log(2), np.log(400), size=mb))  # GO-like term sizes, log-uniform
+    b_bin = (rng.uniform(size=(n, mb)) < (sizes / n)).astype(np.float32)
+    b_bin[nan_rows] = np.nan
+    b_bin = np.asfortranarray(b_bin)                             # the .txt.gz loader's layout
+    mq = 48
+    b_q = rng.normal(size=(n, mq))
+    b_q[:, :8] = np.round(b_q[:, :8] * 64) / 64                  # dyadic columns: exactly representable on the fixed-point grid
+    b_q[nan_rows] = np.nan
+    b_q[rng.uniform(size=(n, mq)) < 0.01] = np.nan
+    out['b_bin'] = np.packbits(np.nan_to_num(b_bin).astype(np.uint8), axis=0)
+    out['b_bin_nan_rows'] = np.sort(nan_rows).astype(np.int32)
+    out['b_q'] = b_q
+
+    nperm = 300
+    for tag, mat, kw in (('bin', b_bin, dict(neighborhood_score_type='sum', random_seed=41)),
+                         ('q_sum', b_q, dict(neighborhood_score_type='sum', random_seed=42)),
+                         ('q_z', b_q, dict(neighborhood_score_type='z-score', random_seed=43))):
+        res = _run_reference(safe, pd, g, A, mat.copy(order='K'), how='randomization', num_permutations=nperm, **kw)
+        out[tag + '_meta'] = np.array([nperm, kw['random_seed']], dtype=np.int64)
+        # p = counts / P exactly (safe.py:532-533): the integer counts carry the same information in 2 bytes
+        for side in ('neg', 'pos'):
+            p = res['pvalues_' + side]
+            c = np.where(np.isnan(p), -1, np.rint(p * nperm)).astype(np.int16)
+            back = np.where(c < 0, np.nan, c / float(nperm))
+            assert np.array_equal(back, p, equal_nan=True)
+            out[tag + '_counts_' + side] = c
+        # NES takes few distinct values (a function of the two counts): dictionary-coded, nes = values[codes] bit for bit
+        vals, codes = np.unique(res['nes'], return_inverse=True)
+        assert vals.size < 65536 and np.array_equal(vals[codes].reshape(res['nes'].shape), res['nes'], equal_nan=True)
+        out[tag + '_nes_values'] = vals
+        out[tag + '_nes_codes'] = codes.reshape(res['nes'].shape).astype(np.uint16)
+        out[tag + '_nes_binary'] = res['nes_binary'].astype(np.int8)
+        out[tag + '_num_enriched'] = res['num_enriched']
+        if tag == 'bin':
+            assert np.array_equal(res['ns'], np.rint(res['ns']))
+            out[tag + '_ns'] = res['ns'].astype(np.int16)
+        else:
+            out[tag + '_ns'] = res['ns']
+    np.savez_compressed(os.path.join(HERE, 'big.npz'), **out)
+
+
 def main():
     import networkx as nx
     import pandas as pd
@@ -431,16 +629,18 @@ def main():
 
     make_domains(safe, safe_io, nx, pd)
     make_io(safe, safe_io, nx, pd)
+    make_fdr(safe, safe_io, nx, pd)
+    make_big(safe, safe_io, nx, pd)
 
-    for f in ('neighborhoods.npz', 'enrichment.npz', 'rng_kat.npz', 'domains.npz', 'io.npz'):
+    for f in ('neighborhoods.npz', 'enrichment.npz', 'rng_kat.npz', 'domains.npz', 'io.npz', 'fdr.npz', 'big.npz'):
         print(f, os.path.getsize(os.path.join(HERE, f)), 'bytes')
 
 
 if __name__ == '__main__':
-    if len(sys.argv) > 1 and sys.argv[1] == 'io':          # only the io vectors (the others stay as committed)
+    if len(sys.argv) > 1 and sys.argv[1] in ('io', 'fdr', 'big'):   # only one file (the others stay as committed)
         import networkx
         import pandas
         _safe, _extras, _io = import_reference()
-        make_io(_safe, _io, networkx, pandas)
+        {'io': make_io, 'fdr': make_fdr, 'big': make_big}[sys.argv[1]](_safe, _io, networkx, pandas)
     else:
         main()

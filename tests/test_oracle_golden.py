@@ -139,10 +139,46 @@ def test_restated_mt19937_matches_reference_stream(golden_rng):
                 assert rng.permutation(base) == [int(v) for v in want]
 
 
+def test_fdrcorrection_equals_statsmodels_rows(golden_fdr):
+    """oracle.fdrcorrection == statsmodels.stats.multitest.fdrcorrection(row)[1] (safe.py:30, 538, 541, 604) bit for
+    bit on rows of length 1 ... 4373: distinct values, counts / P with heavy ties, mostly-one rows, one value, a NaN."""
+    g = golden_fdr
+    assert str(g['statsmodels_version']) == '0.12.2'          # the reference pins 0.14.4: version skew, stated
+    for n in g['row_lengths']:
+        p, want = g['rows_n%d_p' % n], g['rows_n%d_adj' % n]
+        for row, adj in zip(p, want):
+            np.testing.assert_array_equal(orc.fdrcorrection(row), adj)
+        np.testing.assert_array_equal(orc.fdr_rows(p), want)
+    assert np.isnan(g['rows_n7_adj'][-1]).all()               # a NaN poisons the whole row
+
+
+def test_compute_pvalues_with_multiple_testing_equals_reference(golden_fdr):
+    """oracle.compute_pvalues(..., multiple_testing=True) == the unstubbed reference with the real statsmodels:
+    adjusted p-values, NES, nes_binary and the per-attribute counts, bit for bit, every case of fdr.npz."""
+    g = golden_fdr
+    a = g['A'].astype(np.int64)
+    assert len(g['cases']) == 18
+    for tag in g['cases']:
+        kw = eval(str(g[tag + '_kwargs']))                     # a dict literal written by make_golden.py
+        mat = g[str(g[tag + '_input'])].copy()
+        got = orc.compute_pvalues(a, mat, enrichment_type=kw.get('how', 'auto'),
+                                  neighborhood_score_type=kw.get('neighborhood_score_type', 'sum'),
+                                  background=kw.get('background', 'attribute_file'),
+                                  num_permutations=kw.get('num_permutations', 1000), random_seed=kw.get('random_seed'),
+                                  attribute_sign=kw.get('attribute_sign', 'both'), multiple_testing=True)
+        keys = ['pvalues_pos', 'nes', 'nes_binary'] + (['pvalues_neg'] if tag.startswith('rnd') else [])
+        for k in keys:
+            np.testing.assert_array_equal(got[k], g[tag + '_' + k], err_msg='%s %s' % (tag, k))
+        np.testing.assert_array_equal(got['num_neighborhoods_enriched'], g[tag + '_num_enriched'])
+    nan_rows = np.isnan(g['hyp_nan_pvalues_pos']).all(axis=1)    # half-integer hit counts: NaN, and it spreads over those rows
+    assert 0 < nan_rows.sum() < len(nan_rows) and not np.isnan(g['hyp_nan_pvalues_pos'][~nan_rows]).any()
+    assert np.isnan(g['hyp_nan_all_pvalues_pos']).all()         # a non-integer column total: every row
+    assert np.isnan(g['rnd_z_both_pvalues_pos']).all() and not np.isnan(g['rnd_sum_both_pvalues_pos']).any()
+
+
 def test_bh_restatement_against_scipy_independent_implementation():
-    """statsmodels is not installable here, so the oracle restates fdrcorrection from its
-    published algorithm (parity with statsmodels itself unpinned).  SciPy ships an independent
-    Benjamini-Hochberg (p * n / rank instead of p / (rank / n)): equal to the last ulp or two."""
+    """A second, independent check: SciPy's Benjamini-Hochberg (p * n / rank instead of p / (rank / n)) equals the
+    restatement to the last ulp or two."""
     import numpy as np
     from scipy.stats import false_discovery_control
     from oracle import safe_oracle as orc
@@ -157,6 +193,20 @@ def test_bh_restatement_against_scipy_independent_implementation():
     assert np.isnan(orc.fdrcorrection(np.array([0.1, np.nan, 0.5]))).all()
     rows = orc.fdr_rows(np.array([[0.01, 0.04, 0.03], [1.0, 0.0, 0.5]]))
     np.testing.assert_allclose(rows, [[0.03, 0.04, 0.04], [1.0, 0.0, 0.75]])
+
+
+def test_oracle_at_the_second_size_equals_reference(golden_big):
+    """N = 1200, 300 permutations (tests/golden/big.npz, the real reference): binary f32-F, quantitative f64 sum and
+    z-score -- p-values, NES, nes_binary, per-attribute counts exact; scores to 1e-12."""
+    g = golden_big
+    for tag, mat, score in (('bin', g['b_bin'], 'sum'), ('q_sum', g['b_q'], 'sum'), ('q_z', g['b_q'], 'z-score')):
+        got = orc.compute_pvalues(g['A'], mat.copy(order='K'), enrichment_type='randomization', neighborhood_score_type=score,
+                                  num_permutations=g[tag + '_nperm'], random_seed=g[tag + '_seed'])
+        for k in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+            np.testing.assert_array_equal(got[k], g[tag + '_' + k], err_msg='%s %s' % (tag, k))
+        np.testing.assert_array_equal(got['num_neighborhoods_enriched'], g[tag + '_num_enriched'])
+        np.testing.assert_allclose(got['ns'], g[tag + '_ns'], rtol=1e-12, atol=0, equal_nan=True)
+    assert g['bin_pvalues_pos'].max() == 1.0 and (g['bin_pvalues_neg'] * 300 > 255).any()    # counters past one byte
 
 
 def test_oracle_top_attributes_and_domains_vs_reference():
