@@ -1763,7 +1763,10 @@ __device__ double hyp_sf(const double *__restrict__ lf, double x_hits, double po
     const int64_t hi = good < draws ? good : draws;
     if (k_d < static_cast<double>(lo)) return 1.0;
     if (k_d >= static_cast<double>(hi)) return 0.0;
-    const int64_t k = static_cast<int64_t>(floor(k_d));
+    // inside the support a non-integer k is NaN (SciPy 1.15's Boost tail, pinned by tests/golden/fdr.npz `hyp_nan`:
+    // half-integer hit counts of a forced-hypergeometric call on non-0/1 data); outside it the rules above win
+    if (k_d != floor(k_d)) return qnan;
+    const int64_t k = static_cast<int64_t>(k_d);
     const double eps = 2.220446049250313e-16;
     const double mode = floor(static_cast<double>(good + 1) * static_cast<double>(draws + 1) / static_cast<double>(pop + 2));
     // the loops count in doubles (exact: integers below 2^53): 64-bit integer -> double
