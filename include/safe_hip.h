@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define SAFE_HIP_ABI_VERSION 2
+#define SAFE_HIP_ABI_VERSION 3
 
 #define SAFE_OK 0
 #define SAFE_E_INVALID (-1)   /* bad argument */
@@ -53,6 +53,7 @@ typedef struct safe_nbr safe_nbr;       /* neighborhood membership, device resid
 typedef struct safe_attr safe_attr;     /* node x attribute matrix, device resident     */
 typedef struct safe_perms safe_perms;   /* composed row-permutation tables, device res. */
 typedef struct safe_comm safe_comm;     /* RCCL communicator of the attribute-sharded path */
+typedef struct PermRing safe_ring;      /* node-shared permutation stream (shared memory)    */
 
 /* ------------------------------------------------------------------ context ---- */
 int safe_abi_version(void);
@@ -64,6 +65,11 @@ int safe_device_count(int *count);
 int safe_device_pci_bus_id(int device, char *buf, size_t buf_len);
 int safe_ctx_create(int device, safe_ctx **out);
 int safe_ctx_destroy(safe_ctx *ctx);
+/* Host waits of every context in this process: 0 (default) = hipStreamSynchronize, the runtime spins (lowest latency, one
+ * busy core per waiting thread); 1 = sleep on interrupt-backed events (several ranks sharing few host cores: the
+ * reference's worker pool, safepy/safe.py:503-524, simply oversubscribes).  Set before the first context is created;
+ * SAFE_HIP_BLOCKING_SYNC=1 in the environment has the same effect. */
+int safe_set_blocking_sync(int on);
 /* Use an existing hipStream_t (passed as void*) for all subsequent work; NULL restores
  * the context's own stream. */
 int safe_ctx_set_stream(safe_ctx *ctx, void *hip_stream);
@@ -200,6 +206,35 @@ int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutati
  * its workers reseed identically, so they repeat one another -- here every rank draws the ONE cumulative stream of
  * safe_extras.py:46-58 and tests its own range of it, and the ranks' counts add up to the single-process counts). */
 int safe_perms_slice(safe_perms *perms, int64_t p0, int64_t p1, safe_perms **out);
+/* One permutation stream per NODE (multi-GPU runs; the reference's workers each repeat the whole stream,
+ * safepy/safe.py:489-519, 1339-1353).  The stream of safe_extras.py:46-58 is sequential, so a rank cannot draw "its part":
+ * safe_ctx_share_stream attaches the context to a shared-memory ring named `name` (the same string on every rank of the
+ * node, unique per job; capacity_bytes of chunk slots), local rank 0 being the node's producer.  safe_perms_create_shared
+ * then behaves exactly like safe_perms_create -- same arguments, same tables -- but only the producer draws and replays
+ * swaps; it publishes each pipeline chunk's row maps and the other ranks block (futex, no CPU) until a chunk is there,
+ * copy it and upload it.  The call is COLLECTIVE over the ranks of the node: same n, movable rows and permutation count,
+ * same order of calls (checked: SAFE_E_VALUE otherwise; waits time out after SAFE_HIP_RING_TIMEOUT_S, default 120 s).  The
+ * seed is the producer's.  When a chunk (128 x (n + 1) x 4 bytes) does not fit the ring twice, or the context shares no
+ * stream, every rank silently draws for itself (decided from n and the capacity alone, hence identically everywhere). */
+int safe_ctx_share_stream(safe_ctx *ctx, const char *name, int local_rank, int local_world, int64_t capacity_bytes);
+int safe_ctx_unshare_stream(safe_ctx *ctx);
+int safe_perms_create_shared(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations,
+                             int has_seed, uint32_t seed, safe_perms **out);
+/* Host-side timing of a handle's stream, ms: out5[0] = time the draw thread spent drawing, [1] = handle creation -> last
+ * draw finished, [2] = creation -> last chunk's table kernels enqueued, [3] = time this rank blocked waiting for the
+ * node's producer, [4] = role (0 own stream, 1 producer of a shared stream, 2 consumer).  For bench reporting. */
+int safe_perms_timing(safe_perms *perms, double *out5);
+/* The ring by itself (host memory only, no device): what safe_perms_create_shared runs on, exported so that the
+ * multi-process protocol can be tested on a host without GPUs.  local rank 0 creates, the others attach;
+ * safe_ring_begin opens the next call on either side (producer: waits until every consumer has left the previous one;
+ * consumer: waits for the producer's announcement and checks n / k / count / movable_hash against it);
+ * safe_ring_publish / safe_ring_fetch move chunk `chunk` (in order); safe_ring_end leaves the call. */
+int safe_ring_open(const char *name, int local_rank, int local_world, int64_t capacity_bytes, safe_ring **out);
+int safe_ring_close(safe_ring *ring);
+int safe_ring_begin(safe_ring *ring, int64_t n, int64_t k, int64_t count, uint64_t movable_hash, int64_t slot_bytes);
+int safe_ring_publish(safe_ring *ring, int64_t chunk, const void *src_host, size_t bytes);
+int safe_ring_fetch(safe_ring *ring, int64_t chunk, void *dst_host, size_t bytes);
+int safe_ring_end(safe_ring *ring);
 /* Host-only: the raw stream, for pinning against numpy (no device needed).  Writes
  * count permutations of values[0..n_items) back to back into out[count*n_items]. */
 int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_items,
@@ -286,6 +321,14 @@ int safe_export_packed_counts(safe_ctx *ctx, uint32_t *dst_dev, int64_t capacity
 int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad,
                                 int64_t m, int64_t num_permutations, int sign_mode, const double *nes_table_host,
                                 double *nes_dev);
+/* The same exchange for EVERY matrix the reference's compute_pvalues leaves on the instance from the counters
+ * (safepy/safe.py:532-554, 468-472): pvalues_neg, pvalues_pos, nes, nes_binary as f64 [n, m] row-major, any of them NULL =
+ * not wanted.  One integer all-gather (4 bytes per node x attribute) then serves all four full matrices on every rank --
+ * the "final RCCL all-gather of the p-value matrix" without moving 8-byte doubles or transposing blocks. */
+int safe_outputs_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad,
+                                    int64_t m, int64_t num_permutations, int sign_mode, double enrichment_threshold,
+                                    const double *nes_table_host, double *pvalues_neg_dev, double *pvalues_pos_dev,
+                                    double *nes_dev, double *nes_binary_dev);
 
 /* The exchange step of the attribute-sharded path for hosts without their own collective library
  * (replaces np.concatenate(combined_nes, axis=1), safepy/safe.py:1355, and the process pool around it,

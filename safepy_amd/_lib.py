@@ -10,7 +10,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsafe_hip.so')
 
-ABI_VERSION = 2
+ABI_VERSION = 3
 DTYPE_F32, DTYPE_F64 = 0, 1
 SCORE_SUM, SCORE_ZSCORE = 0, 1
 SIGN_HIGHEST, SIGN_LOWEST, SIGN_BOTH = 0, 1, 2
@@ -122,6 +122,7 @@ PROTOTYPES = {
     'safe_fdr_adjust': (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     'safe_export_packed_counts': (C.c_int, [_vp, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_int)]),
     'safe_nes_from_packed_counts': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _vp, _vp]),
+    'safe_outputs_from_packed_counts': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
     'safe_last_kernel_stats': (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), _pi64]),
     'safe_last_mfma_slices': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'safe_perms_create_from_table': (C.c_int, [_vp, _i64, _i64, _vp, _pp]),
@@ -131,6 +132,17 @@ PROTOTYPES = {
     'safe_comm_create': (C.c_int, [_vp, C.c_int, C.c_int, C.c_char_p, C.c_size_t, _pp]),
     'safe_comm_destroy': (C.c_int, [_vp]),
     'safe_allgather_cols': (C.c_int, [_vp, _vp, C.c_size_t, _vp]),
+    'safe_set_blocking_sync': (C.c_int, [C.c_int]),
+    'safe_ctx_share_stream': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, _i64]),
+    'safe_ctx_unshare_stream': (C.c_int, [_vp]),
+    'safe_perms_create_shared': (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, C.c_uint32, _pp]),
+    'safe_perms_timing': (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    'safe_ring_open': (C.c_int, [C.c_char_p, C.c_int, C.c_int, _i64, _pp]),
+    'safe_ring_close': (C.c_int, [_vp]),
+    'safe_ring_begin': (C.c_int, [_vp, _i64, _i64, _i64, C.c_uint64, _i64]),
+    'safe_ring_publish': (C.c_int, [_vp, _i64, _vp, C.c_size_t]),
+    'safe_ring_fetch': (C.c_int, [_vp, _i64, _vp, C.c_size_t]),
+    'safe_ring_end': (C.c_int, [_vp]),
 }
 
 for _name, (_res, _args) in PROTOTYPES.items():

@@ -148,6 +148,22 @@ class Context:
     def set_stream(self, stream_ptr):
         check(lib.safe_ctx_set_stream(self.handle, C.c_void_p(stream_ptr) if stream_ptr else None))
 
+    shared_stream = None        # (name, local_rank, local_world) once share_stream() has attached this context to a node's ring
+
+    def share_stream(self, name, local_rank, local_world, capacity_bytes=64 << 20):
+        """One permutation stream per node (safe_ctx_share_stream): local rank 0 draws, the other ranks of the node receive
+        every chunk's row maps through a shared-memory ring.  Collective over the ranks of the node; afterwards
+        Permutations(..., shared=True) on this context uses the ring."""
+        if int(local_world) <= 1:
+            return False
+        check(lib.safe_ctx_share_stream(self.handle, str(name).encode(), int(local_rank), int(local_world), int(capacity_bytes)))
+        self.shared_stream = (str(name), int(local_rank), int(local_world))
+        return True
+
+    def unshare_stream(self):
+        check(lib.safe_ctx_unshare_stream(self.handle))
+        self.shared_stream = None
+
     def sync(self):
         check(lib.safe_ctx_sync(self.handle))
 
@@ -378,7 +394,10 @@ class Attributes:
 class Permutations:
     """Device-resident composed row-permutation tables (legacy NumPy MT19937 stream)."""
 
-    def __init__(self, ctx, n, movable, num_permutations, seed):
+    def __init__(self, ctx, n, movable, num_permutations, seed, shared=False):
+        """shared=True: a COLLECTIVE call over the ranks of this node whose contexts share a stream (Context.share_stream):
+        only the node's local rank 0 draws (its seed counts), the others receive the row maps.  Without a shared stream on
+        the context it is the plain per-process stream."""
         movable = np.ascontiguousarray(movable, dtype=np.uint8)
         assert movable.shape == (n,)
         if seed is not None:
@@ -389,9 +408,17 @@ class Permutations:
         self.n = int(n)
         self.count = int(num_permutations)
         h = C.c_void_p()
-        check(lib.safe_perms_create(ctx.handle, self.n, _ptr(movable), self.count, 0 if seed is None else 1,
-                                    0 if seed is None else seed, C.byref(h)))
+        create = lib.safe_perms_create_shared if (shared and ctx.shared_stream) else lib.safe_perms_create
+        check(create(ctx.handle, self.n, _ptr(movable), self.count, 0 if seed is None else 1,
+                     0 if seed is None else seed, C.byref(h)))
         self.handle = h
+
+    def timing(self):
+        """Host-side timing of the stream (safe_perms_timing), ms, and this rank's role in it."""
+        out = (C.c_double * 5)()
+        check(lib.safe_perms_timing(self.handle, out))
+        return {'draw_busy_ms': out[0], 'drawn_all_ms': out[1], 'tables_enqueued_ms': out[2], 'waited_for_producer_ms': out[3],
+                'role': ('own', 'producer', 'consumer')[int(out[4])]}
 
     @classmethod
     def from_table(cls, ctx, perm_idx):
@@ -485,6 +512,11 @@ class Comm:
             pass
 
 
+def set_blocking_sync(on):
+    """Host waits sleep on interrupt-backed events instead of spinning (safe_set_blocking_sync); before the first Context."""
+    check(lib.safe_set_blocking_sync(1 if on else 0))
+
+
 def last_mfma_slices(ctx):
     """i8 slices the last matrix-core permutation test ran with (2 / 4 / 6; 0 = it has not run)."""
     v = C.c_int()
@@ -575,6 +607,18 @@ def nes_from_packed_counts(ctx, nbr, counts_ptr, layout, n_pad, m, num_permutati
         table = nes_table(num_permutations)
     check(lib.safe_nes_from_packed_counts(ctx.handle, nbr.handle, C.c_void_p(counts_ptr), int(layout), int(n_pad), int(m),
                                           int(num_permutations), _SIGN[attribute_sign], _ptr(table), C.c_void_p(nes_ptr)))
+
+
+def outputs_from_packed_counts(ctx, nbr, counts_ptr, layout, n_pad, m, num_permutations, attribute_sign, enrichment_threshold,
+                               out_ptrs, table=None):
+    """out_ptrs = (pvalues_neg, pvalues_pos, nes, nes_binary) device pointers of f64 [n, m] matrices, None = not wanted
+    (safe_outputs_from_packed_counts)."""
+    if table is None:
+        table = nes_table(num_permutations)
+    pn, pp, nes, nb = (C.c_void_p(p) if p else None for p in out_ptrs)
+    check(lib.safe_outputs_from_packed_counts(ctx.handle, nbr.handle, C.c_void_p(counts_ptr), int(layout), int(n_pad), int(m),
+                                              int(num_permutations), _SIGN[attribute_sign], float(enrichment_threshold), _ptr(table),
+                                              pn, pp, nes, nb))
 
 
 def block_count(nbr):

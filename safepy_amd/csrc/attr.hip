@@ -224,7 +224,7 @@ int attr_build_support(safe_attr *attr) {
     const int64_t n = attr->n, m = attr->m;
     std::vector<double> sums(m);
     SAFE_HIP_CHECK(hipMemcpyAsync(sums.data(), attr->col_sum, m * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     attr->h_sup_ptr.assign(m + 1, 0);
     int64_t total = 0;
     for (int64_t j = 0; j < m; ++j) {
@@ -302,7 +302,7 @@ int safe_attr_prepare(safe_attr *attr) {
     SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));
     std::vector<uint8_t> h_flags(flag_bytes);
     SAFE_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     attr->n_other = static_cast<int64_t>(h_acc[0]);
     attr->max_nan_col = static_cast<int64_t>(h_acc[1]);
     attr->n_non_integer = static_cast<int64_t>(h_acc[2]);
@@ -358,7 +358,7 @@ int safe_attr_create_host(safe_ctx *ctx, const void *b_host, int dtype, int64_t 
         return rc;
     }
     hipError_t e = hipMemcpyAsync(d, b_host, bytes, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
     if (e != hipSuccess) {
         safe_set_error("safe_attr_create_host: %s", hipGetErrorString(e));
         (void)hipFree(d);
@@ -423,7 +423,7 @@ int safe_attr_reindex(safe_ctx *ctx, const void *table_host, int dtype, int64_t 
             e = hipGetLastError();
         }
         if (e == hipSuccess && out_host) e = hipMemcpyAsync(out_host, d_out, out_bytes, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
     }
     (void)hipFree(d_in);
     (void)hipFree(d_map);
@@ -454,7 +454,7 @@ int safe_attr_value_counts(safe_attr *attr, int64_t *n_nan, int64_t *n_zero, int
         hipLaunchKernelGGL(k_value_census<double>, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const double *>(attr->raw), count, d_acc);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     (void)hipFree(d_acc);
     if (n_nan) *n_nan = static_cast<int64_t>(h_acc[0]);
     if (n_zero) *n_zero = static_cast<int64_t>(h_acc[1]);
@@ -475,7 +475,7 @@ int safe_attr_nan_to_zero(safe_attr *attr) {
     else
         hipLaunchKernelGGL(k_nan_to_zero<double>, dim3(blocks), dim3(256), 0, ctx->stream, reinterpret_cast<double *>(raw), count);
     SAFE_HIP_CHECK(hipGetLastError());
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     // every derived fact is stale now
     attr->stats_ready = false;
     attr->flags_ready = false;
@@ -493,14 +493,14 @@ int safe_attr_download(safe_attr *attr, void *out_host) {
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const size_t bytes = static_cast<size_t>(attr->n) * attr->m * (attr->dtype == SAFE_DTYPE_F32 ? 4 : 8);
     SAFE_HIP_CHECK(hipMemcpyAsync(out_host, attr->raw, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 
 int safe_attr_destroy(safe_attr *attr) {
     if (!attr) return SAFE_OK;
     (void)hipSetDevice(attr->ctx->device);
-    (void)hipStreamSynchronize(attr->ctx->stream);
+    (void)safe_stream_sync(attr->ctx->stream);
     if (attr->owns_raw) (void)hipFree(const_cast<void *>(attr->raw));
     (void)hipFree(attr->row_flags);
     (void)hipFree(attr->col_sum);
@@ -530,7 +530,7 @@ int safe_attr_row_flags(safe_attr *attr, uint8_t *out_host) {
     }
     safe_ctx *ctx = attr->ctx;
     SAFE_HIP_CHECK(hipMemcpyAsync(out_host, attr->row_flags, attr->n, hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 
@@ -547,7 +547,7 @@ int safe_attr_set_row_flags(safe_attr *attr, const uint8_t *flags_host) {
         cnt += tmp[i];
     }
     SAFE_HIP_CHECK(hipMemcpyAsync(attr->row_flags, tmp.data(), flag_bytes, hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     attr->flags_ready = true;
     attr->n_rows_with_value = cnt;
     attr->h_row_flags.assign(tmp.begin(), tmp.begin() + attr->n);

@@ -102,7 +102,7 @@ int safe_comm_create(safe_ctx *ctx, int world_size, int rank, const char *id, si
 int safe_comm_destroy(safe_comm *comm) {
     if (!comm) return SAFE_OK;
     (void)hipSetDevice(comm->ctx->device);
-    (void)hipStreamSynchronize(comm->ctx->stream);
+    (void)safe_stream_sync(comm->ctx->stream);
     if (comm->comm) (void)comm->rccl->comm_destroy(comm->comm);
     delete comm;
     return SAFE_OK;

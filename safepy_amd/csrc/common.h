@@ -24,6 +24,11 @@ void safe_set_error(const char *fmt, ...);
 // SAFE_HIP_TRACE=1: host-side time stamps (ms since the first call) on stderr
 void safe_trace(const char *what);
 
+// hipStreamSynchronize, or a sleeping wait on a blocking event when blocking waits are on (ctx.hip)
+hipError_t safe_stream_sync(hipStream_t s);
+// flags for events the host may wait on: adds hipEventBlockingSync while blocking waits are on
+unsigned safe_event_flags(unsigned base);
+
 #define SAFE_HIP_CHECK(expr)                                                                   \
     do {                                                                                       \
         hipError_t _e = (expr);                                                                \
@@ -71,6 +76,7 @@ struct safe_ctx {
     int last_slices = 0;                        // i8 slices of the last matrix-core permutation test (2 / 4 / 6)
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
     struct safe_perms *perm_cache = nullptr;    // buffers of the last destroyed permutation handle, reused by the next
+    struct PermRing *ring = nullptr;            // node-shared permutation stream (safe_ctx_share_stream), or NULL
     // packed <= / >= counters of the last integer-counter permutation kernel (scratch slot 0):
     // u32 [packed_m][packed_n_pad] = (#less << 16 | #greater); layout 0 = SELL positions,
     // 1 = block order of the MFMA kernel, -1 = none (safe_export_packed_counts)
@@ -258,6 +264,12 @@ struct safe_perms {
     uint16_t *inverse_t = nullptr;
     int64_t inv_stride = 0;
     bool from_table = false;        // rows supplied by the caller (safe_perms_create_from_table): no stream, complete from the start
+    // node-shared stream (ring.h; safe_perms_create_shared): local rank 0 of a node publishes every chunk's row maps,
+    // the other ranks fetch them instead of drawing (no draw thread, no swap workers on those ranks)
+    struct PermRing *ring = nullptr;               // the context's ring while this handle takes part in a shared call, else NULL
+    bool ring_consumer = false;
+    // host-side timing of the stream (safe_perms_timing), ms since the handle was created
+    double t_created_s = 0.0, draw_busy_ms = 0.0, drawn_all_ms = 0.0, enqueued_all_ms = 0.0, ring_wait_ms = 0.0;
 };
 
 // launch-geometry helpers

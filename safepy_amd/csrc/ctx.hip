@@ -1,7 +1,10 @@
 // Context, error reporting and raw device-memory helpers of libsafe_hip.so.
 #include "common.h"
+#include "ring.h"
 
+#include <atomic>
 #include <chrono>
+#include <map>
 
 static thread_local char g_error[1024] = "";
 
@@ -20,12 +23,41 @@ void safe_set_error(const char *fmt, ...) {
     va_end(ap);
 }
 
+// Host waits.  By default hipStreamSynchronize (the runtime spins: lowest latency, one busy core per waiting thread).  With
+// blocking waits switched on (safe_set_blocking_sync / SAFE_HIP_BLOCKING_SYNC=1: several ranks sharing few host cores) the
+// thread sleeps on an interrupt-backed event instead -- a few tens of microseconds later, no CPU meanwhile.
+static std::atomic<int> g_blocking_sync{-1};
+
+static bool blocking_sync_on() {
+    int v = g_blocking_sync.load(std::memory_order_relaxed);
+    if (v < 0) {
+        const char *e = getenv("SAFE_HIP_BLOCKING_SYNC");
+        v = e && atoi(e) != 0 ? 1 : 0;
+        g_blocking_sync.store(v, std::memory_order_relaxed);
+    }
+    return v != 0;
+}
+
+unsigned safe_event_flags(unsigned base) { return blocking_sync_on() ? (base | hipEventBlockingSync) : base; }
+
+hipError_t safe_stream_sync(hipStream_t s) {
+    if (!blocking_sync_on()) return hipStreamSynchronize(s);
+    thread_local std::map<int, hipEvent_t> events;               // one blocking event per (thread, device)
+    int dev = 0;
+    hipError_t e = hipGetDevice(&dev);
+    if (e != hipSuccess) return e;
+    hipEvent_t &ev = events[dev];
+    if (!ev && (e = hipEventCreateWithFlags(&ev, hipEventBlockingSync | hipEventDisableTiming)) != hipSuccess) return e;
+    if ((e = hipEventRecord(ev, s)) != hipSuccess) return e;
+    return hipEventSynchronize(ev);
+}
+
 int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out) {
     if (bytes == 0) bytes = 1;
     if (ctx->scratch_bytes[slot] < bytes) {
         if (ctx->scratch[slot]) {
-            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->side_stream));
+            SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+            SAFE_HIP_CHECK(safe_stream_sync(ctx->side_stream));
             SAFE_HIP_CHECK(hipFree(ctx->scratch[slot]));
             ctx->scratch[slot] = nullptr;
             ctx->scratch_bytes[slot] = 0;
@@ -46,7 +78,7 @@ int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out) {
     std::vector<hipEvent_t> &pool = timing ? ctx->ev_timing : ctx->ev_plain;
     while (pool.size() < count) {
         hipEvent_t e = nullptr;
-        SAFE_HIP_CHECK(timing ? hipEventCreate(&e) : hipEventCreateWithFlags(&e, hipEventDisableTiming));
+        SAFE_HIP_CHECK(timing ? hipEventCreateWithFlags(&e, safe_event_flags(hipEventDefault)) : hipEventCreateWithFlags(&e, safe_event_flags(hipEventDisableTiming)));
         pool.push_back(e);
     }
     *out = pool.data();
@@ -56,8 +88,8 @@ int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out) {
 int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out) {
     if (ctx->pinned_bytes < bytes) {
         if (ctx->pinned) {
-            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
-            SAFE_HIP_CHECK(hipStreamSynchronize(ctx->side_stream));
+            SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+            SAFE_HIP_CHECK(safe_stream_sync(ctx->side_stream));
             SAFE_HIP_CHECK(hipHostFree(ctx->pinned));
             ctx->pinned = nullptr;
             ctx->pinned_bytes = 0;
@@ -126,10 +158,10 @@ int safe_ctx_create(int device, safe_ctx **out) {
         SAFE_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi));
     }
     SAFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
-    SAFE_HIP_CHECK(hipEventCreate(&ctx->t0));
-    SAFE_HIP_CHECK(hipEventCreate(&ctx->t1));
-    SAFE_HIP_CHECK(hipEventCreate(&ctx->k0));
-    SAFE_HIP_CHECK(hipEventCreate(&ctx->k1));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->t0, safe_event_flags(hipEventDefault)));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->t1, safe_event_flags(hipEventDefault)));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->k0, safe_event_flags(hipEventDefault)));
+    SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->k1, safe_event_flags(hipEventDefault)));
     *out = ctx;
     return SAFE_OK;
 }
@@ -137,12 +169,14 @@ int safe_ctx_create(int device, safe_ctx **out) {
 int safe_ctx_destroy(safe_ctx *ctx) {
     if (!ctx) return SAFE_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)safe_stream_sync(ctx->stream);
     if (ctx->t0) (void)hipEventDestroy(ctx->t0);
     if (ctx->t1) (void)hipEventDestroy(ctx->t1);
     if (ctx->k0) (void)hipEventDestroy(ctx->k0);
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
     perms_cache_drop(ctx);
+    if (ctx->ring) ring_close(ctx->ring);
+    ctx->ring = nullptr;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
     for (hipEvent_t e : ctx->ev_timing) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_plain) (void)hipEventDestroy(e);
@@ -155,6 +189,11 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     return SAFE_OK;
 }
 
+int safe_set_blocking_sync(int on) {
+    g_blocking_sync.store(on ? 1 : 0, std::memory_order_relaxed);
+    return SAFE_OK;
+}
+
 int safe_ctx_set_stream(safe_ctx *ctx, void *hip_stream) {
     SAFE_REQUIRE(ctx != nullptr, "safe_ctx_set_stream: ctx is NULL");
     ctx->stream = hip_stream ? static_cast<hipStream_t>(hip_stream) : ctx->own_stream;
@@ -164,7 +203,7 @@ int safe_ctx_set_stream(safe_ctx *ctx, void *hip_stream) {
 int safe_ctx_sync(safe_ctx *ctx) {
     SAFE_REQUIRE(ctx != nullptr, "safe_ctx_sync: ctx is NULL");
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 
@@ -189,7 +228,7 @@ int safe_dev_free(safe_ctx *ctx, void *dev) {
     SAFE_REQUIRE(ctx != nullptr, "safe_dev_free: ctx is NULL");
     if (!dev) return SAFE_OK;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     SAFE_HIP_CHECK(hipFree(dev));
     return SAFE_OK;
 }
@@ -205,7 +244,7 @@ int safe_memcpy_h2d(safe_ctx *ctx, void *dev, const void *host, size_t bytes) {
     if (bytes == 0) return SAFE_OK;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     SAFE_HIP_CHECK(hipMemcpyAsync(dev, host, bytes, hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 
@@ -214,7 +253,7 @@ int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes) {
     if (bytes == 0) return SAFE_OK;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     SAFE_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 

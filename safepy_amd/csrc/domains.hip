@@ -114,13 +114,13 @@ int safe_enriched_components(safe_ctx *ctx, int64_t n, int64_t n_edges, const in
                                d_parent, d_changed);
             hipLaunchKernelGGL(k_cc_compress, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, n, n_cols, d_parent);
             e = hipMemcpyAsync(&changed, d_changed, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-            if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+            if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
             if (e != hipSuccess || !changed) break;
         }
         if (e == hipSuccess) e = hipGetLastError();
         if (e == hipSuccess)
             e = hipMemcpyAsync(labels_host, d_parent, static_cast<size_t>(total) * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
     }
     if (rc == SAFE_OK && e != hipSuccess) {
         safe_set_error("safe_enriched_components: %s", hipGetErrorString(e));
@@ -154,7 +154,7 @@ int safe_jaccard_condensed(safe_ctx *ctx, int64_t m_top, int64_t n, const double
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(out_host, d_out, pairs * sizeof(double), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
         if (e != hipSuccess) {
             safe_set_error("safe_jaccard_condensed: %s", hipGetErrorString(e));
             rc = SAFE_E_HIP;

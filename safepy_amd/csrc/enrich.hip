@@ -1268,6 +1268,13 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
         } else if (out.mode == 3) {                                  // NES only (all-gathered counters of other ranks)
             const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
             out.nes[o] = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
+        } else if (out.mode == 4) {                                  // any subset of the matrices from all-gathered 'sum' counters
+            const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
+            const double nes = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
+            if (out.pvalues_neg) out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(P);
+            if (out.pvalues_pos) out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(P);
+            if (out.nes) out.nes[o] = nes;
+            if (out.nes_binary) out.nes_binary[o] = fabs(nes) > out.nes_threshold ? 1.0 : 0.0;
         } else if (out.mode == 2) {
             const double qnan = __longlong_as_double(0x7FF8000000000000ll);
             const double en = obs_nan ? qnan : out.nes_table[cneg], ep = obs_nan ? qnan : out.nes_table[cpos];
@@ -1937,7 +1944,7 @@ static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_permtest_scatter";
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // order (host vector) and temporaries
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));    // order (host vector) and temporaries
     (void)hipFree(d_order);
     (void)hipFree(d_queue);
     return SAFE_OK;
@@ -2188,7 +2195,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     safe_trace("launch_bits: all enqueued");
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));    // tasks (host vector) and temporaries
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));    // tasks (host vector) and temporaries
     safe_trace("launch_bits: synced");
     for (int64_t c = 0; c < n_launch; ++c) {
         float ms = 0.f;
@@ -2338,7 +2345,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     for (int64_t c = 0; c < n_launch; ++c) {
         float ms = 0.f;
         SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
@@ -2373,7 +2380,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     const double *h_size = static_cast<const double *>(pinned), *h_k = h_size + n;
     SAFE_HIP_CHECK(hipMemcpyAsync(pinned, d_size, n * sizeof(double), hipMemcpyDeviceToHost, hs));
     SAFE_HIP_CHECK(hipMemcpyAsync(static_cast<double *>(pinned) + n, attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, hs));
-    SAFE_HIP_CHECK(hipStreamSynchronize(hs));
+    SAFE_HIP_CHECK(safe_stream_sync(hs));
     // distinct values -> dense ids (both are integers in [0, n] here, or we decline)
     std::vector<int32_t> id_of(n + 2, -1), nvals, kvals, nid(n), kid(mloc);
     int64_t max_n = 0, max_k = 0;
@@ -2418,7 +2425,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hipEvent_t ids_done = nullptr;
     if (split) {
         // the counts are under way on ctx->stream: the table follows them there, cut at their largest value
-        SAFE_HIP_CHECK(hipEventCreateWithFlags(&ids_done, hipEventDisableTiming));
+        SAFE_HIP_CHECK(hipEventCreateWithFlags(&ids_done, safe_event_flags(hipEventDisableTiming)));
         SAFE_HIP_CHECK(hipEventRecord(ids_done, hs));
         SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, ids_done, 0));
     }
@@ -2440,7 +2447,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.enriched = d_enr;
     if (split) {
         const int rc = mfma_counts_split_emit(ctx, nbr, split, hl, nid.data());       // synchronises ctx->stream
-        (void)hipStreamSynchronize(hs);                                    // the id vectors above are host memory
+        (void)safe_stream_sync(hs);                                    // the id vectors above are host memory
         (void)hipEventDestroy(ids_done);
         SAFE_TRY(rc);
     } else if (use_mfma) {
@@ -2456,7 +2463,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
         SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
         ctx->last_kernel.name = "k_counts_bits<hypergeom>";
     }
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the id vectors above are host memory
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // the id vectors above are host memory
     *fused = true;
     return SAFE_OK;
 }
@@ -2656,7 +2663,7 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
     }
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
-    if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab (host) + temporaries
+    if (rc == SAFE_OK && safe_stream_sync(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab (host) + temporaries
     (void)hipFree(tiles.bt);
     return rc;
 }
@@ -2697,7 +2704,7 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
     hipEvent_t ev = nullptr;
     if (rc == SAFE_OK && table && use_mfma && mfma_counts_split_applicable(nbr)) {
         hs = ctx->side_stream;
-        if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, ctx->stream) != hipSuccess ||
+        if (hipEventCreateWithFlags(&ev, safe_event_flags(hipEventDisableTiming)) != hipSuccess || hipEventRecord(ev, ctx->stream) != hipSuccess ||
             hipStreamWaitEvent(hs, ev, 0) != hipSuccess) {
             safe_set_error("safe_hypergeom: stream fork failed");
             rc = SAFE_E_HIP;
@@ -2743,15 +2750,15 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
             }
             ctx->last_kernel.name = "k_hypergeom_tail";
         }
-        if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // lf is host memory
+        if (rc == SAFE_OK && safe_stream_sync(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // lf is host memory
     }
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);
         if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
     }
     if (rc == SAFE_OK) rc = finish_kernel_timing(ctx);
-    if (hipStreamSynchronize(ctx->stream) != hipSuccess && rc == SAFE_OK) rc = SAFE_E_HIP;
-    if (hs != ctx->stream) (void)hipStreamSynchronize(hs);
+    if (safe_stream_sync(ctx->stream) != hipSuccess && rc == SAFE_OK) rc = SAFE_E_HIP;
+    if (hs != ctx->stream) (void)safe_stream_sync(hs);
     if (split) mfma_counts_split_free(split);
     if (ev) (void)hipEventDestroy(ev);
     (void)hipFree(d_lf);
@@ -2798,7 +2805,7 @@ int safe_outputs_from_counts(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_pe
                        n * m, m, P, out);
     hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, m);
     SAFE_HIP_CHECK(hipGetLastError());
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // tab is a host vector
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // tab is a host vector
     return SAFE_OK;
 }
 
@@ -2818,15 +2825,19 @@ int safe_export_packed_counts(safe_ctx *ctx, uint32_t *dst_dev, int64_t capacity
     return SAFE_OK;
 }
 
-int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad, int64_t m,
-                                int64_t num_permutations, int sign_mode, const double *nes_table_host, double *nes_dev) {
-    SAFE_REQUIRE(ctx && nbr && counts_dev && nes_dev, "safe_nes_from_packed_counts: NULL argument");
-    SAFE_REQUIRE(layout == 0 || layout == 1, "safe_nes_from_packed_counts: bad layout %d", layout);
-    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_nes_from_packed_counts: bad sign_mode %d", sign_mode);
-    SAFE_REQUIRE(num_permutations >= 1 && num_permutations <= 65535 && m >= 1, "safe_nes_from_packed_counts: bad sizes");
+int safe_outputs_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad, int64_t m,
+                                    int64_t num_permutations, int sign_mode, double enrichment_threshold,
+                                    const double *nes_table_host, double *pvalues_neg_dev, double *pvalues_pos_dev,
+                                    double *nes_dev, double *nes_binary_dev) {
+    SAFE_REQUIRE(ctx && nbr && counts_dev, "safe_outputs_from_packed_counts: NULL argument");
+    SAFE_REQUIRE(pvalues_neg_dev || pvalues_pos_dev || nes_dev || nes_binary_dev, "safe_outputs_from_packed_counts: no output requested");
+    SAFE_REQUIRE(layout == 0 || layout == 1, "safe_outputs_from_packed_counts: bad layout %d", layout);
+    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_outputs_from_packed_counts: bad sign_mode %d", sign_mode);
+    SAFE_REQUIRE(num_permutations >= 1 && num_permutations <= 65535 && m >= 1, "safe_outputs_from_packed_counts: bad sizes");
+    SAFE_REQUIRE(enrichment_threshold > 0.0 || !nes_binary_dev, "safe_outputs_from_packed_counts: enrichment_threshold must be positive");
     const int32_t *rowmap = layout == 0 ? nbr->sell_row : nbr->bs_rowmap;
     const int64_t want_pad = layout == 0 ? nbr->n_slices * 64 : nbr->bs_groups * 256;
-    SAFE_REQUIRE(rowmap && n_pad == want_pad, "safe_nes_from_packed_counts: counters are for %lld positions, the membership has %lld",
+    SAFE_REQUIRE(rowmap && n_pad == want_pad, "safe_outputs_from_packed_counts: counters are for %lld positions, the membership has %lld",
                  (long long)n_pad, (long long)want_pad);
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const int64_t P = num_permutations;
@@ -2841,13 +2852,24 @@ int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *co
     SAFE_TRY(ctx_scratch(ctx, 7, (P + 1) * sizeof(double), reinterpret_cast<void **>(&d_tab)));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, ctx->stream));
     PermOut out{};
+    out.pvalues_neg = pvalues_neg_dev;
+    out.pvalues_pos = pvalues_pos_dev;
     out.nes = nes_dev;
+    out.nes_binary = nes_binary_dev;
     out.nes_table = d_tab;
+    out.nes_threshold = enrichment_threshold > 0.0 ? -std::log10(enrichment_threshold) : 0.0;
     out.sign_mode = sign_mode;
-    out.mode = 3;
+    out.mode = 4;
     int rc = enrich_finalize_counts(ctx, counts_dev, n_pad, rowmap, m, P, out, nullptr);
-    if (rc == SAFE_OK && hipStreamSynchronize(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab is a host vector
+    if (rc == SAFE_OK && safe_stream_sync(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab is a host vector
     return rc;
+}
+
+int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad, int64_t m,
+                                int64_t num_permutations, int sign_mode, const double *nes_table_host, double *nes_dev) {
+    SAFE_REQUIRE(nes_dev, "safe_nes_from_packed_counts: NULL argument");
+    return safe_outputs_from_packed_counts(ctx, nbr, counts_dev, layout, n_pad, m, num_permutations, sign_mode, 0.05, nes_table_host,
+                                           nullptr, nullptr, nes_dev, nullptr);
 }
 
 }  // extern "C"

@@ -179,7 +179,7 @@ int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m) {
         else FDR_SORT(32);
 #undef FDR_SORT
         SAFE_HIP_CHECK(hipGetLastError());
-        SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
         return SAFE_OK;
     }
     // rows per batch: at most 2^27 keys per library call (temporaries ~ 3 GB)
@@ -215,7 +215,7 @@ int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m) {
         hipLaunchKernelGGL(k_fdr_row, dim3(rows), dim3(256), 0, ctx->stream, keys_out, vals_out, m, block);
         e = hipGetLastError();
     }
-    if (rc == SAFE_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (rc == SAFE_OK && e == hipSuccess) e = safe_stream_sync(ctx->stream);
     if (e != hipSuccess) {
         safe_set_error("safe_fdr_adjust: %s", hipGetErrorString(e));
         rc = SAFE_E_HIP;
@@ -249,7 +249,7 @@ extern "C" int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_
                        -std::log10(enrichment_threshold), nes_p_cut(enrichment_threshold), nes_dev, nes_binary_dev, d_enr);
     hipLaunchKernelGGL(k_fdr_u32_to_f64, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, m);
     hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
     (void)hipFree(d_enr);
     if (e != hipSuccess) {
         safe_set_error("safe_fdr_adjust: %s", hipGetErrorString(e));

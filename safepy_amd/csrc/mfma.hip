@@ -1196,7 +1196,7 @@ int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t co
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_permtest_mfma<counts>";
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the task vector is host memory
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // the task vector is host memory
     return SAFE_OK;
 }
 
@@ -1295,7 +1295,7 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_hyp_emit";                               // (after k_permtest_mfma<counts> and k_hyp_table)
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));                 // the row / task vectors are host memory
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // the row / task vectors are host memory
     return SAFE_OK;
 }
 
@@ -1386,7 +1386,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         SAFE_HIP_CHECK(hipGetLastError());
         int verdict[2] = {0, 0};                   // {bad, bits needed}
         SAFE_HIP_CHECK(hipMemcpyAsync(verdict, d_bad, 2 * sizeof(int), hipMemcpyDeviceToHost, ctx->stream));
-        SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+        SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
         const char *force = getenv("SAFE_HIP_FORCE_PATH");
         if (verdict[0] && !(force && !strcmp(force, "mfma"))) {
             *declined = true;
@@ -1492,7 +1492,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     }
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     for (int64_t c = 0; c < n_launch; ++c) {
         float ms = 0.f;
         SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));

@@ -400,7 +400,7 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
     nbr->h_row_count.resize(n);
     SAFE_HIP_CHECK(hipMemcpyAsync(nbr->h_row_count.data(), d_count, n * sizeof(int32_t), hipMemcpyDeviceToHost,
                                   ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     (void)hipFree(d_count);
 
     std::vector<int32_t> row_ptr(n + 1, 0);
@@ -467,7 +467,7 @@ int nbr_finalize_from_bits(safe_nbr *nbr) {
                            nbr->sell_col2b);
     }
     SAFE_HIP_CHECK(hipGetLastError());
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));   // host vectors above go out of scope
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));   // host vectors above go out of scope
     return SAFE_OK;
 }
 
@@ -481,7 +481,7 @@ int nbr_build_transpose(safe_nbr *nbr) {
     if (nnz) hipLaunchKernelGGL(k_count_cols, dim3(ceil_div(nnz, 256)), dim3(256), 0, ctx->stream, nbr->col, nnz, d_cnt);
     std::vector<int32_t> cnt(n), ptr(n + 1, 0);
     SAFE_HIP_CHECK(hipMemcpyAsync(cnt.data(), d_cnt, n * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     for (int64_t k = 0; k < n; ++k) ptr[k + 1] = ptr[k] + cnt[k];
     SAFE_TRY(dev_alloc(&nbr->at_ptr, n + 1));
     SAFE_TRY(dev_alloc(&nbr->at_col, nnz));
@@ -490,7 +490,7 @@ int nbr_build_transpose(safe_nbr *nbr) {
     hipLaunchKernelGGL(k_fill_transpose, dim3(ceil_div(n * 64, 256)), dim3(256), 0, ctx->stream, nbr->row_ptr, nbr->col, n,
                        nbr->at_ptr, d_cnt, nbr->at_col);
     SAFE_HIP_CHECK(hipGetLastError());
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     (void)hipFree(d_cnt);
     return SAFE_OK;
 }
@@ -596,7 +596,7 @@ int safe_edge_lengths(safe_ctx *ctx, const double *xy_host, int64_t n, int64_t n
                        d_v, d_out);
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipMemcpyAsync(out_host, d_out, n_edges * sizeof(double), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     (void)hipFree(d_xy);
     (void)hipFree(d_out);
     (void)hipFree(d_u);
@@ -669,7 +669,7 @@ int safe_nbr_shortpath(safe_ctx *ctx, int64_t n, int64_t n_edges, const int32_t 
                                n_workers, nbr->bits, nbr->words, nbr->dist);
             e = hipGetLastError();
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
         if (e != hipSuccess) {
             safe_set_error("safe_nbr_shortpath: %s", hipGetErrorString(e));
             rc = SAFE_E_HIP;
@@ -713,7 +713,7 @@ int safe_nbr_from_dense_i64(safe_ctx *ctx, const int64_t *a_host, int64_t n, saf
             e = hipGetLastError();
         }
         if (e == hipSuccess) e = hipMemcpyAsync(&bad, d_bad, sizeof(int), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
         if (e != hipSuccess) {
             safe_set_error("safe_nbr_from_dense_i64: %s", hipGetErrorString(e));
             rc = SAFE_E_HIP;
@@ -737,7 +737,7 @@ int safe_nbr_from_dense_i64(safe_ctx *ctx, const int64_t *a_host, int64_t n, saf
 int safe_nbr_destroy(safe_nbr *nbr) {
     if (!nbr) return SAFE_OK;
     (void)hipSetDevice(nbr->ctx->device);
-    (void)hipStreamSynchronize(nbr->ctx->stream);
+    (void)safe_stream_sync(nbr->ctx->stream);
     nbr_free(nbr);
     return SAFE_OK;
 }
@@ -769,7 +769,7 @@ int safe_nbr_to_dense_i64(safe_nbr *nbr, int64_t *out_host) {
     int rc = safe_nbr_to_dense_i64_dev(nbr, d);
     if (rc == SAFE_OK) {
         hipError_t e = hipMemcpyAsync(out_host, d, nbr->n * nbr->n * sizeof(int64_t), hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
         if (e != hipSuccess) {
             safe_set_error("safe_nbr_to_dense_i64: %s", hipGetErrorString(e));
             rc = SAFE_E_HIP;
@@ -793,7 +793,7 @@ int safe_nbr_csr(safe_nbr *nbr, int32_t *row_ptr_host, int32_t *col_host) {
                                   ctx->stream));
     if (nbr->nnz)
         SAFE_HIP_CHECK(hipMemcpyAsync(col_host, nbr->col, nbr->nnz * sizeof(int32_t), hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 
@@ -804,7 +804,7 @@ int safe_nbr_distances(safe_nbr *nbr, double *out_host) {
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     SAFE_HIP_CHECK(hipMemcpyAsync(out_host, nbr->dist, nbr->n * nbr->n * sizeof(double), hipMemcpyDeviceToHost,
                                   ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 

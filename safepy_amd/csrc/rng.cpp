@@ -22,8 +22,13 @@
 #include <mutex>
 #include <thread>
 
+#include <chrono>
+
 #include "common.h"
 #include "draws.h"
+#include "ring.h"
+
+static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static uint32_t entropy_seed() {
     std::random_device rd;
@@ -241,13 +246,22 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     const int64_t n = p->n, stride = n + 1;
     const int64_t q0 = stage_begin(p, ci), q1 = chunk_end(p, ci), cnt = q1 - q0;
     const int b = static_cast<int>(ci & 1);
-    SwapPool::get().wait();
-    {
-        std::lock_guard<std::mutex> lk(p->draw_mu);          // the chunk's target buffer may be drawn into again
-        p->consumed_chunks = std::max<int64_t>(p->consumed_chunks, ci + 1);
+    if (p->ring_consumer) {
+        // the node's producer drew and replayed this chunk: block until it is published, copy it into this rank's pinned
+        // staging buffer (free once the upload of two chunks ago has completed)
+        if (ci >= 2) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
+        SAFE_TRY(ring_fetch(p->ring, ci, p->h_maps[b], static_cast<size_t>(cnt) * stride * sizeof(int32_t), &p->ring_wait_ms));
+        safe_trace("  gen: chunk fetched from the node's stream");
+    } else {
+        SwapPool::get().wait();
+        {
+            std::lock_guard<std::mutex> lk(p->draw_mu);          // the chunk's target buffer may be drawn into again
+            p->consumed_chunks = std::max<int64_t>(p->consumed_chunks, ci + 1);
+        }
+        p->draw_cv.notify_all();
+        safe_trace("  gen: workers joined");
+        if (p->ring) SAFE_TRY(ring_publish(p->ring, ci, p->h_maps[b], static_cast<size_t>(cnt) * stride * sizeof(int32_t)));
     }
-    p->draw_cv.notify_all();
-    safe_trace("  gen: workers joined");
     int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
     SAFE_HIP_CHECK(hipMemcpyAsync(xa, p->h_maps[b], cnt * stride * sizeof(int32_t), hipMemcpyHostToDevice, gs));
     SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
@@ -263,9 +277,10 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     SAFE_HIP_CHECK(hipMemcpyAsync(p->d_cur, p->table + (q1 - 1) * stride, stride * sizeof(int32_t),
                                   hipMemcpyDeviceToDevice, gs));
     if (static_cast<int64_t>(p->chunk_done.size()) <= ci) p->chunk_done.resize(ci + 1, nullptr);
-    if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], hipEventDisableTiming));
+    if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], safe_event_flags(hipEventDisableTiming)));
     SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[ci], gs));
     p->enqueued = q1;
+    if (q1 >= p->count) p->enqueued_all_ms = 1e3 * (wall_s() - p->t_created_s);
     safe_trace("  gen: chunk enqueued");
     return SAFE_OK;
 }
@@ -283,6 +298,7 @@ static void drawer_main(safe_perms *p) {
         const int64_t q0 = stage_begin(p, c), cnt = chunk_end(p, c) - q0;
         // draw into a buffer only this thread touches, then stream the chunk to the shared one
         uint32_t *h = p->h_local.data();
+        const double t_draw = wall_s();
         for (int64_t q = 0; q < cnt; ++q) {
             draw_stream_targets(p->stream, k, h + q * width);
             if ((q & 15) == 15) {
@@ -296,6 +312,8 @@ static void drawer_main(safe_perms *p) {
         {
             std::lock_guard<std::mutex> lk(p->draw_mu);
             p->drawn_chunks = c + 1;
+            p->draw_busy_ms += 1e3 * (wall_s() - t_draw);
+            if (c + 1 == n_chunks) p->drawn_all_ms = 1e3 * (wall_s() - p->t_created_s);
         }
         p->draw_cv.notify_all();
     }
@@ -304,7 +322,7 @@ static void drawer_main(safe_perms *p) {
 static void drawer_start(safe_perms *p) {
     p->drawn_chunks = p->consumed_chunks = 0;
     p->draw_stop = false;
-    if (p->count > 0) p->drawer = std::thread(drawer_main, p);
+    if (p->count > 0 && !p->ring_consumer) p->drawer = std::thread(drawer_main, p);
 }
 
 static void drawer_stop(safe_perms *p) {
@@ -340,6 +358,10 @@ int perms_generate_until(safe_perms *p, int64_t upto) {
     const int64_t n_chunks = stage_count(p);
     while (p->enqueued < upto) {
         const int64_t ci = chunk_of(p, p->enqueued);
+        if (p->ring_consumer) {                              // no draws, no swaps here: the chunk comes from the node's producer
+            SAFE_TRY(enqueue_chunk(p, ci));
+            continue;
+        }
         if (p->swapping <= stage_begin(p, ci)) {          // its swaps have not been started yet
             {
                 std::unique_lock<std::mutex> lk(p->draw_mu);
@@ -392,7 +414,9 @@ int perms_build_inverse(safe_perms *perms) {
 static void perms_free(safe_perms *p) {
     if (!p) return;
     drawer_stop(p);
-    SwapPool::get().wait();
+    if (!p->ring_consumer && !p->from_table) SwapPool::get().wait();
+    if (p->ring) ring_end_call(p->ring);
+    p->ring = nullptr;
     for (int b = 0; b < 2; ++b) {
         if (p->h_maps[b]) (void)hipHostFree(p->h_maps[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
@@ -433,14 +457,25 @@ int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_i
     return SAFE_OK;
 }
 
-int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, int has_seed,
-                      uint32_t seed, safe_perms **out) {
-    SAFE_REQUIRE(ctx && movable_host && out, "safe_perms_create: NULL argument");
-    SAFE_REQUIRE(n >= 1 && n < (1ll << 31) - 1, "safe_perms_create: n out of range");
-    SAFE_REQUIRE(num_permutations >= 0, "safe_perms_create: negative permutation count");
+// FNV-1a over the movable flags: consumers of a shared stream check that they mark the same rows as the producer
+static uint64_t movable_fingerprint(const uint8_t *movable_host, int64_t n) {
+    uint64_t h = 1469598103934665603ull;
+    for (int64_t i = 0; i < n; ++i) h = (h ^ (movable_host[i] ? 1u : 0u)) * 1099511628211ull;
+    return h;
+}
+
+static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, int has_seed,
+                             uint32_t seed, bool shared, const char *who, safe_perms **out) {
+    SAFE_REQUIRE(ctx && movable_host && out, "%s: NULL argument", who);
+    SAFE_REQUIRE(n >= 1 && n < (1ll << 31) - 1, "%s: n out of range", who);
+    SAFE_REQUIRE(num_permutations >= 0, "%s: negative permutation count", who);
     *out = nullptr;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     safe_trace("perms_create: enter");
+    // a shared call goes through the node's ring when a chunk fits it at least twice; every rank of the node decides this
+    // from (n, ring capacity) alone, hence identically.  Otherwise (and for empty streams) this rank draws for itself.
+    const int64_t slot_bytes = kChunk * (n + 1) * static_cast<int64_t>(sizeof(int32_t));
+    PermRing *ring = shared && ctx->ring && num_permutations > 0 && ring_slots_for(ctx->ring, slot_bytes) >= 2 ? ctx->ring : nullptr;
     safe_perms *p = nullptr;
     bool reused = false;
     if (ctx->perm_cache && ctx->perm_cache->n == n && ctx->perm_cache->count == num_permutations) {
@@ -458,45 +493,51 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
     for (int64_t i = 0; i < n; ++i)
         if (movable_host[i]) p->h_movable.push_back(static_cast<int32_t>(i));
     p->k = static_cast<int64_t>(p->h_movable.size());
-    p->stream = draw_stream_new(has_seed ? seed : entropy_seed());
+    p->ring = ring;
+    p->ring_consumer = ring != nullptr && !ring_is_producer(ring);
+    p->stream = p->ring_consumer ? nullptr : draw_stream_new(has_seed ? seed : entropy_seed());
     p->generated = p->swapping = p->enqueued = 0;
     p->stages = perms_stage_plan(num_permutations);
-    if (reused) {
-        const int64_t stride = n + 1;
-        for (int b = 0; b < 2; ++b) p->h_targets[b].resize(kChunk * std::max<int64_t>(p->k, 1) + 16);
-        p->h_local.resize(kChunk * std::max<int64_t>(p->k, 1) + 16);
-        hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
-        SAFE_HIP_CHECK(hipGetLastError());
-        drawer_start(p);
-        safe_trace("perms_create: done (buffers reused)");
-        *out = p;
-        return SAFE_OK;
-    }
+    p->t_created_s = wall_s();
+    p->draw_busy_ms = p->drawn_all_ms = p->enqueued_all_ms = p->ring_wait_ms = 0.0;
     const int64_t k = p->k, stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
     int rc = SAFE_OK;
     do {
-        if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
-        if (n < 65535) {
-            p->stride16 = (stride + 7) / 8 * 8;
-            if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
+        if (!reused) {
+            if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
+            if (n < 65535) {
+                p->stride16 = (stride + 7) / 8 * 8;
+                if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
+            }
+            if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
+            if ((rc = dev_alloc(&p->d_maps[0], kChunk * stride)) != SAFE_OK) break;
+            if ((rc = dev_alloc(&p->d_maps[1], kChunk * stride)) != SAFE_OK) break;
         }
-        if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
-        if ((rc = dev_alloc(&p->d_maps[0], kChunk * stride)) != SAFE_OK) break;
-        if ((rc = dev_alloc(&p->d_maps[1], kChunk * stride)) != SAFE_OK) break;
         hipError_t e = hipSuccess;
         for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-            p->h_targets[b].resize(kChunk * std::max<int64_t>(k, 1) + 16);
-            p->h_local.resize(kChunk * std::max<int64_t>(k, 1) + 16);
-            e = hipHostMalloc(reinterpret_cast<void **>(&p->h_maps[b]), kChunk * stride * sizeof(int32_t), hipHostMallocDefault);
-            if (e == hipSuccess) e = hipEventCreateWithFlags(&p->staged[b], hipEventDisableTiming);
+            if (!p->ring_consumer) p->h_targets[b].resize(kChunk * std::max<int64_t>(k, 1) + 16);
+            if (!p->h_maps[b]) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_maps[b]), kChunk * stride * sizeof(int32_t), hipHostMallocDefault);
+            if (e == hipSuccess && !p->staged[b]) e = hipEventCreateWithFlags(&p->staged[b], safe_event_flags(hipEventDisableTiming));
         }
+        if (!p->ring_consumer) p->h_local.resize(kChunk * std::max<int64_t>(k, 1) + 16);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
             e = hipGetLastError();
         }
         if (e != hipSuccess) {
-            safe_set_error("safe_perms_create: %s", hipGetErrorString(e));
+            safe_set_error("%s: %s", who, hipGetErrorString(e));
             rc = SAFE_E_HIP;
+            break;
+        }
+        if (ring) {
+            RingCall call;
+            call.n = n;
+            call.k = k;
+            call.count = num_permutations;
+            call.chunk_rows = kChunk;
+            call.movable_hash = movable_fingerprint(movable_host, n);
+            rc = p->ring_consumer ? ring_join_call(ring, call, slot_bytes) : ring_begin_call(ring, call, slot_bytes);
+            if (rc != SAFE_OK) p->ring = nullptr;            // (no call is open on the ring: nothing to end)
         }
     } while (0);
     if (rc != SAFE_OK) {
@@ -504,8 +545,46 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
         return rc;
     }
     drawer_start(p);
-    safe_trace("perms_create: done");
+    safe_trace(reused ? "perms_create: done (buffers reused)" : "perms_create: done");
     *out = p;
+    return SAFE_OK;
+}
+
+int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, int has_seed,
+                      uint32_t seed, safe_perms **out) {
+    return perms_create_impl(ctx, n, movable_host, num_permutations, has_seed, seed, false, "safe_perms_create", out);
+}
+
+int safe_perms_create_shared(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, int has_seed,
+                             uint32_t seed, safe_perms **out) {
+    return perms_create_impl(ctx, n, movable_host, num_permutations, has_seed, seed, true, "safe_perms_create_shared", out);
+}
+
+int safe_ctx_share_stream(safe_ctx *ctx, const char *name, int local_rank, int local_world, int64_t capacity_bytes) {
+    SAFE_REQUIRE(ctx && name, "safe_ctx_share_stream: NULL argument");
+    SAFE_REQUIRE(ctx->ring == nullptr, "safe_ctx_share_stream: this context already shares a stream (safe_ctx_unshare_stream first)");
+    if (local_world <= 1) return SAFE_OK;                      // a node with one rank has nobody to share with
+    perms_cache_drop(ctx);
+    return ring_open(name, local_rank, local_world, capacity_bytes, 120.0, &ctx->ring);
+}
+
+int safe_ctx_unshare_stream(safe_ctx *ctx) {
+    SAFE_REQUIRE(ctx, "safe_ctx_unshare_stream: NULL argument");
+    if (ctx->ring) ring_close(ctx->ring);
+    ctx->ring = nullptr;
+    return SAFE_OK;
+}
+
+int safe_perms_timing(safe_perms *perms, double *out5) {
+    SAFE_REQUIRE(perms && out5, "safe_perms_timing: NULL argument");
+    {
+        std::lock_guard<std::mutex> lk(perms->draw_mu);
+        out5[0] = perms->draw_busy_ms;
+        out5[1] = perms->drawn_all_ms;
+    }
+    out5[2] = perms->enqueued_all_ms;
+    out5[3] = perms->ring_wait_ms;
+    out5[4] = perms->ring ? (perms->ring_consumer ? 2.0 : 1.0) : 0.0;
     return SAFE_OK;
 }
 
@@ -531,18 +610,23 @@ static int perms_table_handle(safe_ctx *ctx, int64_t n, int64_t count, const int
             if ((rc = dev_alloc(&p->table16, static_cast<size_t>(rows) * p->stride16)) != SAFE_OK) break;
             if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
             hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
-            const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), rows), block(256);
-            hipLaunchKernelGGL(k_table16, grid, block, 0, ctx->aux_stream, p->table, stride, p->table16, p->stride16, n);
+            // grid.y is limited to 65535 blocks: row blocks of at most that many (the reference places no cap on num_permutations)
+            for (int64_t r0 = 0; r0 < rows; r0 += 65535) {
+                const int64_t rb = std::min<int64_t>(65535, rows - r0);
+                const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), rb), block(256);
+                hipLaunchKernelGGL(k_table16, grid, block, 0, ctx->aux_stream, p->table + r0 * stride, stride,
+                                   p->table16 + r0 * p->stride16, p->stride16, n);
+            }
             e = hipGetLastError();
         }
         p->stages = perms_stage_plan(count);
         const int64_t n_chunks = stage_count(p);
         p->chunk_done.assign(std::max<int64_t>(n_chunks, 1), nullptr);
         for (size_t c = 0; c < p->chunk_done.size() && e == hipSuccess; ++c) {
-            e = hipEventCreateWithFlags(&p->chunk_done[c], hipEventDisableTiming);
+            e = hipEventCreateWithFlags(&p->chunk_done[c], safe_event_flags(hipEventDisableTiming));
             if (e == hipSuccess) e = hipEventRecord(p->chunk_done[c], ctx->aux_stream);
         }
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->aux_stream);    // `src` may be host memory of the caller's call
+        if (e == hipSuccess) e = safe_stream_sync(ctx->aux_stream);    // `src` may be host memory of the caller's call
         if (e != hipSuccess) {
             safe_set_error("%s: %s", who, hipGetErrorString(e));
             rc = SAFE_E_HIP;
@@ -606,26 +690,32 @@ int safe_perms_destroy(safe_perms *perms) {
     (void)hipSetDevice(perms->ctx->device);
     safe_ctx *ctx = perms->ctx;
     if (perms->from_table) {                              // no stream, no staging buffers: nothing worth caching
-        (void)hipStreamSynchronize(ctx->aux_stream);
-        (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)safe_stream_sync(ctx->aux_stream);
+        (void)safe_stream_sync(ctx->side_stream);
+        (void)safe_stream_sync(ctx->stream);
         perms_free(perms);
         return SAFE_OK;
     }
+    int rc = SAFE_OK;
+    if (perms->ring && !perms->ring_consumer)             // the node's producer publishes the WHOLE stream, whatever it used itself
+        rc = perms_generate_until(perms, perms->count);
     drawer_stop(perms);
-    SwapPool::get().wait();
-    (void)hipStreamSynchronize(ctx->aux_stream);
-    (void)hipStreamSynchronize(ctx->side_stream);
-    (void)hipStreamSynchronize(ctx->stream);
+    if (!perms->ring_consumer) SwapPool::get().wait();
+    if (perms->ring) ring_end_call(perms->ring);
+    perms->ring = nullptr;
+    perms->ring_consumer = false;
+    (void)safe_stream_sync(ctx->aux_stream);
+    (void)safe_stream_sync(ctx->side_stream);
+    (void)safe_stream_sync(ctx->stream);
     // keep the allocations for the next handle of the same shape (hipMalloc / hipHostMalloc / hipFree of
     // ~30 MB per call cost more than a millisecond)
     perms_cache_drop(ctx);
-    draw_stream_free(perms->stream);
+    if (perms->stream) draw_stream_free(perms->stream);
     perms->stream = nullptr;
     (void)hipFree(perms->inverse_t);
     perms->inverse_t = nullptr;
     ctx->perm_cache = perms;
-    return SAFE_OK;
+    return rc;
 }
 
 int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host) {
@@ -640,7 +730,7 @@ int safe_perms_read(safe_perms *perms, int64_t p0, int64_t p1, int32_t *out_host
         SAFE_HIP_CHECK(hipMemcpy2DAsync(out_host, perms->n * sizeof(int32_t), perms->table + p0 * stride,
                                         stride * sizeof(int32_t), perms->n * sizeof(int32_t), p1 - p0,
                                         hipMemcpyDeviceToHost, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamSynchronize(ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
 }
 

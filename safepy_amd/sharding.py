@@ -106,26 +106,67 @@ def agree_on_seed(random_seed, group=None):
     return int(t.item())
 
 
-def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, group=None, table=None):
-    """The final exchange (np.concatenate(axis=1) of the NES blocks, safe.py:1355) on every rank.
+def ensure_shared_stream(ctx, group=None):
+    """One permutation stream per NODE instead of one per rank (every rank drew the whole MT19937 stream --
+    safe_extras.py:46-58 is sequential, a rank cannot draw "its part" -- which made 8 ranks keep 40 host threads busy and
+    capped strong scaling at the serial draw rate).  On first use (collective over the default group) the ranks agree on a
+    job-unique name (one 8-byte broadcast from rank 0) and attach their context to the node's shared-memory ring
+    (Context.share_stream): local rank 0 draws and replays, the others block until a chunk's row maps are published.
+    Local rank / local world come from the launcher (LOCAL_RANK / LOCAL_WORLD_SIZE, set by torch.distributed.run); without
+    them SAFE_HIP_SHARED_STREAM=1 declares all ranks to be on one node.  SAFE_HIP_SHARED_STREAM=0 keeps one stream per
+    rank.  Returns True when this context shares a stream."""
+    import os
+    if ctx is None:
+        return False
+    if ctx.shared_stream is not None:
+        return True
+    if getattr(ctx, '_shared_stream_checked', False):
+        return False
+    ctx._shared_stream_checked = True
+    dist = _dist()
+    mode = os.environ.get('SAFE_HIP_SHARED_STREAM', '')
+    if mode == '0' or group is not None or not dist.is_initialized() or dist.get_world_size() <= 1:
+        return False
+    if 'LOCAL_WORLD_SIZE' in os.environ and 'LOCAL_RANK' in os.environ:
+        local_rank, local_world = int(os.environ['LOCAL_RANK']), int(os.environ['LOCAL_WORLD_SIZE'])
+    elif mode == '1':
+        local_rank, local_world = dist.get_rank(), dist.get_world_size()
+    else:
+        return False
+    import torch
+    token = torch.tensor([int.from_bytes(os.urandom(7), 'little')], dtype=torch.int64, device=_device_for(group))
+    dist.broadcast(token, src=0)
+    return ctx.share_stream('%014x' % int(token.item()), local_rank, local_world)
 
-    When the last randomization call on every rank left packed integer counters on the device
-    (bit-sliced / matrix-core kernels), the ranks all-gather those -- u32 per (node, attribute)
-    instead of f64, attribute-major so a rank's block is one contiguous slab and no transpose
-    copy is needed -- and each rank derives the full [N, M] NES matrix from the counters with
-    the arithmetic of safe.py:532-554.  Otherwise (f64 kernels, no device) the f64 blocks travel
-    (gather_columns).  `local_nes`: this rank's [N, M_r] NES tensor (its values are only used on
-    the fallback path).  Over RCCL the slabs move device to device; over gloo (tests: several
-    ranks on one GPU) they are staged through the host."""
+
+COUNTER_OUTPUTS = ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')     # what the integer counters determine (safe.py:532-554, 468-472)
+
+
+def gather_outputs(ctx, nbr, bufs, names, m_total, num_permutations, attribute_sign, enrichment_threshold=0.05, group=None,
+                   table=None, report=None):
+    """The final exchange (np.concatenate(axis=1) of every rank's block, safe.py:1355; north star: "final RCCL all-gather
+    of the p-value matrix") for any of COUNTER_OUTPUTS, on every rank, from ONE all-gather of integers.
+
+    When the last randomization call on every rank left packed integer counters on the device (bit-sliced / matrix-core
+    'sum' kernels), the ranks all-gather those -- u32 per (node, attribute) instead of one f64 per requested matrix,
+    attribute-major so a rank's block is one contiguous slab and no transpose copy is needed -- and each rank derives the
+    requested full [N, M] matrices from the counters with the arithmetic of safe.py:532-554 and 468-472
+    (safe_outputs_from_packed_counts).  Otherwise (f64 kernels, z-scores, no device) the f64 blocks travel
+    (gather_columns).  `bufs`: this rank's [N, M_r] device tensors by name (their values are only used on the fallback
+    path).  Over RCCL the slabs move device to device; over gloo (tests: several ranks on one GPU) they are staged through
+    the host.  Returns {name: full tensor}; `report` (a dict) receives the form and the bytes this rank received."""
     import torch
     from . import backend as be
     dist = _dist()
+    names = tuple(names)
+    assert names and all(k in COUNTER_OUTPUTS for k in names), names
     world = dist.get_world_size(group)
-    on_device = ctx is not None and local_nes.is_cuda
+    local = bufs[names[0]]
+    on_device = ctx is not None and local.is_cuda
     n_pad, m_loc, layout = be.packed_counts_info(ctx) if on_device else (0, 0, -1)
     shards = column_shards(m_total, world)
     widest = max(c1 - c0 for c0, c1 in shards)
-    dev = local_nes.device
+    dev = local.device
     xdev = _device_for(group)                          # where the collective's buffers live
     # every rank must take the same branch: agree on (layout, n_pad) with one tiny MIN reduce
     key = torch.tensor([layout, -layout, n_pad, -n_pad], dtype=torch.int64, device=xdev)
@@ -133,7 +174,9 @@ def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, g
     key = key.tolist()
     agreed = key[0] >= 0 and key[0] == -key[1] and key[2] == -key[3]
     if not agreed:
-        return gather_columns(local_nes, m_total, group)
+        if report is not None:
+            report.update(form='f64 blocks', bytes_received=int(8 * local.shape[0] * widest * (world - 1) * len(names)))
+        return {k: gather_columns(bufs[k], m_total, group) for k in names}
     mine = torch.zeros(widest * n_pad, dtype=torch.int32, device=dev)       # zero counters = padding columns
     torch.cuda.current_stream().synchronize()          # the fill ran on torch's stream, the export runs on the context's
     be.export_packed_counts(ctx, mine.data_ptr(), m_loc * n_pad)
@@ -145,14 +188,24 @@ def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, g
         staged = torch.empty(world * widest * n_pad, dtype=torch.int32)
         dist.all_gather_into_tensor(staged, mine.cpu(), group=group)
         everyone = staged.to(dev)
-    full = torch.empty((local_nes.shape[0], world * widest), dtype=torch.float64, device=dev)
+    if not all(c1 - c0 == widest for c0, c1 in shards):           # ragged split: drop the padding columns of the narrower ranks
+        slabs = everyone.view(world, widest, n_pad)
+        everyone = torch.cat([slabs[r, :shards[r][1] - shards[r][0]] for r in range(world)], dim=0).contiguous()
+    full = {k: torch.empty((local.shape[0], m_total), dtype=torch.float64, device=dev) for k in names}
     torch.cuda.current_stream().synchronize()          # the collective is ordered on torch's stream
-    be.nes_from_packed_counts(ctx, nbr, everyone.data_ptr(), layout, n_pad, world * widest, num_permutations,
-                              attribute_sign, full.data_ptr(), table=table)
+    be.outputs_from_packed_counts(ctx, nbr, everyone.data_ptr(), layout, n_pad, m_total, num_permutations, attribute_sign,
+                                  enrichment_threshold, [full[k].data_ptr() if k in full else None for k in COUNTER_OUTPUTS],
+                                  table=table)
     ctx.sync()
-    if all(c1 - c0 == widest for c0, c1 in shards):
-        return full
-    return torch.cat([full[:, r * widest:r * widest + (shards[r][1] - shards[r][0])] for r in range(world)], dim=1)
+    if report is not None:
+        report.update(form='packed u32 counters (4 B per node x attribute), %s rebuilt on every rank' % ' / '.join(names),
+                      bytes_received=int(4 * n_pad * widest * (world - 1)))
+    return full
+
+
+def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, group=None, table=None):
+    """The NES matrix alone (gather_outputs with names=('nes',))."""
+    return gather_outputs(ctx, nbr, {'nes': local_nes}, ('nes',), m_total, num_permutations, attribute_sign, 0.05, group, table)['nes']
 
 
 def gather_columns(local, m_total, group=None):
@@ -182,7 +235,7 @@ def gather_columns(local, m_total, group=None):
     return full if full.device == home else full.to(home)
 
 
-def _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold, group):
+def _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold, group, ready=None):
     """multiple_testing=True under attribute sharding, with whole-matrix semantics: Benjamini-Hochberg runs
     along a ROW across all attributes (safe.py:536-542, 599-605), so the p-value blocks are all-gathered
     first and every rank adjusts the full [N, M] matrices (safe_fdr_adjust also rebuilds NES, nes_binary and
@@ -190,7 +243,9 @@ def _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enri
     device blocks by name; returns the full device tensors by name (+ 'num_neighborhoods_enriched')."""
     import torch
     from . import backend as be
-    full = {k: gather_columns(bufs[k], m_total, group).contiguous() for k in ('pvalues_neg', 'pvalues_pos') if k in bufs}
+    ready = ready or {}              # full unadjusted p-value matrices the integer exchange already produced
+    full = {k: (ready[k] if k in ready else gather_columns(bufs[k], m_total, group)).contiguous()
+            for k in ('pvalues_neg', 'pvalues_pos') if k in bufs}
     n = full['pvalues_pos'].shape[0]
     dev = full['pvalues_pos'].device
     full['nes'] = torch.empty((n, m_total), dtype=torch.float64, device=dev)
@@ -213,13 +268,15 @@ def _outputs(bufs, enriched, full, m_total, group, gather, ready=None):
         out = {k: v.cpu().numpy() for k, v in bufs.items()}
         out['num_neighborhoods_enriched'] = enriched.cpu().numpy()
         for k in gather:
-            out['full_' + k] = (ready[k] if k in ready else gather_columns(bufs[k], m_total, group)).cpu().numpy()
+            if k in bufs:                    # (the hypergeometric path has no pvalues_neg / ns: safe.py:556-608 leaves them unset)
+                out['full_' + k] = (ready[k] if k in ready else gather_columns(bufs[k], m_total, group)).cpu().numpy()
         return out
     c0, c1 = column_shards(m_total, dist.get_world_size(group))[dist.get_rank(group)]
     out = {k: (full[k][:, c0:c1] if k in full else v).cpu().numpy() for k, v in bufs.items()}
     out['num_neighborhoods_enriched'] = full['num_neighborhoods_enriched'][c0:c1].cpu().numpy()
     for k in gather:
-        out['full_' + k] = (full[k] if k in full else gather_columns(bufs[k], m_total, group)).cpu().numpy()
+        if k in bufs:
+            out['full_' + k] = (full[k] if k in full else gather_columns(bufs[k], m_total, group)).cpu().numpy()
     return out
 
 
@@ -229,7 +286,7 @@ HYPERGEOM_OUTPUTS = ('pvalues_pos', 'nes', 'nes_binary')
 
 def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
                        neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05, group=None,
-                       table=None, flags=None, exchange=True):
+                       table=None, flags=None, exchange=True, timing=None):
     """One rank's share of compute_pvalues_by_randomization (safe.py:474-554) on DEVICE-resident inputs and
     outputs, plus the path's exchange steps -- the function bench.py times and the host-level drivers below
     call, so what is measured is what runs.
@@ -238,8 +295,10 @@ def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, b
     RANDOMIZATION_OUTPUTS; enriched: f64 [M_r].  flags: whole-matrix row flags when the caller already
     exchanged them (then `random_seed` must already be the agreed seed), else they are exchanged here together
     with the seed.  exchange=True all-gathers the result (integer counters when the kernel left them, f64 NES
-    blocks otherwise) and returns the full [N, m_total] NES device tensor; False returns None (D2H-only runs:
-    every rank keeps its block).  Without a process group it is the plain single-GPU step."""
+    blocks otherwise) and returns the full [N, m_total] NES device tensor; a tuple of names from COUNTER_OUTPUTS returns
+    {name: full tensor} for all of them from the same single exchange; False returns None (D2H-only runs: every rank
+    keeps its block).  Without a process group it is the plain single-GPU step.  `timing`: a dict that
+    receives this rank's host-stream / kernel / exchange times of the step (bench.py)."""
     from . import backend as be
     alone = not _dist().is_initialized()               # a single process: the same step without the two exchanges
     if flags is None:
@@ -250,15 +309,33 @@ def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, b
             random_seed = stats['random_seed']
     if not alone:
         attr.set_row_flags(flags)                      # indx_vals of the FULL matrix (safe_extras.py:51)
-    perms = be.Permutations(ctx, attr.n, flags, int(num_permutations), random_seed)
+    shared = (not alone) and ensure_shared_stream(ctx, group)        # one draw thread per node, not per rank
+    perms = be.Permutations(ctx, attr.n, flags, int(num_permutations), random_seed, shared=shared)
+    if timing is not None:
+        timing['stream_role'] = 'shared' if shared else 'own'
     try:
         be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
                          [bufs[k].data_ptr() for k in RANDOMIZATION_OUTPUTS] + [enriched.data_ptr()], table=table)
+        if timing is not None:
+            import time
+            timing.update(perms.timing())
+            name, k_ms, launches = ctx.last_kernel()
+            timing.update(kernel=name, gpu_kernel_ms=k_ms * max(int(launches), 1))
+            t_x = time.perf_counter()
         if not exchange:
             return None
-        if alone:
+        if alone and exchange is True:
             return bufs['nes']
-        return gather_nes(ctx, nbr, bufs['nes'], m_total, int(num_permutations), attribute_sign, group, table=table)
+        names = ('nes',) if exchange is True else tuple(exchange)
+        if alone:
+            return {k: bufs[k] for k in names}
+        report = {} if timing is not None else None
+        full = gather_outputs(ctx, nbr, bufs, names, m_total, int(num_permutations), attribute_sign, enrichment_threshold, group,
+                              table=table, report=report)
+        if timing is not None:
+            timing['exchange_ms'] = 1e3 * (time.perf_counter() - t_x)
+            timing['exchange'] = report
+        return full['nes'] if exchange is True else full
     finally:
         perms.close()
 
@@ -275,14 +352,16 @@ def _randomization_host(ctx, nbr, attr, m_total, num_permutations, random_seed, 
     import torch
     bufs, enriched = _alloc_outputs(ctx, attr.n, attr.m, RANDOMIZATION_OUTPUTS)
     torch.cuda.current_stream().synchronize()
-    want_nes = ('nes' in gather) and not multiple_testing
-    full_nes = randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
-                                  neighborhood_score_type, attribute_sign, enrichment_threshold, group, flags=flags,
-                                  exchange=want_nes)
+    # every requested matrix the counters determine comes out of ONE integer exchange; with multiple_testing the adjusted
+    # p-values are whole-matrix quantities and the unadjusted ones travel the same way first (_fdr_whole_matrix)
+    wanted = tuple(k for k in COUNTER_OUTPUTS if k in gather) if not multiple_testing else ('pvalues_neg', 'pvalues_pos')
+    ready = randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
+                               neighborhood_score_type, attribute_sign, enrichment_threshold, group, flags=flags,
+                               exchange=wanted if wanted else False)
     ctx.sync()
     full = _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold,
-                             group) if multiple_testing else None
-    return _outputs(bufs, enriched, full, m_total, group, gather, ready={'nes': full_nes} if want_nes else None)
+                             group, ready=ready) if multiple_testing else None
+    return _outputs(bufs, enriched, full, m_total, group, gather, ready=None if multiple_testing else ready)
 
 
 def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, random_seed,
@@ -332,7 +411,7 @@ def permutation_split_randomization(ctx, nbr, attr_host, num_permutations, rando
         ns, neg, pos = (torch.zeros((n, m), dtype=torch.float64, device=dev) for _ in range(3))
         torch.cuda.current_stream().synchronize()
         p0, p1 = column_shards(total, world)[rank]
-        whole = be.Permutations(ctx, n, attr.row_flags(), total, seed)
+        whole = be.Permutations(ctx, n, attr.row_flags(), total, seed, shared=(not alone) and ensure_shared_stream(ctx, group))
         try:
             if p1 > p0:
                 mine = whole.slice(p0, p1)

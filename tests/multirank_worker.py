@@ -4,9 +4,11 @@ fresh child processes).  Every rank builds the same seeded inputs, runs the prod
 
     all-gathered result == the single-process SAFE.compute_pvalues on the unsplit matrix == the oracle
 
-usage: multirank_worker.py RANK WORLD PORT BACKEND OUTDIR
+usage: multirank_worker.py RANK WORLD PORT BACKEND OUTDIR [STREAM]
 BACKEND nccl = RCCL, one GPU per rank (needs >= WORLD devices); gloo = every rank on device 0 with the
-exchange staged through the host (runs on a one-GPU box; same kernels, same integer-counter exchange)."""
+exchange staged through the host (runs on a one-GPU box; same kernels, same integer-counter exchange).
+STREAM shared (default) = one permutation stream per node: LOCAL_RANK / LOCAL_WORLD_SIZE are set as a launcher would and
+local rank 0 draws for everyone (safe_perms_create_shared); own = every rank draws the whole stream itself."""
 import os
 import sys
 
@@ -37,7 +39,13 @@ def cases(rng, n):
 
 def main():
     rank, world, port, backend, outdir = int(sys.argv[1]), int(sys.argv[2]), int(sys.argv[3]), sys.argv[4], sys.argv[5]
+    stream = sys.argv[6] if len(sys.argv) > 6 else 'shared'
     os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    if stream == 'shared':
+        os.environ.update(LOCAL_RANK=str(rank), LOCAL_WORLD_SIZE=str(world))
+    else:
+        os.environ['SAFE_HIP_SHARED_STREAM'] = '0'
+    os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')     # as bench.py / run_batch.py run
     os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
     import torch
     import torch.distributed as dist
@@ -68,13 +76,15 @@ def main():
             out = sharding.sharded_compute_pvalues(
                 ctx, nbr, np.ascontiguousarray(b[:, c0:c1]), m, enrichment_type=kw['how'],
                 num_permutations=kw.get('num_permutations', 1000), random_seed=9, neighborhood_score_type=score,
-                gather=('nes', 'nes_binary', 'pvalues_pos'), multiple_testing=fdr)
+                gather=('nes', 'nes_binary', 'pvalues_pos', 'pvalues_neg'), multiple_testing=fdr)
             # ---- single process, unsplit matrix
             sf.random_seed = 9
             sf.load_attributes(attribute_file=b.copy())
             sf.compute_pvalues(**dict(kw, neighborhood_score_type=score, multiple_testing=fdr))     # (kwargs persist on the object, like the reference's)
             assert out['how'] == ('hypergeometric' if name == 'binary-auto-hypergeometric' else 'randomization'), name
-            for key in ('nes', 'nes_binary', 'pvalues_pos'):
+            # every full matrix the reference leaves on the instance -- for the counter kernels all four come out of ONE
+            # exchange of packed integers (sharding.gather_outputs)
+            for key in ('nes', 'nes_binary', 'pvalues_pos') + (('pvalues_neg',) if out['how'] == 'randomization' else ()):
                 assert np.array_equal(out['full_' + key], getattr(sf, key), equal_nan=True), (name, key, rank)
                 assert np.array_equal(out[key], getattr(sf, key)[:, c0:c1], equal_nan=True), (name, key, rank)
             assert np.array_equal(out['num_neighborhoods_enriched'],
@@ -96,6 +106,21 @@ def main():
             else:
                 np.testing.assert_allclose(out['full_pvalues_pos'], want['pvalues_pos'], rtol=1e-6, atol=1e-300)
                 np.testing.assert_allclose(out['full_nes'], want['nes'], rtol=1e-6, atol=1e-9)
+
+        # who drew: with a shared stream only local rank 0 runs a draw thread, the others fetched every chunk from its ring
+        from safepy_amd import backend as be
+        assert (ctx.shared_stream is not None) == (stream == 'shared' and world > 1), ctx.shared_stream
+        flags = np.ones(n, dtype=np.uint8)
+        flags[::7] = 0
+        perms = be.Permutations(ctx, n, flags, 300, 5, shared=True)           # collective: three pipeline stages
+        table = perms.read()
+        role = perms.timing()['role']
+        perms.close()
+        assert role == ('own' if ctx.shared_stream is None else 'producer' if rank == 0 else 'consumer'), role
+        mine = be.Permutations(ctx, n, flags, 300, 5)                         # this rank's own stream: the same tables
+        assert np.array_equal(table, mine.read())
+        mine.close()
+        assert np.array_equal(table[0][flags == 0], np.flatnonzero(flags == 0))     # rows without a value never move
 
         # random_seed=None: ONE unseeded run of the whole matrix -- every rank must have used rank 0's seed, so the
         # all-gathered matrix is a consistent run: rank r's own block equals its slice of everyone's full matrix, and

@@ -30,29 +30,38 @@ def _device_count():
     return safepy_amd.device_count()
 
 
-def _run_ranks(world, backend, tmp_path, timeout=900):
+def _run_ranks(world, backend, tmp_path, timeout=900, stream='shared'):
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', SAFE_HIP_SWAP_THREADS='1')
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', SAFE_HIP_SWAP_THREADS='1', GPU_MAX_HW_QUEUES='8',
+               SAFE_HIP_RING_TIMEOUT_S='300')
+    # every rank writes to its own file: a rank blocked on a full pipe inside a collective would stall all of them
+    logs = [open(tmp_path / ('rank%d.log' % r), 'w+') for r in range(world)]
     procs = [subprocess.Popen([sys.executable, os.path.join(ROOT, 'tests', 'multirank_worker.py'), str(r), str(world), str(port),
-                               backend, str(tmp_path)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+                               backend, str(tmp_path), stream], env=env, stdout=logs[r], stderr=subprocess.STDOUT)
              for r in range(world)]
-    logs = []
+    timed_out = False
     for p in procs:
         try:
-            out, _ = p.communicate(timeout=timeout)
+            p.wait(timeout=timeout)
         except subprocess.TimeoutExpired:
+            timed_out = True
             for q in procs:
                 q.kill()
-            out = 'TIMEOUT'
-        logs.append(out)
+    text = []
+    for log in logs:
+        log.seek(0)
+        text.append(log.read())
+        log.close()
+    assert not timed_out, 'TIMEOUT\n' + '\n'.join('--- rank %d:\n%s' % (r, t[-3000:]) for r, t in enumerate(text))
     for r, p in enumerate(procs):
-        assert p.returncode == 0 and (tmp_path / ('ok%d' % r)).exists(), 'rank %d failed:\n%s' % (r, logs[r][-4000:])
+        assert p.returncode == 0 and (tmp_path / ('ok%d' % r)).exists(), 'rank %d failed:\n%s' % (r, text[r][-4000:])
 
 
-def test_two_ranks_one_gpu_sharded_equals_unsharded_equals_oracle(tmp_path):
+@pytest.mark.parametrize('stream', ['shared', 'own'])
+def test_two_ranks_one_gpu_sharded_equals_unsharded_equals_oracle(tmp_path, stream):
     if _device_count() < 1:
         pytest.skip('needs a HIP device')
-    _run_ranks(2, 'gloo', tmp_path)
+    _run_ranks(2, 'gloo', tmp_path, stream=stream)
 
 
 def test_three_ranks_one_gpu_uneven_split(tmp_path):
