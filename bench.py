@@ -43,26 +43,21 @@ def parse():
     ap.add_argument('--radius', type=float, default=0.1)
     ap.add_argument('--cpu-perms', type=int, default=40, help='permutations timed for the CPU baseline (0 = skip)')
     ap.add_argument('--extras', type=int, default=1, help='also time the HBM-bound kernels (K1 distance, K4 hypergeometric)')
+    ap.add_argument('--scaling', choices=['weak', 'strong'], default='weak',
+                    help='N > 1: weak = every rank its own block of --attrs columns (the default line); strong = --attrs columns '
+                         'split over the ranks (np.array_split, safe.py:1339): `--scaling strong --perms 10000` is BASELINE configs[2]')
+    ap.add_argument('--workload', choices=['cfg1', 'cfg4'], default='cfg1',
+                    help='cfg1 = the Costanzo-shaped binary workload of configs[1]/[2]; cfg4 = BASELINE configs[4]: 20 000 nodes, '
+                         '6250 quantitative f64 columns per rank x 1000 permutations (matrix-core kernel)')
+    ap.add_argument('--multi-extras', type=int, default=1,
+                    help='N > 1: after the timed weak-scaling line also time configs[2] (strong scaling, 10 000 permutations) and one '
+                         'step of the configs[4] rank share, reported inside the same JSON line')
     return ap.parse_args()
 
 
 def effective_cores():
-    """CPUs this process may actually use: the scheduler affinity, capped by the container's CFS
-    quota (cgroup v2 cpu.max / v1 cfs_quota_us) when there is one."""
-    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
-    try:
-        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
-        if quota != 'max':
-            cores = min(cores, max(1, int(int(quota) / int(period))))
-    except (OSError, ValueError):
-        try:
-            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
-            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
-            if quota > 0:
-                cores = min(cores, max(1, quota // period))
-        except (OSError, ValueError):
-            pass
-    return cores
+    from safepy_amd import backend
+    return backend.effective_cores()
 
 
 def cpu_baseline(a_dense, b, sample_perms):
@@ -299,6 +294,210 @@ def launch_ranks(n_gpus):
     return subprocess.run(cmd, env=env).returncode
 
 
+class Workload:
+    """Inputs of one bench mode, resident in HBM: membership handle, this rank's attribute block, the call's parameters."""
+
+    def __init__(self, args, kind, scaling, perms, rank, world, local_rank, ctx, torch, np):
+        import safepy_amd
+        from safepy_amd import workloads, sharding
+        self.kind, self.scaling, self.P = kind, scaling, int(perms)
+        sf = safepy_amd.SAFE(verbose=False, device=local_rank)
+        if kind == 'cfg4':
+            n, m = 20000, 6250
+            xy = workloads.uniform_layout(4, n)
+            sf.graph = safepy_amd.LayoutGraph(xy)
+            sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.1)
+            b = workloads.quantitative_attributes(3 + 100 * rank, n, m)          # every rank its own 6250 columns of the 50 000
+            self.m_total = m * world
+            self.dtype, self.order = np.float64, 'C'
+            self.b_dev = torch.from_numpy(b).to('cuda')
+            self.b_host = None
+            self.name = ('configs[4]: 20000-node uniform layout, euclidean r=0.1, %d quantitative f64 attributes per rank x %d '
+                         'permutations' % (m, self.P))
+        else:
+            data = workloads.costanzo_surrogate(seed=0, n=args.nodes, m=args.attrs, target_edges=int(28202 * args.nodes / 3971))
+            sf.graph = safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length'])
+            sf.define_neighborhoods(node_distance_metric=args.metric, neighborhood_radius=args.radius)
+            b = data['attributes']
+            if scaling == 'strong':                    # ONE matrix, its columns split over the ranks (np.array_split, safe.py:1339)
+                self.m_total = b.shape[1]
+                c0, c1 = sharding.column_shards(self.m_total, world)[rank]
+                b = np.asfortranarray(b[:, c0:c1])
+            else:                                      # weak: every rank its own attribute block of the same shape
+                if rank > 0:
+                    b = workloads.go_like_binary(np.random.default_rng(1000 + rank), args.nodes, args.attrs, int(182 * args.nodes / 3971))
+                self.m_total = b.shape[1] * world
+            self.dtype, self.order = np.float32, 'F'
+            self.b_dev = torch.from_numpy(np.ascontiguousarray(b.T)).to('cuda')      # F-order [n,m] == C-order [m,n]
+            self.b_host = b
+            self.name = ('configs[%d]: Costanzo-2016-shaped surrogate, %d nodes x %d GO-BP-like binary attributes x %d permutations, '
+                         'metric %s r=%g, seed 0' % (2 if (scaling == 'strong' and self.P == 10000) else 1, b.shape[0],
+                                                     self.m_total if scaling == 'strong' else b.shape[1], self.P, args.metric, args.radius))
+        self.sf = sf
+        self.nbr = sf._nbr
+        self.n, self.m = b.shape
+        self.counts = self.nbr.row_counts()
+        self.units_per_step = float(self.n) * self.m_total * self.P          # node-attribute enrichments per step, all ranks
+
+
+def thread_cpu_ms():
+    """CPU milliseconds (user + system) of every thread of this process so far, by (tid, name): /proc/self/task/*/stat."""
+    out = {}
+    tick = os.sysconf('SC_CLK_TCK')
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            with open('/proc/self/task/%s/stat' % tid) as f:
+                text = f.read()
+            name = text[text.index('(') + 1:text.rindex(')')]
+            rest = text[text.rindex(')') + 2:].split()
+            out[(int(tid), name)] = 1e3 * (int(rest[11]) + int(rest[12])) / tick
+        except (OSError, ValueError):
+            pass
+    return out
+
+
+def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, diag_exchange=False):
+    """Warm-up + exactly n_steps timed steps of sharding.randomization_step on `wl` (barrier + synchronize on both sides, MAX over
+    ranks); returns the numbers of the mode.  A step = one compute_pvalues pass of this rank's block: statistics for the
+    dispatch rule, whole-matrix row flags (N > 1: one small all-gather), the seeded legacy stream (one per node) + table
+    kernels, the permutation-test kernels with the fused p-value / NES / binarisation epilogue and -- N > 1 -- the all-gather
+    of every rank's result over RCCL / xGMI."""
+    n, m, P = wl.n, wl.m, wl.P
+    out = {k: torch.empty((n, m), dtype=torch.float64, device='cuda') for k in sharding.RANDOMIZATION_OUTPUTS}
+    enriched = torch.empty((m,), dtype=torch.float64, device='cuda')
+    table = be.nes_table(P)
+    timings = []
+
+    def step(exchange=True):
+        attr = be.Attributes.from_device(ctx, wl.b_dev.data_ptr(), wl.dtype, n, m, order=wl.order)
+        t = {}
+        try:
+            sharding.randomization_step(ctx, wl.nbr, attr, wl.m_total, P, 0, out, enriched, 'sum', 'both', 0.05,
+                                        table=table, exchange=exchange, timing=t)
+            timings.append(t)
+        finally:
+            attr.close()
+
+    def fence():
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def timed(k, fn):
+        fence()
+        t_begin = time.perf_counter()
+        per_step = []
+        for _ in range(k):
+            ts = time.perf_counter()
+            fn()
+            per_step.append(1e3 * (time.perf_counter() - ts))     # (a step returns after its own stream synchronisation)
+        fence()
+        seconds = time.perf_counter() - t_begin
+        if dist is not None:                                       # the slowest rank's clock
+            t = torch.tensor([seconds], dtype=torch.float64, device='cuda' if dist.get_backend() == 'nccl' else 'cpu')
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            seconds = float(t.item())
+        return seconds, per_step
+
+    for _ in range(n_warmup):
+        step()
+    timings.clear()
+    cpu0 = time.process_time()
+    elapsed, step_ms = timed(n_steps, step)
+    res = {'elapsed': elapsed, 'step_ms': step_ms, 'host_cpu_ms': 1e3 * (time.process_time() - cpu0) / n_steps,
+           'timings': list(timings), 'kernel': ctx.last_kernel(), 'out': out}
+    mean = lambda key: float(np.mean([t.get(key, 0.0) for t in timings])) if timings else 0.0      # noqa: E731
+    mine = {'role': timings[-1].get('role', 'own'), 'host_stream_ms': mean('tables_enqueued_ms'), 'draw_busy_ms': mean('draw_busy_ms'),
+            'waited_for_producer_ms': mean('waited_for_producer_ms'), 'gpu_kernel_ms': mean('gpu_kernel_ms'),
+            'exchange_ms': mean('exchange_ms'), 'host_cpu_ms_per_step': res['host_cpu_ms']}
+    res['exchange_form'] = timings[-1].get('exchange') if timings else None
+    if dist is not None:
+        everyone = [None] * world
+        dist.all_gather_object(everyone, mine)
+        res['per_rank'] = everyone
+    else:
+        res['per_rank'] = [mine]
+    # SURVEY 8(e): the same step with the exchange replaced by a D2H copy of the rank's own NES block (what a host that only
+    # wants the results on disk needs), and with no exchange at all -- diagnostics outside the timed region, N > 1 only
+    if dist is not None and diag_exchange:
+        k_diag = max(2, min(n_steps, 5))
+        host_nes = torch.empty((n, m), dtype=torch.float64).pin_memory()
+
+        def step_d2h():
+            step(exchange=False)
+            host_nes.copy_(out['nes'], non_blocking=True)
+            torch.cuda.current_stream().synchronize()
+
+        t_d2h, _ = timed(k_diag, step_d2h)
+        k_cpu = 200 if os.environ.get('SAFE_BENCH_THREAD_CPU') == '1' else k_diag       # (10 ms clock ticks: many steps for per-thread figures)
+        cpu1, thr1 = time.process_time(), thread_cpu_ms()
+        t_none, _ = timed(k_cpu, lambda: step(exchange=False))
+        cpu_none = [1e3 * (time.process_time() - cpu1) / k_cpu]
+        if os.environ.get('SAFE_BENCH_THREAD_CPU') == '1':
+            thr2 = thread_cpu_ms()
+            busy = sorted(((thr2[k] - thr1.get(k, 0.0)) / k_cpu, k[1], k[0]) for k in thr2)
+            sys.stderr.write('rank %d threads, CPU ms per step (step %.2f ms): %s\n' % (
+                dist.get_rank(), 1e3 * t_none / k_cpu, ', '.join('%s[%d] %.2f' % (nm, tid, ms) for ms, nm, tid in busy[::-1] if ms > 0.02)))
+        t_none, k_diag_none = t_none * k_diag / k_cpu, k_diag
+        everyone = [None] * world
+        dist.all_gather_object(everyone, cpu_none[0])
+        form = res['exchange_form'] or {}
+        res['exchange_report'] = {'all_gather_ms_per_step': 1e3 * elapsed / n_steps, 'd2h_only_ms_per_step': 1e3 * t_d2h / k_diag,
+                                  'no_exchange_ms_per_step': 1e3 * t_none / k_diag, 'steps_timed': k_diag,
+                                  'host_cpu_ms_per_step_no_exchange_per_rank': everyone,
+                                  'form': form.get('form'), 'bytes_received_per_rank': form.get('bytes_received'),
+                                  'd2h_bytes_per_rank': int(8 * n * m)}
+    return res
+
+
+def roofline_of(wl, res, ctx, np, be):
+    """The `roofline` object of the mode's dominant kernel: algorithmic bytes (or ops) per launch over the launch's HIP-event
+    duration.  For the bit-sliced kernel the BINDING resources (VALU issue + LDS gather) come first: it is neither HBM- nor
+    MFMA-bound, the nominal HBM line is kept because the contract asks for hbm | mfma."""
+    n, m, P = wl.n, wl.m, wl.P
+    kname, _, launches = res['kernel']
+    launches = max(int(launches), 1)
+    k_total = float(np.mean([t['gpu_kernel_ms'] for t in res['timings']]))
+    k_ms = k_total / launches                               # average duration of ONE launch (HIP events)
+    span = int(np.ceil(P / launches))                       # permutations per launch
+    if kname.startswith('k_permtest_mfma'):
+        blocks, slices = be.block_count(wl.nbr), be.last_mfma_slices(ctx)
+        ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * slices * (P + 1) / launches
+        useful = 2.0 * float(wl.nbr.nnz) * m * slices * (P + 1) / launches
+        tops = ops / (k_ms * 1e-3) / 1e12
+        return {'bound': 'mfma', 'kernel': kname, 'achieved': tops, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS,
+                'traffic': None, 'kernel_ms': k_ms, 'launches_per_step': launches, 'algorithmic_ops': ops, 'i8_slices': slices,
+                'useful_mac_frac': useful / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                'block_fill': float(wl.nbr.nnz) / (blocks * 256.0 * 32.0)}
+    # Algorithmic HBM bytes of ONE launch (DESIGN.md section 4, K5): SURVEY 8(d) compulsory traffic = one read of the
+    # attribute block, the permutation rows it consumes, the membership, one read-modify-write of its counters.
+    n_wg = -(-m // 64)
+    n_pad = -(-n // 64) * 64
+    nnz = int(wl.nbr.nnz)
+    if kname in ('k_permtest_bits_pre', 'k_permtest_bits_blk'):
+        alg_bytes = 8 * (n + 1) * n_wg + 2 * nnz * span + 2 * nnz + 2 * 4 * n_pad * m
+    elif kname == 'k_permtest_bits':
+        alg_bytes = 8 * (n + 1) * n_wg + 2 * (n + 8) * span + 2 * nnz + 2 * 4 * n_pad * m
+    else:
+        alg_bytes = n * m * 4 + P * (n + 1) * 4 + nnz * 4 + 5 * n * m * 8
+    achieved = alg_bytes / (k_ms * 1e-3) / 1e9
+    traffic, traffic_stamp = pmc_traffic(kname, with_stamp=True)
+    binding = binding_resources(ctx.num_cu, kname)
+    roof = {}
+    if binding is not None and kname.startswith('k_permtest_bits'):
+        # what actually bounds the kernel (PMC passes of this same command, profiles/): the busier of its two pipes
+        roof.update({'binding_resource': 'VALU issue + LDS gather', 'binding_unit': 'fraction of issue slots',
+                     'binding_frac': max(binding['valu_issue_frac'], binding['lds_pipe_busy_frac']),
+                     'binding_resource_utilisation': binding})
+    roof.update({'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
+                 'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_stamp, 'kernel_ms': k_ms,
+                 'launches_per_step': launches, 'permutations_per_launch': span, 'algorithmic_bytes': alg_bytes,
+                 'note': 'nominal: the kernel is not HBM-bound (SURVEY 8d); DESIGN.md section 4',
+                 'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3)})
+    return roof
+
+
 def main():
     args = parse()
     if 'WORLD_SIZE' not in os.environ and args.gpus > 1:
@@ -315,16 +514,19 @@ def main():
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     import numpy as np
     import torch
-    # host threads of the permutation stream per rank: the draw thread and the swap
-    # workers.  Ranks of one node share the host: keep the swap pool within this rank's share of the CPUs
-    # the container may use (4 workers keep pace with the draw thread; fewer only when the host is short).
-    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
-    if 'SAFE_HIP_SWAP_THREADS' not in os.environ:
-        os.environ['SAFE_HIP_SWAP_THREADS'] = str(max(1, min(4, effective_cores() // max(1, local_world) - 1)))
-    import safepy_amd
+    import safepy_amd                                               # noqa: F401
     from safepy_amd import backend as be
-    from safepy_amd import workloads, sharding
+    from safepy_amd import sharding
+    # host threads per rank: ranks of one node share the host -- swap workers within the rank's share of the CPUs, sleeping host
+    # waits when a rank has fewer than three cores to itself (before the context exists)
+    local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
+    host_cfg = be.configure_host_for_ranks(local_world)
 
+    # SAFE_BENCH_SHARE_DEVICE=1 (diagnostics on a one-GPU box): every rank on device 0, exchange staged through gloo -- the same
+    # host pipeline, shared permutation stream and integer exchange; the GPU itself is time-shared, so `value` means nothing
+    share_device = os.environ.get('SAFE_BENCH_SHARE_DEVICE') == '1'
+    if share_device:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     numa_node = None if os.environ.get('SAFE_BENCH_NO_PIN') == '1' else be.pin_threads_to_device_numa(local_rank)
     torch.set_num_threads(1)      # no OpenMP spinning next to the host draw/swap threads (container CPU quotas throttle it)
@@ -338,151 +540,77 @@ def main():
             os.environ.setdefault('MASTER_PORT', '29533')
             os.environ.setdefault('RANK', '0')
             os.environ.setdefault('WORLD_SIZE', '1')
-        dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
-
-    # ---------------- inputs (untimed): network, membership, attributes resident in HBM ----
-    data = workloads.costanzo_surrogate(seed=0, n=args.nodes, m=args.attrs,
-                                        target_edges=int(28202 * args.nodes / 3971))
-    if rank > 0:                                   # weak scaling: every rank its own attribute shard
-        data['attributes'] = workloads.go_like_binary(np.random.default_rng(1000 + rank), args.nodes, args.attrs,
-                                                      int(182 * args.nodes / 3971))
-    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
-    sf = safepy_amd.SAFE(verbose=False, device=local_rank)
-    sf.graph = safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length'])
-    sf.define_neighborhoods(node_distance_metric=args.metric, neighborhood_radius=args.radius)
-    nbr = sf._nbr
-    counts = nbr.row_counts()
-    b_host = data['attributes']
-    n, m = b_host.shape
-    b_dev = torch.from_numpy(np.ascontiguousarray(b_host.T)).to('cuda')      # F-order [n,m] == C-order [m,n]
-    P = args.perms
-
-    out = {k: torch.empty((n, m), dtype=torch.float64, device='cuda') for k in sharding.RANDOMIZATION_OUTPUTS}
-    enriched = torch.empty((m,), dtype=torch.float64, device='cuda')
-    gathered = [None]
-    table = be.nes_table(P)
-    kernel_ms = []
-
-    def step(exchange=True):
-        # one compute_pvalues pass of this rank's block: statistics for the dispatch rule, whole-matrix row flags (N > 1:
-        # one small all-gather), the seeded legacy stream (host) + table kernels, the permutation-test kernels with the fused
-        # p-value / NES / binarisation epilogue and -- N > 1 -- the all-gather of every rank's result over RCCL / xGMI
-        attr = be.Attributes.from_device(ctx, b_dev.data_ptr(), np.float32, n, m, order='F')
-        try:
-            gathered[0] = sharding.randomization_step(ctx, nbr, attr, m * world, P, 0, out, enriched, 'sum', 'both', 0.05,
-                                                      table=table, exchange=exchange)
-            kernel_ms.append(ctx.last_kernel()[1])
-        finally:
-            attr.close()
-
-    def fence():
-        torch.cuda.synchronize()
-        if dist is not None:
-            dist.barrier()
-        torch.cuda.synchronize()
-
-    def timed(n_steps, fn):
-        fence()
-        t_begin = time.perf_counter()
-        per_step = []
-        for _ in range(n_steps):
-            ts = time.perf_counter()
-            fn()
-            per_step.append(1e3 * (time.perf_counter() - ts))     # (a step returns after its own stream synchronisation)
-        fence()
-        seconds = time.perf_counter() - t_begin
-        if dist is not None:                                       # the slowest rank's clock
-            t = torch.tensor([seconds], dtype=torch.float64, device='cuda')
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            seconds = float(t.item())
-        return seconds, per_step
-
-    for _ in range(args.warmup):
-        step()
-    kernel_ms.clear()
-    cpu0 = time.process_time()
-    elapsed, step_ms = timed(args.steps, step)
-    host_cpu_ms = 1e3 * (time.process_time() - cpu0) / args.steps     # all threads of this rank: draws, swaps, launches
-    kernel_ms_timed = list(kernel_ms)
-
-    # the same step with the exchange replaced by a D2H copy of the rank's own NES block (what a host that only
-    # wants the results on disk needs), and with no exchange at all -- diagnostics outside the timed region, N > 1 only
-    exchange_report = None
-    if dist is not None:
-        k_diag = max(2, min(args.steps, 5))
-        host_nes = torch.empty((n, m), dtype=torch.float64).pin_memory()
-
-        def step_d2h():
-            step(exchange=False)
-            host_nes.copy_(out['nes'], non_blocking=True)
-            torch.cuda.current_stream().synchronize()
-
-        t_d2h, _ = timed(k_diag, step_d2h)
-        t_none, _ = timed(k_diag, lambda: step(exchange=False))
-        exchange_report = {'all_gather_ms_per_step': 1e3 * elapsed / args.steps, 'd2h_only_ms_per_step': 1e3 * t_d2h / k_diag,
-                           'no_exchange_ms_per_step': 1e3 * t_none / k_diag, 'steps_timed': k_diag,
-                           'form': 'packed u32 counters (4 B per node x attribute), NES rebuilt on every rank'
-                                   if be.packed_counts_info(ctx)[2] >= 0 else 'f64 NES blocks',
-                           'bytes_received_per_rank': int(4 * be.packed_counts_info(ctx)[0] * m * (world - 1))
-                                                      if be.packed_counts_info(ctx)[2] >= 0 else int(8 * n * m * (world - 1)),
-                           'd2h_bytes_per_rank': int(8 * n * m)}
-    kernel_ms = kernel_ms_timed
-
-    if rank == 0:
-        ms_per_step = 1e3 * elapsed / args.steps
-        units = float(n) * m * P * world                      # node-attribute enrichments per step, all ranks
-        value = units / (elapsed / args.steps)
-        kname, _, launches = ctx.last_kernel()
-        k_ms = float(np.mean(kernel_ms))                      # average duration of ONE launch (HIP events)
-        launches = max(int(launches), 1)
-        span = int(np.ceil(P / launches))                     # permutations per launch
-        # Algorithmic HBM bytes of ONE launch of the dominant kernel:
-        # SURVEY 8(d) compulsory traffic = one read of the attribute block, the permutation rows it
-        # consumes, the membership, and one read-modify-write of its per-(node, attribute) counters.
-        n_wg = -(-m // 64)
-        n_pad = -(-n // 64) * 64
-        if kname in ('k_permtest_bits_pre', 'k_permtest_bits_blk'):
-            # attribute bit words + the span's pre-permuted member lists (2 B per membership entry and
-            # permutation) + the resident member list (observed pass) + counter read-modify-write
-            alg_bytes = 8 * (n + 1) * n_wg + 2 * int(nbr.nnz) * span + 2 * int(nbr.nnz) + 2 * 4 * n_pad * m
-        elif kname == 'k_permtest_bits':
-            alg_bytes = 8 * (n + 1) * n_wg + 2 * (n + 8) * span + 2 * int(nbr.nnz) + 2 * 4 * n_pad * m
+        if share_device:
+            dist.init_process_group(backend='gloo')
         else:
-            alg_bytes = n * m * 4 + P * (n + 1) * 4 + int(nbr.nnz) * 4 + 5 * n * m * 8
-        achieved = alg_bytes / (k_ms * 1e-3) / 1e9
-        traffic, traffic_stamp = pmc_traffic(kname, with_stamp=True)
+            dist.init_process_group(backend='nccl', device_id=torch.device('cuda', local_rank))
+    ctx.set_stream(torch.cuda.current_stream().cuda_stream)
+
+    # ---------------- the timed mode: inputs (untimed) resident in HBM, then W warm-up and exactly K timed steps ----
+    wl = Workload(args, args.workload, args.scaling, args.perms, rank, world, local_rank, ctx, torch, np)
+    res = run_mode(wl, args.steps, args.warmup, ctx, dist, torch, np, be, sharding, world, diag_exchange=True)
+
+    line = None
+    if rank == 0:
+        ms_per_step = 1e3 * res['elapsed'] / args.steps
+        value = wl.units_per_step / (res['elapsed'] / args.steps)
+        kname = res['kernel'][0]
+        roof = roofline_of(wl, res, ctx, np, be)
         line = {
             'metric': 'node-attribute enrichments/sec (nodes x attrs x perms), compute_pvalues permutation test',
             'value': value, 'unit': 'enrichments/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
-            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
-            'dtype': 'u1 (bit-sliced integer counts; f64 outputs)' if kname != 'k_permtest_gather' else 'f64',
-            'data': 'synthetic',
-            'config': {'workload': 'configs[1]: Costanzo-2016-shaped surrogate, %d nodes x %d GO-BP-like binary attributes '
-                                   'x %d permutations, metric %s r=%g, seed 0' % (n, m, P, args.metric, args.radius),
-                       'nodes': n, 'attributes_per_gpu': m, 'permutations': P, 'membership_nnz': int(nbr.nnz),
-                       'neighbors_per_node_mean': float(counts.mean()), 'neighbors_per_node_std': float(counts.std()),
-                       'parallelism': 'attribute shards x%d' % world},
-            'roofline': {'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
-                         'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_stamp, 'kernel_ms': k_ms,
-                         'launches_per_step': launches, 'permutations_per_launch': span,
-                         'algorithmic_bytes': alg_bytes,
-                         'binding_resource': 'VALU issue + LDS gather (not HBM, not MFMA): see DESIGN.md section 4 and '
-                                             'profiles/ for the PMC evidence',
-                         'enrichments_per_s_kernel_only': float(n) * m * span / (k_ms * 1e-3),
-                         'binding_resource_utilisation': binding_resources(ctx.num_cu, kname)},
-            'kernel_share_of_step': k_ms * launches / ms_per_step,
-            'host_cpu_ms_per_step': host_cpu_ms, 'host_cores_usable': effective_cores(),
-            'swap_threads': int(os.environ.get('SAFE_HIP_SWAP_THREADS', '4')), 'pinned_to_numa_node': numa_node,
-            'step_ms_min_median_max': [float(np.min(step_ms)), float(np.median(step_ms)), float(np.max(step_ms))],
-            'step_ms_slowest3': [float(x) for x in sorted(step_ms)[-3:]],
+            'ms_per_step': ms_per_step, 'higher_is_better': True, 'scaling': wl.scaling, 'vs_baseline': None,
+            'dtype': ('i8 (exact fixed-point slices on the matrix cores; f64 outputs)' if kname.startswith('k_permtest_mfma') else
+                      'u1 (bit-sliced integer counts; f64 outputs)' if kname != 'k_permtest_gather' else 'f64'),
+            'data': 'synthetic' if not share_device else 'synthetic (DIAGNOSTIC: all ranks share device 0, value is not a measurement)',
+            'config': {'workload': wl.name, 'nodes': wl.n, 'attributes_per_gpu': wl.m, 'attributes_total': wl.m_total,
+                       'permutations': wl.P, 'membership_nnz': int(wl.nbr.nnz),
+                       'neighbors_per_node_mean': float(wl.counts.mean()), 'neighbors_per_node_std': float(wl.counts.std()),
+                       'parallelism': 'attribute shards x%d (%s scaling)' % (world, wl.scaling)},
+            'roofline': roof,
+            'kernel_share_of_step': roof['kernel_ms'] * roof['launches_per_step'] / ms_per_step,
+            'per_rank': res['per_rank'],
+            'host_cpu_ms_per_step': res['host_cpu_ms'], 'host_cores_usable': effective_cores(), 'host': host_cfg,
+            'pinned_to_numa_node': numa_node,
+            'step_ms_min_median_max': [float(np.min(res['step_ms'])), float(np.median(res['step_ms'])), float(np.max(res['step_ms']))],
+            'step_ms_slowest3': [float(x) for x in sorted(res['step_ms'])[-3:]],
         }
-        if exchange_report is not None:
-            line['exchange'] = exchange_report
-        if args.cpu_perms > 0 and world == 1:                 # the CPU leg runs on rank 0 at N = 1 only
-            a_dense = sf.neighborhoods
+        if 'exchange_report' in res:
+            line['exchange'] = res['exchange_report']
+    a_dense = wl.sf.neighborhoods if (rank == 0 and args.cpu_perms > 0 and world == 1 and wl.kind == 'cfg1') else None
+    b_host = wl.b_host
+    del res
+
+    # ---------------- N > 1: the other configurations BASELINE.json names for several GPUs, outside the timed region -----------
+    if world > 1 and args.multi_extras and args.workload == 'cfg1' and args.scaling == 'weak':
+        extras = {}
+        wl2 = Workload(args, 'cfg1', 'strong', 10000, rank, world, local_rank, ctx, torch, np)
+        r2 = run_mode(wl2, 3, 1, ctx, dist, torch, np, be, sharding, world)
+        if rank == 0:
+            extras['configs2_strong_scaling'] = {
+                'workload': wl2.name + ', columns np.array_split over %d ranks' % world, 'scaling': 'strong', 'steps': 3,
+                'ms_per_step': 1e3 * r2['elapsed'] / 3, 'value': wl2.units_per_step / (r2['elapsed'] / 3), 'unit': 'enrichments/s',
+                'attributes_per_gpu': wl2.m, 'per_rank': r2['per_rank'], 'exchange': r2['exchange_form'],
+                'amdahl_note': 'the permutation stream is sequential (one draw thread per node, ~1.7-2.2 ms per 1000 permutations): '
+                               'a 10 000-permutation step cannot go below that thread\'s time, whatever the rank count'}
+        del wl2, r2
+        wl4 = Workload(args, 'cfg4', 'weak', 1000, rank, world, local_rank, ctx, torch, np)
+        r4 = run_mode(wl4, 1, 1, ctx, dist, torch, np, be, sharding, world)
+        if rank == 0:
+            extras['configs4_rank_share'] = {
+                'workload': wl4.name, 'scaling': 'weak', 'steps': 1, 'ms_per_step': 1e3 * r4['elapsed'],
+                'value': wl4.units_per_step / r4['elapsed'], 'unit': 'enrichments/s', 'attributes_per_gpu': wl4.m,
+                'per_rank': r4['per_rank'], 'exchange': r4['exchange_form'], 'roofline': roofline_of(wl4, r4, ctx, np, be)}
+        del wl4, r4
+        if rank == 0:
+            line['multi_gpu_configs'] = extras
+
+    if rank == 0:
+        if a_dense is not None:                               # the CPU leg runs on rank 0 at N = 1 only
             line['cpu_baseline'] = cpu_baseline(a_dense, b_host, args.cpu_perms)
-            line['speedup_vs_cpu_baseline'] = value / line['cpu_baseline']['value']
-        if args.extras and world == 1:
+            line['cpu_baseline']['gpu_over_cpu'] = line['value'] / line['cpu_baseline']['value']      # mostly the algorithm (sparse bit slices vs dense dgemm), not kernel quality
+        if args.extras and world == 1 and args.workload == 'cfg1':
+            del wl
             line['hbm_bound_kernels'] = hbm_kernels(ctx, torch, np, be)
             line['mfma_bound_kernels'] = mfma_kernel(ctx, np, be)
     # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe): tear the group down and flush every

@@ -301,7 +301,9 @@ int safe_jaccard_condensed(safe_ctx *ctx, int64_t m_top, int64_t n, const double
 /* Counts of a whole call -> outputs (safepy/safe.py:528-554 and 468-472): counts_neg / counts_pos are #(S_p <= S_obs) /
  * #(S_p >= S_obs) as f64 [n, m] on the device (e.g. safe_permtest_counts results summed over the ranks of a
  * permutation-axis split), ns_dev the observed scores (NaN = no test; may be NULL).  Writes p-values, NES
- * (nes_table_host as in safe_randomization), nes_binary [n, m] and num_enriched [m]. */
+ * (nes_table_host as in safe_randomization), nes_binary [n, m] and num_enriched [m].  Precondition: every count is a
+ * whole number in [0, num_permutations] wherever the observed score is not NaN -- SAFE_E_VALUE otherwise (e.g. the
+ * sum of ranks that each ran the full num_permutations). */
 int safe_outputs_from_counts(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutations, int sign_mode,
                              double enrichment_threshold, const double *nes_table_host, const double *counts_neg_dev,
                              const double *counts_pos_dev, const double *ns_dev, double *pvalues_neg_dev, double *pvalues_pos_dev,

@@ -6,6 +6,7 @@ library reports an error (no HIP device, bad arguments, ...).
 """
 import collections
 import ctypes as C
+import os
 
 import numpy as np
 
@@ -510,6 +511,41 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def effective_cores():
+    """CPUs this process may actually use: the scheduler affinity, capped by the container's CFS quota (cgroup v2 cpu.max /
+    v1 cfs_quota_us) when there is one."""
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, 'sched_getaffinity') else (os.cpu_count() or 1)
+    try:
+        quota, period = open('/sys/fs/cgroup/cpu.max').read().split()[:2]
+        if quota != 'max':
+            cores = min(cores, max(1, int(int(quota) / int(period))))
+    except (OSError, ValueError):
+        try:
+            quota = int(open('/sys/fs/cgroup/cpu/cpu.cfs_quota_us').read())
+            period = int(open('/sys/fs/cgroup/cpu/cpu.cfs_period_us').read())
+            if quota > 0:
+                cores = min(cores, max(1, quota // period))
+        except (OSError, ValueError):
+            pass
+    return cores
+
+
+def configure_host_for_ranks(local_world):
+    """Host-side settings of one rank among `local_world` on this node, BEFORE its Context exists: the swap pool stays within
+    the rank's share of the CPUs (4 workers keep pace with the draw thread; only the node's producer uses them when the
+    stream is shared), and when a rank has fewer than three cores to itself its host waits sleep instead of spinning
+    (a spinning launcher + draw thread + workers per rank on a 16-CPU quota gets the whole job throttled).
+    Environment overrides: SAFE_HIP_SWAP_THREADS, SAFE_HIP_BLOCKING_SYNC.  Returns what was chosen."""
+    local_world = max(1, int(local_world))
+    share = effective_cores() / local_world
+    if 'SAFE_HIP_SWAP_THREADS' not in os.environ:
+        os.environ['SAFE_HIP_SWAP_THREADS'] = str(max(1, min(4, int(share) - 1)))
+    blocking = os.environ.get('SAFE_HIP_BLOCKING_SYNC')
+    blocking = (share < 3) if blocking is None else (blocking not in ('0', ''))
+    set_blocking_sync(blocking)
+    return {'cores_per_rank': share, 'swap_threads': int(os.environ['SAFE_HIP_SWAP_THREADS']), 'blocking_sync': bool(blocking)}
 
 
 def set_blocking_sync(on):

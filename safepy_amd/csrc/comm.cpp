@@ -5,6 +5,8 @@
 // already holds a copy (PyTorch-ROCm ships one) shares that copy.
 #include <dlfcn.h>
 
+#include <mutex>
+
 #include "common.h"
 
 namespace {
@@ -24,7 +26,9 @@ struct Rccl {
 int load_rccl(Rccl **out) {
     static Rccl r;
     static int state = 0;                                    // 0 = not tried, 1 = loaded, -1 = unavailable
-    if (state == 0) {
+    static char why[256] = "missing symbols";                // the loader's reason, kept from the one attempt
+    static std::once_flag once;
+    std::call_once(once, [] {
         const char *names[] = {"librccl.so", "librccl.so.1", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"};
         for (const char *nm : names)                         // a copy the process already holds first
             if ((r.lib = dlopen(nm, RTLD_NOW | RTLD_NOLOAD))) break;
@@ -39,10 +43,14 @@ int load_rccl(Rccl **out) {
             r.comm_destroy = reinterpret_cast<decltype(r.comm_destroy)>(dlsym(r.lib, "ncclCommDestroy"));
             r.get_error_string = reinterpret_cast<decltype(r.get_error_string)>(dlsym(r.lib, "ncclGetErrorString"));
         }
+        if (!r.lib) {
+            const char *msg = dlerror();                     // (dlerror() clears the message: read it once)
+            if (msg) snprintf(why, sizeof(why), "%s", msg);
+        }
         state = (r.lib && r.get_unique_id && r.comm_init_rank && r.all_gather && r.comm_destroy) ? 1 : -1;
-    }
+    });
     if (state < 0) {
-        safe_set_error("RCCL is not available: librccl.so could not be loaded (%s)", dlerror() ? dlerror() : "missing symbols");
+        safe_set_error("RCCL is not available: librccl.so could not be loaded (%s)", why);
         return SAFE_E_UNSUPPORTED;
     }
     *out = &r;

@@ -143,6 +143,11 @@ int safe_ctx_create(int device, safe_ctx **out) {
     }
     SAFE_REQUIRE(device >= 0 && device < count, "safe_ctx_create: device %d out of range [0,%d)", device, count);
     SAFE_HIP_CHECK(hipSetDevice(device));
+    if (blocking_sync_on()) {
+        // every host wait of the runtime on this device (synchronous copies, torch's own synchronize) sleeps too; refused by
+        // some runtimes once the device is active: the library's own waits (safe_stream_sync, blocking events) do not depend on it
+        if (hipSetDeviceFlags(hipDeviceScheduleBlockingSync) != hipSuccess) (void)hipGetLastError();
+    }
     safe_ctx *ctx = new safe_ctx();
     ctx->device = device;
     hipDeviceProp_t prop;

@@ -2476,8 +2476,15 @@ __global__ __launch_bounds__(256) void k_counts_to_outputs(const double *__restr
     const int64_t idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (idx >= total) return;
     const double qnan = __longlong_as_double(0x7FF8000000000000ll);
-    const bool obs_nan = ns && ns[idx] != ns[idx];
-    const unsigned int kn = static_cast<unsigned int>(counts_neg[idx]), kp = static_cast<unsigned int>(counts_pos[idx]);
+    bool obs_nan = ns && ns[idx] != ns[idx];
+    // counts are whole numbers in [0, num_permutations] (the NES table has P + 1 entries): anything else -- sums of ranks
+    // that each ran the full P, negative or NaN counts -- is reported (flag behind the enriched counters), never looked up
+    const double cn = counts_neg[idx], cp = counts_pos[idx], Pd = static_cast<double>(n_perm);
+    if (!obs_nan && !(cn >= 0.0 && cn <= Pd && cp >= 0.0 && cp <= Pd)) {
+        atomicOr(&out.enriched[m], 1u);
+        obs_nan = true;
+    }
+    const unsigned int kn = obs_nan ? 0u : static_cast<unsigned int>(cn), kp = obs_nan ? 0u : static_cast<unsigned int>(cp);
     const double en = obs_nan ? qnan : out.nes_table[kn], ep = obs_nan ? qnan : out.nes_table[kp];
     double nes = ep - en;
     if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
@@ -2805,7 +2812,16 @@ int safe_outputs_from_counts(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_pe
                        n * m, m, P, out);
     hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(m, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, m);
     SAFE_HIP_CHECK(hipGetLastError());
+    unsigned int *bad = nullptr;
+    SAFE_TRY(ctx_pinned(ctx, sizeof(unsigned int), reinterpret_cast<void **>(&bad)));
+    SAFE_HIP_CHECK(hipMemcpyAsync(bad, d_enr + m, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // tab is a host vector
+    if (*bad) {
+        safe_set_error("safe_outputs_from_counts: a count lies outside [0, num_permutations = %lld] (or is NaN where the observed "
+                       "score is not): the counts of a permutation-axis split must add up to ONE run of num_permutations",
+                       (long long)P);
+        return SAFE_E_VALUE;
+    }
     return SAFE_OK;
 }
 

@@ -22,6 +22,8 @@
 #include <mutex>
 #include <thread>
 
+#include <pthread.h>
+
 #include <chrono>
 
 #include "common.h"
@@ -155,6 +157,7 @@ private:
         for (std::thread &t : threads_) t.join();
     }
     void loop(int w, int W) {
+        pthread_setname_np(pthread_self(), "safe-swap");
         uint64_t seen = 0;
         for (;;) {
             std::function<void(int, int)> fn;
@@ -286,6 +289,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
 }
 
 static void drawer_main(safe_perms *p) {
+    pthread_setname_np(pthread_self(), "safe-draw");
     const int64_t k = p->k, width = std::max<int64_t>(k, 1);
     const int64_t n_chunks = stage_count(p);
     for (int64_t c = 0; c < n_chunks; ++c) {

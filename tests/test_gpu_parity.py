@@ -807,6 +807,113 @@ def test_nes_from_gathered_packed_counts(amd, ctx, kind):
     nbr.close()
 
 
+@pytest.mark.parametrize('kind', ['binary', 'quantitative'])
+def test_every_output_from_gathered_packed_counts(amd, ctx, kind):
+    """safe_outputs_from_packed_counts: pvalues_neg, pvalues_pos, nes and nes_binary [N, M] from the concatenated integer
+    counters of two column blocks == the unsharded call's matrices (safe.py:532-554, 468-472), any subset of them."""
+    import torch
+    from safepy_amd import backend as be, sharding
+    rng = np.random.default_rng(5)
+    n, m, nperm, seed = 650, 71, 40, 4
+    xy = rng.uniform(size=(n, 2))
+    b = (rng.uniform(size=(n, m)) < 0.06).astype(np.float64) if kind == 'binary' else rng.normal(size=(n, m))
+    b[rng.choice(n, 25, replace=False)] = np.nan
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    flags = (~np.isnan(b)).any(axis=1).astype(np.uint8)
+    shards = sharding.column_shards(m, 2)                 # 36 + 35 columns: the compacted (ragged) form
+    for sign in ('both', 'lowest'):
+        want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=seed,
+                                   attribute_sign=sign, enrichment_threshold=0.1)
+        slabs = []
+        for c0, c1 in shards:
+            attr = be.Attributes.from_host(ctx, np.ascontiguousarray(b[:, c0:c1]))
+            attr.set_row_flags(flags)
+            perms = be.Permutations(ctx, n, flags, nperm, seed)
+            outs = [ctx.alloc_f64(n, c1 - c0) for _ in range(5)] + [ctx.alloc_f64(c1 - c0)]
+            be.randomization(ctx, nbr, attr, perms, 'sum', sign, 0.1, [o.ptr for o in outs])
+            n_pad, m_loc, layout = be.packed_counts_info(ctx)
+            slab = torch.zeros(m_loc * n_pad, dtype=torch.int32, device='cuda')
+            torch.cuda.synchronize()
+            be.export_packed_counts(ctx, slab.data_ptr(), m_loc * n_pad)
+            ctx.sync()
+            slabs.append(slab)
+            perms.close()
+            attr.close()
+        everyone = torch.cat(slabs)
+        names = ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')
+        for subset in (names, ('nes_binary',), ('pvalues_pos', 'nes')):
+            full = {k: torch.full((n, m), -7.0, dtype=torch.float64, device='cuda') for k in subset}
+            torch.cuda.synchronize()
+            be.outputs_from_packed_counts(ctx, nbr, everyone.data_ptr(), layout, n_pad, m, nperm, sign, 0.1,
+                                          [full[k].data_ptr() if k in full else None for k in names])
+            for k in subset:
+                np.testing.assert_array_equal(full[k].cpu().numpy(), want[k], err_msg='%s %s %s' % (kind, sign, k))
+    with pytest.raises(amd.SafeHipError):
+        be.outputs_from_packed_counts(ctx, nbr, everyone.data_ptr(), layout, n_pad, m, nperm, 'both', 0.1, [None] * 4)
+    nbr.close()
+
+
+def test_counts_outside_the_permutation_count_are_refused(amd, ctx):
+    """safe_outputs_from_counts: counts are whole numbers in [0, num_permutations]; sums of ranks that each ran the full
+    count, negative or NaN counts are an error (SAFE_E_VALUE), not an out-of-bounds table read."""
+    from safepy_amd import backend as be
+    n, m, nperm = 40, 9, 20
+    rng = np.random.default_rng(0)
+    ns = rng.normal(size=(n, m))
+    ns[3, 4] = np.nan
+    neg = rng.integers(0, nperm + 1, size=(n, m)).astype(np.float64)
+    pos = nperm - neg
+    neg[3, 4] = np.nan                                     # no test where the observed score is NaN: its counts do not matter
+    d = [ctx.alloc_f64(n, m) for _ in range(7)] + [ctx.alloc_f64(m)]
+
+    def run(cn, cp):
+        d[0].upload(cn)
+        d[1].upload(cp)
+        d[2].upload(ns)
+        be.outputs_from_counts(ctx, n, m, nperm, 'both', 0.05, d[0].ptr, d[1].ptr, d[2].ptr, [x.ptr for x in d[3:]])
+        ctx.sync()
+        return d[3].download((n, m)), d[4].download((n, m))
+
+    p_neg, p_pos = run(neg, pos)
+    ok = ~np.isnan(ns)
+    assert np.array_equal(p_neg[ok], neg[ok] / nperm) and np.array_equal(p_pos[ok], pos[ok] / nperm) and np.isnan(p_neg[3, 4])
+    for bad_value in (nperm + 1.0, 2.0 * nperm, -1.0, np.nan):
+        bad = neg.copy()
+        bad[7, 2] = bad_value
+        with pytest.raises(amd.SafeHipError) as err:
+            run(bad, pos)
+        assert err.value.code == amd._lib.E_VALUE and 'outside' in str(err.value)
+    run(neg, pos)                                          # the context is still usable
+
+
+def test_more_than_65535_caller_supplied_permutations(amd, ctx):
+    """A from-table / sliced handle with more rows than one grid dimension holds (the reference places no cap on
+    num_permutations): 16-bit table copies are made in row blocks."""
+    from safepy_amd import backend as be
+    n, count = 12, 70000
+    rng = np.random.default_rng(1)
+    tables = np.argsort(rng.uniform(size=(count, n)), axis=1).astype(np.int32)
+    perms = be.Permutations.from_table(ctx, tables)
+    assert np.array_equal(perms.read(65530, 65545), tables[65530:65545])
+    part = perms.slice(100, 69000)
+    assert part.count == 68900 and np.array_equal(part.read(68000, 68900), tables[68100:69000])
+    # the permutation test reads the 16-bit copy: counts over the LAST rows of the table against NumPy
+    a = (rng.uniform(size=(n, n)) < 0.4).astype(np.int64)
+    np.fill_diagonal(a, 1)
+    b = (rng.uniform(size=(n, 3)) < 0.5).astype(np.float64)
+    nbr = amd.Neighborhoods.from_dense(ctx, a)
+    attr = be.Attributes.from_host(ctx, b)
+    tail = perms.slice(69000, 70000)
+    neg, pos = ctx.alloc_f64(n, 3), ctx.alloc_f64(n, 3)
+    be.permtest_counts(ctx, nbr, attr, tail, 'sum', None, neg.ptr, pos.ptr)
+    obs = a @ b
+    want_n = sum(((a @ b[row]) <= obs) for row in tables[69000:70000]).astype(np.float64)
+    assert np.array_equal(neg.download((n, 3)), want_n)
+    for h in (tail, part, perms, attr, nbr):
+        h.close()
+
+
 def test_gather_nes_over_rccl_single_rank(amd, ctx):
     """The collective path itself (RCCL process group of one rank): packed counters are
     exported, all-gathered and turned into the NES matrix."""

@@ -1,6 +1,9 @@
 #!/bin/bash
 # PMC passes for the headline bench step (bit-sliced permutation kernel); run on the GPU box through gpurun.
 # usage: pmc_bits.sh <out tag> [env assignments for the bench, e.g. SAFE_HIP_BITS_KERNEL=pre]
+# the benched configuration (bench.py / run_batch.py set it for themselves; under rocprofv3 the runtime is initialised
+# before Python runs, so it must come from the shell)
+export GPU_MAX_HW_QUEUES=8
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-pb}; mkdir -p $O; shift; for kv in "$@"; do export "$kv"; done
 cd /tmp; export TMPDIR=/tmp
 CMD="python3 $R/bench.py --steps 1 --warmup 1 --cpu-perms 0 --extras 0"

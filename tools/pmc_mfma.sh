@@ -1,6 +1,9 @@
 #!/bin/bash
 # PMC passes for k_permtest_mfma at one rank's config-5 shape (run on the GPU box through gpurun)
 # usage: pmc_mfma.sh <out tag> [sum|z-score]
+# the benched configuration (bench.py / run_batch.py set it for themselves; under rocprofv3 the runtime is initialised
+# before Python runs, so it must come from the shell)
+export GPU_MAX_HW_QUEUES=8
 R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/${1:-d}; mkdir -p $O; cd /tmp; export TMPDIR=/tmp
 CMD="python3 $R/tools/bench_big.py quant 1024 128 ${2:-sum}"
 timeout 300 rocprofv3 --pmc SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD --kernel-trace -d $O/pmc1 -o r -- $CMD > $O/pmc1.log 2>&1

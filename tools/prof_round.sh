@@ -5,6 +5,9 @@
 # Writes text summaries under gpurun_out/<tag>/; tools/update_profiles.py <tag> turns them into profiles/rNN_* (run it
 # in the build container right after, at the commit that was profiled).
 # usage: prof_round.sh [tag]
+# the benched configuration (bench.py / run_batch.py set it for themselves; under rocprofv3 the runtime is initialised
+# before Python runs, so it must come from the shell)
+export GPU_MAX_HW_QUEUES=8
 TAG=${1:-prof}
 ROOT=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$ROOT/gpurun_out/$TAG
