@@ -984,7 +984,9 @@ __device__ __forceinline__ void vripple_lv(uint32_t (&s)[LV], uint32_t t8) {
 // The id words are fetched TWO blocks ahead into two register quads that swap roles (no copies): a block's adds take
 // 100-200 cycles, a load from L2 / MALL several hundred -- one block of look-ahead left every wave waiting at vmcnt(0)
 // at the top of each block (the lists have a tail of two blocks, so the look-ahead never leaves the buffer).
-template <int LV, int SHIFT, bool GATHER>
+// GATHER: 1 = the real thing; 0 = no LDS reads (diagnostic); 2 = LDS reads at conflict-free addresses (diagnostic: bits 3..7 of
+// every address replaced by the lane's number mod 32 -- the same number of gathers, every bank pair used once per lane group)
+template <int LV, int SHIFT, int GATHER>
 __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ refill, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     uint32_t a[8];
     a[0] = (c.x & 0xFFFFu) << SHIFT;
@@ -996,6 +998,11 @@ __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ ref
     a[6] = (c.w & 0xFFFFu) << SHIFT;
     a[7] = (c.w >> 16) << SHIFT;
     c = *refill;                                                                          // the block after next
+    if (GATHER == 2) {
+        const uint32_t lane_bits = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 31u) << 3;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = (a[u] & 0xFF00u) | lane_bits;
+    }
     uint32_t x0[8], x1[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) {
@@ -1016,7 +1023,7 @@ __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ ref
     }
 }
 
-template <int LV, int SHIFT, bool GATHER>
+template <int LV, int SHIFT, int GATHER>
 __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     // `ids` is the slice's first block, the same for the whole wave (scalar registers); the lane is the offset
 #pragma unroll
@@ -1033,17 +1040,22 @@ __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane,
 
 // one wave, one task: observed sums, then every permutation of the task's range; counters come back in g / l
 // (levels above CL stay zero), the observed sums in oo (levels above LV zero)
-template <int LV, int CL, int DBG>
-__device__ __forceinline__ void blk_task(const uint32_t *__restrict__ obs, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
-                                         int lane, int nblk, int np, uint32_t (&g0)[CL], uint32_t (&g1)[CL], uint32_t (&l0)[CL],
-                                         uint32_t (&l1)[CL]) {
-    constexpr bool GATHER = !(DBG & 1);
+// CLT <= CL: levels the task really counts with (a task of at most 2^CLT - 1 permutations); OBSMEM: the observed sums are
+// re-read from memory (L1 / L2 resident: 2 * LV coalesced 256-byte loads per permutation) in the compare step instead of
+// being held in 2 * LV registers for the whole task -- the wide classes trade them for a fifth wave per SIMD.
+template <int LV, int CLT, int DBG, bool OBSMEM>
+__device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
+                                              int lane, int nblk, int np, uint32_t (&g0)[CLT], uint32_t (&g1)[CLT], uint32_t (&l0)[CLT],
+                                              uint32_t (&l1)[CLT]) {
+    constexpr int GATHER = (DBG & 1) ? 0 : (DBG & 8) ? 2 : 1;
     // observed sums of this (word group, slice): computed once per call by k_bits_observed, vertical like the permuted sums
-    uint32_t o0[LV], o1[LV];
+    uint32_t o0[OBSMEM ? 1 : LV], o1[OBSMEM ? 1 : LV];
+    if (!OBSMEM) {
 #pragma unroll
-    for (int l = 0; l < LV; ++l) {
-        o0[l] = obs[l * 64 + lane];
-        o1[l] = obs[(BT_LV + l) * 64 + lane];
+        for (int l = 0; l < LV; ++l) {
+            o0[OBSMEM ? 0 : l] = obs[l * 64 + lane];
+            o1[OBSMEM ? 0 : l] = obs[(BT_LV + l) * 64 + lane];
+        }
     }
     uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
     for (int p = 0; p < np; ++p, perm_ids += perm_stride) {
@@ -1057,27 +1069,50 @@ __device__ __forceinline__ void blk_task(const uint32_t *__restrict__ obs, const
         uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
 #pragma unroll
         for (int l = 0; l < LV; ++l) {
+            const uint32_t a0 = OBSMEM ? obs[l * 64 + lane] : o0[OBSMEM ? 0 : l];
+            const uint32_t a1 = OBSMEM ? obs[(BT_LV + l) * 64 + lane] : o1[OBSMEM ? 0 : l];
             // f(s, o, b) = (s != o) ? o : b  -> 0x8E ;  (s != o) ? s : b -> 0xB2
-            lt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], lt0, 0x8E);
-            gt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], gt0, 0xB2);
-            lt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], lt1, 0x8E);
-            gt1 = __builtin_amdgcn_bitop3_b32(s1[l], o1[l], gt1, 0xB2);
+            lt0 = __builtin_amdgcn_bitop3_b32(s0[l], a0, lt0, 0x8E);
+            gt0 = __builtin_amdgcn_bitop3_b32(s0[l], a0, gt0, 0xB2);
+            lt1 = __builtin_amdgcn_bitop3_b32(s1[l], a1, lt1, 0x8E);
+            gt1 = __builtin_amdgcn_bitop3_b32(s1[l], a1, gt1, 0xB2);
         }
-        vcount<CL>(g0, gp0, gt0);
-        vcount<CL>(g1, gp1, gt1);
-        vcount<CL>(l0, lp0, lt0);
-        vcount<CL>(l1, lp1, lt1);
+        vcount<CLT>(g0, gp0, gt0);
+        vcount<CLT>(g1, gp1, gt1);
+        vcount<CLT>(l0, lp0, lt0);
+        vcount<CLT>(l1, lp1, lt1);
         if ((p & 7) == 7) {
-            vflush<CL>(g0, gp0);
-            vflush<CL>(g1, gp1);
-            vflush<CL>(l0, lp0);
-            vflush<CL>(l1, lp1);
+            vflush<CLT>(g0, gp0);
+            vflush<CLT>(g1, gp1);
+            vflush<CLT>(l0, lp0);
+            vflush<CLT>(l1, lp1);
         }
     }
-    vflush<CL>(g0, gp0);
-    vflush<CL>(g1, gp1);
-    vflush<CL>(l0, lp0);
-    vflush<CL>(l1, lp1);
+    vflush<CLT>(g0, gp0);
+    vflush<CLT>(g1, gp1);
+    vflush<CLT>(l0, lp0);
+    vflush<CLT>(l1, lp1);
+}
+
+template <int LV, int CL, int DBG, int CLT = CL, bool OBSMEM = false>
+__device__ __forceinline__ void blk_task(const uint32_t *__restrict__ obs, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
+                                         int lane, int nblk, int np, uint32_t (&G0)[CL], uint32_t (&G1)[CL], uint32_t (&L0)[CL],
+                                         uint32_t (&L1)[CL]) {
+    if constexpr (CLT == CL) {
+        blk_task_core<LV, CL, DBG, OBSMEM>(obs, perm_ids, perm_stride, lane, nblk, np, G0, G1, L0, L1);      // (zeroed by the caller)
+    } else {
+        uint32_t g0[CLT], g1[CLT], l0[CLT], l1[CLT];
+#pragma unroll
+        for (int l = 0; l < CLT; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
+        blk_task_core<LV, CLT, DBG, OBSMEM>(obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+#pragma unroll
+        for (int l = 0; l < CLT; ++l) {
+            G0[l] = g0[l];
+            G1[l] = g1[l];
+            L0[l] = l0[l];
+            L1[l] = l1[l];
+        }
+    }
 }
 
 // Observed neighborhood sums of every (word group, slice), once per call (safe.py:496-499): vertical counters
@@ -1087,7 +1122,7 @@ template <int LV>
 __device__ __forceinline__ void observed_wave(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t *__restrict__ obs,
                                               uint32_t (&oo0)[BT_LV], uint32_t (&oo1)[BT_LV]) {
     uint32_t o0[LV], o1[LV];
-    blk_sum<LV, 2, true>(ids, lane, nblk, o0, o1);
+    blk_sum<LV, 2, 1>(ids, lane, nblk, o0, o1);
 #pragma unroll
     for (int l = 0; l < BT_LV; ++l) {
         oo0[l] = l < LV ? o0[l < LV ? l : 0] : 0u;
@@ -1162,8 +1197,11 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
     }
 }
 
-template <int CL, int DBG>
-__global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
+// WPS = waves per SIMD the kernel is built for: 4 (128 registers; every class keeps its observed sums in registers and counts
+// with CL levels) or 5 (96 registers: the classes of more than 56 members count with five levels -- their tasks hold at most
+// 31 permutations -- and re-read the observed sums; five workgroups per CU when T fits five times).
+template <int CL, int DBG, int WPS = 4>
+__global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
     const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
@@ -1205,13 +1243,16 @@ __global__ __launch_bounds__(256, 4) void k_permtest_bits_blk(
         uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
 #pragma unroll
         for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
+        constexpr int CLW = WPS > 4 ? 5 : CL;                             // counter levels of the wide classes
+        constexpr int CLN = WPS > 4 ? 6 : CL;                             // ... and of the narrow ones (tasks of at most 63 permutations)
+        constexpr bool OM = WPS > 4;                                      // the wide classes' observed sums come from memory
         // a neighborhood of wdt members cannot sum past wdt: levels by slice width (wave-uniform branch)
         if (np <= 0) {
-        } else if (wdt <= 8) blk_task<4, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-        else if (wdt <= 56) blk_task<6, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-        else if (wdt <= 248) blk_task<8, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-        else if (wdt <= 504) blk_task<9, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
-        else blk_task<BT_LV, CL, DBG>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        } else if (wdt <= 8) blk_task<4, CL, DBG, CLN>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else if (wdt <= 56) blk_task<6, CL, DBG, CLN>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else if (wdt <= 248) blk_task<8, CL, DBG, CLW, OM>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else if (wdt <= 504) blk_task<9, CL, DBG, CLW, OM>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        else blk_task<BT_LV, CL, DBG, CLW, OM>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
 
         const int64_t spos = s * 64 + lane;
         if (!(DBG & 2)) {
@@ -2004,6 +2045,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int64_t blocks_per_perm = 0;
     for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / 4] = std::max<int64_t>(sg_blocks[s / 4], nbr->h_slice_width[s] / 8);
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
+    // five waves per SIMD (k_permtest_bits_blk<.., 5>) when T fits five times into a CU's LDS; its wide classes count with five
+    // levels, so their tasks hold at most 31 permutations
+    const size_t lds_T = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
+    bool occ5 = 5 * lds_T <= 160 * 1024;
+    if (const char *e = getenv("SAFE_HIP_BITS_OCC")) occ5 = occ5 && atoi(e) >= 5;
+    else occ5 = false;                                   // (experimental: opt-in)
     int tasks_per_slot = 2;                              // queue depth per workgroup slot: balance against the per-task costs (T reload, counter flush);
                                                          // 2 measured best of 1..6 once the host stream stopped being the bottleneck (tools/step_sweep2.sh)
     if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
@@ -2017,7 +2064,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         std::vector<TaskCost> tc;
         for (int64_t g = 0; g < n_sg; ++g) {
             const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
-            int64_t ppt = std::min<int64_t>(std::min<int64_t>(span_c, 255), std::max<int64_t>(16, target / bl));   // <= 255: eight counter levels
+            const int64_t ppt_cap = !occ5 ? 255 : (bl * 8 > 56 ? 31 : 63);      // counter levels of the task's class: 8, or 5 / 6
+            int64_t ppt = std::min<int64_t>(std::min<int64_t>(span_c, ppt_cap), std::max<int64_t>(16, target / bl));
             const int64_t chunks = ceil_div(span_c, ppt);
             ppt = ceil_div(span_c, chunks);
             for (int64_t c = 0; c < chunks; ++c) {
@@ -2081,11 +2129,13 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 7;
-    const void *blk_fn = dbg == 0   ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 15;
+    const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
+                         : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
                          : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
                          : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>)
                          : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
+                         : dbg == 8 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {
@@ -2150,7 +2200,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                 (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c, (void *)&mloc, (void *)&d_gl,
                                 (void *)&n_pad};
                 const int64_t blocks_blk = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
-                                                                          std::max<size_t>(1, std::min<size_t>(4, (160 * 1024) / lds_pre)));   // 4: the register file holds 16 waves per CU
+                                                                          std::max<size_t>(1, std::min<size_t>(occ5 ? 5 : 4, (160 * 1024) / lds_pre)));   // 4 (5): the register file holds 16 (20) waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
             } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,

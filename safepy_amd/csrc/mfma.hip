@@ -21,6 +21,7 @@
 //     (row group, 32-column tile, permutation span) task; tasks are queued per XCD by column
 //     tile so the slice rows a tile needs stay in that XCD's L2.
 #include <algorithm>
+#include <array>
 #include <cmath>
 #include <numeric>
 
@@ -394,7 +395,10 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
 //                completes the square sums cross over with one shuffle and the owner of column a evaluates
 //                mean / sqrt(EXX - mean^2) in f64, in the reference's order of operations, on the EXACT integer sums.
 //                Counters then hold (#>= << 16 | #<=) like the f64 kernels' (NaN scores compare false).
-template <bool COUNTS, int NS, bool Z = false>
+// EPI (counts form only): which epilogue this instantiation carries -- 0 = packed u16 counts for k_hyp_emit (the default split
+// form), 1 = plain counts, 2 = table lookup fused into the epilogue.  One kernel with all three kept the fused form's pipelined
+// table values (16 x double2 + nodes + slab offsets) in the register budget of the main loop: 60 VGPRs spilled.
+template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
     const unsigned char *__restrict__ bs, int64_t row_bytes, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
@@ -536,6 +540,14 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 if (gth && more2) load_rows(src_use, L_load);
 
                 const unsigned char *bbuf = lds + buf * BUF + r_base;
+                // this wave's 32 x 32 piece of a block may hold no member at all (42 % of the pieces at configs[4]: a 256-row
+                // group spans more of the layout than one neighborhood radius): multiplying zeros is skipped, wave-uniformly
+                // -- the SIMD's matrix pipe goes to its other wave.  (The LDS operand reads stay unconditional: skipping them too
+                // measured 1.44 s against 1.37 s at the configs[4] rank share -- the branches break the one-k-step-ahead read
+                // schedule and cost four spilled registers.)
+                bool nz[4];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) nz[k] = !SKIP || __builtin_amdgcn_ballot_w64(aw[k] != 0u) != 0ull;
                 // B operands of k-step k+1 are read from LDS before the MFMAs of k-step k are issued
                 v4i b_cur[NS], b_nxt[NS];
 #pragma unroll
@@ -552,13 +564,15 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                         for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
                     }
                     __builtin_amdgcn_sched_barrier(0);               // keep the LDS reads ahead of this k-step's MFMAs
-                    v4i a;
-                    a[0] = static_cast<int>(expand4(aw[k], 16 * h));
-                    a[1] = static_cast<int>(expand4(aw[k], 16 * h + 4));
-                    a[2] = static_cast<int>(expand4(aw[k], 16 * h + 8));
-                    a[3] = static_cast<int>(expand4(aw[k], 16 * h + 12));
+                    if (nz[k]) {
+                        v4i a;
+                        a[0] = static_cast<int>(expand4(aw[k], 16 * h));
+                        a[1] = static_cast<int>(expand4(aw[k], 16 * h + 4));
+                        a[2] = static_cast<int>(expand4(aw[k], 16 * h + 8));
+                        a[3] = static_cast<int>(expand4(aw[k], 16 * h + 12));
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[s], 0, 0, 0);
+                        for (int s = 0; s < NS; ++s) acc[s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[s], 0, 0, 0);
+                    }
                     // a quarter of the next super-step's tile goes to the other buffer while the
                     // matrix pipe works through this k-step
                     if (gth && more1) store_quarter(L_store, k, buf ^ 1);
@@ -619,24 +633,27 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             if constexpr (COUNTS) {
                 // ---- the counts of six column tiles are complete (n_q = 1): write them through `hl`.
                 //      Loads first, in batches the hardware can overlap: row -> node -> table slab -> value
-                int32_t node[16];
-                uint32_t slab[16];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    node[r] = rowmap[static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
-#pragma unroll
-                for (int r = 0; r < 16; ++r)
-                    slab[r] = (hl.tab && node[r] >= 0) ? static_cast<uint32_t>(hl.nid[node[r]]) * static_cast<uint32_t>(hl.n_kid * hl.xs) : 0u;
+                int32_t node[EPI == 0 ? 1 : 16];
+                uint32_t slab[EPI == 0 ? 1 : 16];
                 uint32_t kofs[NS];
                 bool col_ok[NS];
                 const uint32_t n_kid_u = static_cast<uint32_t>(hl.n_kid);     // table layout [size id][x][count id]
+                if constexpr (EPI != 0) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) {
-                    const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
-                    col_ok[s] = col < mloc;
-                    kofs[s] = (hl.tab && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) : 0u;
+                    for (int r = 0; r < 16; ++r)
+                        node[EPI == 0 ? 0 : r] = rowmap[static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+#pragma unroll
+                    for (int r = 0; r < 16; ++r)
+                        slab[EPI == 0 ? 0 : r] = (EPI == 2 && node[EPI == 0 ? 0 : r] >= 0)
+                                                     ? static_cast<uint32_t>(hl.nid[node[EPI == 0 ? 0 : r]]) * static_cast<uint32_t>(hl.n_kid * hl.xs) : 0u;
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) {
+                        const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
+                        col_ok[s] = col < mloc;
+                        kofs[s] = (EPI == 2 && col_ok[s]) ? static_cast<uint32_t>(hl.kid[col]) : 0u;
+                    }
                 }
-                if (hl.cnt16) {
+                if constexpr (EPI == 0) {
                     // split form: the counts leave as u16, six tiles of one (row, column-in-tile) packed into
                     // 12 bytes, 384 contiguous bytes per row and half-wave; k_hyp_emit streams the results out
                     static_assert(NS == 6, "packed counts hold six tiles");
@@ -659,7 +676,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 #pragma unroll
                     for (int d = 32; d >= 1; d >>= 1) mx = max(mx, __shfl_xor(mx, d));
                     if (lane == 0) atomicMax(&wg_xmax, static_cast<unsigned int>(mx));   // (LDS; published below, once per task at most)
-                } else if (!hl.tab) {                                 // plain counts ('sum' scores of 0/1 attributes)
+                } else if constexpr (EPI == 1) {                      // plain counts ('sum' scores of 0/1 attributes)
 #pragma unroll
                     for (int s = 0; s < NS; ++s) {
                         const int64_t col = (static_cast<int64_t>(ct) * NS + s) * 32 + col_in_tile;
@@ -737,7 +754,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             if constexpr (COUNTS) {
                 // the call's largest count: every wave of every task on ONE global address cost 8 % of the kernel; the
                 // workgroup keeps its own maximum in LDS and publishes it only when it grew
-                if (tid == 0 && hl.cnt16 && wg_xmax > published) {
+                if (EPI == 0 && tid == 0 && wg_xmax > published) {
                     published = wg_xmax;
                     atomicMax(hl.xmax, published);
                 }
@@ -844,6 +861,8 @@ int build_blocks(safe_nbr *nbr) {
     std::vector<std::vector<uint32_t>> g_bits(n_groups);
     const int n_thr = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({8, n_groups, static_cast<int64_t>(std::thread::hardware_concurrency())})));
     std::atomic<int64_t> next_group{0};
+    const char *deal_env = getenv("SAFE_HIP_MFMA_DEAL");
+    const bool deal_blocks = !(deal_env && !strcmp(deal_env, "0"));
     auto worker = [&]() {
         std::vector<int32_t> slot(n_kb, -1), touched;
         for (;;) {
@@ -877,6 +896,65 @@ int build_blocks(safe_nbr *nbr) {
                 }
             }
             for (int32_t kb : touched) slot[kb] = -1;
+            // The kernel works through a group four blocks (one super-step) at a time, every wave on its own 32 rows, and skips
+            // the pieces that hold no member; waves w and w + 4 share a SIMD's matrix pipe and all waves meet at a barrier
+            // after every super-step.  Deal the blocks into super-steps so that the busiest SIMD of each has as little to do as
+            // possible (greedy, heaviest blocks first): at configs[4] 4.98 instead of 5.83 multiply steps per super-step on the
+            // critical SIMD (8 without the skip; tools/notes/mfma_subtile_stats.py).  The sum over a group's blocks does not
+            // depend on their order.
+            const int64_t real = static_cast<int64_t>(touched.size()), n_ss = count / 4;
+            if (deal_blocks && n_ss > 1) {
+                std::vector<std::array<int, 4>> simd(real);
+                std::vector<int> weight(real, 0);
+                for (int64_t i = 0; i < real; ++i) {
+                    simd[i] = {0, 0, 0, 0};
+                    for (int w = 0; w < 8; ++w) {
+                        uint32_t any = 0;
+                        for (int r = 0; r < 32; ++r) any |= bit_out[i * MF_R + w * 32 + r];
+                        if (any) {
+                            ++simd[i][w & 3];
+                            ++weight[i];
+                        }
+                    }
+                }
+                std::vector<int64_t> by_weight(real);
+                std::iota(by_weight.begin(), by_weight.end(), 0);
+                std::stable_sort(by_weight.begin(), by_weight.end(), [&](int64_t a, int64_t b) { return weight[a] > weight[b]; });
+                std::vector<std::array<int, 4>> load(n_ss, std::array<int, 4>{0, 0, 0, 0});
+                std::vector<int> filled(n_ss, 0);
+                std::vector<std::vector<int64_t>> members(n_ss);
+                for (int64_t i : by_weight) {
+                    int64_t best = -1;
+                    int best_max = 0, best_fill = 0;
+                    for (int64_t ss = 0; ss < n_ss; ++ss) {
+                        if (filled[ss] >= 4) continue;
+                        int mx = 0;
+                        for (int q = 0; q < 4; ++q) mx = std::max(mx, load[ss][q] + simd[i][q]);
+                        if (best < 0 || mx < best_max || (mx == best_max && filled[ss] < best_fill)) {
+                            best = ss;
+                            best_max = mx;
+                            best_fill = filled[ss];
+                        }
+                    }
+                    for (int q = 0; q < 4; ++q) load[best][q] += simd[i][q];
+                    ++filled[best];
+                    members[best].push_back(i);
+                }
+                std::vector<int32_t> kb_new(count, static_cast<int32_t>(n_kb));
+                std::vector<uint32_t> bit_new(count * MF_R, 0u);
+                int64_t at = 0;
+                for (int64_t ss = 0; ss < n_ss; ++ss) {
+                    std::sort(members[ss].begin(), members[ss].end());           // ascending column blocks inside a super-step
+                    for (size_t j = 0; j < 4; ++j, ++at) {
+                        if (j >= members[ss].size()) continue;                    // (padding block: no members, source row n)
+                        const int64_t i = members[ss][j];
+                        kb_new[at] = kb_out[i];
+                        std::copy(bit_out.begin() + i * MF_R, bit_out.begin() + (i + 1) * MF_R, bit_new.begin() + at * MF_R);
+                    }
+                }
+                kb_out.swap(kb_new);
+                bit_out.swap(bit_new);
+            }
         }
     };
     {
@@ -1168,19 +1246,25 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
     hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
                        static_cast<const int32_t *>(nullptr), 0, cs->d_src);
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
-    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       static_cast<int>(lds_bytes)));
+    for (const void *fn : {reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 0>),
+                           reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 1>),
+                           reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 2>)})
+        SAFE_HIP_CHECK(hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     return SAFE_OK;
 }
 
 void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl, int spare_cus = 0) {
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks.size()), std::max(1, ctx->num_cu - spare_cus));
-    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs, cs.row_bytes,
-                       static_cast<int64_t>(MF_CN * 32), cs.d_src,
-                       cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits, cs.d_tasks, cs.d_qoff, cs.d_qctr, cs.mloc,
-                       static_cast<unsigned int *>(nullptr), nbr->bs_groups * MF_R, nbr->bs_rowmap, static_cast<const double *>(nullptr),
-                       static_cast<double *>(nullptr), hl);
+#define COUNTS_LAUNCH(EPI)                                                                                                              \
+    hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN, false, true, EPI>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs,      \
+                       cs.row_bytes, static_cast<int64_t>(MF_CN * 32), cs.d_src, cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits,    \
+                       cs.d_tasks, cs.d_qoff, cs.d_qctr, cs.mloc, static_cast<unsigned int *>(nullptr), nbr->bs_groups * MF_R,           \
+                       nbr->bs_rowmap, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), hl)
+    if (hl.cnt16) COUNTS_LAUNCH(0);                 // packed counts for k_hyp_emit
+    else if (!hl.tab) COUNTS_LAUNCH(1);             // plain counts
+    else COUNTS_LAUNCH(2);                          // table lookup in the epilogue
+#undef COUNTS_LAUNCH
 }
 
 }  // namespace
