@@ -1200,27 +1200,49 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
 // WPS = waves per SIMD the kernel is built for: 4 (128 registers; every class keeps its observed sums in registers and counts
 // with CL levels) or 5 (96 registers: the classes of more than 56 members count with five levels -- their tasks hold at most
 // 31 permutations -- and re-read the observed sums; five workgroups per CU when T fits five times).
+struct BitsQueues {
+    int off[9];                                                           // tasks [off[q], off[q+1]) belong to queue q
+};
+
 template <int CL, int DBG, int WPS = 4>
 __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
-    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
+    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, BitsQueues qs,
     const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_pad) {
     extern __shared__ unsigned int lds[];
     const int64_t t_words = 2 * ((n + 2) & ~int64_t(1));               // T: (n+1) uint2, 16-B padded
     uint2 *T = reinterpret_cast<uint2 *>(lds);
-    unsigned int *slot_box = lds + t_words;
+    int *slot_box = reinterpret_cast<int *>(lds + t_words);
     // the member ids ARE LDS addresses of T rows: T must sit at LDS address 0 (it does: no static LDS in this kernel)
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds) != 0u) __builtin_trap();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    // One task queue per XCD (workgroups are dealt to the 8 XCDs round-robin: blockIdx & 7).  All word groups of one
+    // (slice group, permutation range) sit in ONE queue, so the member-id lists of that range -- read by every one of its
+    // 69 word-group tasks -- are fetched into one XCD's L2, not into all eight (the id stream was 8 x 41 MB of fabric
+    // reads per launch); a workgroup whose queue has run dry takes from the others.
+    const int home = blockIdx.x & 7;
+    int tried = 0;                                                        // (thread 0's copy is the one that counts)
 
     for (;;) {
-        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        if (threadIdx.x == 0) {
+            int slot = -1;
+            while (tried < 8) {
+                const int q = (home + tried) & 7;
+                const unsigned int got = atomicAdd(queue + q, 1u);
+                if (got < static_cast<unsigned int>(qs.off[q + 1] - qs.off[q])) {
+                    slot = qs.off[q] + static_cast<int>(got);
+                    break;
+                }
+                ++tried;
+            }
+            *slot_box = slot;
+        }
         __syncthreads();
-        const int64_t slot = *slot_box;
+        const int slot = *slot_box;
         __syncthreads();
-        if (slot >= n_tasks) break;
+        if (slot < 0) break;
         const int4 task = tasks[slot];
         const int wg = task.x;
         // a task = four adjacent slices (one per wave) of one word group over a permutation range
@@ -2080,15 +2102,44 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         for (size_t i = 0; i < tc.size(); ++i) out[i] = tc[i].t;
         return out;
     };
+    // the blocked kernel's per-XCD queues: the tasks of one (slice group, permutation range) -- one per word group, adjacent
+    // after the stable sort -- go to one queue, (group, range) pairs dealt round-robin in heaviest-first order
+    const char *xq_env = getenv("SAFE_HIP_BITS_XCDQ");
+    const bool xcd_queues = !(xq_env && !strcmp(xq_env, "0"));
+    auto split_queues = [&](const std::vector<int4> &list, int (&off)[9]) {
+        std::vector<std::vector<int4>> q(8);
+        int64_t pair = -1;
+        int last_g = -1, last_p0 = -1;
+        for (size_t i = 0; i < list.size(); ++i) {
+            if (!xcd_queues) pair = static_cast<int64_t>(i);
+            else if (list[i].y != last_g || list[i].z != last_p0) {
+                ++pair;
+                last_g = list[i].y;
+                last_p0 = list[i].z;
+            }
+            q[pair & 7].push_back(list[i]);
+        }
+        std::vector<int4> out;
+        out.reserve(list.size());
+        off[0] = 0;
+        for (int k = 0; k < 8; ++k) {
+            out.insert(out.end(), q[k].begin(), q[k].end());
+            off[k + 1] = static_cast<int>(out.size());
+        }
+        return out;
+    };
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     std::vector<int4> tasks;                             // the lists back to back
     std::vector<int64_t> list_span, list_first, list_count, launch_list(std::max<int64_t>(n_launch, 1), 0);
+    std::vector<BitsQueues> list_queues;
     for (int64_t c = 0; c < n_launch; ++c) {
         const int64_t span_c = starts[c + 1] - starts[c];
         size_t k = 0;
         while (k < list_span.size() && list_span[k] != span_c) ++k;
         if (k == list_span.size()) {
-            const std::vector<int4> one = build_tasks(span_c);
+            BitsQueues bq{};
+            const std::vector<int4> one = split_queues(build_tasks(span_c), bq.off);
+            list_queues.push_back(bq);
             list_span.push_back(span_c);
             list_first.push_back(static_cast<int64_t>(tasks.size()));
             list_count.push_back(static_cast<int64_t>(one.size()));
@@ -2102,14 +2153,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     unsigned int *d_gl = nullptr;
     {
         void *ws = nullptr;       // tasks + queue words in one scratch buffer
-        SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int4) + (n_launch + 4) * sizeof(unsigned int), &ws));
+        SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int4) + (8 * n_launch + 4) * sizeof(unsigned int), &ws));
         d_tasks = static_cast<int4 *>(ws);
         d_queue = reinterpret_cast<unsigned int *>(d_tasks + tasks.size());
     }
     const int64_t n_pad = nbr->n_slices * 64;
     SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), reinterpret_cast<void **>(&d_gl)));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, n_launch * sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, 8 * n_launch * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), ctx->stream));
     safe_trace("launch_bits: buffers ready");
     int4 *const d_task_lists = d_tasks;
@@ -2194,9 +2245,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
             if (blk) {
                 const uint16_t *ids_c = d_ids[c & 1];
-                unsigned int *queue_c = d_queue + c;
+                unsigned int *queue_c = d_queue + 8 * c;
+                BitsQueues bq = list_queues[launch_list[c]];
                 void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
-                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits, (void *)&n_tasks,
+                                (void *)&nbr->slice_width, (void *)&d_obs, (void *)&nbr->n_slices, (void *)&d_bits, (void *)&bq,
                                 (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c, (void *)&mloc, (void *)&d_gl,
                                 (void *)&n_pad};
                 const int64_t blocks_blk = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
@@ -2205,15 +2257,15 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
-                                   n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
+                                   n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
             else if (wide)
                 hipLaunchKernelGGL(k_permtest_bits_pre<16>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
-                                   n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
+                                   n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
             else
                 hipLaunchKernelGGL(k_permtest_bits_pre<10>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
-                                   n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, d_gl, n_pad, out.ns);
+                                   n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
             SAFE_HIP_CHECK(hipGetLastError());
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
             continue;
@@ -2222,7 +2274,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
 #define LAUNCH_BITS(CLV, SC)                                                                                          \
         hipLaunchKernelGGL((k_permtest_bits<CLV, SC>), dim3(blocks), dim3(256), lds_bytes, ks, n, P,                  \
                            perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,          \
-                           nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + c, mloc, \
+                           nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, \
                            d_gl, n_pad, out.ns)
         if (wide && scaled) LAUNCH_BITS(16, true);
         else if (wide) LAUNCH_BITS(16, false);
