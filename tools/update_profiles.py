@@ -37,10 +37,38 @@ def get(vals, sub, ctr):
     return None
 
 
+# ---- calibration of the two counters on this box (tools/pmc_calib.sh -> gpurun_out/calib/calib.txt): known bytes / reported
+calib = {}
+calib_path = os.path.join(ROOT, 'gpurun_out', 'calib', 'calib.txt')
+if os.path.exists(calib_path):
+    cv = counters(calib_path)
+    known = 2.0 * (2 << 30) / 1024.0                       # two launches of 2 GiB each, in KiB
+    for kern, ctr in (('k_read16', 'FETCH_SIZE'), ('k_read12', 'FETCH_SIZE'), ('k_read8', 'FETCH_SIZE'), ('k_read4', 'FETCH_SIZE'),
+                      ('k_gather192', 'FETCH_SIZE'), ('k_write16', 'WRITE_SIZE'), ('k_atomic4', 'WRITE_SIZE'), ('k_atomic4', 'FETCH_SIZE')):
+        v = get(cv, kern, ctr) if 'get' in globals() else None
+        if v is None:
+            for (k, c), vv in cv.items():
+                if kern in k and c == ctr:
+                    v = vv
+        if v is not None:
+            calib['%s:%s' % (kern, ctr)] = {'reported_KiB': v[0], 'requested_KiB': known,
+                                            'bytes_per_reported_byte': (known / v[0]) if v[0] > 1e3 else None}
+    calib['_reading'] = ('every coalesced read width (4 / 8 / 12 / 16 B per lane) reports exactly half of the bytes read, random 192-byte row '
+                         'gathers two thirds of the bytes requested = half of the 128-byte lines touched: FETCH_SIZE x 2 = bytes that crossed '
+                         'the fabric, for every kernel here; WRITE_SIZE is exact for 16 B/lane stores; a 4 B/lane atomicAdd counts its bytes '
+                         'once as WRITE_SIZE and not at all as FETCH_SIZE (the read-modify-write happens memory-side)')
+    json.dump(dict(calib, _stamp=stamp), open(os.path.join(ROOT, 'profiles', 'pmc_calibration.json'), 'w'), indent=1)
+    open(os.path.join(ROOT, 'profiles', '%s_pmc_calibration.txt' % rnd), 'w').write(
+        '# tools/pmc_calib.sh (tools/ubench/fetch_calib.hip: 2 launches x 2 GiB per kernel; rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, separate '
+        'passes; round %s, commit %s, MI355X); unit KiB\n' % (rnd, commit) + open(calib_path).read())
+
 out = {}
 
 
-def entry(key, sub, corr=1.0, note=None):
+FETCH_CORR = 2.0                                           # calibrated above: holds for every read pattern of these kernels
+
+
+def entry(key, sub, corr=FETCH_CORR, note=None):
     f, w = get(traffic, sub, 'FETCH_SIZE'), get(traffic, sub, 'WRITE_SIZE')
     if f is None or w is None:
         return
@@ -54,17 +82,19 @@ def entry(key, sub, corr=1.0, note=None):
 entry('k_permtest_bits_blk', 'k_permtest_bits_blk')
 entry('k_bits_observed', 'k_bits_observed')
 entry('k_euclid_dense', 'k_euclid_dense')
-entry('k_hyp_emit', 'k_hyp_emit', 1.0,
-      'reads are 12 B/lane count records + 16 B/lane table slabs (mostly L2 hits): the x2 correction of 16 B/lane streams is not '
-      'applied (uncalibrated width); algorithmic bytes 5.21 GB (4.80 GB written + 0.41 GB of packed counts read)')
-entry('k_permtest_mfma<counts> (split form)', 'k_permtest_mfma<true, 6>', 2.0)
-entry('k_permtest_mfma', 'k_permtest_mfma<false, 6>', 2.0)
-entry('k_mfma_planes01_rows', 'k_mfma_planes01_rows', 2.0)
+entry('k_hyp_emit', 'k_hyp_emit', FETCH_CORR,
+      'reads are 12 B/lane count records (calibrated: x2 like every coalesced width) + 16 B/lane table slabs (mostly L2 hits); '
+      'algorithmic bytes 5.21 GB (4.80 GB written + 0.41 GB of packed counts read)')
+entry('k_permtest_mfma<counts> (split form)', 'k_permtest_mfma<true, 6')
+entry('k_permtest_mfma', 'k_permtest_mfma<false, 6')
+entry('k_mfma_planes01_rows', 'k_mfma_planes01_rows')
 entry('k_permute_cols', 'k_permute_cols')
 entry('k_counts_finalize', 'k_counts_finalize')
 out['_source'] = ('rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) -- python3 bench.py --steps 1 --warmup 1 '
-                  '--cpu-perms 0 (tools/prof_round.sh), round %s, MI355X; counter unit KiB; x2 gfx950 FETCH_SIZE correction applied only to '
-                  'kernels whose reads are 16 B/lane streams (MI355X_MICROARCH.md, HBM section); see profiles/%s_pmc_traffic.txt' % (rnd, rnd))
+                  '--cpu-perms 0 (tools/prof_round.sh), round %s, MI355X; counter unit KiB; FETCH_SIZE x 2 for every kernel (gfx950 counts 128-byte '
+                  'requests at 64 B: MI355X_MICROARCH.md, HBM section, re-measured for the access widths of these kernels in '
+                  'profiles/pmc_calibration.json); Infinity-Cache hits are counted too: these are FABRIC bytes, an upper bound of the HBM bytes; '
+                  'see profiles/%s_pmc_traffic.txt' % (rnd, rnd))
 out['_stamp'] = stamp
 json.dump(out, open(os.path.join(ROOT, 'profiles', 'pmc_traffic.json'), 'w'), indent=1)
 hdr = ('# rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (separate passes) --kernel-trace -- python3 bench.py --steps 1 --warmup 1 --cpu-perms 0 '
