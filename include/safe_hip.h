@@ -206,6 +206,16 @@ int safe_perms_create_from_table(safe_ctx *ctx, int64_t n, int64_t num_permutati
  * its workers reseed identically, so they repeat one another -- here every rank draws the ONE cumulative stream of
  * safe_extras.py:46-58 and tests its own range of it, and the ranks' counts add up to the single-process counts). */
 int safe_perms_slice(safe_perms *perms, int64_t p0, int64_t p1, safe_perms **out);
+/* UNSEEDED runs (random_seed=None -- the reference's default, safepy/safe.py:88; np.random.seed(None) at safe_extras.py:46 takes
+ * OS entropy, so there is no stream to reproduce): the tables are generated ON THE DEVICE.  The reference's cumulative in-place
+ * shuffles (safe_extras.py:58) make the composed tables i.i.d. uniform permutations of the movable rows, so each table row is
+ * drawn directly: one lane per permutation runs Fisher-Yates in LDS with Philox4x32-10 words (key = `key`, counter =
+ * permutation, word block) and unbiased bounded draws (Lemire's multiply-shift with rejection).  No host thread, nothing
+ * sequential across permutations; every rank of a sharded run generates identical tables from the same key.  num movable rows
+ * <= 65535.  The same arguments and the same handle as safe_perms_create otherwise; tables depend on (key, movable rows,
+ * num_permutations index) only -- restated in oracle/safe_oracle.py for the tests. */
+int safe_perms_create_device(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations,
+                             uint64_t key, safe_perms **out);
 /* One permutation stream per NODE (multi-GPU runs; the reference's workers each repeat the whole stream,
  * safepy/safe.py:489-519, 1339-1353).  The stream of safe_extras.py:46-58 is sequential, so a rank cannot draw "its part":
  * safe_ctx_share_stream attaches the context to a shared-memory ring named `name` (the same string on every rank of the
@@ -222,7 +232,8 @@ int safe_perms_create_shared(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
                              int has_seed, uint32_t seed, safe_perms **out);
 /* Host-side timing of a handle's stream, ms: out5[0] = time the draw thread spent drawing, [1] = handle creation -> last
  * draw finished, [2] = creation -> last chunk's table kernels enqueued, [3] = time this rank blocked waiting for the
- * node's producer, [4] = role (0 own stream, 1 producer of a shared stream, 2 consumer).  For bench reporting. */
+ * node's producer, [4] = role (0 own stream, 1 producer of a shared stream, 2 consumer, 3 generated on the device).  For
+ * bench reporting. */
 int safe_perms_timing(safe_perms *perms, double *out5);
 /* The ring by itself (host memory only, no device): what safe_perms_create_shared runs on, exported so that the
  * multi-process protocol can be tested on a host without GPUs.  local rank 0 creates, the others attach;

@@ -287,6 +287,58 @@ def compute_pvalues(neighborhoods, node2attribute, enrichment_type='auto', neigh
 
 
 # ---------------------------------------------------------------------------
+# The device stream of UNSEEDED runs (safepy_amd/csrc/rng.cpp, k_perms_device), restated for the tests.  It has no counterpart
+# to reproduce in the reference -- random_seed=None seeds from OS entropy (safe.py:88, safe_extras.py:46) -- so what is pinned
+# here is the product's own documented algorithm: table row q is a Fisher-Yates shuffle (from the top, like the legacy one) of
+# the movable rows with Philox4x32-10 words (key = the call's 64-bit key, counter = (q, word block, 0x5AFE, 0)) and Lemire's
+# unbiased bounded draw.  The statistical claims (uniform, independent rows) are tested separately.
+# ---------------------------------------------------------------------------
+
+def _philox4x32_10(c0, c1, c2, c3, k0, k1):
+    """Vectorised Philox4x32-10 over uint64 arrays holding 32-bit values; returns the four output words."""
+    m0, m1, mask = np.uint64(0xD2511F53), np.uint64(0xCD9E8D57), np.uint64(0xFFFFFFFF)
+    c0, c1, c2, c3 = (np.asarray(v, dtype=np.uint64) for v in (c0, c1, c2, c3))
+    k0, k1 = np.uint64(k0), np.uint64(k1)
+    for _ in range(10):
+        p0, p1 = m0 * c0, m1 * c2
+        hi0, lo0, hi1, lo1 = p0 >> np.uint64(32), p0 & mask, p1 >> np.uint64(32), p1 & mask
+        c0, c1, c2, c3 = hi1 ^ c1 ^ k0, lo1, hi0 ^ c3 ^ k1, lo0
+        k0 = (k0 + np.uint64(0x9E3779B9)) & mask
+        k1 = (k1 + np.uint64(0xBB67AE85)) & mask
+    return c0, c1, c2, c3
+
+
+def device_stream_tables(n, movable, num_permutations, key):
+    """int64 [P, n]: the composed tables safe_perms_create_device generates for `key` (a 64-bit integer)."""
+    movable = np.asarray(movable).astype(bool)
+    mov = np.flatnonzero(movable)
+    k = len(mov)
+    key0, key1 = int(key) & 0xFFFFFFFF, (int(key) >> 32) & 0xFFFFFFFF
+    out = np.tile(np.arange(n, dtype=np.int64), (num_permutations, 1))
+    n_blocks = (k + 3) // 4 + 8                                # (a rejection consumes one more word: a few spare blocks)
+    blocks = np.arange(n_blocks, dtype=np.uint64)
+    for q in range(num_permutations):
+        w = np.stack(_philox4x32_10(np.full(n_blocks, q, dtype=np.uint64), blocks, np.full(n_blocks, 0x5AFE, dtype=np.uint64),
+                                    np.zeros(n_blocks, dtype=np.uint64), key0, key1), axis=1).reshape(-1)
+        words = [int(v) for v in w]
+        at = 0
+        a = list(range(k))
+        for i in range(k - 1, 0, -1):
+            rng_range = i + 1
+            m = words[at] * rng_range
+            at += 1
+            if (m & 0xFFFFFFFF) < rng_range:
+                thresh = ((1 << 32) - rng_range) % rng_range
+                while (m & 0xFFFFFFFF) < thresh:
+                    m = words[at] * rng_range
+                    at += 1
+            j = m >> 32
+            a[i], a[j] = a[j], a[i]
+        out[q, mov] = mov[np.array(a, dtype=np.int64)] if k else mov
+    return out
+
+
+# ---------------------------------------------------------------------------
 # Legacy MT19937 permutation stream, restated (numpy legacy RandomState;
 # SURVEY Appendix A.3).  Used to pin the product's host RNG against an
 # independent statement AND against numpy itself.

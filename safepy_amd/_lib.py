@@ -136,6 +136,7 @@ PROTOTYPES = {
     'safe_ctx_share_stream': (C.c_int, [_vp, C.c_char_p, C.c_int, C.c_int, _i64]),
     'safe_ctx_unshare_stream': (C.c_int, [_vp]),
     'safe_perms_create_shared': (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, C.c_uint32, _pp]),
+    'safe_perms_create_device': (C.c_int, [_vp, _i64, _vp, _i64, C.c_uint64, _pp]),
     'safe_perms_timing': (C.c_int, [_vp, C.POINTER(C.c_double)]),
     'safe_ring_open': (C.c_int, [C.c_char_p, C.c_int, C.c_int, _i64, _pp]),
     'safe_ring_close': (C.c_int, [_vp]),

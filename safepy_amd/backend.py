@@ -395,10 +395,16 @@ class Attributes:
 class Permutations:
     """Device-resident composed row-permutation tables (legacy NumPy MT19937 stream)."""
 
-    def __init__(self, ctx, n, movable, num_permutations, seed, shared=False):
-        """shared=True: a COLLECTIVE call over the ranks of this node whose contexts share a stream (Context.share_stream):
+    def __init__(self, ctx, n, movable, num_permutations, seed, shared=False, device_key=None):
+        """seed: the reference's random_seed -- an integer reproduces np.random.seed(seed) + np.random.permutation exactly
+        (safe_extras.py:46-58).  seed=None (the reference's default: OS entropy, nothing to reproduce) generates the tables
+        ON THE DEVICE (safe_perms_create_device: i.i.d. uniform permutations, counter-based generator) keyed by `device_key`
+        (64 bits; default: OS entropy) -- unless SAFE_HIP_DEVICE_STREAM=0 or more than 65535 rows move, then the NumPy-compatible
+        stream runs from an entropy seed as before.
+        shared=True: a COLLECTIVE call over the ranks of this node whose contexts share a stream (Context.share_stream):
         only the node's local rank 0 draws (its seed counts), the others receive the row maps.  Without a shared stream on
-        the context it is the plain per-process stream."""
+        the context it is the plain per-process stream.  (Device-generated tables need no sharing: every rank generates the
+        same tables from the same key.)"""
         movable = np.ascontiguousarray(movable, dtype=np.uint8)
         assert movable.shape == (n,)
         if seed is not None:
@@ -409,9 +415,14 @@ class Permutations:
         self.n = int(n)
         self.count = int(num_permutations)
         h = C.c_void_p()
-        create = lib.safe_perms_create_shared if (shared and ctx.shared_stream) else lib.safe_perms_create
-        check(create(ctx.handle, self.n, _ptr(movable), self.count, 0 if seed is None else 1,
-                     0 if seed is None else seed, C.byref(h)))
+        self.device_key = None
+        if seed is None and device_stream_enabled() and int(movable.sum()) <= 65535:
+            self.device_key = int.from_bytes(os.urandom(8), 'little') if device_key is None else int(device_key) & 0xFFFFFFFFFFFFFFFF
+            check(lib.safe_perms_create_device(ctx.handle, self.n, _ptr(movable), self.count, C.c_uint64(self.device_key), C.byref(h)))
+        else:
+            create = lib.safe_perms_create_shared if (shared and ctx.shared_stream) else lib.safe_perms_create
+            check(create(ctx.handle, self.n, _ptr(movable), self.count, 0 if seed is None else 1,
+                         0 if seed is None else seed, C.byref(h)))
         self.handle = h
 
     def timing(self):
@@ -419,7 +430,7 @@ class Permutations:
         out = (C.c_double * 5)()
         check(lib.safe_perms_timing(self.handle, out))
         return {'draw_busy_ms': out[0], 'drawn_all_ms': out[1], 'tables_enqueued_ms': out[2], 'waited_for_producer_ms': out[3],
-                'role': ('own', 'producer', 'consumer')[int(out[4])]}
+                'role': ('own', 'producer', 'consumer', 'device')[int(out[4])]}
 
     @classmethod
     def from_table(cls, ctx, perm_idx):
@@ -511,6 +522,11 @@ class Comm:
             self.close()
         except Exception:
             pass
+
+
+def device_stream_enabled():
+    """Unseeded runs generate their permutation tables on the device unless SAFE_HIP_DEVICE_STREAM=0."""
+    return os.environ.get('SAFE_HIP_DEVICE_STREAM', '1') != '0'
 
 
 def effective_cores():

@@ -266,6 +266,8 @@ struct safe_perms {
     bool from_table = false;        // rows supplied by the caller (safe_perms_create_from_table): no stream, complete from the start
     // node-shared stream (ring.h; safe_perms_create_shared): local rank 0 of a node publishes every chunk's row maps,
     // the other ranks fetch them instead of drawing (no draw thread, no swap workers on those ranks)
+    bool device_gen = false;        // tables generated on the device (safe_perms_create_device): no host stream at all
+    int32_t *d_movpos = nullptr;    // device generation: [n] movable rows (first k used) | [n] position of a row in that list (-1: fixed)
     struct PermRing *ring = nullptr;               // the context's ring while this handle takes part in a shared call, else NULL
     bool ring_consumer = false;
     // host-side timing of the stream (safe_perms_timing), ms since the handle was created

@@ -91,6 +91,96 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 }
 
 // --------------------------------------------------------------------------------------
+// Device-side stream for UNSEEDED runs (random_seed=None, the reference's default: safe.py:88, np.random.seed(None) at
+// safe_extras.py:46 seeds from OS entropy, so there is no stream to reproduce).  The reference shuffles the rows in place once
+// per iteration (safe_extras.py:58): cur_q = cur_{q-1} o M_q with independent uniform M_q, and a uniform permutation composed
+// with anything independent of it is uniform and independent of the past -- the tables cur_1 .. cur_P are i.i.d. uniform
+// permutations of the movable rows.  So every table row is generated directly and independently: one lane runs the
+// Fisher-Yates shuffle of one permutation on a 16-bit position array in LDS (steps are dependent LDS round trips, but a
+// thousand permutations run side by side), draws come from Philox4x32-10 keyed by the call's 64-bit key with the counter
+// (permutation, block of four words), bounded without bias (Lemire's multiply-shift with rejection).  Every rank of a
+// sharded run generates the SAME tables from the agreed key: no host thread, no exchange, nothing sequential.
+// The algorithm is restated in oracle/safe_oracle.py (device_stream_tables) and compared bit for bit.
+// --------------------------------------------------------------------------------------
+struct Philox {
+    uint32_t key0, key1, q, block, w[4];
+    int have;
+    __device__ __forceinline__ void refill() {
+        uint32_t c0 = q, c1 = block, c2 = 0x5AFEu, c3 = 0u, k0 = key0, k1 = key1;
+#pragma unroll
+        for (int r = 0; r < 10; ++r) {
+            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+            c0 = hi1 ^ c1 ^ k0;
+            c1 = lo1;
+            c2 = hi0 ^ c3 ^ k1;
+            c3 = lo0;
+            k0 += 0x9E3779B9u;
+            k1 += 0xBB67AE85u;
+        }
+        w[0] = c0, w[1] = c1, w[2] = c2, w[3] = c3;
+        ++block;
+        have = 4;
+    }
+    __device__ __forceinline__ uint32_t next() {
+        if (have == 0) refill();
+        const uint32_t v = have == 4 ? w[0] : have == 3 ? w[1] : have == 2 ? w[2] : w[3];
+        --have;
+        return v;
+    }
+};
+
+// one workgroup (one wave) = G permutations; lane g < G shuffles permutation q0 + g in its own LDS array, then the wave
+// writes the G table rows out together
+__global__ __launch_bounds__(64) void k_perms_device(int64_t n, int64_t k, int64_t count, int G, uint32_t key0, uint32_t key1,
+                                                     const int32_t *__restrict__ mov, const int32_t *__restrict__ pos_of,
+                                                     int32_t *__restrict__ table, uint16_t *__restrict__ table16, int64_t stride16) {
+    extern __shared__ uint16_t fy[];                                  // [G][kpad]
+    const int lane = threadIdx.x;
+    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * G, kpad = (k + 1) & ~int64_t(1);
+    const int g_here = static_cast<int>(count - q0 < G ? count - q0 : G);
+    for (int64_t t = lane; t < k; t += 64)
+        for (int g = 0; g < g_here; ++g) fy[g * kpad + t] = static_cast<uint16_t>(t);
+    __syncthreads();
+    if (lane < g_here && k >= 2) {                                    // (k - 1 wraps for k = 0: nothing to shuffle below two rows)
+        uint16_t *a = fy + lane * kpad;
+        Philox rng{key0, key1, static_cast<uint32_t>(q0 + lane), 0u, {0u, 0u, 0u, 0u}, 0};
+        for (uint32_t i = static_cast<uint32_t>(k) - 1u; i >= 1u; --i) {          // Fisher-Yates from the top, like the legacy shuffle
+            const uint32_t range = i + 1u;
+            uint32_t x = rng.next();
+            uint64_t m = static_cast<uint64_t>(x) * range;
+            if (static_cast<uint32_t>(m) < range) {                                 // Lemire: reject the few low products that would bias
+                const uint32_t thresh = (0u - range) % range;
+                while (static_cast<uint32_t>(m) < thresh) {
+                    x = rng.next();
+                    m = static_cast<uint64_t>(x) * range;
+                }
+            }
+            const uint32_t j = static_cast<uint32_t>(m >> 32);
+            const uint16_t ai = a[i], aj = a[j];
+            a[i] = aj;
+            a[j] = ai;
+        }
+    }
+    __syncthreads();
+    const int64_t stride = n + 1;
+    for (int g = 0; g < g_here; ++g) {
+        const uint16_t *a = fy + g * kpad;
+        int32_t *row = table + (q0 + g) * stride;
+        uint16_t *row16 = table16 ? table16 + (q0 + g) * stride16 : nullptr;
+        for (int64_t r = lane; r < (row16 ? stride16 : stride); r += 64) {
+            int32_t v = static_cast<int32_t>(n);                       // entry n (and the 16-bit row's padding) = the padding row
+            if (r < n) {
+                const int32_t t = pos_of[r];
+                v = t < 0 ? static_cast<int32_t>(r) : mov[a[t]];      // safe_extras.py:58: the row at indx_vals[t] is now old row perm[t]
+            }
+            if (r < stride) row[r] = v;
+            if (row16) row16[r] = static_cast<uint16_t>(v);
+        }
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // chunked generation
 // --------------------------------------------------------------------------------------
 static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
@@ -418,7 +508,7 @@ int perms_build_inverse(safe_perms *perms) {
 static void perms_free(safe_perms *p) {
     if (!p) return;
     drawer_stop(p);
-    if (!p->ring_consumer && !p->from_table) SwapPool::get().wait();
+    if (!p->ring_consumer && !p->from_table && !p->device_gen) SwapPool::get().wait();
     if (p->ring) ring_end_call(p->ring);
     p->ring = nullptr;
     for (int b = 0; b < 2; ++b) {
@@ -429,6 +519,7 @@ static void perms_free(safe_perms *p) {
     for (hipEvent_t e : p->chunk_done)
         if (e) (void)hipEventDestroy(e);
     (void)hipFree(p->d_cur);
+    (void)hipFree(p->d_movpos);
     (void)hipFree(p->table);
     (void)hipFree(p->table16);
     (void)hipFree(p->inverse_t);
@@ -461,6 +552,43 @@ int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_i
     return SAFE_OK;
 }
 
+// whole table on the device (k_perms_device); every pipeline stage is complete once the kernel has run
+static int perms_generate_on_device(safe_perms *p, uint64_t key) {
+    safe_ctx *ctx = p->ctx;
+    const int64_t n = p->n, k = p->k, count = p->count;
+    SAFE_REQUIRE(k <= 65535, "device permutation stream: %lld movable rows (16-bit positions hold 65535)", (long long)k);
+    if (!p->d_movpos) SAFE_TRY(dev_alloc(&p->d_movpos, static_cast<size_t>(2 * n)));      // (kept with the handle's other buffers)
+    int32_t *d_mov = p->d_movpos, *d_pos = p->d_movpos + n;
+    std::vector<int32_t> h(static_cast<size_t>(2 * n), -1);
+    for (int64_t t = 0; t < k; ++t) {
+        h[t] = p->h_movable[t];
+        h[n + p->h_movable[t]] = static_cast<int32_t>(t);
+    }
+    int32_t *staging = p->h_maps[0];                           // the handle's own pinned chunk buffer (128 x (n + 1) entries): unused otherwise
+    memcpy(staging, h.data(), h.size() * sizeof(int32_t));
+    hipStream_t gs = ctx->aux_stream;
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_mov, staging, h.size() * sizeof(int32_t), hipMemcpyHostToDevice, gs));
+    const int64_t kpad = (k + 1) & ~int64_t(1);
+    const size_t per_perm = static_cast<size_t>(std::max<int64_t>(kpad, 2)) * sizeof(uint16_t);
+    const int G = static_cast<int>(std::max<size_t>(1, std::min<size_t>(16, (96 * 1024) / per_perm)));
+    const size_t lds = per_perm * G;
+    SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_perms_device), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       static_cast<int>(lds)));
+    hipLaunchKernelGGL(k_perms_device, dim3(ceil_div(count, G)), dim3(64), lds, gs, n, k, count, G, static_cast<uint32_t>(key),
+                       static_cast<uint32_t>(key >> 32), d_mov, d_pos, p->table, p->table16, p->stride16);
+    SAFE_HIP_CHECK(hipGetLastError());
+    const int64_t n_chunks = stage_count(p);
+    if (static_cast<int64_t>(p->chunk_done.size()) < n_chunks) p->chunk_done.resize(n_chunks, nullptr);
+    for (int64_t c = 0; c < n_chunks; ++c) {
+        if (!p->chunk_done[c]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[c], safe_event_flags(hipEventDisableTiming)));
+        SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[c], gs));
+    }
+    SAFE_HIP_CHECK(hipMemcpyAsync(p->d_cur, p->table + (count - 1) * (n + 1), (n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, gs));
+    p->generated = p->swapping = p->enqueued = count;
+    p->enqueued_all_ms = 1e3 * (wall_s() - p->t_created_s);
+    return SAFE_OK;
+}
+
 // FNV-1a over the movable flags: consumers of a shared stream check that they mark the same rows as the producer
 static uint64_t movable_fingerprint(const uint8_t *movable_host, int64_t n) {
     uint64_t h = 1469598103934665603ull;
@@ -469,7 +597,8 @@ static uint64_t movable_fingerprint(const uint8_t *movable_host, int64_t n) {
 }
 
 static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, int has_seed,
-                             uint32_t seed, bool shared, const char *who, safe_perms **out) {
+                             uint32_t seed, bool shared, const char *who, safe_perms **out, bool device_gen = false,
+                             uint64_t device_key = 0) {
     SAFE_REQUIRE(ctx && movable_host && out, "%s: NULL argument", who);
     SAFE_REQUIRE(n >= 1 && n < (1ll << 31) - 1, "%s: n out of range", who);
     SAFE_REQUIRE(num_permutations >= 0, "%s: negative permutation count", who);
@@ -479,7 +608,7 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     // a shared call goes through the node's ring when a chunk fits it at least twice; every rank of the node decides this
     // from (n, ring capacity) alone, hence identically.  Otherwise (and for empty streams) this rank draws for itself.
     const int64_t slot_bytes = kChunk * (n + 1) * static_cast<int64_t>(sizeof(int32_t));
-    PermRing *ring = shared && ctx->ring && num_permutations > 0 && ring_slots_for(ctx->ring, slot_bytes) >= 2 ? ctx->ring : nullptr;
+    PermRing *ring = !device_gen && shared && ctx->ring && num_permutations > 0 && ring_slots_for(ctx->ring, slot_bytes) >= 2 ? ctx->ring : nullptr;
     safe_perms *p = nullptr;
     bool reused = false;
     if (ctx->perm_cache && ctx->perm_cache->n == n && ctx->perm_cache->count == num_permutations) {
@@ -499,7 +628,8 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     p->k = static_cast<int64_t>(p->h_movable.size());
     p->ring = ring;
     p->ring_consumer = ring != nullptr && !ring_is_producer(ring);
-    p->stream = p->ring_consumer ? nullptr : draw_stream_new(has_seed ? seed : entropy_seed());
+    p->device_gen = device_gen;
+    p->stream = (p->ring_consumer || device_gen) ? nullptr : draw_stream_new(has_seed ? seed : entropy_seed());
     p->generated = p->swapping = p->enqueued = 0;
     p->stages = perms_stage_plan(num_permutations);
     p->t_created_s = wall_s();
@@ -544,11 +674,12 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
             if (rc != SAFE_OK) p->ring = nullptr;            // (no call is open on the ring: nothing to end)
         }
     } while (0);
+    if (rc == SAFE_OK && device_gen && num_permutations > 0) rc = perms_generate_on_device(p, device_key);
     if (rc != SAFE_OK) {
         perms_free(p);
         return rc;
     }
-    drawer_start(p);
+    if (!device_gen) drawer_start(p);
     safe_trace(reused ? "perms_create: done (buffers reused)" : "perms_create: done");
     *out = p;
     return SAFE_OK;
@@ -562,6 +693,11 @@ int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int
 int safe_perms_create_shared(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, int has_seed,
                              uint32_t seed, safe_perms **out) {
     return perms_create_impl(ctx, n, movable_host, num_permutations, has_seed, seed, true, "safe_perms_create_shared", out);
+}
+
+int safe_perms_create_device(safe_ctx *ctx, int64_t n, const uint8_t *movable_host, int64_t num_permutations, uint64_t key,
+                             safe_perms **out) {
+    return perms_create_impl(ctx, n, movable_host, num_permutations, 0, 0u, false, "safe_perms_create_device", out, true, key);
 }
 
 int safe_ctx_share_stream(safe_ctx *ctx, const char *name, int local_rank, int local_world, int64_t capacity_bytes) {
@@ -588,7 +724,7 @@ int safe_perms_timing(safe_perms *perms, double *out5) {
     }
     out5[2] = perms->enqueued_all_ms;
     out5[3] = perms->ring_wait_ms;
-    out5[4] = perms->ring ? (perms->ring_consumer ? 2.0 : 1.0) : 0.0;
+    out5[4] = perms->device_gen ? 3.0 : perms->ring ? (perms->ring_consumer ? 2.0 : 1.0) : 0.0;
     return SAFE_OK;
 }
 
@@ -704,7 +840,7 @@ int safe_perms_destroy(safe_perms *perms) {
     if (perms->ring && !perms->ring_consumer)             // the node's producer publishes the WHOLE stream, whatever it used itself
         rc = perms_generate_until(perms, perms->count);
     drawer_stop(perms);
-    if (!perms->ring_consumer) SwapPool::get().wait();
+    if (!perms->ring_consumer && !perms->device_gen) SwapPool::get().wait();
     if (perms->ring) ring_end_call(perms->ring);
     perms->ring = nullptr;
     perms->ring_consumer = false;

@@ -628,7 +628,10 @@ class SAFE:
         nbr = self._device_neighborhoods()
         attr = _attr if _attr is not None else be.Attributes.from_host(ctx, self.node2attribute)
         n, m = attr.n, attr.m
-        perms = be.Permutations(ctx, n, attr.row_flags(), self.num_permutations, self.random_seed)
+        # random_seed=None (the default, like the reference's): the tables are generated on the device (backend.Permutations);
+        # `device_stream_key` (None = OS entropy) makes such a run repeatable for tests and debugging
+        perms = be.Permutations(ctx, n, attr.row_flags(), self.num_permutations, self.random_seed,
+                                device_key=getattr(self, 'device_stream_key', None))
         bufs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
         try:
             be.randomization(ctx, nbr, attr, perms, score_type, self.attribute_sign, self.enrichment_threshold,

@@ -280,13 +280,24 @@ def _outputs(bufs, enriched, full, m_total, group, gather, ready=None):
     return out
 
 
+def _call_permutations(ctx, n, flags, num_permutations, random_seed, unseeded, alone, group):
+    """The permutation tables of one (collective) call.  Seeded: NumPy's legacy stream, drawn once per node when the ranks
+    share one (ensure_shared_stream).  Unseeded: generated on every rank's device from the agreed value -- `random_seed` is
+    then rank 0's entropy draw (reduce_flags_and_stats / agree_on_seed), or None in a single process."""
+    from . import backend as be
+    if unseeded and be.device_stream_enabled() and int(np.count_nonzero(flags)) <= 65535:
+        return be.Permutations(ctx, n, flags, num_permutations, None, device_key=random_seed)
+    shared = (not alone) and ensure_shared_stream(ctx, group)        # one draw thread per node, not per rank
+    return be.Permutations(ctx, n, flags, num_permutations, random_seed, shared=shared)
+
+
 RANDOMIZATION_OUTPUTS = ('ns', 'pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')
 HYPERGEOM_OUTPUTS = ('pvalues_pos', 'nes', 'nes_binary')
 
 
 def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
                        neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05, group=None,
-                       table=None, flags=None, exchange=True, timing=None):
+                       table=None, flags=None, exchange=True, timing=None, unseeded=None):
     """One rank's share of compute_pvalues_by_randomization (safe.py:474-554) on DEVICE-resident inputs and
     outputs, plus the path's exchange steps -- the function bench.py times and the host-level drivers below
     call, so what is measured is what runs.
@@ -298,9 +309,13 @@ def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, b
     blocks otherwise) and returns the full [N, m_total] NES device tensor; a tuple of names from COUNTER_OUTPUTS returns
     {name: full tensor} for all of them from the same single exchange; False returns None (D2H-only runs: every rank
     keeps its block).  Without a process group it is the plain single-GPU step.  `timing`: a dict that
-    receives this rank's host-stream / kernel / exchange times of the step (bench.py)."""
+    receives this rank's host-stream / kernel / exchange times of the step (bench.py).
+    random_seed=None (or unseeded=True with `random_seed` = the value the ranks agreed on): an UNSEEDED run -- the tables are
+    generated on every rank's device from the agreed value (backend.Permutations, device stream): no host stream, no sharing."""
     from . import backend as be
     alone = not _dist().is_initialized()               # a single process: the same step without the two exchanges
+    if unseeded is None:
+        unseeded = random_seed is None
     if flags is None:
         stats = attr.stats()                           # (the dispatch rule's inputs: part of every compute_pvalues pass)
         flags = attr.row_flags()
@@ -309,10 +324,9 @@ def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, b
             random_seed = stats['random_seed']
     if not alone:
         attr.set_row_flags(flags)                      # indx_vals of the FULL matrix (safe_extras.py:51)
-    shared = (not alone) and ensure_shared_stream(ctx, group)        # one draw thread per node, not per rank
-    perms = be.Permutations(ctx, attr.n, flags, int(num_permutations), random_seed, shared=shared)
+    perms = _call_permutations(ctx, attr.n, flags, int(num_permutations), random_seed, unseeded, alone, group)
     if timing is not None:
-        timing['stream_role'] = 'shared' if shared else 'own'
+        timing['stream_role'] = perms.timing()['role']
     try:
         be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
                          [bufs[k].data_ptr() for k in RANDOMIZATION_OUTPUTS] + [enriched.data_ptr()], table=table)
@@ -348,7 +362,7 @@ def _alloc_outputs(ctx, n, mloc, names):
 
 
 def _randomization_host(ctx, nbr, attr, m_total, num_permutations, random_seed, flags, neighborhood_score_type,
-                        attribute_sign, enrichment_threshold, group, gather, multiple_testing):
+                        attribute_sign, enrichment_threshold, group, gather, multiple_testing, unseeded=False):
     import torch
     bufs, enriched = _alloc_outputs(ctx, attr.n, attr.m, RANDOMIZATION_OUTPUTS)
     torch.cuda.current_stream().synchronize()
@@ -357,7 +371,7 @@ def _randomization_host(ctx, nbr, attr, m_total, num_permutations, random_seed, 
     wanted = tuple(k for k in COUNTER_OUTPUTS if k in gather) if not multiple_testing else ('pvalues_neg', 'pvalues_pos')
     ready = randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
                                neighborhood_score_type, attribute_sign, enrichment_threshold, group, flags=flags,
-                               exchange=wanted if wanted else False)
+                               exchange=wanted if wanted else False, unseeded=unseeded)
     ctx.sync()
     full = _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold,
                              group, ready=ready) if multiple_testing else None
@@ -380,7 +394,7 @@ def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, 
         flags, stats = reduce_flags_and_stats(attr.row_flags(), attr.stats(), group, random_seed)
         return _randomization_host(ctx, nbr, attr, m_total, num_permutations, stats['random_seed'], flags,
                                    neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
-                                   multiple_testing)
+                                   multiple_testing, unseeded=random_seed is None)
     finally:
         attr.close()
 
@@ -411,7 +425,7 @@ def permutation_split_randomization(ctx, nbr, attr_host, num_permutations, rando
         ns, neg, pos = (torch.zeros((n, m), dtype=torch.float64, device=dev) for _ in range(3))
         torch.cuda.current_stream().synchronize()
         p0, p1 = column_shards(total, world)[rank]
-        whole = be.Permutations(ctx, n, attr.row_flags(), total, seed, shared=(not alone) and ensure_shared_stream(ctx, group))
+        whole = _call_permutations(ctx, n, attr.row_flags(), total, seed, random_seed is None, alone, group)
         try:
             if p1 > p0:
                 mine = whole.slice(p0, p1)
@@ -502,7 +516,7 @@ def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type=
         else:
             out = _randomization_host(ctx, nbr, attr, m_total, num_permutations, stats['random_seed'], flags,
                                       neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
-                                      multiple_testing)
+                                      multiple_testing, unseeded=random_seed is None)
             out['how'] = 'randomization'
     finally:
         attr.close()

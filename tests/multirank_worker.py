@@ -122,22 +122,34 @@ def main():
         mine.close()
         assert np.array_equal(table[0][flags == 0], np.flatnonzero(flags == 0))     # rows without a value never move
 
-        # random_seed=None: ONE unseeded run of the whole matrix -- every rank must have used rank 0's seed, so the
-        # all-gathered matrix is a consistent run: rank r's own block equals its slice of everyone's full matrix, and
-        # the full matrices are identical on all ranks
+        # random_seed=None: ONE unseeded run of the whole matrix -- every rank generates the SAME tables on its device from the
+        # value rank 0 drew, so the all-gathered matrix is a consistent run: the full matrices are identical on all ranks and
+        # equal the single-process unseeded run keyed with that value
         name, b, kw = cases(np.random.default_rng(21), n)[0]
         m = b.shape[1]
         c0, c1 = sharding.column_shards(m, world)[rank]
         out = sharding.sharded_compute_pvalues(ctx, nbr, np.ascontiguousarray(b[:, c0:c1]), m, enrichment_type='randomization',
-                                               num_permutations=40, random_seed=None, gather=('nes',))
+                                               num_permutations=40, random_seed=None, gather=('nes', 'pvalues_pos'))
         seed = out['stats']['random_seed']
         seeds = [None] * world
         dist.all_gather_object(seeds, seed)
         assert len(set(seeds)) == 1, seeds
-        sf.random_seed = seed
+        sf.random_seed = None
+        sf.device_stream_key = seed
         sf.load_attributes(attribute_file=b.copy())
         sf.compute_pvalues(how='randomization', num_permutations=40, neighborhood_score_type='sum', multiple_testing=False)
         assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+        assert np.array_equal(out['full_pvalues_pos'], sf.pvalues_pos, equal_nan=True)
+        sf.device_stream_key = None
+        # the same with the device stream switched off: the NumPy-compatible stream from the agreed seed, as in round 2
+        os.environ['SAFE_HIP_DEVICE_STREAM'] = '0'
+        out = sharding.sharded_compute_pvalues(ctx, nbr, np.ascontiguousarray(b[:, c0:c1]), m, enrichment_type='randomization',
+                                               num_permutations=40, random_seed=None, gather=('nes',))
+        sf.random_seed = out['stats']['random_seed']
+        sf.load_attributes(attribute_file=b.copy())
+        sf.compute_pvalues(how='randomization', num_permutations=40, neighborhood_score_type='sum', multiple_testing=False)
+        assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)
+        del os.environ['SAFE_HIP_DEVICE_STREAM']
         # permutation-axis split (fewer attributes than ranks -- BASELINE configs[0] is ONE column): every rank passes the
         # whole matrix, tests its range of the one stream, the counts are all-reduced; the result on every rank is the
         # single-process result
@@ -169,6 +181,15 @@ def main():
                                            random_seed=9, neighborhood_score_type=score)
                 for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
                     assert np.array_equal(out[key], want[key], equal_nan=True), (name, key, rank)
+        # permutation-axis split of an UNSEEDED call: every rank generates the whole table on its device from the agreed value
+        out = sharding.permutation_split_randomization(ctx, nbr, one, 60, None)
+        sf.random_seed = None
+        sf.device_stream_key = out['stats']['random_seed']
+        sf.load_attributes(attribute_file=one.copy())
+        sf.compute_pvalues(how='randomization', num_permutations=60, neighborhood_score_type='sum', multiple_testing=False)
+        for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+            assert np.array_equal(out[key], getattr(sf, key), equal_nan=True), ('unseeded split', key, rank)
+        sf.device_stream_key = None
         if backend == 'nccl':
             # the exchange through the C ABI's own RCCL communicator (safe_comm_* / safe_allgather_cols): the id travels
             # over the process group here; a non-torch host would use a file or MPI
