@@ -356,7 +356,7 @@ def thread_cpu_ms():
     return out
 
 
-def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, diag_exchange=False):
+def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, diag_exchange=False, seed=0):
     """Warm-up + exactly n_steps timed steps of sharding.randomization_step on `wl` (barrier + synchronize on both sides, MAX over
     ranks); returns the numbers of the mode.  A step = one compute_pvalues pass of this rank's block: statistics for the
     dispatch rule, whole-matrix row flags (N > 1: one small all-gather), the seeded legacy stream (one per node) + table
@@ -372,7 +372,8 @@ def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, d
         attr = be.Attributes.from_device(ctx, wl.b_dev.data_ptr(), wl.dtype, n, m, order=wl.order)
         t = {}
         try:
-            sharding.randomization_step(ctx, wl.nbr, attr, wl.m_total, P, 0, out, enriched, 'sum', 'both', 0.05,
+            # seed 0: the NumPy-compatible seeded stream (BASELINE's configuration); None: an unseeded call, tables generated on the device
+            sharding.randomization_step(ctx, wl.nbr, attr, wl.m_total, P, seed, out, enriched, 'sum', 'both', 0.05,
                                         table=table, exchange=exchange, timing=t)
             timings.append(t)
         finally:
@@ -577,6 +578,25 @@ def main():
         }
         if 'exchange_report' in res:
             line['exchange'] = res['exchange_report']
+    # the same workload as an UNSEEDED call (random_seed=None, the reference's default): tables generated on the device, no host
+    # stream -- outside the timed region, reported beside the seeded headline
+    if args.extras and args.workload == 'cfg1' and args.scaling == 'weak':
+        unseeded = {}
+        for perms_u, steps_u in ((wl.P, max(5, min(args.steps, 20))), (10000, 5)):
+            wl_u = wl if perms_u == wl.P else Workload(args, 'cfg1', 'weak', perms_u, rank, world, local_rank, ctx, torch, np)
+            r_u = run_mode(wl_u, steps_u, 2, ctx, dist, torch, np, be, sharding, world, seed=None)
+            if rank == 0:
+                unseeded['%d_permutations' % perms_u] = {
+                    'ms_per_step': 1e3 * r_u['elapsed'] / steps_u, 'value': wl_u.units_per_step / (r_u['elapsed'] / steps_u),
+                    'unit': 'enrichments/s', 'steps': steps_u, 'stream': r_u['per_rank'][0]['role'],
+                    'gpu_kernel_ms': r_u['per_rank'][0]['gpu_kernel_ms'], 'host_cpu_ms_per_step': r_u['host_cpu_ms']}
+            del r_u
+            if wl_u is not wl:
+                del wl_u
+        if rank == 0:
+            line['unseeded_device_stream'] = dict(unseeded, note='random_seed=None (the reference default: OS entropy, no stream to reproduce): '
+                                                  'i.i.d. uniform permutations generated on the GPU (Philox4x32-10 + Fisher-Yates in LDS); '
+                                                  'the seeded headline above reproduces NumPy\'s MT19937 stream on the host')
     a_dense = wl.sf.neighborhoods if (rank == 0 and args.cpu_perms > 0 and world == 1 and wl.kind == 'cfg1') else None
     b_host = wl.b_host
     del res
@@ -593,7 +613,13 @@ def main():
                 'attributes_per_gpu': wl2.m, 'per_rank': r2['per_rank'], 'exchange': r2['exchange_form'],
                 'amdahl_note': 'the permutation stream is sequential (one draw thread per node, ~1.7-2.2 ms per 1000 permutations): '
                                'a 10 000-permutation step cannot go below that thread\'s time, whatever the rank count'}
-        del wl2, r2
+        r2u = run_mode(wl2, 3, 1, ctx, dist, torch, np, be, sharding, world, seed=None)
+        if rank == 0:
+            extras['configs2_strong_scaling_unseeded'] = {
+                'workload': wl2.name + ', columns np.array_split over %d ranks, random_seed=None (tables generated on every rank\'s device)' % world,
+                'scaling': 'strong', 'steps': 3, 'ms_per_step': 1e3 * r2u['elapsed'] / 3, 'value': wl2.units_per_step / (r2u['elapsed'] / 3),
+                'unit': 'enrichments/s', 'attributes_per_gpu': wl2.m, 'per_rank': r2u['per_rank'], 'exchange': r2u['exchange_form']}
+        del wl2, r2, r2u
         wl4 = Workload(args, 'cfg4', 'weak', 1000, rank, world, local_rank, ctx, torch, np)
         r4 = run_mode(wl4, 1, 1, ctx, dist, torch, np, be, sharding, world)
         if rank == 0:

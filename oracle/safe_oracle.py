@@ -289,9 +289,9 @@ def compute_pvalues(neighborhoods, node2attribute, enrichment_type='auto', neigh
 # ---------------------------------------------------------------------------
 # The device stream of UNSEEDED runs (safepy_amd/csrc/rng.cpp, k_perms_device), restated for the tests.  It has no counterpart
 # to reproduce in the reference -- random_seed=None seeds from OS entropy (safe.py:88, safe_extras.py:46) -- so what is pinned
-# here is the product's own documented algorithm: table row q is a Fisher-Yates shuffle (from the top, like the legacy one) of
-# the movable rows with Philox4x32-10 words (key = the call's 64-bit key, counter = (q, word block, 0x5AFE, 0)) and Lemire's
-# unbiased bounded draw.  The statistical claims (uniform, independent rows) are tested separately.
+# here is the product's own documented algorithm (a scatter shuffle: 64 random buckets, Fisher-Yates inside each, Philox4x32-10
+# words named by counters, Lemire's unbiased bounded draw -- see device_stream_tables).  The statistical claims (uniform,
+# independent rows) are tested separately.
 # ---------------------------------------------------------------------------
 
 def _philox4x32_10(c0, c1, c2, c3, k0, k1):
@@ -308,33 +308,63 @@ def _philox4x32_10(c0, c1, c2, c3, k0, k1):
     return c0, c1, c2, c3
 
 
+def _device_draw(q, b, i, key0, key1):
+    rng_range = i + 1
+    thresh = ((1 << 32) - rng_range) % rng_range
+    w = _philox4x32_10([q], [(b << 16) | (i >> 2)], [0x5AFE], [0], key0, key1)
+    m = int(w[i & 3][0]) * rng_range
+    if (m & 0xFFFFFFFF) >= thresh:
+        return m >> 32
+    r = 0
+    while True:
+        w = _philox4x32_10([q], [(b << 16) | i], [0xFA11], [r], key0, key1)
+        for t in range(4):
+            m = int(w[t][0]) * rng_range
+            if (m & 0xFFFFFFFF) >= thresh:
+                return m >> 32
+        r += 1
+
+
 def device_stream_tables(n, movable, num_permutations, key):
-    """int64 [P, n]: the composed tables safe_perms_create_device generates for `key` (a 64-bit integer)."""
+    """int64 [P, n]: the composed tables safe_perms_create_device generates for `key` (a 64-bit integer).  Row q: every movable
+    position e draws a bucket (six bits of byte e & 3 of word (e >> 2) & 3 of Philox counter (q, e >> 4, 0xB0C7, 0)); buckets
+    keep their elements in ascending order and are shuffled in place by Fisher-Yates from the top with draws from counter
+    (q, bucket << 16 | i >> 2, 0x5AFE, 0), word i & 3 (Lemire's multiply-shift; a rejected word falls back to the words of
+    (q, bucket << 16 | i, 0xFA11, r)); the buckets laid end to end are the permutation."""
     movable = np.asarray(movable).astype(bool)
     mov = np.flatnonzero(movable)
     k = len(mov)
     key0, key1 = int(key) & 0xFFFFFFFF, (int(key) >> 32) & 0xFFFFFFFF
     out = np.tile(np.arange(n, dtype=np.int64), (num_permutations, 1))
-    n_blocks = (k + 3) // 4 + 8                                # (a rejection consumes one more word: a few spare blocks)
-    blocks = np.arange(n_blocks, dtype=np.uint64)
+    if k == 0:
+        return out
+    e = np.arange(k, dtype=np.uint64)
+    n_blocks = (k + 15) // 16
+    # the FIRST word of every Fisher-Yates step of every bucket, in bulk: steps i < bucket size <= k
     for q in range(num_permutations):
-        w = np.stack(_philox4x32_10(np.full(n_blocks, q, dtype=np.uint64), blocks, np.full(n_blocks, 0x5AFE, dtype=np.uint64),
-                                    np.zeros(n_blocks, dtype=np.uint64), key0, key1), axis=1).reshape(-1)
-        words = [int(v) for v in w]
-        at = 0
-        a = list(range(k))
-        for i in range(k - 1, 0, -1):
-            rng_range = i + 1
-            m = words[at] * rng_range
-            at += 1
-            if (m & 0xFFFFFFFF) < rng_range:
-                thresh = ((1 << 32) - rng_range) % rng_range
-                while (m & 0xFFFFFFFF) < thresh:
-                    m = words[at] * rng_range
-                    at += 1
-            j = m >> 32
-            a[i], a[j] = a[j], a[i]
-        out[q, mov] = mov[np.array(a, dtype=np.int64)] if k else mov
+        blocks = np.stack(_philox4x32_10(np.full(n_blocks, q, dtype=np.uint64), np.arange(n_blocks, dtype=np.uint64),
+                                         np.full(n_blocks, 0xB0C7, dtype=np.uint64), np.zeros(n_blocks, dtype=np.uint64), key0, key1), axis=1)
+        word = blocks[(e >> np.uint64(4)).astype(np.int64), ((e >> np.uint64(2)) & np.uint64(3)).astype(np.int64)]
+        bucket = ((word >> (np.uint64(8) * (e & np.uint64(3)))) & np.uint64(63)).astype(np.int64)
+        a = []
+        for b in range(64):
+            xb = [int(v) for v in np.flatnonzero(bucket == b)]
+            size = len(xb)
+            if size >= 2:
+                steps = np.arange(size, dtype=np.uint64)
+                first = np.stack(_philox4x32_10(np.full(size, q, dtype=np.uint64), (np.uint64(b) << np.uint64(16)) | (steps >> np.uint64(2)),
+                                                np.full(size, 0x5AFE, dtype=np.uint64), np.zeros(size, dtype=np.uint64), key0, key1), axis=1)
+                first = first[np.arange(size), (steps & np.uint64(3)).astype(np.int64)]
+                rng_range = steps + np.uint64(1)
+                thresh = (np.uint64(1 << 32) - rng_range) % rng_range
+                m = first * rng_range
+                accepted = (m & np.uint64(0xFFFFFFFF)) >= thresh
+                draws = (m >> np.uint64(32)).astype(np.int64)
+                for i in range(size - 1, 0, -1):
+                    j = int(draws[i]) if accepted[i] else _device_draw(q, b, i, key0, key1)
+                    xb[i], xb[j] = xb[j], xb[i]
+            a.extend(xb)
+        out[q, mov] = mov[np.array(a, dtype=np.int64)]
     return out
 
 

@@ -95,89 +95,131 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 // safe_extras.py:46 seeds from OS entropy, so there is no stream to reproduce).  The reference shuffles the rows in place once
 // per iteration (safe_extras.py:58): cur_q = cur_{q-1} o M_q with independent uniform M_q, and a uniform permutation composed
 // with anything independent of it is uniform and independent of the past -- the tables cur_1 .. cur_P are i.i.d. uniform
-// permutations of the movable rows.  So every table row is generated directly and independently: one lane runs the
-// Fisher-Yates shuffle of one permutation on a 16-bit position array in LDS (steps are dependent LDS round trips, but a
-// thousand permutations run side by side), draws come from Philox4x32-10 keyed by the call's 64-bit key with the counter
-// (permutation, block of four words), bounded without bias (Lemire's multiply-shift with rejection).  Every rank of a
-// sharded run generates the SAME tables from the agreed key: no host thread, no exchange, nothing sequential.
+// permutations of the movable rows.  So every table row is generated directly and independently, one wave per permutation
+// (k_perms_device below: a scatter shuffle, 64 buckets + Fisher-Yates inside each), all random bits from Philox4x32-10 keyed
+// by the call's 64-bit key with counters that name (permutation, element or bucket / step) -- every draw is independent of
+// every other -- and bounded draws without bias (Lemire's multiply-shift with rejection).  Every rank of a sharded run
+// generates the SAME tables from the agreed key: no host thread, no exchange, nothing sequential across permutations.
 // The algorithm is restated in oracle/safe_oracle.py (device_stream_tables) and compared bit for bit.
 // --------------------------------------------------------------------------------------
-struct Philox {
-    uint32_t key0, key1, q, block, w[4];
-    int have;
-    __device__ __forceinline__ void refill() {
-        uint32_t c0 = q, c1 = block, c2 = 0x5AFEu, c3 = 0u, k0 = key0, k1 = key1;
+// Philox4x32-10 (Salmon et al. 2011): four 32-bit words from a 128-bit counter and a 64-bit key
+__device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
+                                              uint32_t (&w)[4]) {
 #pragma unroll
-        for (int r = 0; r < 10; ++r) {
-            const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
-            const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
-            c0 = hi1 ^ c1 ^ k0;
-            c1 = lo1;
-            c2 = hi0 ^ c3 ^ k1;
-            c3 = lo0;
-            k0 += 0x9E3779B9u;
-            k1 += 0xBB67AE85u;
-        }
-        w[0] = c0, w[1] = c1, w[2] = c2, w[3] = c3;
-        ++block;
-        have = 4;
+    for (int r = 0; r < 10; ++r) {
+        const uint32_t hi0 = __umulhi(0xD2511F53u, c0), lo0 = 0xD2511F53u * c0;
+        const uint32_t hi1 = __umulhi(0xCD9E8D57u, c2), lo1 = 0xCD9E8D57u * c2;
+        c0 = hi1 ^ c1 ^ k0;
+        c1 = lo1;
+        c2 = hi0 ^ c3 ^ k1;
+        c3 = lo0;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
     }
-    __device__ __forceinline__ uint32_t next() {
-        if (have == 0) refill();
-        const uint32_t v = have == 4 ? w[0] : have == 3 ? w[1] : have == 2 ? w[2] : w[3];
-        --have;
-        return v;
-    }
-};
+    w[0] = c0, w[1] = c1, w[2] = c2, w[3] = c3;
+}
 
-// one workgroup (one wave) = G permutations; lane g < G shuffles permutation q0 + g in its own LDS array, then the wave
-// writes the G table rows out together
-__global__ __launch_bounds__(64) void k_perms_device(int64_t n, int64_t k, int64_t count, int G, uint32_t key0, uint32_t key1,
+// bucket of element e of permutation q: six bits of a byte of the Philox words of counter (q, e >> 4, 0xB0C7, 0)
+__device__ __forceinline__ uint32_t device_bucket_word(uint32_t q, uint32_t e, uint32_t key0, uint32_t key1, uint32_t &cached_block,
+                                                       uint32_t (&w)[4]) {
+    if ((e >> 4) != cached_block) {
+        cached_block = e >> 4;
+        philox4x32_10(q, cached_block, 0xB0C7u, 0u, key0, key1, w);
+    }
+    const uint32_t word = (e >> 2) & 3u;
+    const uint32_t v = word == 0 ? w[0] : word == 1 ? w[1] : word == 2 ? w[2] : w[3];
+    return (v >> (8u * (e & 3u))) & 63u;
+}
+
+// the draw of step i of bucket b of permutation q: uniform on [0, i] by Lemire's multiply-shift; the word is word (i & 3) of
+// counter (q, b << 16 | i >> 2, 0x5AFE, 0); the few low products that would bias the draw (probability (i + 1) / 2^32) are
+// rejected and the draw falls back to the words of counters (q, b << 16 | i, 0xFA11, r), r = 0, 1, ..., in order
+__device__ __forceinline__ uint32_t device_draw(uint32_t q, uint32_t b, uint32_t i, uint32_t key0, uint32_t key1) {
+    const uint32_t range = i + 1u, thresh = (0u - range) % range;
+    uint32_t w[4];
+    philox4x32_10(q, (b << 16) | (i >> 2), 0x5AFEu, 0u, key0, key1, w);
+    const uint32_t first = (i & 3u) == 0 ? w[0] : (i & 3u) == 1 ? w[1] : (i & 3u) == 2 ? w[2] : w[3];
+    uint64_t m = static_cast<uint64_t>(first) * range;
+    if (static_cast<uint32_t>(m) >= thresh) return static_cast<uint32_t>(m >> 32);
+    for (uint32_t r = 0;; ++r) {
+        philox4x32_10(q, (b << 16) | i, 0xFA11u, r, key0, key1, w);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) {
+            m = static_cast<uint64_t>(w[t]) * range;
+            if (static_cast<uint32_t>(m) >= thresh) return static_cast<uint32_t>(m >> 32);
+        }
+    }
+}
+
+// One wave = one permutation, shuffled in three parallel steps (Rao-Sandelius scatter shuffle): every element draws one of
+// 64 buckets; a stable counting sort groups the elements by bucket (lane l owns a contiguous range of elements, so "stable" =
+// ascending element index: deterministic); lane b then Fisher-Yates-shuffles bucket b in place -- a chain of ~k / 64 dependent
+// LDS steps instead of k.  Buckets laid end to end are a uniform permutation: for a target order, the elements' buckets are
+// determined by the bucket sizes (probability 64^-k) and every bucket must come out in the target's order (1 / size! each),
+// whatever the target.
+__global__ __launch_bounds__(64) void k_perms_device(int64_t n, int64_t k, int64_t count, uint32_t key0, uint32_t key1,
                                                      const int32_t *__restrict__ mov, const int32_t *__restrict__ pos_of,
                                                      int32_t *__restrict__ table, uint16_t *__restrict__ table16, int64_t stride16) {
-    extern __shared__ uint16_t fy[];                                  // [G][kpad]
+    extern __shared__ uint32_t lds32[];                               // hist [64 lanes][64 buckets] u32 | x [kpad] u16
     const int lane = threadIdx.x;
-    const int64_t q0 = static_cast<int64_t>(blockIdx.x) * G, kpad = (k + 1) & ~int64_t(1);
-    const int g_here = static_cast<int>(count - q0 < G ? count - q0 : G);
-    for (int64_t t = lane; t < k; t += 64)
-        for (int g = 0; g < g_here; ++g) fy[g * kpad + t] = static_cast<uint16_t>(t);
+    const uint32_t q = blockIdx.x;
+    uint32_t *hist = lds32;
+    uint16_t *x = reinterpret_cast<uint16_t *>(lds32 + 64 * 64);
+    const uint32_t ku = static_cast<uint32_t>(k), ce = (ku + 63u) / 64u;
+    const uint32_t e0 = min(ku, lane * ce), e1 = min(ku, e0 + ce);
+    uint32_t *my_hist = hist + lane * 64;
+    for (int b = 0; b < 64; ++b) my_hist[b] = 0;
+    uint32_t cached = 0xFFFFFFFFu, w[4] = {0u, 0u, 0u, 0u};
+    for (uint32_t e = e0; e < e1; ++e) my_hist[device_bucket_word(q, e, key0, key1, cached, w)] += 1u;
     __syncthreads();
-    if (lane < g_here && k >= 2) {                                    // (k - 1 wraps for k = 0: nothing to shuffle below two rows)
-        uint16_t *a = fy + lane * kpad;
-        Philox rng{key0, key1, static_cast<uint32_t>(q0 + lane), 0u, {0u, 0u, 0u, 0u}, 0};
-        for (uint32_t i = static_cast<uint32_t>(k) - 1u; i >= 1u; --i) {          // Fisher-Yates from the top, like the legacy shuffle
-            const uint32_t range = i + 1u;
-            uint32_t x = rng.next();
-            uint64_t m = static_cast<uint64_t>(x) * range;
-            if (static_cast<uint32_t>(m) < range) {                                 // Lemire: reject the few low products that would bias
-                const uint32_t thresh = (0u - range) % range;
-                while (static_cast<uint32_t>(m) < thresh) {
-                    x = rng.next();
-                    m = static_cast<uint64_t>(x) * range;
-                }
-            }
-            const uint32_t j = static_cast<uint32_t>(m >> 32);
-            const uint16_t ai = a[i], aj = a[j];
-            a[i] = aj;
-            a[j] = ai;
+    // lane b: size of bucket b, its start (exclusive scan over the buckets), and every lane's first slot inside it
+    uint32_t total = 0;
+    for (int l = 0; l < 64; ++l) total += hist[l * 64 + lane];
+    uint32_t start = total;
+#pragma unroll
+    for (int d = 1; d < 64; d <<= 1) {
+        const uint32_t up = __shfl_up(start, d);
+        if (lane >= d) start += up;
+    }
+    start -= total;
+    uint32_t run = start;
+    for (int l = 0; l < 64; ++l) {
+        const uint32_t c = hist[l * 64 + lane];
+        hist[l * 64 + lane] = run;
+        run += c;
+    }
+    __syncthreads();
+    cached = 0xFFFFFFFFu;
+    for (uint32_t e = e0; e < e1; ++e) {
+        const uint32_t b = device_bucket_word(q, e, key0, key1, cached, w);
+        const uint32_t at = my_hist[b];
+        my_hist[b] = at + 1u;
+        x[at] = static_cast<uint16_t>(e);
+    }
+    __syncthreads();
+    if (total >= 2u) {                                                // Fisher-Yates from the top inside bucket `lane`
+        uint16_t *xb = x + start;
+        for (uint32_t i = total - 1u; i >= 1u; --i) {
+            const uint32_t j = device_draw(q, static_cast<uint32_t>(lane), i, key0, key1);
+            const uint16_t xi = xb[i], xj = xb[j];
+            xb[i] = xj;
+            xb[j] = xi;
         }
     }
     __syncthreads();
     const int64_t stride = n + 1;
-    for (int g = 0; g < g_here; ++g) {
-        const uint16_t *a = fy + g * kpad;
-        int32_t *row = table + (q0 + g) * stride;
-        uint16_t *row16 = table16 ? table16 + (q0 + g) * stride16 : nullptr;
-        for (int64_t r = lane; r < (row16 ? stride16 : stride); r += 64) {
-            int32_t v = static_cast<int32_t>(n);                       // entry n (and the 16-bit row's padding) = the padding row
-            if (r < n) {
-                const int32_t t = pos_of[r];
-                v = t < 0 ? static_cast<int32_t>(r) : mov[a[t]];      // safe_extras.py:58: the row at indx_vals[t] is now old row perm[t]
-            }
-            if (r < stride) row[r] = v;
-            if (row16) row16[r] = static_cast<uint16_t>(v);
+    int32_t *row = table + static_cast<int64_t>(q) * stride;
+    uint16_t *row16 = table16 ? table16 + static_cast<int64_t>(q) * stride16 : nullptr;
+    for (int64_t r = lane; r < (row16 ? stride16 : stride); r += 64) {
+        int32_t v = static_cast<int32_t>(n);                           // entry n (and the 16-bit row's padding) = the padding row
+        if (r < n) {
+            const int32_t t = pos_of[r];
+            v = t < 0 ? static_cast<int32_t>(r) : mov[x[t]];          // safe_extras.py:58: the row at indx_vals[t] is now old row perm[t]
         }
+        if (r < stride) row[r] = v;
+        if (row16) row16[r] = static_cast<uint16_t>(v);
     }
+    (void)count;
 }
 
 // --------------------------------------------------------------------------------------
@@ -569,12 +611,10 @@ static int perms_generate_on_device(safe_perms *p, uint64_t key) {
     hipStream_t gs = ctx->aux_stream;
     SAFE_HIP_CHECK(hipMemcpyAsync(d_mov, staging, h.size() * sizeof(int32_t), hipMemcpyHostToDevice, gs));
     const int64_t kpad = (k + 1) & ~int64_t(1);
-    const size_t per_perm = static_cast<size_t>(std::max<int64_t>(kpad, 2)) * sizeof(uint16_t);
-    const int G = static_cast<int>(std::max<size_t>(1, std::min<size_t>(16, (96 * 1024) / per_perm)));
-    const size_t lds = per_perm * G;
+    const size_t lds = 64 * 64 * sizeof(uint32_t) + static_cast<size_t>(std::max<int64_t>(kpad, 2)) * sizeof(uint16_t);
     SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_perms_device), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
-    hipLaunchKernelGGL(k_perms_device, dim3(ceil_div(count, G)), dim3(64), lds, gs, n, k, count, G, static_cast<uint32_t>(key),
+    hipLaunchKernelGGL(k_perms_device, dim3(count), dim3(64), lds, gs, n, k, count, static_cast<uint32_t>(key),
                        static_cast<uint32_t>(key >> 32), d_mov, d_pos, p->table, p->table16, p->stride16);
     SAFE_HIP_CHECK(hipGetLastError());
     const int64_t n_chunks = stage_count(p);
