@@ -291,14 +291,15 @@ std::vector<int64_t> perms_stage_plan(int64_t count);
 // SAFE_HIP_BITS_SPAN=<n> forces uniform spans.  *span = the longest launch.
 // merge > 1: after the three start-up stages (32, 96, 128 permutations) a launch covers `merge` stages -- fewer,
 // longer launches once the stream is ahead of the kernels.
-static inline std::vector<int64_t> perm_launch_starts(int64_t P, int64_t *span, int merge = 1) {
+static inline std::vector<int64_t> perm_launch_starts(const safe_perms *perms, int64_t *span, int merge = 1) {
+    const int64_t P = perms->count;
     std::vector<int64_t> starts;
     int64_t uniform = 0;
     if (const char *e = getenv("SAFE_HIP_BITS_SPAN")) uniform = std::max<int64_t>(16, atoll(e));
     if (uniform > 0) {
         for (int64_t p = 0; p < P; p += uniform) starts.push_back(p);
     } else {
-        const std::vector<int64_t> plan = perms_stage_plan(P);
+        const std::vector<int64_t> &plan = perms->stages;          // the handle's own stages (host pipeline, or even spans for device tables)
         const int64_t nc = static_cast<int64_t>(plan.size()) - 1;
         for (int64_t c = 0; c < nc; ++c)
             if (c < 3 || merge <= 1 || (c - 3) % merge == 0) starts.push_back(plan[c]);

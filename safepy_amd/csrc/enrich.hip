@@ -2058,7 +2058,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // launch waits for its last stage.
     int merge = 1;
     if (const char *e = getenv("SAFE_HIP_BITS_MERGE")) merge = std::max(1, atoi(e));
-    const std::vector<int64_t> starts = perm_launch_starts(P, &span, merge);
+    const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
@@ -2360,7 +2360,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 #undef PREP
     }
     int64_t span = 1;
-    const std::vector<int64_t> starts = perm_launch_starts(P, &span);
+    const std::vector<int64_t> starts = perm_launch_starts(perms, &span);
     const size_t lds_bytes = ldsf64_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;

@@ -1495,7 +1495,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         q_off[qx + 1] = static_cast<int32_t>(tasks.size());
     }
     int64_t span = 1;
-    const std::vector<int64_t> starts = perm_launch_starts(P, &span);
+    const std::vector<int64_t> starts = perm_launch_starts(perms, &span);
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     void *ws = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + (8 * n_launch + 8) * sizeof(unsigned int), &ws));

@@ -672,6 +672,15 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     p->stream = (p->ring_consumer || device_gen) ? nullptr : draw_stream_new(has_seed ? seed : entropy_seed());
     p->generated = p->swapping = p->enqueued = 0;
     p->stages = perms_stage_plan(num_permutations);
+    if (device_gen) {
+        // no host pipeline to follow: the whole table is there before the first launch, so the launches are even spans of
+        // 128 permutations (the short first stages of the host plan cost 6.5 us per permutation against 3.2 in a full launch)
+        p->stages.clear();
+        for (int64_t q = 0; q < num_permutations; q += kChunk) p->stages.push_back(q);
+        p->stages.push_back(num_permutations);
+        if (p->stages.size() >= 3 && num_permutations - p->stages[p->stages.size() - 2] < kChunk / 4)
+            p->stages.erase(p->stages.end() - 2);                        // a short tail joins its predecessor
+    }
     p->t_created_s = wall_s();
     p->draw_busy_ms = p->drawn_all_ms = p->enqueued_all_ms = p->ring_wait_ms = 0.0;
     const int64_t k = p->k, stride = n + 1, rows = std::max<int64_t>(num_permutations, 1);
