@@ -253,6 +253,11 @@ def mfma_kernel(ctx, np, be):
                   'kernel_ms': ms * launches, 'call_ms': 1e3 * dt, 'algorithmic_ops': ops, 'achieved': tops,
                   'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS, 'i8_slices': slices,
                   'membership_blocks_256x32': blocks, 'block_fill': nbr.nnz / (blocks * 256.0 * 32.0),
+                  # the executed-block rate above counts whole 256 x 32 blocks (27 % fill; since round 3 the kernel skips the
+                  # 32 x 32 pieces without a member, so part of those ops is no longer executed at all); the USEFUL rate counts
+                  # one multiply-add per membership entry, column, permutation and slice
+                  'useful_ops': 2.0 * float(nbr.nnz) * m * slices * (nperm + 1),
+                  'useful_frac_of_peak': 2.0 * float(nbr.nnz) * m * slices * (nperm + 1) / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                   'enrichments_per_s': float(n) * m * nperm / dt,
                   'config5_rank_share_seconds': dt}}
     # the same share with neighborhood_score_type='z-score' (safe_extras.py:19-31): 16-column tiles carrying value digits,
