@@ -92,6 +92,16 @@ def _worker(rank, world, port, tmpdir):
         # gather_nes without device counters (gloo): agrees on the fallback and moves the f64 blocks
         full_again = sharding.gather_nes(None, None, torch.from_numpy(cn), m, nperm, 'both').numpy()
         assert np.array_equal(full_again, want_cn)
+        # gather_outputs: every requested matrix in one call; without device counters every rank agrees on the f64 fallback and
+        # reports it (the device path, one exchange of packed integers for all of them, is tests/test_gpu_multirank.py)
+        report = {}
+        both = sharding.gather_outputs(None, None, {'pvalues_neg': torch.from_numpy(cn / nperm), 'pvalues_pos': torch.from_numpy(cp / nperm)},
+                                       ('pvalues_neg', 'pvalues_pos'), m, nperm, 'both', 0.05, report=report)
+        assert np.array_equal(both['pvalues_neg'].numpy(), want_cn / nperm) and np.array_equal(both['pvalues_pos'].numpy(), want_cp / nperm)
+        assert report['form'] == 'f64 blocks' and report['bytes_received'] > 0
+        # the node-shared permutation stream is a device feature: without a context nothing is shared, and the decision is
+        # remembered per context so that no rank can enter the setup's broadcast alone
+        assert sharding.ensure_shared_stream(None) is False
         # multiple_testing=True under sharding: p-value blocks gathered, full rows adjusted on every rank (the oracle stands in
         # for safe_fdr_adjust), local blocks = slices of the adjusted matrix; untouched outputs stay the rank's own
         p_local = cp / nperm
