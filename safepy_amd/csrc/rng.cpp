@@ -100,7 +100,7 @@ __global__ void k_invert_perms(const int32_t *__restrict__ table, int64_t stride
 // by the call's 64-bit key with counters that name (permutation, element or bucket / step) -- every draw is independent of
 // every other -- and bounded draws without bias (Lemire's multiply-shift with rejection).  Every rank of a sharded run
 // generates the SAME tables from the agreed key: no host thread, no exchange, nothing sequential across permutations.
-// The algorithm is restated in oracle/safe_oracle.py (device_stream_tables) and compared bit for bit.
+// The algorithm is restated by the tests' CPU checker (its device_stream_tables) and compared bit for bit.
 // --------------------------------------------------------------------------------------
 // Philox4x32-10 (Salmon et al. 2011): four 32-bit words from a 128-bit counter and a 64-bit key
 __device__ __forceinline__ void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1,
