@@ -356,12 +356,14 @@ __global__ void k_mfma_colcheck(const unsigned int *__restrict__ cnt, const unsi
 // source-row maps of a span: row 0 = identity (observed score), row 1 + q = permutation p_base + q
 __global__ __launch_bounds__(256) void k_mfma_src(const int32_t *__restrict__ order, int64_t n_src, int64_t n,
                                                   const int32_t *__restrict__ table, int64_t p_base,
-                                                  int32_t *__restrict__ out) {
+                                                  int32_t *__restrict__ out, int dbg_window = 0) {
     const int64_t u = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
     if (u >= n_src) return;
     const int64_t q = blockIdx.y;
     const int32_t node = order[u];
-    out[q * n_src + u] = q == 0 ? node : table[(p_base + q - 1) * (n + 1) + node];
+    int32_t src = q == 0 ? node : table[(p_base + q - 1) * (n + 1) + node];
+    if (dbg_window > 0) src %= dbg_window;                  // diagnostic (SAFE_HIP_MFMA_DBG_WINDOW): every gather inside a small L2-resident window
+    out[q * n_src + u] = src;
 }
 
 // ---------------------------------------------------------------------------------------
@@ -989,6 +991,8 @@ int build_blocks(safe_nbr *nbr) {
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!kbs.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_kb, kbs.data(), kbs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!bits.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS") && !bits.empty())          // diagnostic: every piece empty -> no MFMA is issued (wrong results)
+        SAFE_HIP_CHECK(hipMemset(nbr->bs_bits, 0, bits.size() * sizeof(uint32_t)));
     nbr->blocks_ready = true;
     (void)ctx;
     return SAFE_OK;
@@ -1544,8 +1548,9 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         if (long_launches && c >= 1) SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev[2 * (c - 1) + 1], 0));
         SAFE_TRY(perms_wait(perms, p_limit, ks));
+        static const int dbg_window = getenv("SAFE_HIP_MFMA_DBG_WINDOW") ? atoi(getenv("SAFE_HIP_MFMA_DBG_WINDOW")) : 0;
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
-                           p_base, d_src[c & 1]);
+                           p_base, d_src[c & 1], dbg_window);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
         {
             const int32_t *src_c = d_src[c & 1];
