@@ -175,6 +175,7 @@ struct HypLookup {
     unsigned int *enriched;
     unsigned int *cnt16;       // split form of the matrix-core counts: packed u16 counts [group][position][32][6], else NULL
     unsigned int *xmax;        // split form: largest count of the call (written by the count kernel, read by the emit kernel)
+    int dbg = 0;               // diagnostic builds of the matrix-core permutation kernel (SAFE_HIP_MFMA_DBG; wrong results)
 };
 
 // |nes| > -log10(enrichment_threshold) (safe.py:468-470) for nes = -log10(p), p in [0, 1], restated as a

@@ -400,7 +400,7 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
 // EPI (counts form only): which epilogue this instantiation carries -- 0 = packed u16 counts for k_hyp_emit (the default split
 // form), 1 = plain counts, 2 = table lookup fused into the epilogue.  One kernel with all three kept the fused form's pipelined
 // table values (16 x double2 + nodes + slab offsets) in the register budget of the main loop: 60 VGPRs spilled.
-template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0>
+template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0, bool PREF = true>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
     const unsigned char *__restrict__ bs, int64_t row_bytes, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
@@ -539,7 +539,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 #pragma unroll
                 for (int k = 0; k < 4; ++k) aw_next[k] = bits_w[static_cast<int64_t>(4 * t1 + k) * MF_R];
                 if (gth && more3) src_load = load_src(q3, t3);
-                if (gth && more2) load_rows(src_use, L_load);
+                if (gth && more2 && !(hl.dbg & 2)) load_rows(src_use, L_load);
 
                 const unsigned char *bbuf = lds + buf * BUF + r_base;
                 // this wave's 32 x 32 piece of a block may hold no member at all (42 % of the pieces at configs[4]: a 256-row
@@ -550,23 +550,30 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 bool nz[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) nz[k] = !SKIP || __builtin_amdgcn_ballot_w64(aw[k] != 0u) != 0ull;
-                // B operands of k-step k+1 are read from LDS before the MFMAs of k-step k are issued
-                v4i b_cur[NS], b_nxt[NS];
+                // PF: the B operands of k-step k+1 are read from LDS before the MFMAs of k-step k are issued (two operand sets).
+                // !PF: one operand set, read right before its MFMAs and only for the pieces that hold members -- the SIMD's other
+                // wave covers the LDS latency; the z-score form (seven slices: no room for a second set) always runs this way
+                constexpr bool PF = PREF && !Z;
+                v4i b_cur[NS], b_nxt[PF ? NS : 1];
+                if constexpr (PF) {
 #pragma unroll
-                for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
+                    for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
+                }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    if (k < 3 && !Z) {                               // (z-scores: seven slices -- no room for a second operand set,
-#pragma unroll                                                       //  the other wave of the SIMD covers the LDS latency)
-                        for (int s = 0; s < NS; ++s)
-                            b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
-                    }
-                    if (Z && k > 0) {
+                    if constexpr (PF) {
+                        if (k < 3) {
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+                            for (int s = 0; s < NS; ++s)
+                                b_nxt[PF ? s : 0] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads ahead of this k-step's MFMAs
                     }
-                    __builtin_amdgcn_sched_barrier(0);               // keep the LDS reads ahead of this k-step's MFMAs
                     if (nz[k]) {
+                        if constexpr (!PF) {
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+                        }
                         v4i a;
                         a[0] = static_cast<int>(expand4(aw[k], 16 * h));
                         a[1] = static_cast<int>(expand4(aw[k], 16 * h + 4));
@@ -577,16 +584,16 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     }
                     // a quarter of the next super-step's tile goes to the other buffer while the
                     // matrix pipe works through this k-step
-                    if (gth && more1) store_quarter(L_store, k, buf ^ 1);
-                    if (!Z) {
+                    if (gth && more1 && !(hl.dbg & 1)) store_quarter(L_store, k, buf ^ 1);
+                    if constexpr (PF) {
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
+                        for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[PF ? s : 0];
                     }
                 }
 
                 if constexpr (COUNTS) {
                     // (the counts are written once, after the loop)
-                } else if (t == S - 1) {                             // a score is complete
+                } else if (t == S - 1 && !(hl.dbg & 8)) {            // a score is complete
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         constexpr int NV = Z ? MF_NS : NS;                  // value slices
@@ -622,7 +629,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) aw[k] = aw_next[k];
-                __syncthreads();
+                if (!(hl.dbg & 4)) __syncthreads();
                 q = q1, t = t1;
                 q1 = q2, t1 = t2;
                 q2 = q3, t2 = t3;
@@ -1517,7 +1524,10 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
 
     const size_t lds_bytes = 2 * static_cast<size_t>(4 * n_slices * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    const char *pref_env = getenv("SAFE_HIP_MFMA_PREF");
+    const bool pref = !(pref_env && !strcmp(pref_env, "0"));
     const void *kfn = z               ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>)
+                      : !pref && n_slices == 6 ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS, false, true, 0, false>)
                       : n_slices == 2 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
                       : n_slices == 4 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 4>)
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
@@ -1558,6 +1568,8 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             unsigned int *qctr_c = d_qctr + 8 * c;
             double *ns_c = c == 0 ? out.ns : static_cast<double *>(nullptr);
             HypLookup no_lookup{};
+            static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
+            no_lookup.dbg = mfma_dbg;        // 1: no transposes / LDS stores of the gathered rows, 2: no row gathers, 4: no barrier per super-step, 8: no score completion
             void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
                             (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup};
