@@ -1031,7 +1031,8 @@ __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane,
     u32x4 ca = ids[lane], cb = ids[64 + lane];
     const u32x4 *pc = ids + 128 + lane;
     int b = 0;
-    for (; b + 1 < nblk; b += 2, pc += 128) {
+    constexpr int STEP = GATHER == 3 ? 0 : 128;            // GATHER 3 (diagnostic): every id load re-reads the slice's first blocks (L1 hits)
+    for (; b + 1 < nblk; b += 2, pc += STEP) {
         blk_add8<LV, SHIFT, GATHER>(ca, pc, s0, s1);
         blk_add8<LV, SHIFT, GATHER>(cb, pc + 64, s0, s1);
     }
@@ -1047,7 +1048,7 @@ template <int LV, int CLT, int DBG, bool OBSMEM>
 __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
                                               int lane, int nblk, int np, uint32_t (&g0)[CLT], uint32_t (&g1)[CLT], uint32_t (&l0)[CLT],
                                               uint32_t (&l1)[CLT]) {
-    constexpr int GATHER = (DBG & 1) ? 0 : (DBG & 8) ? 2 : 1;
+    constexpr int GATHER = (DBG & 1) ? 0 : (DBG & 8) ? 2 : (DBG & 16) ? 3 : 1;
     // observed sums of this (word group, slice): computed once per call by k_bits_observed, vertical like the permuted sums
     uint32_t o0[OBSMEM ? 1 : LV], o1[OBSMEM ? 1 : LV];
     if (!OBSMEM) {
@@ -2180,13 +2181,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 15;
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 31;
     const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
                          : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
                          : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>)
                          : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
                          : dbg == 8 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>)
+                         : dbg == 16 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {
