@@ -422,7 +422,12 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     // gather role: thread -> (k-step of the super-step, row quad, 16-byte chunk of the row segment)
     constexpr int CH = 2 * NS, GT = 4 * 8 * CH;
     const bool gth = tid < GT;
-    const int chunk = tid % CH, rq = (tid / CH) % 8, ks_g = tid / (8 * CH);
+    // EVERY thread issues the gather's loads (the 512 - GT threads without a gather role repeat another thread's: same cache
+    // lines, results dropped): with the loads inside `if (gth)` the compiler's wait-count pass had to assume the fewest
+    // outstanding loads at every wait, and a gather wave then waited for the membership words it had requested a moment ago --
+    // a full L2 round trip at the top of every super-step
+    const int gt = tid % GT;
+    const int chunk = gt % CH, rq = (gt / CH) % 8, ks_g = gt / (8 * CH);
     const int s_g = chunk >> 1, half_g = chunk & 1;
     // this thread's LDS write base inside a buffer; column i of its 16 goes to lane slot
     // (i & 3) + 4 * half + 8 * (i >> 2)
@@ -469,6 +474,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             for (int r = 0; r < 16; ++r) cnt[r] = 0;
 
             auto load_src = [&](int q, int t) -> int4 {
+                q = q < n_q ? q : n_q - 1;                           // (look-ahead past the task's end: a valid row of indices, never used)
                 const int kb = kb_list[4 * t + ks_g];
                 return *reinterpret_cast<const int4 *>(srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + 4 * rq);
             };
@@ -512,16 +518,19 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             advance(q1, t1);
             q2 = q1, t2 = t1;
             advance(q2, t2);
-            if (gth) {
+            {
+                // (all look-ahead loads are unconditional -- past the task's end they fetch valid rows nobody uses: a load inside
+                // `if (more)` made the wait-count pass assume the path without it, and every super-step then began with a wait
+                // for the membership words requested a moment earlier)
                 const int4 s0 = load_src(0, 0);
                 load_rows(s0, L_b);
-                if (total > 1) {
-                    const int4 s1 = load_src(q1, t1);
-                    load_rows(s1, L_a);                              // stored during iteration 0
-                }
-                if (total > 2) src_a = load_src(q2, t2);            // gathered at the top of iteration 0
+                const int4 s1 = load_src(q1, t1);
+                load_rows(s1, L_a);                                  // stored during iteration 0
+                src_a = load_src(q2, t2);                            // gathered at the top of iteration 0
+                if (gth) {
 #pragma unroll
-                for (int cw = 0; cw < 4; ++cw) store_quarter(L_b, cw, 0);
+                    for (int cw = 0; cw < 4; ++cw) store_quarter(L_b, cw, 0);
+                }
             }
             uint32_t aw[4];
 #pragma unroll
@@ -534,12 +543,12 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 const int buf = it & 1;
                 q3 = q2, t3 = t2;
                 advance(q3, t3);
-                const bool more1 = it + 1 < total, more2 = it + 2 < total, more3 = it + 3 < total;
+                const bool more1 = it + 1 < total;
                 uint32_t aw_next[4];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) aw_next[k] = bits_w[static_cast<int64_t>(4 * t1 + k) * MF_R];
-                if (gth && more3) src_load = load_src(q3, t3);
-                if (gth && more2 && !(hl.dbg & 2)) load_rows(src_use, L_load);
+                src_load = load_src(q3, t3);
+                load_rows(src_use, L_load);
 
                 const unsigned char *bbuf = lds + buf * BUF + r_base;
                 // this wave's 32 x 32 piece of a block may hold no member at all (42 % of the pieces at configs[4]: a 256-row
@@ -1569,7 +1578,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             double *ns_c = c == 0 ? out.ns : static_cast<double *>(nullptr);
             HypLookup no_lookup{};
             static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
-            no_lookup.dbg = mfma_dbg;        // 1: no transposes / LDS stores of the gathered rows, 2: no row gathers, 4: no barrier per super-step, 8: no score completion
+            no_lookup.dbg = mfma_dbg;        // 1: no transposes / LDS stores of the gathered rows, 4: no barrier per super-step, 8: no score completion
             void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
                             (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup};
