@@ -1194,12 +1194,14 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
         transpose32(m);
         const int64_t c_first = col0 + half * 32;
         const int n_valid = static_cast<int>(mloc - c_first < 32 ? (mloc - c_first > 0 ? mloc - c_first : 0) : 32);
-        unsigned int *pp = gl_counts + c_first * n_pad + spos;
+        // (the OFFSET walks in a vector register pair, the base stays the kernel argument: laundering the pointer itself made it a
+        // generic one, and the 64 updates became flat atomics -- both wait counters, the slower path)
+        int64_t off = c_first * n_pad + spos;
 #pragma unroll
         for (int bit = 0; bit < 32; ++bit) {
-            asm volatile("" : "+v"(pp));
-            if (bit < n_valid && active && m[bit]) atomicAdd(pp, m[bit]);
-            pp += n_pad;
+            asm volatile("" : "+v"(off));
+            if (bit < n_valid && active && m[bit]) atomicAdd(gl_counts + off, m[bit]);
+            off += n_pad;
         }
     }
 }

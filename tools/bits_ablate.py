@@ -20,6 +20,8 @@ def one(P):
     sf.define_neighborhoods()
     nbr = sf._nbr
     b = data['attributes']; n, m = b.shape
+    if os.environ.get('SORT_COLS') == '1':            # experiment: attributes in order of annotation count (dense ones share word groups)
+        b = np.asfortranarray(b[:, np.argsort(np.nansum(b, axis=0), kind='stable')])
     attr = be.Attributes.from_host(ctx, b)
     attr.stats()
     flags = attr.row_flags()
