@@ -754,7 +754,7 @@ int safe_ctx_share_stream(safe_ctx *ctx, const char *name, int local_rank, int l
     SAFE_REQUIRE(ctx->ring == nullptr, "safe_ctx_share_stream: this context already shares a stream (safe_ctx_unshare_stream first)");
     if (local_world <= 1) return SAFE_OK;                      // a node with one rank has nobody to share with
     perms_cache_drop(ctx);
-    return ring_open(name, local_rank, local_world, capacity_bytes, 120.0, &ctx->ring);
+    return ring_open(name, local_rank, local_world, capacity_bytes, 20.0, &ctx->ring);     // (the ranks call this together: 20 s covers their skew)
 }
 
 int safe_ctx_unshare_stream(safe_ctx *ctx) {

@@ -136,7 +136,19 @@ def ensure_shared_stream(ctx, group=None):
     import torch
     token = torch.tensor([int.from_bytes(os.urandom(7), 'little')], dtype=torch.int64, device=_device_for(group))
     dist.broadcast(token, src=0)
-    return ctx.share_stream('%014x' % int(token.item()), local_rank, local_world)
+    try:
+        ok = ctx.share_stream('%014x' % int(token.item()), local_rank, local_world)
+    except Exception:                                  # no /dev/shm, no room, a local rank 0 that never showed up ...
+        ok = False
+    # all or nothing: a node whose ring could not be set up falls back to one stream per rank -- on EVERY rank, or the
+    # collective calls that follow would disagree about who draws
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=_device_for(group))
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+    if int(flag.item()) == 0:
+        if ctx.shared_stream is not None:
+            ctx.unshare_stream()
+        return False
+    return True
 
 
 COUNTER_OUTPUTS = ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary')     # what the integer counters determine (safe.py:532-554, 468-472)
