@@ -240,7 +240,9 @@ std::vector<int64_t> perms_stage_plan(int64_t count) {
     if (count > kFirst) b.push_back(kFirst);
     for (int64_t q = kChunk; q < count; q += kChunk) b.push_back(q);
     const int64_t last = b.back();
-    if (count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
+    static const int tail_rule = getenv("SAFE_HIP_TAIL_STAGE") ? atoi(getenv("SAFE_HIP_TAIL_STAGE")) : 1;
+    if (tail_rule == 1 && count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
+    if (tail_rule == 2 && b.size() >= 3 && count - last < 64) b.pop_back();                   // a short tail joins its predecessor
     b.push_back(count);
     return b;
 }
