@@ -2249,7 +2249,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
             // workgroup to finish.  A few CUs are therefore left out of the grid (SAFE_HIP_BITS_SPARE, default 8 of 256):
             // the median step shrinks by ~3 % at 1000 permutations, ~6 % at 10 000 (tools/step_sweep.sh)
-            int spare = std::min(8, ctx->num_cu / 8);
+            int spare = std::min(16, ctx->num_cu / 8);        // (8 until the kernels got faster than k_permute_cols on 8 CUs: 10 000-permutation step 27.1 -> 26.3 ms with 16)
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
