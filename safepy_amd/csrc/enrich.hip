@@ -794,14 +794,32 @@ __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict
     const uint4 *src = reinterpret_cast<const uint4 *>(cur16 + (p0 + q) * stride16);
     for (int64_t v = threadIdx.x; v < stride16 / 8; v += 256) reinterpret_cast<uint4 *>(row)[v] = src[v];
     __syncthreads();
+    // eight entries per thread and trip: one 16-byte load of ids, eight LDS look-ups, one 16-byte store (2-byte global
+    // accesses made this kernel as slow as the main one once that got faster: it runs on the few CUs left to it)
     const int64_t e0 = static_cast<int64_t>(blockIdx.x) * 4096;
-#pragma unroll 4
-    for (int j = 0; j < 16; ++j) {
-        const int64_t e = e0 + j * 256 + threadIdx.x;
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        const int64_t e = e0 + (j * 256 + threadIdx.x) * 8;
         if (e >= entries_pad) break;
-        uint32_t v = pad_off;
-        if (e < entries) v = static_cast<uint32_t>(row[sell_col2[e] >> 1]) << 3;
-        out[q * entries_pad + e] = static_cast<uint16_t>(v);
+        uint4 o;
+        if (e + 8 <= entries) {
+            const uint4 c = *reinterpret_cast<const uint4 *>(sell_col2 + e);
+            const uint32_t a0 = row[(c.x & 0xFFFFu) >> 1], a1 = row[c.x >> 17], a2 = row[(c.y & 0xFFFFu) >> 1], a3 = row[c.y >> 17];
+            const uint32_t a4 = row[(c.z & 0xFFFFu) >> 1], a5 = row[c.z >> 17], a6 = row[(c.w & 0xFFFFu) >> 1], a7 = row[c.w >> 17];
+            o.x = (a0 << 3) | (a1 << 19);
+            o.y = (a2 << 3) | (a3 << 19);
+            o.z = (a4 << 3) | (a5 << 19);
+            o.w = (a6 << 3) | (a7 << 19);
+        } else {
+            uint32_t v[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) v[u] = e + u < entries ? static_cast<uint32_t>(row[sell_col2[e + u] >> 1]) << 3 : pad_off;
+            o.x = (v[0] & 0xFFFFu) | (v[1] << 16);
+            o.y = (v[2] & 0xFFFFu) | (v[3] << 16);
+            o.z = (v[4] & 0xFFFFu) | (v[5] << 16);
+            o.w = (v[6] & 0xFFFFu) | (v[7] << 16);
+        }
+        *reinterpret_cast<uint4 *>(out + q * entries_pad + e) = o;
     }
 }
 
