@@ -1155,12 +1155,15 @@ __device__ __forceinline__ void hyp_emit_rows(const unsigned int *__restrict__ s
 template <int UN, bool TAIL>
 __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict__ cnt16, int64_t n_padr, int64_t n_grp,
                                                   const int4 *__restrict__ rows, const int2 *__restrict__ tasks, int64_t mloc,
-                                                  HypLookup hl, int lds_entries) {
+                                                  HypLookup hl, int lds_entries, int order) {
     extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
     double2 *slab = reinterpret_cast<double2 *>(emit_lds);
     const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int c = lane & 31, hh = lane >> 5;
-    const int2 task = tasks[blockIdx.y];
+    // order 0: the column blocks of a task are neighbours in dispatch order; 1 / 2: all tasks of one column block, then the
+    // next block (1: last block first -- the counts the matrix-core kernel wrote last are read first, out of the memory-side cache)
+    const unsigned int cblk = order == 0 ? blockIdx.x : order == 1 ? gridDim.y - 1 - blockIdx.y : blockIdx.y;
+    const int2 task = tasks[order == 0 ? blockIdx.y : blockIdx.x];
     const int nid = rows[task.x].z;
     const uint32_t xc = min(static_cast<uint32_t>(*hl.xmax) + 1u, static_cast<uint32_t>(hl.xs));
     const uint32_t n_kid = static_cast<uint32_t>(hl.n_kid), xs = static_cast<uint32_t>(hl.xs);
@@ -1178,7 +1181,7 @@ __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict
         }
         __syncthreads();
     }
-    const int64_t grp = static_cast<int64_t>(blockIdx.x) * 8 + wave;
+    const int64_t grp = static_cast<int64_t>(cblk) * 8 + wave;
     if (grp >= n_grp) return;
     int64_t col[3];
     uint32_t kofs[3];
@@ -1381,14 +1384,16 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                 // the timed kernel of this form is the HBM-bound one
     const char *un_env = getenv("SAFE_HIP_EMIT_UN");
     const int un = un_env ? atoi(un_env) : EMIT_UN;
-    const dim3 egrid(ceil_div(n_grp, 8), st->tasks.size());
+    const char *order_env = getenv("SAFE_HIP_EMIT_ORDER");
+    const int order = order_env ? atoi(order_env) : 0;
+    const dim3 egrid = order == 0 ? dim3(ceil_div(n_grp, 8), st->tasks.size()) : dim3(st->tasks.size(), ceil_div(n_grp, 8));
     const int lds_entries = lds_bytes / static_cast<int>(sizeof(double2));
 #define EMIT_LAUNCH(U, T)                                                                                                              \
     do {                                                                                                                            \
         SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit<U, T>), hipFuncAttributeMaxDynamicSharedMemorySize, \
                                            lds_bytes));                                                                             \
         hipLaunchKernelGGL((k_hyp_emit<U, T>), egrid, dim3(512), lds_bytes, ctx->stream, st->cnt16, n_padr, n_grp, d_rows, d_tasks,    \
-                           st->cs.mloc, hl, lds_entries);                                                                           \
+                           st->cs.mloc, hl, lds_entries, order);                                                                      \
     } while (0)
     const char *tail_env = getenv("SAFE_HIP_EMIT_TAIL");
     const bool tail = !(tail_env && !strcmp(tail_env, "0"));
