@@ -40,40 +40,69 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     __syncthreads();
     unsigned int c_nan = 0, c_other = 0, c_nonint = 0;
     double mx = 0.0, sum = 0.0;
-    const int64_t n_round = r_begin + (r_end - r_begin + RL - 1) / RL * RL;    // every thread runs the same trip count (ballots)
-    for (int64_t i = r_begin + ry; i < n_round; i += RL) {
-        bool has = false;
-        if (i < r_end && j < m) {
-            const double v = load_attr<T>(raw, i * rs + j * cs);
-            if (v != v) {
-                ++c_nan;
-            } else {
-                has = true;
-                sum += v;
-                if (v != 0.0 && v != 1.0) ++c_other;
-                if (v != floor(v)) ++c_nonint;
-                const double a = fabs(v);
-                if (a > mx) mx = a;
-            }
+    // four rows per thread and trip, all four loads issued before the first is used (a trip is one memory latency, not four);
+    // every thread runs the same trip count (ballots)
+    constexpr int UN = 4;
+    const int64_t n_round = r_begin + (r_end - r_begin + UN * RL - 1) / (UN * RL) * (UN * RL);
+    for (int64_t i0 = r_begin + ry; i0 < n_round; i0 += UN * RL) {
+        double v[UN];
+        bool inb[UN];
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t i = i0 + u * RL;
+            inb[u] = i < r_end && j < m;
+            v[u] = inb[u] ? load_attr<T>(raw, i * rs + j * cs) : 0.0;
         }
-        const unsigned long long bal = __ballot(has);
-        if (GC == 1) {
-            // the wave holds 64 consecutive rows starting at i - lane: two bitmap words, owned by this wave
-            const int64_t r0 = i - lane;
-            if (lane == 0 && bal) {
-                if (r0 < r_end) s_bits[r0 >> 5] |= static_cast<unsigned int>(bal);
-                if (r0 + 32 < r_end) s_bits[(r0 >> 5) + 1] |= static_cast<unsigned int>(bal >> 32);
+#pragma unroll
+        for (int u = 0; u < UN; ++u) {
+            const int64_t i = i0 + u * RL;
+            bool has = false;
+            if (inb[u]) {
+                if (v[u] != v[u]) {
+                    ++c_nan;
+                } else {
+                    has = true;
+                    sum += v[u];
+                    if (v[u] != 0.0 && v[u] != 1.0) ++c_other;
+                    if (v[u] != floor(v[u])) ++c_nonint;
+                    const double a = fabs(v[u]);
+                    if (a > mx) mx = a;
+                }
             }
-        } else {
-            // the wave holds ONE row (i) across 64 columns
-            if (lane == 0 && bal && i < r_end) atomicOr(&s_bits[i >> 5], 1u << (i & 31));
+            const unsigned long long bal = __ballot(has);
+            if (GC == 1) {
+                // the wave holds 64 consecutive rows starting at i - lane: two bitmap words, owned by this wave
+                const int64_t r0 = i - lane;
+                if (lane == 0 && bal) {
+                    if (r0 < r_end) s_bits[r0 >> 5] |= static_cast<unsigned int>(bal);
+                    if (r0 + 32 < r_end) s_bits[(r0 >> 5) + 1] |= static_cast<unsigned int>(bal >> 32);
+                }
+            } else {
+                // the wave holds ONE row (i) across 64 columns
+                if (lane == 0 && bal && i < r_end) atomicOr(&s_bits[i >> 5], 1u << (i & 31));
+            }
         }
     }
-    s_sum[threadIdx.x] = sum;
-    s_max[threadIdx.x] = mx;
-    s_nan[threadIdx.x] = c_nan;
-    s_other[threadIdx.x] = c_other;
-    s_nonint[threadIdx.x] = c_nonint;
+    if (GC == 1) {
+        // one column per workgroup: the 256 partial results meet by wave shuffles, then four per column in LDS
+        // (a single thread adding 256 x 5 LDS values took longer than the loads)
+        for (int off = 32; off; off >>= 1) {
+            sum += __shfl_down(sum, off);
+            const double o = __shfl_down(mx, off);
+            mx = o > mx ? o : mx;
+            c_nan += __shfl_down(c_nan, off);
+            c_other += __shfl_down(c_other, off);
+            c_nonint += __shfl_down(c_nonint, off);
+        }
+    }
+    const int slot = GC == 1 ? (lane == 0 ? static_cast<int>(threadIdx.x >> 6) : -1) : static_cast<int>(threadIdx.x);
+    if (slot >= 0) {
+        s_sum[slot] = sum;
+        s_max[slot] = mx;
+        s_nan[slot] = c_nan;
+        s_other[slot] = c_other;
+        s_nonint[slot] = c_nonint;
+    }
     __syncthreads();
     for (int64_t w = w_begin + threadIdx.x; w < w_end; w += 256) {
         const unsigned int mine = s_bits[w];
@@ -82,7 +111,7 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     if (ry == 0 && j < m) {
         double total = 0.0, tmx = 0.0;
         unsigned long long t_nan = 0, t_other = 0, t_nonint = 0;
-        for (int r = 0; r < RL; ++r) {
+        for (int r = 0; r < (GC == 1 ? 4 : RL); ++r) {
             const int t = GC == 1 ? r : r * GC + cx;
             total += s_sum[t];
             if (s_max[t] > tmx) tmx = s_max[t];
@@ -102,32 +131,38 @@ __global__ __launch_bounds__(256) void k_attr_stats(const void *__restrict__ raw
     }
 }
 
-// acc[0] = sum of acc[4 .. 68), acc[2] = sum of acc[68 .. 132)  (one wave)
-__global__ __launch_bounds__(64) void k_fold_parts(unsigned long long *__restrict__ acc) {
-    unsigned long long a = acc[4 + threadIdx.x], b = acc[68 + threadIdx.x];
-    for (int off = 32; off; off >>= 1) {
-        a += __shfl_down(a, off);
-        b += __shfl_down(b, off);
-    }
-    if (threadIdx.x == 0) {
-        acc[0] = a;
-        acc[2] = b;
-    }
-}
-
-__global__ __launch_bounds__(256) void k_max_u32(const unsigned int *__restrict__ v, int64_t count, unsigned long long *__restrict__ out) {
+// One workgroup finishes the pass: acc[0] = sum of acc[4 .. 68) (#values outside {0,1}), acc[2] = sum of acc[68 .. 132)
+// (#non-integers), acc[1] = largest NaN count of a column, row bitmap -> one byte per row; the four words are copied behind
+// the flags (tail) so that ONE device-to-host copy brings everything the host needs.
+__global__ __launch_bounds__(256) void k_stats_finish(unsigned long long *__restrict__ acc, const unsigned int *__restrict__ col_nan, int64_t m,
+                                                      const unsigned int *__restrict__ bits, int64_t n, uint8_t *__restrict__ bytes,
+                                                      unsigned long long *__restrict__ tail) {
+    __shared__ unsigned int s_mx[4];
+    __shared__ unsigned long long s_fold[2];
     unsigned int mx = 0;
-    for (int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x; i < count; i += static_cast<int64_t>(gridDim.x) * 256) mx = v[i] > mx ? v[i] : mx;
+    for (int64_t i = threadIdx.x; i < m; i += 256) mx = col_nan[i] > mx ? col_nan[i] : mx;
     for (int off = 32; off; off >>= 1) {
         const unsigned int o = __shfl_down(mx, off);
         mx = o > mx ? o : mx;
     }
-    if ((threadIdx.x & 63) == 0) atomicMax(out, static_cast<unsigned long long>(mx));
-}
-
-__global__ void k_bits_to_bytes(const unsigned int *__restrict__ bits, int64_t n, uint8_t *__restrict__ bytes) {
-    const int64_t i = static_cast<int64_t>(blockIdx.x) * blockDim.x + threadIdx.x;
-    if (i < n) bytes[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+    if ((threadIdx.x & 63) == 0) s_mx[threadIdx.x >> 6] = mx;
+    if (threadIdx.x < 64) {
+        unsigned long long a = acc[4 + threadIdx.x], b = acc[68 + threadIdx.x];
+        for (int off = 32; off; off >>= 1) {
+            a += __shfl_down(a, off);
+            b += __shfl_down(b, off);
+        }
+        if (threadIdx.x == 0) s_fold[0] = a, s_fold[1] = b;
+    }
+    for (int64_t i = threadIdx.x; i < n; i += 256) bytes[i] = (bits[i >> 5] >> (i & 31)) & 1u;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int m01 = s_mx[0] > s_mx[1] ? s_mx[0] : s_mx[1], m23 = s_mx[2] > s_mx[3] ? s_mx[2] : s_mx[3];
+        tail[0] = acc[0] = s_fold[0];
+        tail[1] = acc[1] = m01 > m23 ? m01 : m23;
+        tail[2] = acc[2] = s_fold[1];
+        tail[3] = acc[3];
+    }
 }
 
 // one wave per column: rows holding a 1, ascending, by ballot compaction
@@ -247,12 +282,15 @@ int attr_build_support(safe_attr *attr) {
     return SAFE_OK;
 }
 
+// device block of the row flags: one byte per row, then (8-aligned) four result words of the statistics pass
+static size_t flags_block_bytes(int64_t n) { return static_cast<size_t>(ceil_div(n, 8)) * 8 + 32; }
+
 int safe_attr_prepare(safe_attr *attr) {
     if (attr->stats_ready) return SAFE_OK;
     safe_ctx *ctx = attr->ctx;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
     const int64_t n = attr->n, m = attr->m;
-    const size_t flag_bytes = static_cast<size_t>(ceil_div(n, 4)) * 4;
+    const size_t flag_bytes = flags_block_bytes(n), tail_off = flag_bytes - 32;
     // temporaries in one grow-only scratch block of the context (five hipMalloc / hipFree pairs per call cost more
     // than the kernel): accumulators u64 [4 + 2 x 64 partial sums] | row bitmap u32 [n_words] | NaN count per column u32 [m]
     const int64_t n_words = (n + 31) / 32;
@@ -265,11 +303,11 @@ int safe_attr_prepare(safe_attr *attr) {
     unsigned int *d_colnan = d_rowbits + n_words;
     SAFE_HIP_CHECK(hipMemsetAsync(tmp, 0, tmp_bytes, ctx->stream));
     uint8_t *flags = nullptr;
-    SAFE_TRY(dev_alloc(&flags, flag_bytes));
-    if (!attr->col_sum) SAFE_TRY(dev_alloc(&attr->col_sum, m));
-    SAFE_HIP_CHECK(hipMemsetAsync(attr->col_sum, 0, m * sizeof(double), ctx->stream));
+    SAFE_TRY(ctx_block_alloc(ctx, flag_bytes, reinterpret_cast<void **>(&flags)));
+    if (!attr->col_sum) SAFE_TRY(ctx_block_alloc(ctx, static_cast<size_t>(m) * sizeof(double), reinterpret_cast<void **>(&attr->col_sum)));
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
     const bool c_order = attr->col_stride == 1 && m > 1;
+    if (c_order) SAFE_HIP_CHECK(hipMemsetAsync(attr->col_sum, 0, m * sizeof(double), ctx->stream));   // (several row chunks add up)
 #define STATS(T, GC, RPB)                                                                                          \
     do {                                                                                                           \
         if (n_words * sizeof(unsigned int) > 32 * 1024)                                                            \
@@ -293,16 +331,16 @@ int safe_attr_prepare(safe_attr *attr) {
         else STATS(double, 1, n);
     }
 #undef STATS
-    hipLaunchKernelGGL(k_fold_parts, dim3(1), dim3(64), 0, ctx->stream, d_acc);
-    hipLaunchKernelGGL(k_max_u32, dim3(static_cast<unsigned>(std::min<int64_t>(ceil_div(m, 256), 64))), dim3(256), 0, ctx->stream,
-                       d_colnan, m, d_acc + 1);
-    hipLaunchKernelGGL(k_bits_to_bytes, dim3(ceil_div(n, 256)), dim3(256), 0, ctx->stream, d_rowbits, n, flags);
+    hipLaunchKernelGGL(k_stats_finish, dim3(1), dim3(256), 0, ctx->stream, d_acc, d_colnan, m, d_rowbits, n, flags,
+                       reinterpret_cast<unsigned long long *>(flags + tail_off));
     SAFE_HIP_CHECK(hipGetLastError());
-    unsigned long long h_acc[4];
-    SAFE_HIP_CHECK(hipMemcpyAsync(h_acc, d_acc, sizeof(h_acc), hipMemcpyDeviceToHost, ctx->stream));
-    std::vector<uint8_t> h_flags(flag_bytes);
-    SAFE_HIP_CHECK(hipMemcpyAsync(h_flags.data(), flags, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));
+    void *pinned = nullptr;                                   // flags and the four result words in one DMA copy
+    SAFE_TRY(ctx_pinned(ctx, flag_bytes, &pinned));
+    SAFE_HIP_CHECK(hipMemcpyAsync(pinned, flags, flag_bytes, hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+    const uint8_t *h_flags = static_cast<const uint8_t *>(pinned);
+    unsigned long long h_acc[4];
+    memcpy(h_acc, h_flags + tail_off, sizeof(h_acc));
     attr->n_other = static_cast<int64_t>(h_acc[0]);
     attr->max_nan_col = static_cast<int64_t>(h_acc[1]);
     attr->n_non_integer = static_cast<int64_t>(h_acc[2]);
@@ -310,15 +348,15 @@ int safe_attr_prepare(safe_attr *attr) {
     memcpy(&mx, &h_acc[3], sizeof(double));
     attr->max_abs = mx;
     if (!attr->flags_ready) {
-        if (attr->row_flags) (void)hipFree(attr->row_flags);
+        if (attr->row_flags) ctx_block_free(ctx, attr->row_flags, flag_bytes);
         attr->row_flags = flags;
         attr->flags_ready = true;
         int64_t cnt = 0;
         for (int64_t i = 0; i < n; ++i) cnt += h_flags[i] != 0;
         attr->n_rows_with_value = cnt;
-        attr->h_row_flags.assign(h_flags.begin(), h_flags.begin() + n);
+        attr->h_row_flags.assign(h_flags, h_flags + n);
     } else {
-        (void)hipFree(flags);    // caller supplied global flags (sharded run): keep them
+        ctx_block_free(ctx, flags, flag_bytes);    // caller supplied global flags (sharded run): keep them
     }
     attr->stats_ready = true;
     return SAFE_OK;
@@ -502,8 +540,8 @@ int safe_attr_destroy(safe_attr *attr) {
     (void)hipSetDevice(attr->ctx->device);
     (void)safe_stream_sync(attr->ctx->stream);
     if (attr->owns_raw) (void)hipFree(const_cast<void *>(attr->raw));
-    (void)hipFree(attr->row_flags);
-    (void)hipFree(attr->col_sum);
+    ctx_block_free(attr->ctx, attr->row_flags, flags_block_bytes(attr->n));
+    ctx_block_free(attr->ctx, attr->col_sum, static_cast<size_t>(attr->m) * sizeof(double));
     (void)hipFree(attr->sup_ptr);
     (void)hipFree(attr->sup_row);
     delete attr;
@@ -538,8 +576,8 @@ int safe_attr_set_row_flags(safe_attr *attr, const uint8_t *flags_host) {
     SAFE_REQUIRE(attr && flags_host, "safe_attr_set_row_flags: NULL argument");
     safe_ctx *ctx = attr->ctx;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t flag_bytes = static_cast<size_t>(ceil_div(attr->n, 4)) * 4;
-    if (!attr->row_flags) SAFE_TRY(dev_alloc(&attr->row_flags, flag_bytes));
+    const size_t flag_bytes = flags_block_bytes(attr->n);
+    if (!attr->row_flags) SAFE_TRY(ctx_block_alloc(ctx, flag_bytes, reinterpret_cast<void **>(&attr->row_flags)));
     std::vector<uint8_t> tmp(flag_bytes, 0);
     int64_t cnt = 0;
     for (int64_t i = 0; i < attr->n; ++i) {

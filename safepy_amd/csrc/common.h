@@ -86,6 +86,7 @@ struct safe_ctx {
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     std::vector<hipEvent_t> ev_timing, ev_plain;   // reused per-launch events (creating 20 per call costs ~0.1 ms)
+    std::vector<std::pair<size_t, void *>> block_cache;   // small device blocks of destroyed handles (ctx_block_alloc)
     static constexpr int N_SCRATCH = 12;
     void *scratch[N_SCRATCH] = {};
     size_t scratch_bytes[N_SCRATCH] = {};
@@ -100,6 +101,10 @@ int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out);
 // `count` reusable events of the context (timing-enabled, or hipEventDisableTiming); valid until the next request of the same kind
 int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out);
 void perms_cache_drop(safe_ctx *ctx);   // frees ctx->perm_cache (rng.cpp)
+// small per-handle device blocks (row flags, column sums): hipMalloc + hipFree cost tens of microseconds each and a handle
+// is made per compute_pvalues pass, so freed blocks wait in the context for the next handle of the same shape
+int ctx_block_alloc(safe_ctx *ctx, size_t bytes, void **out);
+void ctx_block_free(safe_ctx *ctx, void *p, size_t bytes);
 
 // RAII-less device buffer helper: all frees go through the owning handle's destroy.
 template <typename T>

@@ -74,6 +74,35 @@ int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out) {
     return SAFE_OK;
 }
 
+static size_t block_class(size_t bytes) { return (std::max<size_t>(bytes, 1) + 255) / 256 * 256; }
+
+int ctx_block_alloc(safe_ctx *ctx, size_t bytes, void **out) {
+    const size_t want = block_class(bytes);
+    for (size_t i = 0; i < ctx->block_cache.size(); ++i)
+        if (ctx->block_cache[i].first == want) {
+            *out = ctx->block_cache[i].second;
+            ctx->block_cache.erase(ctx->block_cache.begin() + static_cast<std::ptrdiff_t>(i));
+            return SAFE_OK;
+        }
+    hipError_t e = hipMalloc(out, want);
+    if (e != hipSuccess) {
+        safe_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
+        return SAFE_E_NOMEM;
+    }
+    return SAFE_OK;
+}
+
+// the caller has synchronised every stream that may still touch the block
+void ctx_block_free(safe_ctx *ctx, void *p, size_t bytes) {
+    if (!p) return;
+    const size_t have = block_class(bytes);
+    if (have > (8u << 20) || ctx->block_cache.size() >= 32) {
+        (void)hipFree(p);
+        return;
+    }
+    ctx->block_cache.emplace_back(have, p);
+}
+
 int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out) {
     std::vector<hipEvent_t> &pool = timing ? ctx->ev_timing : ctx->ev_plain;
     while (pool.size() < count) {
@@ -187,6 +216,7 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     for (hipEvent_t e : ctx->ev_plain) (void)hipEventDestroy(e);
     for (int i = 0; i < safe_ctx::N_SCRATCH; ++i)
         if (ctx->scratch[i]) (void)hipFree(ctx->scratch[i]);
+    for (auto &b : ctx->block_cache) (void)hipFree(b.second);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
