@@ -1180,16 +1180,22 @@ __global__ __launch_bounds__(256) void k_bits_observed(int64_t n, const int32_t 
     else if (wdt <= 248) observed_wave<8>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
     else if (wdt <= 504) observed_wave<9>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
     else observed_wave<BT_LV>(ids, lane, wdt >> 3, my_obs, oo0, oo1);
-    const int32_t row = sell_row[s * 64 + lane];
-    if (ns_out && row >= 0) {
-        const int64_t obase = static_cast<int64_t>(row) * mloc;
+    if (ns_out) {
+        // ns (safe.py:514-515) is [node][attribute]: the lanes hold one row each, so the 64 x 64 values of the wave go through
+        // LDS (u16, rows 33 dwords apart: no bank conflicts either way) and leave as 512 contiguous bytes of one row per store
+        const int32_t row = sell_row[s * 64 + lane];
+        uint16_t *tile = reinterpret_cast<uint16_t *>(lds + 2 * ((n + 2) & ~int64_t(1)) + 4) + wave * (64 * 66);
 #pragma unroll
         for (int half = 0; half < 2; ++half)
-            for (int bit = 0; bit < 32; ++bit) {
-                const int64_t jc = wg * 64 + half * 32 + bit;
-                if (jc >= mloc) break;
-                ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(oo1, bit) : vextract<BT_LV>(oo0, bit));
-            }
+#pragma unroll
+            for (int bit = 0; bit < 32; ++bit)
+                tile[lane * 66 + half * 32 + bit] = static_cast<uint16_t>(half ? vextract<BT_LV>(oo1, bit) : vextract<BT_LV>(oo0, bit));
+        const int64_t jc = wg * 64 + lane;
+#pragma unroll 8
+        for (int r = 0; r < 64; ++r) {
+            const int32_t row_r = __shfl(row, r);
+            if (row_r >= 0 && jc < mloc) ns_out[static_cast<int64_t>(row_r) * mloc + jc] = static_cast<double>(tile[r * 66 + lane]);
+        }
     }
 }
 
@@ -2222,9 +2228,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         // observed sums of every (word group, slice), once: the compare operand of every task, and `ns`
         SAFE_TRY(ctx_scratch(ctx, 7, static_cast<size_t>(n_wg) * nbr->n_slices * 2 * BT_LV * 64 * sizeof(uint32_t),
                              reinterpret_cast<void **>(&d_obs)));
+        const size_t lds_obs = lds_pre + (out.ns ? 4 * 64 * 66 * sizeof(uint16_t) : 0);            // + the waves' transposition tiles
         SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_bits_observed), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds_pre)));
-        hipLaunchKernelGGL(k_bits_observed, dim3(n_wg, ceil_div(nbr->n_slices, 4)), dim3(256), lds_pre, ctx->stream, n, nbr->sell_row,
+                                           static_cast<int>(lds_obs)));
+        hipLaunchKernelGGL(k_bits_observed, dim3(n_wg, ceil_div(nbr->n_slices, 4)), dim3(256), lds_obs, ctx->stream, n, nbr->sell_row,
                            nbr->slice_off, nbr->slice_width, nbr->sell_col2b, nbr->n_slices, d_bits, mloc, d_obs, out.ns);
         SAFE_HIP_CHECK(hipGetLastError());
     }

@@ -237,8 +237,27 @@ std::vector<int64_t> perms_stage_plan(int64_t count) {
     std::vector<int64_t> b;
     b.push_back(0);
     if (count <= 0) return b;
-    if (count > kFirst) b.push_back(kFirst);
-    for (int64_t q = kChunk; q < count; q += kChunk) b.push_back(q);
+    // SAFE_HIP_STAGES="32,96,224": the first boundaries by hand (A/B of the pipeline's fill), 128-permutation stages after them
+    static const std::vector<int64_t> head = [] {
+        std::vector<int64_t> h;
+        if (const char *e = getenv("SAFE_HIP_STAGES"))
+            for (const char *c = e; *c;) {
+                char *end = nullptr;
+                const long long v = strtoll(c, &end, 10);
+                if (end == c) break;
+                if (v > (h.empty() ? 0 : h.back())) h.push_back(v);
+                c = *end ? end + 1 : end;
+            }
+        return h;
+    }();
+    if (!head.empty()) {
+        for (int64_t q : head)
+            if (q < count) b.push_back(q);
+        for (int64_t q = head.back() + kChunk; q < count; q += kChunk) b.push_back(q);
+    } else {
+        if (count > kFirst) b.push_back(kFirst);
+        for (int64_t q = kChunk; q < count; q += kChunk) b.push_back(q);
+    }
     const int64_t last = b.back();
     static const int tail_rule = getenv("SAFE_HIP_TAIL_STAGE") ? atoi(getenv("SAFE_HIP_TAIL_STAGE")) : 1;
     if (tail_rule == 1 && count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
