@@ -119,6 +119,18 @@ static inline int dev_alloc(T **p, size_t count) {
     return SAFE_OK;
 }
 
+struct BitsQueues {
+    int off[9];                                                           // tasks [off[q], off[q+1]) belong to queue q
+};
+// Task lists of the bit-sliced permutation kernel for one launch plan (launch_bits): a function of the membership structure and of
+// `key` only, so the handle keeps the last one (building them took 90 us of every compute_pvalues pass)
+struct BitsTaskPlan {
+    std::vector<int64_t> key;
+    std::vector<int4> tasks;                                              // the lists back to back
+    std::vector<int64_t> list_span, list_first, list_count, launch_list;
+    std::vector<BitsQueues> list_queues;
+};
+
 // Membership structure.  Canonical form: bit matrix; derived: CSR and SELL-64 (sliced
 // ELLPACK with rows sorted by descending count so each 64-row slice is nearly uniform).
 struct safe_nbr {
@@ -141,6 +153,7 @@ struct safe_nbr {
     uint16_t *sell_col2 = nullptr;  // [sell_entries + 1024] 2*column id as u16 (n < 32768 only): LDS byte offsets of a u16 table
     uint16_t *sell_col2b = nullptr; // the same list in blocked order: 8 members of a lane adjacent (one 16-byte load per lane and block)
     std::vector<int32_t> h_slice_width;
+    BitsTaskPlan bits_plan;         // (launch_bits' cache)
     std::vector<int64_t> h_slice_off;
     std::vector<int32_t> h_row_count;   // host copy of per-row counts
     double *dist = nullptr;         // optional [n][n]

@@ -1233,10 +1233,6 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
 // WPS = waves per SIMD the kernel is built for: 4 (128 registers; every class keeps its observed sums in registers and counts
 // with CL levels) or 5 (96 registers: the classes of more than 56 members count with five levels -- their tasks hold at most
 // 31 permutations -- and re-read the observed sums; five workgroups per CU when T fits five times).
-struct BitsQueues {
-    int off[9];                                                           // tasks [off[q], off[q+1]) belong to queue q
-};
-
 template <int CL, int DBG, int WPS = 4>
 __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
@@ -2162,24 +2158,33 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         return out;
     };
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
-    std::vector<int4> tasks;                             // the lists back to back
-    std::vector<int64_t> list_span, list_first, list_count, launch_list(std::max<int64_t>(n_launch, 1), 0);
-    std::vector<BitsQueues> list_queues;
-    for (int64_t c = 0; c < n_launch; ++c) {
-        const int64_t span_c = starts[c + 1] - starts[c];
-        size_t k = 0;
-        while (k < list_span.size() && list_span[k] != span_c) ++k;
-        if (k == list_span.size()) {
-            BitsQueues bq{};
-            const std::vector<int4> one = split_queues(build_tasks(span_c), bq.off);
-            list_queues.push_back(bq);
-            list_span.push_back(span_c);
-            list_first.push_back(static_cast<int64_t>(tasks.size()));
-            list_count.push_back(static_cast<int64_t>(one.size()));
-            tasks.insert(tasks.end(), one.begin(), one.end());
+    // the lists only depend on the handle and on these numbers: the handle keeps the last plan
+    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, n_launch};
+    plan_key.insert(plan_key.end(), starts.begin(), starts.end());
+    BitsTaskPlan &plan = nbr->bits_plan;
+    if (plan.key != plan_key) {
+        plan = BitsTaskPlan{};
+        plan.launch_list.assign(std::max<int64_t>(n_launch, 1), 0);
+        for (int64_t c = 0; c < n_launch; ++c) {
+            const int64_t span_c = starts[c + 1] - starts[c];
+            size_t k = 0;
+            while (k < plan.list_span.size() && plan.list_span[k] != span_c) ++k;
+            if (k == plan.list_span.size()) {
+                BitsQueues bq{};
+                const std::vector<int4> one = split_queues(build_tasks(span_c), bq.off);
+                plan.list_queues.push_back(bq);
+                plan.list_span.push_back(span_c);
+                plan.list_first.push_back(static_cast<int64_t>(plan.tasks.size()));
+                plan.list_count.push_back(static_cast<int64_t>(one.size()));
+                plan.tasks.insert(plan.tasks.end(), one.begin(), one.end());
+            }
+            plan.launch_list[c] = static_cast<int64_t>(k);
         }
-        launch_list[c] = static_cast<int64_t>(k);
+        plan.key = plan_key;
     }
+    const std::vector<int4> &tasks = plan.tasks;
+    const std::vector<int64_t> &list_first = plan.list_first, &list_count = plan.list_count, &launch_list = plan.launch_list;
+    const std::vector<BitsQueues> &list_queues = plan.list_queues;
     safe_trace("launch_bits: tasks built");
     int4 *d_tasks = nullptr;
     unsigned int *d_queue = nullptr;
