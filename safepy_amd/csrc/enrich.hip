@@ -596,6 +596,26 @@ __device__ __forceinline__ void vflush(uint32_t (&c)[CL], uint32_t &pend) {
     pend = 0;
 }
 
+// A workgroup's copy of one word column into LDS: T[r] = src[r], r = 0 .. n.  Sixteen loads per thread are in flight before the
+// first LDS store (the plain loop compiled to load - wait - store per 256 rows: 16 L2 latencies in a row at N = 3971, 12-16 us
+// of every task, all four waves waiting at the barrier behind it).
+__device__ __forceinline__ void load_word_column(uint2 *__restrict__ T, const uint2 *__restrict__ src, int64_t n) {
+    constexpr int UNL = 16;
+    for (int64_t r0 = threadIdx.x; r0 <= n; r0 += 256 * UNL) {
+        uint2 v[UNL];
+#pragma unroll
+        for (int u = 0; u < UNL; ++u) {
+            const int64_t r = r0 + u * 256;
+            v[u] = src[r <= n ? r : n];
+        }
+#pragma unroll
+        for (int u = 0; u < UNL; ++u) {
+            const int64_t r = r0 + u * 256;
+            if (r <= n) T[r] = v[u];
+        }
+    }
+}
+
 template <int LEVELS>
 __device__ __forceinline__ unsigned int vextract(const uint32_t (&c)[LEVELS], int bit) {
     unsigned int v = 0;
@@ -667,7 +687,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
-        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        load_word_column(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
         if (p_end > p_begin)
             for (int v = threadIdx.x; v < vec_per_row; v += 256)
                 reinterpret_cast<uint4_alias *>(CUR)[v] =
@@ -882,7 +902,7 @@ __global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
-        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        load_word_column(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
         const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
         const bool active = s < n_slices;
         const int32_t row = active ? sell_row[s * 64 + lane] : -1;
@@ -1168,7 +1188,7 @@ __global__ __launch_bounds__(256) void k_bits_observed(int64_t n, const int32_t 
     if ((uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds) != 0u) __builtin_trap();
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int64_t wg = blockIdx.x, s = static_cast<int64_t>(blockIdx.y) * 4 + wave;
-    for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[wg * (n + 1) + r];
+    load_word_column(T, bbits + wg * (n + 1), n);
     __syncthreads();
     if (s >= n_slices) return;
     const int wdt = __builtin_amdgcn_readfirstlane(slice_width[s]);
@@ -1281,7 +1301,7 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
         int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end < p_begin || !active) p_end = p_begin;                  // (nothing to do for this wave; it still joins the barriers)
 
-        for (int64_t r = threadIdx.x; r <= n; r += 256) T[r] = bbits[static_cast<int64_t>(wg) * (n + 1) + r];
+        load_word_column(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
         const int64_t my_blk = (active ? slice_off[s] : 0) / 8;             // in uint4 units (slice offsets are multiples of 512); wave-uniform
         const int wdt = __builtin_amdgcn_readfirstlane(active ? slice_width[s] : 0);
         const int nblk = wdt >> 3;
@@ -2109,14 +2129,17 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // One task list per DISTINCT launch size: the stream's stages are 32, 96, 128 ... and short last ones, and a list cut for 128
     // permutations leaves a 32-permutation launch with half-empty and empty tasks (each still reloads T): a 32-permutation launch
     // took 207 us, 6.5 us per permutation against 3.2 in the long launches.
+    int64_t min_ppt = 16, target_min = 256;              // floors of a task's size: permutations, block-permutations
+    if (const char *e = getenv("SAFE_HIP_BITS_MINPPT")) min_ppt = std::max(1, atoi(e));
+    if (const char *e = getenv("SAFE_HIP_BITS_TARGETMIN")) target_min = std::max(1, atoi(e));
     struct TaskCost { int4 t; int64_t cost; };
     auto build_tasks = [&](int64_t span_c) {
-        const int64_t target = std::max<int64_t>(256, blocks_per_perm * span_c / tasks_per_wg);    // block-permutations per task
+        const int64_t target = std::max<int64_t>(target_min, blocks_per_perm * span_c / tasks_per_wg);    // block-permutations per task
         std::vector<TaskCost> tc;
         for (int64_t g = 0; g < n_sg; ++g) {
             const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
             const int64_t ppt_cap = !occ5 ? 255 : (bl * 8 > 56 ? 31 : 63);      // counter levels of the task's class: 8, or 5 / 6
-            int64_t ppt = std::min<int64_t>(std::min<int64_t>(span_c, ppt_cap), std::max<int64_t>(16, target / bl));
+            int64_t ppt = std::min<int64_t>(std::min<int64_t>(span_c, ppt_cap), std::max<int64_t>(min_ppt, target / bl));
             const int64_t chunks = ceil_div(span_c, ppt);
             ppt = ceil_div(span_c, chunks);
             for (int64_t c = 0; c < chunks; ++c) {
@@ -2159,7 +2182,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     };
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     // the lists only depend on the handle and on these numbers: the handle keeps the last plan
-    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, n_launch};
+    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch};
     plan_key.insert(plan_key.end(), starts.begin(), starts.end());
     BitsTaskPlan &plan = nbr->bits_plan;
     if (plan.key != plan_key) {
@@ -2414,6 +2437,9 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
     const int64_t tasks_per_tile = std::max<int64_t>(1, ceil_div(6 * slots, n_tiles));
     const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_tile);
+    int64_t min_ppt = 16, target_min = 256;              // floors of a task's size: permutations, block-permutations
+    if (const char *e = getenv("SAFE_HIP_BITS_MINPPT")) min_ppt = std::max(1, atoi(e));
+    if (const char *e = getenv("SAFE_HIP_BITS_TARGETMIN")) target_min = std::max(1, atoi(e));
     struct TaskCost { int4 t; int64_t cost; };
     std::vector<TaskCost> tc;
     for (int64_t g = 0; g < n_sg; ++g) {
