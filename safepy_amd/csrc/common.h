@@ -176,6 +176,11 @@ struct safe_nbr {
     uint32_t *bs_bits = nullptr;    // [bs_blocks][256] membership bits of the block's 256 rows
     std::vector<int32_t> h_bs_ptr;
     std::vector<int32_t> h_bs_rowmap;   // host copy of bs_rowmap
+    // task list of the matrix-core COUNT kernel (one i8 plane per tile): (row group, column group) pairs in eight per-XCD queues;
+    // a function of the block structure and the number of column groups only, kept for the next call (counts_setup)
+    std::vector<int2> counts_tasks;
+    int32_t counts_qoff[9] = {0};
+    int64_t counts_tasks_grp = -1;
 };
 
 // Hypergeometric epilogue by table lookup (enrich.hip: k_hyp_table builds tab): instead of a count X
@@ -343,7 +348,8 @@ int launch_mfma_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t co
 struct MfmaCountsSplit;
 bool mfma_counts_split_applicable(const safe_nbr *nbr);
 int mfma_counts_split_begin(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, MfmaCountsSplit **out);
-int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl, const int32_t *h_nid);
+int mfma_counts_split_rows(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const int32_t *h_nid, hipStream_t hs, void *pinned_stage);
+int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl);
 void mfma_counts_split_free(MfmaCountsSplit *st);
 const unsigned int *mfma_counts_split_xmax(const MfmaCountsSplit *st);   // device: largest count of the call
 void nbr_free_blocks(safe_nbr *nbr);

@@ -2538,14 +2538,20 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, int64_t col1, int64_t pop,
                            const double *d_size, double p_cut, double *p_dev, double *nes_dev,
                            double *nb_dev, unsigned int *d_enr, bool use_mfma, hipStream_t hs, MfmaCountsSplit *split,
-                           bool *fused) {
+                           bool *fused, double *enriched_f64 = nullptr, bool *enriched_done = nullptr) {
     // hs = the stream of the table's own work: ctx->stream, or the side stream while the first half of the
     // split matrix-core form (which needs nothing from here) runs on ctx->stream
     *fused = false;
     const int64_t n = nbr->n, mloc = col1 - col0;
+    // pinned staging: [neighborhood sizes | column sums] coming back, then everything that goes up (ids, and the split form's row
+    // lists).  Uploads from pageable vectors went through the runtime's staging path: one 80 KB copy took 0.38 ms and held the
+    // table kernel back behind the count kernel's end.
     void *pinned = nullptr;
-    SAFE_TRY(ctx_pinned(ctx, static_cast<size_t>(n + mloc) * sizeof(double), &pinned));
+    const size_t down_bytes = static_cast<size_t>(n + mloc) * sizeof(double);
+    const size_t up_bytes = static_cast<size_t>(2 * (n + mloc) + 8) * sizeof(int32_t) + static_cast<size_t>(n) * (sizeof(int4) + sizeof(int2));
+    SAFE_TRY(ctx_pinned(ctx, down_bytes + up_bytes, &pinned));
     const double *h_size = static_cast<const double *>(pinned), *h_k = h_size + n;
+    int32_t *up = reinterpret_cast<int32_t *>(static_cast<char *>(pinned) + down_bytes);
     SAFE_HIP_CHECK(hipMemcpyAsync(pinned, d_size, n * sizeof(double), hipMemcpyDeviceToHost, hs));
     SAFE_HIP_CHECK(hipMemcpyAsync(static_cast<double *>(pinned) + n, attr->col_sum + col0, mloc * sizeof(double), hipMemcpyDeviceToHost, hs));
     SAFE_HIP_CHECK(safe_stream_sync(hs));
@@ -2586,12 +2592,17 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n_nid) * n_kid * xs * sizeof(double2), reinterpret_cast<void **>(&d_tab)));
     SAFE_TRY(ctx_scratch(ctx, 6, static_cast<size_t>(n_nid + n_kid + n + mloc) * sizeof(int32_t), reinterpret_cast<void **>(&d_ids)));
     int32_t *d_nvals = d_ids, *d_kvals = d_nvals + n_nid, *d_nid = d_kvals + n_kid, *d_kid = d_nid + n;
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_nvals, nvals.data(), n_nid * sizeof(int32_t), hipMemcpyHostToDevice, hs));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_kvals, kvals.data(), n_kid * sizeof(int32_t), hipMemcpyHostToDevice, hs));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_nid, nid.data(), n * sizeof(int32_t), hipMemcpyHostToDevice, hs));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_kid, kid.data(), mloc * sizeof(int32_t), hipMemcpyHostToDevice, hs));
+    // d_ids = [nvals | kvals | nid | kid]: one copy out of the pinned block
+    memcpy(up, nvals.data(), n_nid * sizeof(int32_t));
+    memcpy(up + n_nid, kvals.data(), n_kid * sizeof(int32_t));
+    memcpy(up + n_nid + n_kid, nid.data(), n * sizeof(int32_t));
+    memcpy(up + n_nid + n_kid + n, kid.data(), mloc * sizeof(int32_t));
+    const int64_t n_up = n_nid + n_kid + n + mloc;
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_ids, up, n_up * sizeof(int32_t), hipMemcpyHostToDevice, hs));
     hipEvent_t ids_done = nullptr;
     if (split) {
+        // the second half's row lists travel on this stream too (staged behind the ids, 16-byte aligned)
+        SAFE_TRY(mfma_counts_split_rows(ctx, nbr, split, nid.data(), hs, up + (n_up + 3) / 4 * 4));
         // the counts are under way on ctx->stream: the table follows them there, cut at their largest value
         SAFE_HIP_CHECK(hipEventCreateWithFlags(&ids_done, safe_event_flags(hipEventDisableTiming)));
         SAFE_HIP_CHECK(hipEventRecord(ids_done, hs));
@@ -2614,7 +2625,11 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
     hl.nes_binary = nb_dev;
     hl.enriched = d_enr;
     if (split) {
-        const int rc = mfma_counts_split_emit(ctx, nbr, split, hl, nid.data());       // synchronises ctx->stream
+        int rc = mfma_counts_split_emit(ctx, nbr, split, hl);
+        if (rc == SAFE_OK && enriched_f64) {                           // per-attribute counts right behind the emit kernel (no host round trip between)
+            hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, enriched_f64, mloc);
+            if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
+        }
         (void)safe_stream_sync(hs);                                    // the id vectors above are host memory
         (void)hipEventDestroy(ids_done);
         SAFE_TRY(rc);
@@ -2631,6 +2646,7 @@ static int hypergeom_fused(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_
         SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
         ctx->last_kernel.name = "k_counts_bits<hypergeom>";
     }
+    if (split && enriched_f64 && enriched_done) *enriched_done = true;
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // the id vectors above are host memory
     *fused = true;
     return SAFE_OK;
@@ -2886,11 +2902,12 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
         }
         if (rc == SAFE_OK) rc = mfma_counts_split_begin(ctx, nbr, attr, col0, col1, &split);
     }
-    bool fused = false;
+    bool fused = false, enriched_done = false;
     if (rc == SAFE_OK) {
         hipLaunchKernelGGL(k_nbr_size, dim3(ceil_div(n, 4)), dim3(256), 0, hs, nbr->row_ptr, nbr->col, attr->row_flags, n, d_size);
         if (table) rc = hypergeom_fused(ctx, nbr, attr, col0, col1, pop, d_size, nes_p_cut(enrichment_threshold),
-                                        pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr, use_mfma, hs, split, &fused);
+                                        pvalues_pos_dev, nes_dev, nes_binary_dev, d_enr, use_mfma, hs, split, &fused, num_enriched_dev,
+                                        &enriched_done);
     }
     if (hs != ctx->stream) {                                                // join (the fallback below reads d_size)
         if (ev && hipEventRecord(ev, hs) == hipSuccess) (void)hipStreamWaitEvent(ctx->stream, ev, 0);
@@ -2927,7 +2944,7 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
         }
         if (rc == SAFE_OK && safe_stream_sync(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // lf is host memory
     }
-    if (rc == SAFE_OK) {
+    if (rc == SAFE_OK && !enriched_done) {
         hipLaunchKernelGGL(k_u32_to_f64, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_enr, num_enriched_dev, mloc);
         if (hipGetLastError() != hipSuccess) rc = SAFE_E_HIP;
     }

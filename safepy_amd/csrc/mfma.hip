@@ -1207,7 +1207,7 @@ __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict
 
 // planes, task queues and source map of the counts form, enqueued on ctx->stream
 struct CountsSetup {
-    std::vector<int2> tasks;              // host memory behind an asynchronous copy: lives until the stream is synchronised
+    const std::vector<int2> *tasks = nullptr;   // the membership handle's cached list (host memory behind an asynchronous copy)
     int32_t q_off[9] = {0};
     unsigned char *d_bs = nullptr;
     int2 *d_tasks = nullptr;
@@ -1221,6 +1221,36 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
     const int64_t n = nbr->n, mloc = col1 - col0;
     const int64_t n_ct = ceil_div(mloc, 32), n_grp = ceil_div(n_ct, MF_CN), row_bytes = n_grp * MF_CN * 32, n_src = nbr->bs_src;
     cs->n_grp = n_grp, cs->row_bytes = row_bytes, cs->n_src = n_src, cs->mloc = mloc;
+    // task list, queue words and source map first: they do not depend on the planes, and behind the planes kernel in stream
+    // order they were 45 us of copies, fills and a tiny kernel between it and the count kernel
+    if (nbr->counts_tasks_grp != n_grp) {
+        std::vector<int32_t> g_order(nbr->bs_groups);
+        std::iota(g_order.begin(), g_order.end(), 0);
+        const std::vector<int32_t> &bp = nbr->h_bs_ptr;
+        std::stable_sort(g_order.begin(), g_order.end(), [&](int32_t a, int32_t b) { return bp[a + 1] - bp[a] > bp[b + 1] - bp[b]; });
+        nbr->counts_tasks.clear();
+        nbr->counts_qoff[0] = 0;
+        for (int qx = 0; qx < 8; ++qx) {
+            for (int64_t ct = qx; ct < n_grp; ct += 8)
+                for (int32_t g : g_order) nbr->counts_tasks.push_back(make_int2(g, static_cast<int>(ct)));
+            nbr->counts_qoff[qx + 1] = static_cast<int32_t>(nbr->counts_tasks.size());
+        }
+        nbr->counts_tasks_grp = n_grp;
+    }
+    const std::vector<int2> &tasks = nbr->counts_tasks;
+    cs->tasks = &nbr->counts_tasks;
+    memcpy(cs->q_off, nbr->counts_qoff, sizeof(cs->q_off));
+    void *ws = nullptr;
+    SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + 16 * sizeof(unsigned int), &ws));
+    cs->d_tasks = static_cast<int2 *>(ws);
+    cs->d_qoff = reinterpret_cast<int32_t *>(cs->d_tasks + tasks.size());
+    cs->d_qctr = reinterpret_cast<unsigned int *>(cs->d_qoff + 16);
+    SAFE_TRY(ctx_scratch(ctx, 4, static_cast<size_t>(n_src) * sizeof(int32_t), reinterpret_cast<void **>(&cs->d_src)));
+    SAFE_HIP_CHECK(hipMemcpyAsync(cs->d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(cs->d_qoff, nbr->counts_qoff, sizeof(cs->q_off), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(cs->d_qctr, 0, 16 * sizeof(unsigned int), ctx->stream));
+    hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
+                       static_cast<const int32_t *>(nullptr), 0, cs->d_src);
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&cs->d_bs)));
     if (attr->col_stride == 1) {                                          // C order: straight through
         const dim3 grid(ceil_div(row_bytes / 4, 256), ceil_div(n + 1, 8));
@@ -1247,27 +1277,6 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
             hipLaunchKernelGGL(k_mfma_planes01<double>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_grp, cs->d_bs);
     }
-    std::vector<int32_t> g_order(nbr->bs_groups);
-    std::iota(g_order.begin(), g_order.end(), 0);
-    const std::vector<int32_t> &bp = nbr->h_bs_ptr;
-    std::stable_sort(g_order.begin(), g_order.end(), [&](int32_t a, int32_t b) { return bp[a + 1] - bp[a] > bp[b + 1] - bp[b]; });
-    std::vector<int2> &tasks = cs->tasks;
-    for (int qx = 0; qx < 8; ++qx) {
-        for (int64_t ct = qx; ct < n_grp; ct += 8)
-            for (int32_t g : g_order) tasks.push_back(make_int2(g, static_cast<int>(ct)));
-        cs->q_off[qx + 1] = static_cast<int32_t>(tasks.size());
-    }
-    void *ws = nullptr;
-    SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + 16 * sizeof(unsigned int), &ws));
-    cs->d_tasks = static_cast<int2 *>(ws);
-    cs->d_qoff = reinterpret_cast<int32_t *>(cs->d_tasks + tasks.size());
-    cs->d_qctr = reinterpret_cast<unsigned int *>(cs->d_qoff + 16);
-    SAFE_TRY(ctx_scratch(ctx, 4, static_cast<size_t>(n_src) * sizeof(int32_t), reinterpret_cast<void **>(&cs->d_src)));
-    SAFE_HIP_CHECK(hipMemcpyAsync(cs->d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(cs->d_qoff, cs->q_off, sizeof(cs->q_off), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(cs->d_qctr, 0, 16 * sizeof(unsigned int), ctx->stream));
-    hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
-                       static_cast<const int32_t *>(nullptr), 0, cs->d_src);
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
     for (const void *fn : {reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 0>),
                            reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 1>),
@@ -1278,7 +1287,7 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
 
 void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl, int spare_cus = 0) {
     const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
-    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks.size()), std::max(1, ctx->num_cu - spare_cus));
+    const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks->size()), std::max(1, ctx->num_cu - spare_cus));
 #define COUNTS_LAUNCH(EPI)                                                                                                              \
     hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN, false, true, EPI>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs,      \
                        cs.row_bytes, static_cast<int64_t>(MF_CN * 32), cs.d_src, cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits,    \
@@ -1316,6 +1325,8 @@ struct MfmaCountsSplit {
     unsigned int *cnt16 = nullptr;
     std::vector<int4> rows;
     std::vector<int2> tasks;
+    int4 *d_rows = nullptr;
+    int2 *d_tasks = nullptr;
 };
 
 bool mfma_counts_split_applicable(const safe_nbr *nbr) {
@@ -1345,15 +1356,13 @@ void mfma_counts_split_free(MfmaCountsSplit *st) { delete st; }
 
 const unsigned int *mfma_counts_split_xmax(const MfmaCountsSplit *st) { return st->cs.d_qctr + 12; }
 
-// second half: hl carries the table, the ids and the outputs; h_nid[node] = neighborhood-size id (host)
-int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl_in, const int32_t *h_nid) {
-    HypLookup hl = hl_in;
-    hl.cnt16 = st->cnt16;
-    hl.xmax = st->cs.d_qctr + 12;
-    const int64_t n_padr = nbr->bs_groups * MF_R, n_grp = st->cs.n_grp;
-    constexpr int EMIT_UN = 2, EMIT_CHUNK = 64;             // rows per batch: 2 measured best of 1, 2, 3, 4, 8 (1.21 / 1.30 / 1.53 ms at 4 / 8)
-    // rows grouped by neighborhood size, every group cut into chunks of <= 64 rows, long chunks first
-    // (counting sort: the ids are dense)
+// rows grouped by neighborhood size for the second half, uploaded on `hs` (the side stream, idle while the count kernel runs on
+// ctx->stream; the caller makes ctx->stream wait for it): h_nid[node] = neighborhood-size id (host)
+// pinned_stage: pinned host memory for n int4 + n int2 (the uploads must not go through the runtime's pageable staging)
+int mfma_counts_split_rows(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const int32_t *h_nid, hipStream_t hs, void *pinned_stage) {
+    const int64_t n_padr = nbr->bs_groups * MF_R;
+    constexpr int EMIT_CHUNK = 64;
+    // every group cut into chunks of <= 64 rows, long chunks first (counting sort: the ids are dense)
     int32_t n_ids = 0;
     for (int64_t i = 0; i < nbr->n; ++i) n_ids = std::max(n_ids, h_nid[i] + 1);
     std::vector<int32_t> first(n_ids + 1, 0);
@@ -1373,10 +1382,25 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     std::stable_sort(st->tasks.begin(), st->tasks.end(), [](const int2 &a, const int2 &b) { return a.y - a.x > b.y - b.x; });
     void *ws = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 8, st->rows.size() * sizeof(int4) + st->tasks.size() * sizeof(int2), &ws));
-    int4 *d_rows = static_cast<int4 *>(ws);
-    int2 *d_tasks = reinterpret_cast<int2 *>(d_rows + st->rows.size());
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_rows, st->rows.data(), st->rows.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, st->tasks.data(), st->tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
+    st->d_rows = static_cast<int4 *>(ws);
+    st->d_tasks = reinterpret_cast<int2 *>(st->d_rows + st->rows.size());
+    const size_t bytes = st->rows.size() * sizeof(int4) + st->tasks.size() * sizeof(int2);
+    memcpy(pinned_stage, st->rows.data(), st->rows.size() * sizeof(int4));
+    memcpy(static_cast<char *>(pinned_stage) + st->rows.size() * sizeof(int4), st->tasks.data(), st->tasks.size() * sizeof(int2));
+    SAFE_HIP_CHECK(hipMemcpyAsync(ws, pinned_stage, bytes, hipMemcpyHostToDevice, hs));
+    return SAFE_OK;
+}
+
+// second half: hl carries the table, the ids and the outputs.  Nothing here waits for the stream: the row / task vectors live in
+// `st` until the caller has synchronised (mfma_counts_split_free)
+int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, const HypLookup &hl_in) {
+    HypLookup hl = hl_in;
+    hl.cnt16 = st->cnt16;
+    hl.xmax = st->cs.d_qctr + 12;
+    const int64_t n_padr = nbr->bs_groups * MF_R, n_grp = st->cs.n_grp;
+    constexpr int EMIT_UN = 2;                              // rows per batch: 2 measured best of 1, 2, 3, 4, 8 (1.21 / 1.30 / 1.53 ms at 4 / 8)
+    const int4 *d_rows = st->d_rows;
+    const int2 *d_tasks = st->d_tasks;
     const int64_t want = hl.n_kid * hl.xs * static_cast<int64_t>(sizeof(double2));
     const char *lds_env = getenv("SAFE_HIP_EMIT_LDS_KB");                // tests: 0 forces the global-gather loop
     const int64_t lds_cap = lds_env ? std::max(0, atoi(lds_env)) * 1024ll : (64ll << 10);
@@ -1404,7 +1428,6 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     ctx->last_kernel.name = "k_hyp_emit";                               // (after k_permtest_mfma<counts> and k_hyp_table)
-    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // the row / task vectors are host memory
     return SAFE_OK;
 }
 
@@ -1417,6 +1440,7 @@ void nbr_free_blocks(safe_nbr *nbr) {
     nbr->bs_order = nbr->bs_rowmap = nbr->bs_ptr = nbr->bs_kb = nullptr;
     nbr->bs_bits = nullptr;
     nbr->blocks_ready = false;
+    nbr->counts_tasks_grp = -1;
 }
 
 bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *attr, const safe_perms *perms, bool z) {
