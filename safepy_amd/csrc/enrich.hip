@@ -1341,67 +1341,88 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
 // 512-byte writes along the columns of each row.
 // DIRECT = false: counters hold (#less << 16 | #greater)  (bit-sliced kernel)
 // DIRECT = true : counters hold (#>=   << 16 | #<=) and NaN observed scores matter (f64 kernel)
-template <bool DIRECT>
+// MODE = out.mode (1 raw counts, 2 everything, 3 NES only, 4 any subset), a template parameter so that the row loop has no
+// branches; TAB_LDS: the NES table (P + 1 doubles) is staged in LDS.  The row loop then holds no global load at all (row ids
+// and the table come from LDS), so its stores stream: the first form loaded the row id, the two table entries and (DIRECT) the
+// observed score per row with `s_waitcnt vmcnt(0)` between them -- vmcnt retires in order, so every row also waited for the
+// previous row's stores: 158 us for 0.63 GB.
+template <bool DIRECT, int MODE, bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ counts, int64_t n_pad,
                                                          const int32_t *__restrict__ sell_row,
                                                          const double *__restrict__ ns, int64_t mloc, int64_t n_perm,
                                                          PermOut out) {
     __shared__ unsigned int tile[64][65];
     __shared__ unsigned int part[4][64];
+    __shared__ int32_t rows[64];
+    extern __shared__ double tab_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
     const int64_t spos0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
-    for (int cc = wave; cc < 64; cc += 4) {
-        const int64_t c = c0 + cc;
-        tile[cc][lane] = c < mloc ? counts[c * n_pad + spos0 + lane] : 0u;
+    {
+        unsigned int v[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {                                   // sixteen loads in flight
+            const int64_t c = c0 + wave + 4 * k;
+            v[k] = counts[(c < mloc ? c : mloc - 1) * n_pad + spos0 + lane];
+        }
+#pragma unroll
+        for (int k = 0; k < 16; ++k) tile[wave + 4 * k][lane] = c0 + wave + 4 * k < mloc ? v[k] : 0u;
     }
+    if (wave == 0) rows[lane] = sell_row[spos0 + lane];
+    if (TAB_LDS && MODE != 1)
+        for (int64_t i = threadIdx.x; i <= n_perm; i += 256) tab_lds[i] = out.nes_table[i];
     __syncthreads();
+    const double *tab = TAB_LDS ? tab_lds : out.nes_table;
     const int64_t c = c0 + lane;
     const unsigned int P = static_cast<unsigned int>(n_perm);
+    const double p_f = static_cast<double>(P);
     unsigned int hits = 0;
-    for (int ss = wave; ss < 64; ss += 4) {
-        const int32_t row = sell_row[spos0 + ss];
-        if (row < 0 || c >= mloc) continue;
-        const unsigned int v = tile[lane][ss];
-        const int64_t o = static_cast<int64_t>(row) * mloc + c;
-        unsigned int cneg, cpos;
-        bool obs_nan = false;
-        if (DIRECT) {
-            cneg = v & 0xFFFFu;
-            cpos = v >> 16;
-            const double obs = ns[o];
-            obs_nan = obs != obs;
-        } else {
-            cneg = P - (v & 0xFFFFu);           // #(S_p <= S_obs) = P - #greater
-            cpos = P - (v >> 16);               // #(S_p >= S_obs) = P - #less
-        }
-        if (out.mode == 1) {
-            out.counts_neg[o] = static_cast<double>(cneg);
-            out.counts_pos[o] = static_cast<double>(cpos);
-        } else if (out.mode == 3) {                                  // NES only (all-gathered counters of other ranks)
-            const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
-            out.nes[o] = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
-        } else if (out.mode == 4) {                                  // any subset of the matrices from all-gathered 'sum' counters
-            const double en = out.nes_table[cneg], ep = out.nes_table[cpos];
-            const double nes = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
-            if (out.pvalues_neg) out.pvalues_neg[o] = static_cast<double>(cneg) / static_cast<double>(P);
-            if (out.pvalues_pos) out.pvalues_pos[o] = static_cast<double>(cpos) / static_cast<double>(P);
-            if (out.nes) out.nes[o] = nes;
-            if (out.nes_binary) out.nes_binary[o] = fabs(nes) > out.nes_threshold ? 1.0 : 0.0;
-        } else if (out.mode == 2) {
-            const double qnan = __longlong_as_double(0x7FF8000000000000ll);
-            const double en = obs_nan ? qnan : out.nes_table[cneg], ep = obs_nan ? qnan : out.nes_table[cpos];
-            double nes = ep - en;
-            if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
-            if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
-            const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
-            out.pvalues_neg[o] = obs_nan ? qnan : static_cast<double>(cneg) / static_cast<double>(P);
-            out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / static_cast<double>(P);
-            out.nes[o] = nes;
-            out.nes_binary[o] = hit ? 1.0 : 0.0;
-            hits += hit;
+    if (c < mloc) {
+#pragma unroll 4
+        for (int ss = wave; ss < 64; ss += 4) {
+            const int32_t row = rows[ss];
+            if (row < 0) continue;
+            const unsigned int v = tile[lane][ss];
+            const int64_t o = static_cast<int64_t>(row) * mloc + c;
+            unsigned int cneg, cpos;
+            bool obs_nan = false;
+            if (DIRECT) {
+                cneg = v & 0xFFFFu;
+                cpos = v >> 16;
+                const double obs = ns[o];
+                obs_nan = obs != obs;
+            } else {
+                cneg = P - (v & 0xFFFFu);           // #(S_p <= S_obs) = P - #greater
+                cpos = P - (v >> 16);               // #(S_p >= S_obs) = P - #less
+            }
+            if (MODE == 1) {
+                out.counts_neg[o] = static_cast<double>(cneg);
+                out.counts_pos[o] = static_cast<double>(cpos);
+            } else if (MODE == 3) {                                  // NES only (all-gathered counters of other ranks)
+                const double en = tab[cneg], ep = tab[cpos];
+                out.nes[o] = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
+            } else if (MODE == 4) {                                  // any subset of the matrices from all-gathered 'sum' counters
+                const double en = tab[cneg], ep = tab[cpos];
+                const double nes = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
+                if (out.pvalues_neg) out.pvalues_neg[o] = static_cast<double>(cneg) / p_f;
+                if (out.pvalues_pos) out.pvalues_pos[o] = static_cast<double>(cpos) / p_f;
+                if (out.nes) out.nes[o] = nes;
+                if (out.nes_binary) out.nes_binary[o] = fabs(nes) > out.nes_threshold ? 1.0 : 0.0;
+            } else if (MODE == 2) {
+                const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+                const double en = obs_nan ? qnan : tab[cneg], ep = obs_nan ? qnan : tab[cpos];
+                double nes = ep - en;
+                if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
+                if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
+                const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
+                out.pvalues_neg[o] = obs_nan ? qnan : static_cast<double>(cneg) / p_f;
+                out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / p_f;
+                out.nes[o] = nes;
+                out.nes_binary[o] = hit ? 1.0 : 0.0;
+                hits += hit;
+            }
         }
     }
-    if (out.mode == 2) {
+    if (MODE == 2) {
         part[wave][lane] = hits;
         __syncthreads();
         if (wave == 0 && c < mloc) {
@@ -1409,6 +1430,34 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
             if (t) atomicAdd(&out.enriched[c], t);
         }
     }
+}
+
+// ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
+int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
+                           int64_t n_perm, const PermOut &out, const double *ns_direct) {
+    const dim3 grid(n_pad / 64, ceil_div(mloc, 64));
+    const size_t tab_bytes = static_cast<size_t>(n_perm + 1) * sizeof(double);
+    const bool tab_lds = out.mode != 1 && tab_bytes <= 40 * 1024;
+    const size_t dyn = tab_lds ? tab_bytes : 0;
+#define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, ctx->stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out)
+#define FIN_MODE(D, L)                      \
+    do {                                    \
+        if (out.mode == 1) FIN(D, 1, false); \
+        else if (out.mode == 2) FIN(D, 2, L); \
+        else if (out.mode == 3) FIN(D, 3, L); \
+        else if (out.mode == 4) FIN(D, 4, L); \
+    } while (0)
+    if (ns_direct) {
+        if (tab_lds) FIN_MODE(true, true);
+        else FIN_MODE(true, false);
+    } else {
+        if (tab_lds) FIN_MODE(false, true);
+        else FIN_MODE(false, false);
+    }
+#undef FIN_MODE
+#undef FIN
+    SAFE_HIP_CHECK(hipGetLastError());
+    return SAFE_OK;
 }
 
 // bbits[wg][r] = 64 attribute bits of row r for word group wg (row n = 0: SELL padding)
@@ -1420,11 +1469,23 @@ __global__ __launch_bounds__(256) void k_bits_prep(const void *__restrict__ raw,
     const int64_t wg = idx / (n + 1), r = idx % (n + 1);
     uint32_t w[2] = {0, 0};
     if (r < n) {
-        for (int a = 0; a < 64; ++a) {
-            const int64_t j = wg * 64 + a;
-            if (j >= mloc) break;
-            const T x = reinterpret_cast<const T *>(raw)[r * rs + (col0 + j) * cs];
-            if (x == static_cast<T>(1)) w[a >> 5] |= 1u << (a & 31);
+        const T *src = reinterpret_cast<const T *>(raw) + r * rs + (col0 + wg * 64) * cs;
+        if (wg * 64 + 64 <= mloc) {
+            // a whole word group: sixteen loads in flight at a time (the loop below is load - wait - test per column)
+#pragma unroll
+            for (int a0 = 0; a0 < 64; a0 += 16) {
+                T x[16];
+#pragma unroll
+                for (int u = 0; u < 16; ++u) x[u] = src[(a0 + u) * cs];
+#pragma unroll
+                for (int u = 0; u < 16; ++u)
+                    if (x[u] == static_cast<T>(1)) w[(a0 + u) >> 5] |= 1u << ((a0 + u) & 31);
+            }
+        } else {
+            for (int a = 0; a < 64; ++a) {
+                if (wg * 64 + a >= mloc) break;
+                if (src[a * cs] == static_cast<T>(1)) w[a >> 5] |= 1u << (a & 31);
+            }
         }
     }
     bbits[idx] = make_uint2(w[0], w[1]);
@@ -2349,8 +2410,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, d_gl, n_pad,
-                       nbr->sell_row, static_cast<const double *>(nullptr), mloc, P, out);
+    SAFE_TRY(enrich_finalize_counts(ctx, d_gl, n_pad, nbr->sell_row, mloc, P, out, nullptr));
     ctx->packed_counts = d_gl;
     ctx->packed_n_pad = n_pad;
     ctx->packed_m = mloc;
@@ -2508,8 +2568,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    hipLaunchKernelGGL(k_counts_finalize<true>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, d_counts,
-                       n_pad, nbr->sell_row, static_cast<const double *>(d_ns), mloc, P, out);
+    SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_pad, nbr->sell_row, mloc, P, out, d_ns));
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
@@ -2679,19 +2738,6 @@ __global__ __launch_bounds__(256) void k_counts_to_outputs(const double *__restr
     out.nes[idx] = nes;
     out.nes_binary[idx] = hit ? 1.0 : 0.0;
     if (hit) atomicAdd(&out.enriched[idx % m], 1u);
-}
-
-// ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
-int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
-                           int64_t n_perm, const PermOut &out, const double *ns_direct) {
-    if (ns_direct)
-        hipLaunchKernelGGL(k_counts_finalize<true>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, counts, n_pad,
-                           rowmap, ns_direct, mloc, n_perm, out);
-    else
-        hipLaunchKernelGGL(k_counts_finalize<false>, dim3(n_pad / 64, ceil_div(mloc, 64)), dim3(256), 0, ctx->stream, counts, n_pad,
-                           rowmap, static_cast<const double *>(nullptr), mloc, n_perm, out);
-    SAFE_HIP_CHECK(hipGetLastError());
-    return SAFE_OK;
 }
 
 static int finish_kernel_timing(safe_ctx *ctx) {

@@ -1052,6 +1052,30 @@ __global__ __launch_bounds__(256) void k_mfma_planes01_rows(const T *__restrict_
     const int64_t j = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 4;
     if (j >= row_bytes) return;
     const int64_t r0 = static_cast<int64_t>(blockIdx.y) * 8;
+    if (VEC && j + 4 <= mloc && r0 + 8 <= n) {
+        // the common case: eight rows, all eight loads in flight before the first compare (the general loop below compiles to
+        // load - wait - store per row: one load in flight per thread)
+        T v[8][4];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const T *src = raw + (r0 + i) * rs + col0 + j;
+            if constexpr (sizeof(T) == 4) {
+                const float4 q = *reinterpret_cast<const float4 *>(src);
+                v[i][0] = q.x, v[i][1] = q.y, v[i][2] = q.z, v[i][3] = q.w;
+            } else {
+                const double2 q0 = *reinterpret_cast<const double2 *>(src), q1 = *reinterpret_cast<const double2 *>(src + 2);
+                v[i][0] = q0.x, v[i][1] = q0.y, v[i][2] = q1.x, v[i][3] = q1.y;
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            uint32_t w = 0;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) w |= (v[i][k] == static_cast<T>(1) ? 1u : 0u) << (8 * k);
+            *reinterpret_cast<uint32_t *>(bs + (r0 + i) * row_bytes + j) = w;
+        }
+        return;
+    }
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
         const int64_t r = r0 + i;
