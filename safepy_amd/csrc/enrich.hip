@@ -1346,42 +1346,53 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
 // and the table come from LDS), so its stores stream: the first form loaded the row id, the two table entries and (DIRECT) the
 // observed score per row with `s_waitcnt vmcnt(0)` between them -- vmcnt retires in order, so every row also waited for the
 // previous row's stores: 158 us for 0.63 GB.
+// Tile shape: FIN_TP SELL positions x FIN_TC columns.  A 64 x 64 tile wrote 512-byte runs (3.6 TB/s); with 16 x 512 a wave
+// writes 4 KiB of one output row back to back (the counter reads become 64-byte pieces, but they are an eighth of the bytes).
+constexpr int FIN_TP = 16, FIN_TC = 512;
 template <bool DIRECT, int MODE, bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ counts, int64_t n_pad,
                                                          const int32_t *__restrict__ sell_row,
                                                          const double *__restrict__ ns, int64_t mloc, int64_t n_perm,
                                                          PermOut out) {
-    __shared__ unsigned int tile[64][65];
-    __shared__ unsigned int part[4][64];
-    __shared__ int32_t rows[64];
+    __shared__ unsigned int tile[FIN_TC][FIN_TP + 1];
+    __shared__ unsigned int part[4][FIN_TC];
+    __shared__ int32_t rows[FIN_TP];
     extern __shared__ double tab_lds[];
     const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-    const int64_t spos0 = static_cast<int64_t>(blockIdx.x) * 64, c0 = static_cast<int64_t>(blockIdx.y) * 64;
+    const int64_t spos0 = static_cast<int64_t>(blockIdx.x) * FIN_TP, c0 = static_cast<int64_t>(blockIdx.y) * FIN_TC;
     {
-        unsigned int v[16];
+        // thread t: position t % 16 of columns t / 16 + 16 k -- sixteen loads in flight, two rounds
+        const int p = threadIdx.x & (FIN_TP - 1), cq = threadIdx.x / FIN_TP;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {                                   // sixteen loads in flight
-            const int64_t c = c0 + wave + 4 * k;
-            v[k] = counts[(c < mloc ? c : mloc - 1) * n_pad + spos0 + lane];
+        for (int half = 0; half < 2; ++half) {
+            unsigned int v[16];
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const int64_t c = c0 + cq + 16 * (half * 16 + k);
+                v[k] = counts[(c < mloc ? c : mloc - 1) * n_pad + spos0 + p];
+            }
+#pragma unroll
+            for (int k = 0; k < 16; ++k) tile[cq + 16 * (half * 16 + k)][p] = v[k];
         }
-#pragma unroll
-        for (int k = 0; k < 16; ++k) tile[wave + 4 * k][lane] = c0 + wave + 4 * k < mloc ? v[k] : 0u;
     }
-    if (wave == 0) rows[lane] = sell_row[spos0 + lane];
+    if (threadIdx.x < FIN_TP) rows[threadIdx.x] = sell_row[spos0 + threadIdx.x];
     if (TAB_LDS && MODE != 1)
         for (int64_t i = threadIdx.x; i <= n_perm; i += 256) tab_lds[i] = out.nes_table[i];
     __syncthreads();
     const double *tab = TAB_LDS ? tab_lds : out.nes_table;
-    const int64_t c = c0 + lane;
     const unsigned int P = static_cast<unsigned int>(n_perm);
     const double p_f = static_cast<double>(P);
-    unsigned int hits = 0;
-    if (c < mloc) {
-#pragma unroll 4
-        for (int ss = wave; ss < 64; ss += 4) {
-            const int32_t row = rows[ss];
-            if (row < 0) continue;
-            const unsigned int v = tile[lane][ss];
+    unsigned int hits[FIN_TC / 64];
+#pragma unroll
+    for (int ct = 0; ct < FIN_TC / 64; ++ct) hits[ct] = 0;
+    for (int ss = wave; ss < FIN_TP; ss += 4) {
+        const int32_t row = rows[ss];
+        if (row < 0) continue;
+#pragma unroll
+        for (int ct = 0; ct < FIN_TC / 64; ++ct) {
+            const int64_t c = c0 + ct * 64 + lane;
+            if (c >= mloc) continue;
+            const unsigned int v = tile[ct * 64 + lane][ss];
             const int64_t o = static_cast<int64_t>(row) * mloc + c;
             unsigned int cneg, cpos;
             bool obs_nan = false;
@@ -1418,16 +1429,17 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
                 out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / p_f;
                 out.nes[o] = nes;
                 out.nes_binary[o] = hit ? 1.0 : 0.0;
-                hits += hit;
+                hits[ct] += hit;
             }
         }
     }
     if (MODE == 2) {
-        part[wave][lane] = hits;
+#pragma unroll
+        for (int ct = 0; ct < FIN_TC / 64; ++ct) part[wave][ct * 64 + lane] = hits[ct];
         __syncthreads();
-        if (wave == 0 && c < mloc) {
-            const unsigned int t = part[0][lane] + part[1][lane] + part[2][lane] + part[3][lane];
-            if (t) atomicAdd(&out.enriched[c], t);
+        for (int cc = threadIdx.x; cc < FIN_TC; cc += 256) {
+            const unsigned int t = part[0][cc] + part[1][cc] + part[2][cc] + part[3][cc];
+            if (t && c0 + cc < mloc) atomicAdd(&out.enriched[c0 + cc], t);
         }
     }
 }
@@ -1435,9 +1447,9 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
 // ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
                            int64_t n_perm, const PermOut &out, const double *ns_direct) {
-    const dim3 grid(n_pad / 64, ceil_div(mloc, 64));
+    const dim3 grid(n_pad / FIN_TP, ceil_div(mloc, FIN_TC));
     const size_t tab_bytes = static_cast<size_t>(n_perm + 1) * sizeof(double);
-    const bool tab_lds = out.mode != 1 && tab_bytes <= 40 * 1024;
+    const bool tab_lds = out.mode != 1 && tab_bytes <= 20 * 1024;          // (next to 43 KB of static LDS)
     const size_t dyn = tab_lds ? tab_bytes : 0;
 #define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, ctx->stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out)
 #define FIN_MODE(D, L)                      \
