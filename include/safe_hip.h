@@ -367,6 +367,11 @@ int safe_last_mfma_slices(safe_ctx *ctx, int *slices);
 int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *avg_ms,
                            int64_t *launches);
 
+/* Time (ms) during which at least one launch of that kernel was running in the last enrichment call: the union of the launches'
+ * intervals.  Consecutive launches of the permutation kernels run on two streams and overlap, so launches x avg_ms exceeds it
+ * (and can exceed the call).  Measurement only; no reference counterpart. */
+int safe_last_kernel_busy_ms(safe_ctx *ctx, double *busy_ms);
+
 #ifdef __cplusplus
 }
 #endif

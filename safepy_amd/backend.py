@@ -197,6 +197,12 @@ class Context:
         check(lib.safe_last_kernel_stats(self.handle, name, 128, C.byref(ms), C.byref(cnt)))
         return name.value.decode(), ms.value, cnt.value
 
+    def last_kernel_busy_ms(self):
+        """Time during which at least one launch of the dominant kernel of the last call was running (launches overlap)."""
+        ms = C.c_double()
+        check(lib.safe_last_kernel_busy_ms(self.handle, C.byref(ms)))
+        return ms.value
+
     def edge_lengths(self, xy, edge_u, edge_v):
         xy = np.ascontiguousarray(xy, dtype=np.float64)
         eu = np.ascontiguousarray(edge_u, dtype=np.int32)

@@ -59,6 +59,7 @@ struct KernelStat {
     std::string name;
     double total_ms = 0.0;
     int64_t launches = 0;
+    double busy_ms = 0.0;           // union of the launches' intervals (consecutive launches overlap on two streams); 0 = not measured
 };
 
 struct safe_ctx {
@@ -103,6 +104,7 @@ int ctx_events(safe_ctx *ctx, bool timing, size_t count, hipEvent_t **out);
 void perms_cache_drop(safe_ctx *ctx);   // frees ctx->perm_cache (rng.cpp)
 // small per-handle device blocks (row flags, column sums): hipMalloc + hipFree cost tens of microseconds each and a handle
 // is made per compute_pvalues pass, so freed blocks wait in the context for the next handle of the same shape
+int kernel_stat_from_events(safe_ctx *ctx, hipEvent_t *ev, int64_t n_launch);   // enrich.hip
 int ctx_block_alloc(safe_ctx *ctx, size_t bytes, void **out);
 void ctx_block_free(safe_ctx *ctx, void *p, size_t bytes);
 

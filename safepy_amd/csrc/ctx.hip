@@ -322,4 +322,10 @@ int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *a
     return SAFE_OK;
 }
 
+int safe_last_kernel_busy_ms(safe_ctx *ctx, double *busy_ms) {
+    SAFE_REQUIRE(ctx && busy_ms, "safe_last_kernel_busy_ms: NULL argument");
+    *busy_ms = ctx->last_kernel.busy_ms;
+    return SAFE_OK;
+}
+
 }  // extern "C"

@@ -2160,6 +2160,24 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
     return PATH_GATHER;
 }
 
+// ev[2c], ev[2c+1] bracket launch c (recorded on alternating streams, all complete): sum of the durations, their count, and the
+// union of the intervals -- consecutive launches overlap, so the sum exceeds the time the GPU spent on them
+int kernel_stat_from_events(safe_ctx *ctx, hipEvent_t *ev, int64_t n_launch) {
+    double busy = 0.0, covered_to = 0.0;
+    for (int64_t c = 0; c < n_launch; ++c) {
+        float ms = 0.f, t0 = 0.f;
+        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
+        if (c) SAFE_HIP_CHECK(hipEventElapsedTime(&t0, ev[0], ev[2 * c]));
+        ctx->last_kernel.total_ms += ms;
+        ctx->last_kernel.launches += 1;
+        const double a = std::max<double>(t0, covered_to), b = static_cast<double>(t0) + ms;
+        if (b > a) busy += b - a;
+        covered_to = std::max(covered_to, b);
+    }
+    ctx->last_kernel.busy_ms = busy;
+    return SAFE_OK;
+}
+
 static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
                        const PermOut &out) {
     const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64), P = perms->count;
@@ -2348,6 +2366,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     ctx->last_kernel.name = blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
+    ctx->last_kernel.busy_ms = 0.0;
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
@@ -2434,12 +2453,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     safe_trace("launch_bits: all enqueued");
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));    // tasks (host vector) and temporaries
     safe_trace("launch_bits: synced");
-    for (int64_t c = 0; c < n_launch; ++c) {
-        float ms = 0.f;
-        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
-        ctx->last_kernel.total_ms += ms;
-        ctx->last_kernel.launches += 1;
-    }
+    SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
     return SAFE_OK;
 }
 
@@ -2558,6 +2572,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     LDS_DISPATCH(LDS_SETATTR);
     ctx->last_kernel.name = "k_permtest_lds";
     ctx->last_kernel.total_ms = 0.0;
+    ctx->last_kernel.busy_ms = 0.0;
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
@@ -2585,12 +2600,7 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
-    for (int64_t c = 0; c < n_launch; ++c) {
-        float ms = 0.f;
-        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
-        ctx->last_kernel.total_ms += ms;
-        ctx->last_kernel.launches += 1;
-    }
+    SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
     (void)hipFree(d_tasks);
     (void)hipFree(d_queue);
     return SAFE_OK;
@@ -2760,6 +2770,7 @@ static int finish_kernel_timing(safe_ctx *ctx) {
     float ms = 0.f;
     SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->k0, ctx->k1));
     ctx->last_kernel.total_ms = ms;
+    ctx->last_kernel.busy_ms = ms;
     ctx->last_kernel.launches = 1;
     return SAFE_OK;
 }

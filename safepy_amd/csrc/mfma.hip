@@ -1608,6 +1608,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     if (z && !out.ns) SAFE_TRY(ctx_scratch(ctx, 2, static_cast<size_t>(n) * mloc * sizeof(double), reinterpret_cast<void **>(&out.ns)));
     ctx->last_kernel.name = "k_permtest_mfma";
     ctx->last_kernel.total_ms = 0.0;
+    ctx->last_kernel.busy_ms = 0.0;
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
@@ -1656,11 +1657,6 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
-    for (int64_t c = 0; c < n_launch; ++c) {
-        float ms = 0.f;
-        SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ev[2 * c], ev[2 * c + 1]));
-        ctx->last_kernel.total_ms += ms;
-        ctx->last_kernel.launches += 1;
-    }
+    SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
     return SAFE_OK;
 }

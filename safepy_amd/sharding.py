@@ -346,7 +346,7 @@ def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, b
             import time
             timing.update(perms.timing())
             name, k_ms, launches = ctx.last_kernel()
-            timing.update(kernel=name, gpu_kernel_ms=k_ms * max(int(launches), 1))
+            timing.update(kernel=name, gpu_kernel_ms=k_ms * max(int(launches), 1), gpu_kernel_busy_ms=ctx.last_kernel_busy_ms())
             t_x = time.perf_counter()
         if not exchange:
             return None
