@@ -1073,3 +1073,31 @@ def test_numa_pinning_and_paired_draw_threads(amd, ctx, monkeypatch):
         assert np.array_equal(got[k], cur), k
     os.sched_setaffinity(0, before)
 
+
+
+@pytest.mark.parametrize('kind', ['binary-sum', 'quantitative-sum', 'quantitative-z'])
+def test_more_permutations_than_the_lds_table_holds(amd, kind):
+    """k_counts_finalize keeps the NES table in LDS up to 2559 permutations and reads it from memory beyond: the second form,
+    for the integer counters (bit-sliced kernel) and for the direct ones of the f64 kernels (safe.py:528-554)."""
+    rng = np.random.default_rng(77)
+    n, m, nperm = 180, 70, 2700
+    a = (rng.uniform(size=(n, n)) < 0.08).astype(np.int64)
+    a |= a.T
+    np.fill_diagonal(a, 1)
+    if kind == 'binary-sum':
+        b = (rng.uniform(size=(n, m)) < 0.1).astype(np.float64)
+    else:
+        b = np.round(rng.normal(size=(n, m)) * 8.0) / 8.0        # dyadic: sums and their comparisons are exact in any order
+        b[:, 5] = np.nan
+    b[rng.choice(n, 9, replace=False)] = np.nan
+    score = 'z-score' if kind.endswith('-z') else 'sum'
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', neighborhood_score_type=score, num_permutations=nperm,
+                               random_seed=3)
+    sf = amd.SAFE(verbose=False)
+    sf.random_seed = 3
+    sf.neighborhoods = a
+    sf.load_attributes(attribute_file=b)
+    sf.compute_pvalues(how='randomization', neighborhood_score_type=score, num_permutations=nperm, verbose=False)
+    for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
+        np.testing.assert_array_equal(getattr(sf, key), want[key], err_msg=key)
+    np.testing.assert_allclose(sf.ns, want['ns'], rtol=1e-12, atol=0, equal_nan=True)
