@@ -17,9 +17,10 @@ b_dev = torch.from_numpy(np.ascontiguousarray(b.T)).to('cuda')
 out = {k: torch.empty((n, m), dtype=torch.float64, device='cuda') for k in sharding.RANDOMIZATION_OUTPUTS}
 enr = torch.empty((m,), dtype=torch.float64, device='cuda')
 table = be.nes_table(1000)
+SEED = None if os.environ.get('TRACE_SEED', '0') == 'none' else int(os.environ.get('TRACE_SEED', '0'))   # 'none': unseeded (device stream)
 def step():
     attr = be.Attributes.from_device(ctx, b_dev.data_ptr(), np.float32, n, m, order='F')
-    sharding.randomization_step(ctx, nbr, attr, m, 1000, 0, out, enr, table=table)
+    sharding.randomization_step(ctx, nbr, attr, m, 1000, SEED, out, enr, table=table)
     attr.close()
 for _ in range(3): step()
 torch.cuda.synchronize()
