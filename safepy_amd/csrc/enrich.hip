@@ -1103,8 +1103,23 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
         }
     }
     uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
+    // one-block slices (17 of 63 on the bench network): blk_sum requests three blocks per permutation and uses one, and waits for it
+    // at once.  Here the ids of the permutation after next are requested while this one is added: two quads that swap roles.
+    u32x4 ca{}, cb{};
+    const bool single = LV == 4 && nblk == 1 && GATHER != 3;
+    if (single) {
+        ca = perm_ids[lane];
+        cb = perm_ids[(np > 1 ? perm_stride : 0) + lane];
+    }
     for (int p = 0; p < np; ++p, perm_ids += perm_stride) {
         uint32_t s0[LV], s1[LV];
+        if (single) {
+#pragma unroll
+            for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+            const u32x4 *ahead = perm_ids + (p + 2 < np ? 2 * perm_stride : 0) + lane;
+            if (p & 1) blk_add8<LV, 0, GATHER>(cb, ahead, s0, s1);
+            else blk_add8<LV, 0, GATHER>(ca, ahead, s0, s1);
+        } else
         blk_sum<LV, 0, GATHER>(perm_ids, lane, nblk, s0, s1);
         if (DBG & 4) {
             g0[0] ^= s0[0] ^ s0[LV - 1];
