@@ -1101,3 +1101,26 @@ def test_more_permutations_than_the_lds_table_holds(amd, kind):
     for key in ('pvalues_neg', 'pvalues_pos', 'nes', 'nes_binary'):
         np.testing.assert_array_equal(getattr(sf, key), want[key], err_msg=key)
     np.testing.assert_allclose(sf.ns, want['ns'], rtol=1e-12, atol=0, equal_nan=True)
+
+
+def test_kernel_busy_time_is_the_union_of_the_launch_intervals(amd):
+    """safe_last_kernel_busy_ms (bench.py's roofline.kernel_busy_ms_per_step): positive, and no more than the sum of the launches'
+    durations that safe_last_kernel_stats reports (consecutive launches overlap on two streams)."""
+    from safepy_amd import backend as be
+    rng = np.random.default_rng(5)
+    n, m, nperm = 600, 130, 300
+    xy = rng.uniform(size=(n, 2))
+    ctx = be.Context.default(0)
+    nbr = be.Neighborhoods.euclidean(ctx, xy, 0.12)
+    b = (rng.uniform(size=(n, m)) < 0.1).astype(np.float64)
+    attr = be.Attributes.from_host(ctx, b)
+    perms = be.Permutations(ctx, n, attr.row_flags(), nperm, 1)
+    outs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
+    be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [o.ptr for o in outs])
+    ctx.sync()
+    name, avg_ms, launches = ctx.last_kernel()
+    busy = ctx.last_kernel_busy_ms()
+    perms.close()
+    attr.close()
+    assert name.startswith('k_permtest') and launches >= 1
+    assert 0.0 < busy <= avg_ms * launches * 1.001
