@@ -1633,18 +1633,32 @@ __global__ __launch_bounds__(64) void k_counts_bits(const int32_t *__restrict__ 
     } else {
         const int64_t kofs = col_ok ? static_cast<int64_t>(hl.kid[jc]) : 0;
         unsigned int hits = 0;
-        for (int r = 0; r < 64; ++r) {
-            const int32_t rr = sell_row[s * 64 + r];                    // wave-uniform
-            if (rr < 0 || !col_ok) continue;
-            const double2 *slab = hl.tab + static_cast<int64_t>(hl.nid[rr]) * hl.n_kid * hl.xs;
-            const double2 e = slab[static_cast<int64_t>(tile[r][lane]) * hl.n_kid + kofs];
-            const double p = e.x, nes = e.y;                            // p and -log10 p (safe.py:608), both from the table
-            const bool hit = p < hl.p_cut;                              // safe.py:468-470 (nes_p_cut)
-            const int64_t o = static_cast<int64_t>(rr) * mloc + jc;
-            hl.pvalues_pos[o] = p;
-            hl.nes[o] = nes;
-            hl.nes_binary[o] = hit ? 1.0 : 0.0;
-            hits += hit;
+        // row ids and their neighborhood-size ids once per wave (lane r holds row r's), then four rows per trip: the four table
+        // gathers are in flight together and their twelve stores follow back to back (the plain loop was a chain of three
+        // dependent loads -- row id, size id, table entry -- in front of every row's stores)
+        const int32_t my_nid = row >= 0 ? hl.nid[row] : 0;
+        const int64_t slab_stride = hl.n_kid * hl.xs;
+        for (int r0 = 0; r0 < 64; r0 += 4) {
+            int32_t rr[4];
+            double2 e[4];
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                rr[u] = __shfl(row, r0 + u);
+                const int32_t nid_u = __shfl(my_nid, r0 + u);
+                const double2 *slab = hl.tab + static_cast<int64_t>(nid_u) * slab_stride;
+                e[u] = slab[(rr[u] >= 0 && col_ok ? static_cast<int64_t>(tile[r0 + u][lane]) * hl.n_kid + kofs : 0)];
+            }
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                if (rr[u] < 0 || !col_ok) continue;
+                const double p = e[u].x, nes = e[u].y;                  // p and -log10 p (safe.py:608), both from the table
+                const bool hit = p < hl.p_cut;                          // safe.py:468-470 (nes_p_cut)
+                const int64_t o = static_cast<int64_t>(rr[u]) * mloc + jc;
+                hl.pvalues_pos[o] = p;
+                hl.nes[o] = nes;
+                hl.nes_binary[o] = hit ? 1.0 : 0.0;
+                hits += hit;
+            }
         }
         if (hits) atomicAdd(&hl.enriched[jc], hits);
     }
