@@ -12,6 +12,7 @@
 // minimum from the right passes through the group's last member).  NaN p-values sort last and
 // np.minimum propagates them through the whole row, so a row with any NaN becomes all NaN.
 //
+// Randomization form (p = counts / num_permutations): no sort, the row's histogram over the counts (k_fdr_row_counts).
 // Rows of up to 8192 attributes are adjusted by ONE kernel, one workgroup per row: block-wide radix sort of the
 // row's p-values with their column ids, then the Benjamini-Hochberg pass on the registers that hold the
 // sorted row (k_fdr_row_sort, instead of the library's segmented radix sort of the whole matrix + its temporaries).  Longer rows: hipCUB segmented radix sort,
@@ -126,6 +127,83 @@ __global__ __launch_bounds__(256) void k_fdr_row_sort(double *__restrict__ pvals
     }
 }
 
+// The same adjustment WITHOUT a sort, for p-values that are counts / num_permutations (the randomization form: every entry is one of
+// P + 1 values).  All members of a tie end up with the value of the tie's LAST sorted position (header above), so a row needs only
+// its histogram over the counts: cum[c] = #entries with count <= c is that last position, raw[c] = (c / P) / (cum[c] / n) the
+// value statsmodels computes there -- the same two divisions on the same doubles -- and adj[c] = min over the occupied c' >= c.
+// One workgroup per row: LDS histogram, block scan, reverse running minimum, one table look-up per entry.  0.9 ms -> HBM speed
+// per matrix at 3971 x 4373.  An entry that is not exactly c / P raises `flag` (the caller then sorts instead).
+__global__ __launch_bounds__(256) void k_fdr_row_counts(double *__restrict__ pvals, int64_t m, int64_t n_perm, unsigned int *__restrict__ flag) {
+    extern __shared__ unsigned char fdr_lds[];
+    const int bins = static_cast<int>(n_perm) + 1;
+    double *adj = reinterpret_cast<double *>(fdr_lds);                    // [bins]
+    unsigned int *hist = reinterpret_cast<unsigned int *>(adj + bins);   // [bins]
+    __shared__ unsigned int part_u[256];
+    __shared__ double part_d[256];
+    __shared__ int bad;
+    const int t = threadIdx.x;
+    double *p = pvals + static_cast<int64_t>(blockIdx.x) * m;
+    const double P = static_cast<double>(n_perm), n_d = static_cast<double>(m);
+    for (int c = t; c < bins; c += 256) hist[c] = 0u;
+    if (t == 0) bad = 0;
+    __syncthreads();
+    int mine_bad = 0;                                                     // 1: a NaN (poisons the row), 2: not a count ratio
+    for (int64_t e = t; e < m; e += 256) {
+        const double v = p[e];
+        if (v != v) {
+            mine_bad |= 1;
+            continue;
+        }
+        const double cf = rint(v * P);
+        if (!(cf >= 0.0 && cf <= P) || cf / P != v) {
+            mine_bad |= 2;
+            continue;
+        }
+        atomicAdd(&hist[static_cast<int>(cf)], 1u);
+    }
+    if (mine_bad) atomicOr(&bad, mine_bad);
+    __syncthreads();
+    if (bad & 2) {
+        if (t == 0) atomicOr(flag, 1u);
+        return;
+    }
+    if (bad & 1) {                                                        // np.minimum propagates the NaN through the whole row
+        const double qnan = __longlong_as_double(0x7FF8000000000000ll);
+        for (int64_t e = t; e < m; e += 256) p[e] = qnan;
+        return;
+    }
+    // cum over ascending counts: thread t owns the bins [b0, b1)
+    const int per = (bins + 255) / 256, b0 = t * per < bins ? t * per : bins, b1 = b0 + per < bins ? b0 + per : bins;
+    unsigned int local = 0;
+    for (int c = b0; c < b1; ++c) local += hist[c];
+    part_u[t] = local;
+    __syncthreads();
+    unsigned int before = 0;
+    for (int u = 0; u < t; ++u) before += part_u[u];
+    // raw values of the occupied bins (unoccupied: +inf), then the running minimum from the right
+    const double inf = __longlong_as_double(0x7FF0000000000000ll);
+    double mn = inf;
+    {
+        unsigned int cum = before;
+        for (int c = b0; c < b1; ++c) {
+            const unsigned int h = hist[c];
+            cum += h;
+            adj[c] = h ? (static_cast<double>(c) / P) / (static_cast<double>(cum) / n_d) : inf;
+        }
+        for (int c = b1 - 1; c >= b0; --c) mn = fmin(mn, adj[c]);
+    }
+    part_d[t] = mn;
+    __syncthreads();
+    double carry = inf;
+    for (int u = t + 1; u < 256; ++u) carry = fmin(carry, part_d[u]);
+    for (int c = b1 - 1; c >= b0; --c) {
+        carry = fmin(carry, adj[c]);
+        adj[c] = carry > 1.0 ? 1.0 : carry;
+    }
+    __syncthreads();
+    for (int64_t e = t; e < m; e += 256) p[e] = adj[static_cast<int>(rint(p[e] * P))];
+}
+
 // NES / binarisation from (adjusted) p-values; n_perm == 0: hypergeometric form nes = -log10(p_pos)
 __global__ __launch_bounds__(256) void k_nes_from_pvalues(const double *__restrict__ p_neg, const double *__restrict__ p_pos,
                                                           int64_t n, int64_t m, double inv_perm, int sign_mode,
@@ -164,8 +242,29 @@ __global__ void k_fdr_u32_to_f64(const unsigned int *__restrict__ in, double *__
     if (i < count) out[i] = static_cast<double>(in[i]);
 }
 
-int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m) {
-    const char *sort_env = getenv("SAFE_HIP_FDR_SORT");                   // "cub": library sort for every row length (tests)
+int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m, int64_t n_perm = 0) {
+    const char *sort_env = getenv("SAFE_HIP_FDR_SORT");                   // "cub": library sort for every row length (tests); "sort": never the histogram form
+    // randomization form: p-values are counts / n_perm -- no sort needed (k_fdr_row_counts); table + histogram must fit LDS
+    if (n_perm > 0 && (n_perm + 1) * 12 <= 60 * 1024 && !sort_env) {
+        unsigned int *d_flag = nullptr;
+        SAFE_TRY(ctx_scratch(ctx, 10, sizeof(unsigned int), reinterpret_cast<void **>(&d_flag)));
+        SAFE_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(unsigned int), ctx->stream));
+        const size_t lds = static_cast<size_t>(n_perm + 1) * 12;
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_fdr_row_counts), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds)));
+        hipLaunchKernelGGL(k_fdr_row_counts, dim3(n), dim3(256), lds, ctx->stream, p_dev, m, n_perm, d_flag);
+        SAFE_HIP_CHECK(hipGetLastError());
+        void *pinned = nullptr;
+        SAFE_TRY(ctx_pinned(ctx, sizeof(unsigned int), &pinned));
+        SAFE_HIP_CHECK(hipMemcpyAsync(pinned, d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+        if (*static_cast<unsigned int *>(pinned) == 0u) return SAFE_OK;
+        // some entry is not a count ratio: rows the kernel left untouched are sorted below; rows it already adjusted hold
+        // values that are not count ratios any more either -- refuse rather than adjust twice
+        safe_set_error("safe_fdr_adjust: num_permutations = %lld but a p-value is not a multiple of 1 / num_permutations",
+                       (long long)n_perm);
+        return SAFE_E_VALUE;
+    }
     if (m <= 8192 && !(sort_env && !strcmp(sort_env, "cub"))) {
         const int64_t ipt = ceil_div(m, 256);                                // items per thread: the sort pads the row to 256 * IPT
 #define FDR_SORT(I) hipLaunchKernelGGL(k_fdr_row_sort<I>, dim3(n), dim3(256), 0, ctx->stream, p_dev, m)
@@ -239,8 +338,8 @@ extern "C" int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_
     SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_fdr_adjust: bad sign_mode %d", sign_mode);
     SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_fdr_adjust: enrichment_threshold must be in (0,1)");
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    if (num_permutations > 0) SAFE_TRY(fdr_matrix(ctx, pvalues_neg_dev, n, m));
-    SAFE_TRY(fdr_matrix(ctx, pvalues_pos_dev, n, m));
+    if (num_permutations > 0) SAFE_TRY(fdr_matrix(ctx, pvalues_neg_dev, n, m, num_permutations));
+    SAFE_TRY(fdr_matrix(ctx, pvalues_pos_dev, n, m, num_permutations));
     unsigned int *d_enr = nullptr;
     SAFE_TRY(dev_alloc(&d_enr, m));
     SAFE_HIP_CHECK(hipMemsetAsync(d_enr, 0, m * sizeof(unsigned int), ctx->stream));

@@ -30,14 +30,14 @@ def test_fdr_fixture_lists_the_cases_tested_here(golden_fdr):
     assert sorted(str(c) for c in golden_fdr['cases']) == sorted(FDR_CASES)
 
 
-@pytest.mark.parametrize('sort', ['block', 'cub'])
+@pytest.mark.parametrize('sort', ['auto', 'block', 'cub'])
 @pytest.mark.parametrize('tag', FDR_CASES)
 def test_multiple_testing_vs_reference(amd, golden_fdr, monkeypatch, tag, sort):
     """SAFE.compute_pvalues(multiple_testing=True) == the reference with statsmodels' fdrcorrection (safe.py:536-554,
     599-608): adjusted empirical p-values bit for bit (same divisions in the same order), hypergeometric ones within
     1e-6 relative of SciPy's tail; NES within 1e-12 (the device's log10); nes_binary and the per-attribute counts exact."""
-    if sort == 'cub':
-        monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
+    if sort != 'auto':                                           # 'auto': the sort-free histogram form where p = counts / P
+        monkeypatch.setenv('SAFE_HIP_FDR_SORT', sort)
     g = golden_fdr
     kw = eval(str(g[tag + '_kwargs']))                           # a dict literal written by make_golden.py
     attrs = {k: kw.pop(k) for k in ('attribute_sign', 'random_seed') if k in kw}
@@ -65,8 +65,8 @@ def test_fdr_rows_equal_statsmodels(amd, golden_fdr, monkeypatch, sort):
     values, counts / P with heavy ties, mostly ones, one value, a NaN): bit for bit."""
     import torch
     from safepy_amd import backend as be
-    if sort == 'cub':
-        monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
+    if sort != 'auto':                                           # 'auto': the sort-free histogram form where p = counts / P
+        monkeypatch.setenv('SAFE_HIP_FDR_SORT', sort)
     ctx = amd.Context.default(0)
     g = golden_fdr
     for m in (int(v) for v in g['row_lengths']):

@@ -957,15 +957,15 @@ def test_gather_nes_over_rccl_single_rank(amd, ctx):
 
 # ------------------------------------------------------------- multiple_testing=True ----
 
-@pytest.mark.parametrize('sort', ['block', 'cub'])
+@pytest.mark.parametrize('sort', ['auto', 'block', 'cub'])
 @pytest.mark.parametrize('sign', ['both', 'highest'])
 def test_fdr_randomization_vs_oracle(amd, sign, sort, monkeypatch):
     """safe.py:536-554 with multiple_testing=True: Benjamini-Hochberg per row, then NES and the
     binarised map from the adjusted p-values.  Empirical p-values are multiples of 1/P (many
     ties, zeros, ones), quantitative attributes, a NaN column under z-score.  Both row sorts: the
     bitonic network in LDS (rows up to 8192 attributes) and the library's segmented radix sort."""
-    if sort == 'cub':
-        monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
+    if sort != 'auto':                                           # 'auto': the sort-free histogram form where p = counts / P
+        monkeypatch.setenv('SAFE_HIP_FDR_SORT', sort)
     rng = np.random.default_rng(61)
     n, m, nperm = 400, 150, 50
     xy = rng.uniform(size=(n, 2))
@@ -993,8 +993,8 @@ def test_fdr_randomization_vs_oracle(amd, sign, sort, monkeypatch):
 def test_fdr_hypergeometric_vs_oracle_with_nan_rows(amd, sort, monkeypatch):
     """safe.py:599-608 with multiple_testing=True; a non-integer column makes hypergeom.sf NaN,
     and NumPy's minimum.accumulate then turns every adjusted p-value of those rows into NaN."""
-    if sort == 'cub':
-        monkeypatch.setenv('SAFE_HIP_FDR_SORT', 'cub')
+    if sort != 'auto':                                           # 'auto': the sort-free histogram form where p = counts / P
+        monkeypatch.setenv('SAFE_HIP_FDR_SORT', sort)
     rng = np.random.default_rng(62)
     n, m = 300, 90
     xy = rng.uniform(size=(n, 2))
@@ -1124,3 +1124,48 @@ def test_kernel_busy_time_is_the_union_of_the_launch_intervals(amd):
     attr.close()
     assert name.startswith('k_permtest') and launches >= 1
     assert 0.0 < busy <= avg_ms * launches * 1.001
+
+
+@pytest.mark.parametrize('nperm,m', [(10, 1), (10, 7), (40, 129), (1000, 4373), (5000, 300)])
+def test_fdr_without_a_sort_equals_fdrcorrection(amd, nperm, m):
+    """Randomization form of safe_fdr_adjust: p-values are counts / P, adjusted from the row's histogram over the counts instead
+    of a sort (safe.py:536-542).  Against the oracle's fdrcorrection (itself equal to statsmodels' bit for bit): heavy ties, zeros,
+    rows of ones, a single distinct value, and a row with a NaN (np.minimum.accumulate poisons the whole row)."""
+    import torch
+    from safepy_amd import backend as be
+    ctx = amd.Context.default(0)
+    rng = np.random.default_rng(nperm + m)
+    n = 24
+    counts = rng.integers(0, nperm + 1, size=(2, n, m))
+    counts[0, 1] = nperm                                          # all ones
+    counts[0, 2] = 0                                              # all zeros
+    counts[0, 3] = rng.integers(0, 3, size=m)                     # very heavy ties
+    counts[1, 4] = counts[1, 4, 0]                                # one distinct value
+    p = counts.astype(np.float64) / float(nperm)
+    p[0, 5, m // 2] = np.nan
+    want = [np.stack([orc.fdrcorrection(row) for row in mat]) for mat in p]
+    t = [torch.from_numpy(p[0].copy()).to('cuda'), torch.from_numpy(p[1].copy()).to('cuda'),
+         torch.empty((n, m), dtype=torch.float64, device='cuda'), torch.empty((n, m), dtype=torch.float64, device='cuda'),
+         torch.empty((m,), dtype=torch.float64, device='cuda')]
+    torch.cuda.synchronize()
+    be.fdr_adjust(ctx, n, m, nperm, 'both', 0.05, [x.data_ptr() for x in t])
+    ctx.sync()
+    for got, w in zip(t[:2], want):
+        np.testing.assert_array_equal(got.cpu().numpy(), w)
+    assert np.isnan(t[0].cpu().numpy()[5]).all()
+
+
+def test_fdr_without_a_sort_refuses_other_values(amd):
+    """num_permutations > 0 promises p = counts / num_permutations; anything else is refused, not adjusted wrongly."""
+    import torch
+    from safepy_amd import backend as be
+    ctx = amd.Context.default(0)
+    n, m, nperm = 4, 33, 20
+    p = np.random.default_rng(1).integers(0, nperm + 1, size=(n, m)).astype(np.float64) / nperm
+    p[2, 7] = 0.123456
+    t = [torch.from_numpy(p.copy()).to('cuda'), torch.from_numpy(p.copy()).to('cuda'),
+         torch.empty((n, m), dtype=torch.float64, device='cuda'), torch.empty((n, m), dtype=torch.float64, device='cuda'),
+         torch.empty((m,), dtype=torch.float64, device='cuda')]
+    torch.cuda.synchronize()
+    with pytest.raises(Exception, match='num_permutations'):
+        be.fdr_adjust(ctx, n, m, nperm, 'both', 0.05, [x.data_ptr() for x in t])
