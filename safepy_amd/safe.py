@@ -9,7 +9,6 @@ domains and output writers of the reference are out of scope (SURVEY.md section 
 import configparser
 import logging
 import os
-import warnings
 
 import numpy as np
 
@@ -780,17 +779,21 @@ class SAFE:
         primary = ids[real][np.argmax(t, axis=1)]                # first maximum, like DataFrame.idxmax
         primary = np.where(t_max == 0, 0, primary)
         node2domain['primary_domain'] = primary
-        # the highest NES among the attributes of the primary domain (safe.py:703-705); NaNs are skipped
-        with np.errstate(invalid='ignore'), warnings.catch_warnings():
-            warnings.simplefilter('ignore', RuntimeWarning)
-            best = np.stack([np.nanmax(np.where(np.isnan(self.nes[:, dom == d]), -np.inf, self.nes[:, dom == d]), axis=1)
-                             for d in ids], axis=1)
-            allnan = np.stack([np.isnan(self.nes[:, dom == d]).all(axis=1) for d in ids], axis=1)
-        best = np.where(allnan, np.nan, best)
-        col_of = {d: i for i, d in enumerate(ids)}
+        # the highest NES among the attributes of the primary domain (safe.py:703-705); NaNs are skipped.  Only the
+        # (node, primary domain) pairs are evaluated: a domain's columns for the nodes that have it as primary domain
+        # (all columns of every domain for every node -- domain 0 holds most of the matrix -- took 0.23 s at 3971 x 4373)
         if np.any(~np.isin(primary, ids)):
             raise KeyError(0)                                     # the reference's o.loc[row, 0] with no attribute outside the domains
-        node2domain['primary_nes'] = best[np.arange(best.shape[0]), [col_of[d] for d in primary]]
+        primary_nes = np.full(primary.shape[0], np.nan)
+        with np.errstate(invalid='ignore'):
+            for d in ids:
+                rows = np.nonzero(primary == d)[0]
+                if rows.size == 0:
+                    continue
+                block = self.nes[np.ix_(rows, np.nonzero(dom == d)[0])]
+                nan = np.isnan(block)
+                primary_nes[rows] = np.where(nan.all(axis=1), np.nan, np.where(nan, -np.inf, block).max(axis=1))
+        node2domain['primary_nes'] = primary_nes
         self.node2domain = node2domain
         if self.verbose:
             per_domain = attrs.loc[attrs['domain'] > 0].groupby('domain')['id'].count()
