@@ -732,8 +732,8 @@ class SAFE:
                 pos_of = {a: i for i, a in enumerate(attrs.index.values)}
                 for row, a in enumerate(cand):
                     lab = labels[row]
-                    comp = np.sort(np.bincount(lab[lab >= 0]))[::-1]
-                    comp = comp[comp > 0]
+                    comp = np.bincount(lab[lab >= 0])
+                    comp = np.sort(comp[comp > 0])[::-1]                  # (a few components, not the n bins, are sorted)
                     i = pos_of[a]
                     num_cc[i] = len(comp)
                     sizes[i] = comp
