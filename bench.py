@@ -530,7 +530,7 @@ def main():
     import safepy_amd                                               # noqa: F401
     from safepy_amd import backend as be
     from safepy_amd import sharding
-    # host threads per rank: ranks of one node share the host -- swap workers within the rank's share of the CPUs, sleeping host
+    # host threads per rank: ranks of one node share the host -- sleeping host
     # waits when a rank has fewer than three cores to itself (before the context exists)
     local_world = int(os.environ.get('LOCAL_WORLD_SIZE', str(world)))
     host_cfg = be.configure_host_for_ranks(local_world)
@@ -542,7 +542,7 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     numa_node = None if os.environ.get('SAFE_BENCH_NO_PIN') == '1' else be.pin_threads_to_device_numa(local_rank)
-    torch.set_num_threads(1)      # no OpenMP spinning next to the host draw/swap threads (container CPU quotas throttle it)
+    torch.set_num_threads(1)      # no OpenMP spinning next to the host draw thread (container CPU quotas throttle it)
     ctx = be.Context.default(local_rank)          # (before the process group: see GPU_MAX_HW_QUEUES above)
     dist = None
     force_dist = os.environ.get('SAFE_BENCH_FORCE_DIST') == '1'      # exercise the collectives with a single rank

@@ -22,8 +22,7 @@ def _ptr(a):
 
 
 def pin_threads_to_device_numa(device=0):
-    """Keep every thread this process has -- and those it starts later: the draw thread, the
-    swap workers -- on the CPUs of the NUMA node the GPU hangs off.  A container may be scheduled on any CPU of a
+    """Keep every thread this process has -- and those it starts later: the draw thread -- on the CPUs of the NUMA node the GPU hangs off.  A container may be scheduled on any CPU of a
     two-socket host; with the draw thread on the far socket a whole run is ~15-20 % slower (5.2 vs 5.4-6.2
     ms/step at configs[1]).  Returns the node, or None when the topology cannot be read (nothing is changed
     then).  For launchers (bench.py, run_batch): a library does not re-pin its caller behind its back."""
@@ -555,19 +554,17 @@ def effective_cores():
 
 
 def configure_host_for_ranks(local_world):
-    """Host-side settings of one rank among `local_world` on this node, BEFORE its Context exists: the swap pool stays within
-    the rank's share of the CPUs (4 workers keep pace with the draw thread; only the node's producer uses them when the
-    stream is shared), and when a rank has fewer than three cores to itself its host waits sleep instead of spinning
-    (a spinning launcher + draw thread + workers per rank on a 16-CPU quota gets the whole job throttled).
-    Environment overrides: SAFE_HIP_SWAP_THREADS, SAFE_HIP_BLOCKING_SYNC.  Returns what was chosen."""
+    """Host-side settings of one rank among `local_world` on this node, BEFORE its Context exists: when a rank has fewer than
+    three cores to itself its host waits sleep instead of spinning (a spinning launcher + draw thread per rank on a 16-CPU
+    quota gets the whole job throttled).  The only host thread of the permutation stream is the draw thread of a seeded
+    call (one per node when the stream is shared); the swaps are replayed on the device.
+    Environment override: SAFE_HIP_BLOCKING_SYNC.  Returns what was chosen."""
     local_world = max(1, int(local_world))
     share = effective_cores() / local_world
-    if 'SAFE_HIP_SWAP_THREADS' not in os.environ:
-        os.environ['SAFE_HIP_SWAP_THREADS'] = str(max(1, min(4, int(share) - 1)))
     blocking = os.environ.get('SAFE_HIP_BLOCKING_SYNC')
     blocking = (share < 3) if blocking is None else (blocking not in ('0', ''))
     set_blocking_sync(blocking)
-    return {'cores_per_rank': share, 'swap_threads': int(os.environ['SAFE_HIP_SWAP_THREADS']), 'blocking_sync': bool(blocking)}
+    return {'cores_per_rank': share, 'blocking_sync': bool(blocking)}
 
 
 def set_blocking_sync(on):

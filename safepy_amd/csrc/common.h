@@ -262,24 +262,29 @@ struct safe_perms {
     int64_t k = 0;                  // number of movable rows (indx_vals)
     std::vector<int32_t> h_movable;
     DrawStream *stream = nullptr;
-    // pipeline positions (in permutations): drawn >= handed to the swap workers >= enqueued on the GPU
-    int64_t generated = 0, swapping = 0, enqueued = 0;
+    // pipeline positions (in permutations): drawn >= enqueued on the GPU
+    int64_t generated = 0, enqueued = 0;
     std::vector<int64_t> stages;                   // pipeline stage boundaries of this handle (perms_stage_plan(count))
     std::vector<hipEvent_t> chunk_done;            // recorded on ctx->aux_stream after each enqueued chunk
-    std::vector<uint32_t> h_targets[2];            // swap targets of a chunk (draw thread -> workers)
-    std::vector<uint32_t> h_local;                 // the draw thread's private chunk buffer
-    // the draw thread: runs the sequential MT19937 / rejection stream chunk by chunk, at most two
-    // chunks ahead of the swap workers (one target buffer each), independent of the thread that
-    // launches kernels
+    std::vector<uint32_t> h_local;                 // the draw thread's private buffer: the targets of one shuffle (L1-resident)
+    // the draw thread: runs the sequential MT19937 / rejection stream chunk by chunk into the pinned staging buffers, at most
+    // kStage chunks ahead of the uploads, independent of the thread that launches kernels
     std::thread drawer;
     std::mutex draw_mu;
     std::condition_variable draw_cv;
-    int64_t drawn_chunks = 0;                      // chunks whose targets are complete in h_targets[c & 1]
-    int64_t consumed_chunks = 0;                   // chunks whose swaps have finished (their buffer is free again)
+    int64_t drawn_chunks = 0;                      // chunks whose targets are complete in h_stage[c % kStage]
+    int64_t enqueued_chunks = 0;                   // chunks whose upload has been queued (staged[c % kStage] recorded)
     bool draw_stop = false;
-    int32_t *h_maps[2] = {nullptr, nullptr};       // pinned: row maps of a chunk (workers -> GPU)
-    hipEvent_t staged[2] = {nullptr, nullptr};
-    int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] scan ping-pong
+    static constexpr int kStage = 3;
+    void *h_stage[kStage] = {nullptr, nullptr, nullptr};   // pinned: accepted swap targets of a chunk, [chunk][target_width] u16 (k <= 65535) or u32
+    hipEvent_t staged[kStage] = {nullptr, nullptr, nullptr};
+    size_t stage_bytes = 0;                        // capacity of each staging buffer (sized for k = n)
+    int target_bytes = 2;                          // bytes per swap target on the wire (2 when k <= 65535)
+    int64_t target_width = 0;                      // targets per permutation row: k - 1 rounded up to 8
+    void *d_targets = nullptr;                     // device copy of the chunk being replayed
+    int32_t *d_big = nullptr;                      // k > 65535 only: [chunk][k] position arrays of the global-memory replay
+    int32_t *h_movpos = nullptr;                   // pinned [2n]: staging of d_movpos
+    int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] row maps / scan ping-pong
     int32_t *d_cur = nullptr;       // [n+1] running composition (last emitted row)
     int32_t *table = nullptr;       // [count][n+1] device; entry n is the padding row (== n)
     // 16-bit copy of the table, rows padded to a multiple of 8 entries (n < 65535 only)
@@ -293,7 +298,7 @@ struct safe_perms {
     // node-shared stream (ring.h; safe_perms_create_shared): local rank 0 of a node publishes every chunk's row maps,
     // the other ranks fetch them instead of drawing (no draw thread, no swap workers on those ranks)
     bool device_gen = false;        // tables generated on the device (safe_perms_create_device): no host stream at all
-    int32_t *d_movpos = nullptr;    // device generation: [n] movable rows (first k used) | [n] position of a row in that list (-1: fixed)
+    int32_t *d_movpos = nullptr;    // [n] movable rows (first k used) | [n] position of a row in that list (-1: fixed)
     struct PermRing *ring = nullptr;               // the context's ring while this handle takes part in a shared call, else NULL
     bool ring_consumer = false;
     // host-side timing of the stream (safe_perms_timing), ms since the handle was created

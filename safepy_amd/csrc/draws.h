@@ -10,3 +10,5 @@ void draw_stream_free(DrawStream *s);
 void draw_stream_targets(DrawStream *s, int64_t k, uint32_t *steps);
 // streaming (non-temporal) copy for hand-offs to other cores
 void draws_nt_copy(void *dst, const void *src, size_t bytes);
+// 32-bit swap targets (all < 65536) packed to 16 bits
+void draws_pack_u16(uint16_t *dst, const uint32_t *src, size_t count);

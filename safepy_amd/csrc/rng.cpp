@@ -5,20 +5,23 @@
 //
 // Split of the work.  The only inherently sequential part is the draw stream: how many
 // 32-bit outputs a shuffle consumes depends on its rejections, so permutation q+1 cannot
-// start before q has finished drawing.  The host therefore produces just the accepted swap
-// targets j[q][i] (draws.cpp: bulk MT19937 generation + batch-resolved rejection, well under
-// 1 ns per draw) on one thread.  The rest is parallel and runs chunk by chunk, overlapping the draw
-// thread's next chunk and the enrichment kernel of the previous one:
-//   host workers       replay the swaps of each permutation on a copy of indx_vals (independent
-//                      across permutations: a few threads keep up with the draw thread) and
-//                      emit the row map M_q
+// start before q has finished drawing, and the state a draw leaves behind depends on every
+// word before it (two runs of the rule started a few words apart never meet again: measured,
+// tools/ubench/chain_merge.c).  One host thread therefore produces just the accepted swap
+// targets j[q][i] (draws.cpp: bulk MT19937 generation + batch-resolved rejection, ~0.3 ns per
+// draw) straight into pinned staging memory, 2 bytes per target.  Everything else runs on the
+// device, chunk by chunk, overlapping the draw thread's next chunk and the enrichment kernels
+// of the previous one:
+//   k_replay_targets   one wave per permutation: the Fisher-Yates swaps replayed on an LDS copy
+//                      of the positions, 64 steps at a time (steps that touch a location a lower
+//                      lane of the batch also touches are settled in lane order afterwards), then
+//                      the row map M_q
 //   k_scan_round x log2(chunk), k_emit_rows
 //                      cur_q = cur_{q-1} o M_q is a prefix product under composition: a
-//                      log-depth parallel scan on the GPU, emitting the composed table rows
+//                      log-depth parallel scan, emitting the composed table rows
 #include <algorithm>
 #include <random>
 #include <condition_variable>
-#include <functional>
 #include <mutex>
 #include <thread>
 
@@ -226,13 +229,11 @@ __global__ __launch_bounds__(64) void k_perms_device(int64_t n, int64_t k, int64
 // chunked generation
 // --------------------------------------------------------------------------------------
 static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
-static const int64_t kFirst = 32;       // the first stage is short so that the first kernel starts early
+static const int64_t kFirst = 64;       // the first stage is short so that the first kernel starts early (32: the launch that covers it
+                                        // costs twice as much per permutation; kernels 2.86 -> 2.67 ms per 1000, tools/exp_stages.sh)
 
-// Stage boundaries of the host / GPU pipeline for `count` permutations: [0, 32), [32, 128), [128, 256), ... and a SHORT last
-// stage: the final stages are cut to <= 72 and 32 permutations.  That rule dates from the host-bound pipeline (draw thread:
-// 128 permutations per ~0.4 ms; whatever the last stage held ran after the draws had ended, 0.25 ms more tail with a last
-// stage of ~100).  With the faster draw loop the kernels bound the step and a first stage of 16 ... 96 or an uncut tail
-// measure the same within run-to-run noise (4.0-4.4 ms), so the plan stayed.
+// Stage boundaries of the host / GPU pipeline for `count` permutations: [0, 64), [64, 128), [128, 256), ... and a SHORT last
+// stage: the final stages are cut to <= 72 and 32 permutations (what the last stage holds runs after the draws have ended).
 std::vector<int64_t> perms_stage_plan(int64_t count) {
     std::vector<int64_t> b;
     b.push_back(0);
@@ -272,155 +273,211 @@ static int64_t chunk_of(const safe_perms *p, int64_t perm) {
 }
 static int64_t chunk_end(const safe_perms *p, int64_t ci) { return stage_begin(p, ci + 1); }
 
-// A small process-wide pool of swap workers (creating threads per chunk costs more than the
-// chunk's draws).  One job at a time: parallel-for over the permutations of a chunk.
-class SwapPool {
-public:
-    static SwapPool &get() {
-        static SwapPool pool;
-        return pool;
-    }
-    // runs fn(w, W) on every worker; returns immediately
-    void submit(std::function<void(int, int)> fn) {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return pending_ == 0; });
-        fn_ = std::move(fn);
-        pending_ = static_cast<int>(threads_.size());
-        ++epoch_;
-        cv_work_.notify_all();
-    }
-    void wait() {
-        std::unique_lock<std::mutex> lk(mu_);
-        cv_done_.wait(lk, [&] { return pending_ == 0; });
-    }
-
-private:
-    SwapPool() {
-        const char *e = getenv("SAFE_HIP_SWAP_THREADS");
-        int W = e ? atoi(e) : 4;
-        W = W < 1 ? 1 : (W > 64 ? 64 : W);
-        for (int w = 0; w < W; ++w) threads_.emplace_back([this, w, W] { loop(w, W); });
-    }
-    ~SwapPool() {
-        {
-            std::unique_lock<std::mutex> lk(mu_);
-            stop_ = true;
-            cv_work_.notify_all();
+// --------------------------------------------------------------------------------------
+// Replay of the accepted swap targets (np.random.permutation = legacy shuffle: for i = k-1 .. 1: swap(a[i], a[j_i]);
+// safepy/safe_extras.py:58) on the device.  One wave per permutation; the positions 0..k-1 live in LDS as 16-bit values.
+// A shuffle is one dependent chain of k - 1 swaps, but 64 consecutive steps rarely touch a common location (their own
+// positions i are distinct, only the targets j can coincide: ~64^2 / k pairs per batch), so a batch runs in two phases:
+//   every lane stamps its two locations in a hashed tag table with an atomic min of (batch, lane) -- the LOWEST lane that
+//   touches a location owns it; a lane that owns both of its locations shares neither with a lower lane, so its swap commutes
+//   with every lower lane's and runs at once; the other lanes (they share a location, or just a tag slot, with a lower lane)
+//   run afterwards one by one in lane order.
+// Order is kept exactly where it matters: between two steps that share a location the lower one is either unflagged (first
+// phase) or earlier in the second phase.  Stamps decrease from batch to batch, so the table is never cleared.
+// --------------------------------------------------------------------------------------
+static const int kReplayBlock = 1024;      // targets staged in LDS at a time (16 batches)
+// ROWIDS: the LDS array holds the ROW that sits at each position (n <= 65535: a row id fits 16 bits) -- the row map then needs
+// no gather through `mov` at the end; otherwise it holds the original position and the rows are looked up when the map is written.
+// `mov` and `pos_of` are padded to a multiple of 4 entries with -1 (16-byte loads).
+template <bool ROWIDS>
+__global__ __launch_bounds__(64) void k_replay_targets(const uint16_t *__restrict__ targets, int64_t width, int64_t n, int64_t k,
+                                                       const int32_t *__restrict__ mov, const int32_t *__restrict__ pos_of,
+                                                       int32_t *__restrict__ maps, uint32_t hash_mask) {
+    extern __shared__ uint32_t lds32[];                               // tag [hash_mask + 1] u32 | tb [1024] u16 | a [kpad] u16
+    uint32_t *tag = lds32;
+    uint16_t *tb = reinterpret_cast<uint16_t *>(lds32 + hash_mask + 1);
+    uint16_t *a = tb + kReplayBlock;
+    const uint32_t lane = threadIdx.x;
+    const int64_t q = blockIdx.x;
+    for (uint32_t t = lane; t <= hash_mask; t += 64) tag[t] = 0xFFFFFFFFu;
+    if (ROWIDS) {
+#pragma unroll 4
+        for (uint32_t t = 4 * lane; t < static_cast<uint32_t>(k); t += 256) {      // (a[] is padded to a multiple of 4)
+            const int4 m = *reinterpret_cast<const int4 *>(mov + t);
+            a[t] = static_cast<uint16_t>(m.x), a[t + 1] = static_cast<uint16_t>(m.y);
+            a[t + 2] = static_cast<uint16_t>(m.z), a[t + 3] = static_cast<uint16_t>(m.w);
         }
-        for (std::thread &t : threads_) t.join();
+    } else {
+        for (uint32_t t = lane; t < static_cast<uint32_t>(k); t += 64) a[t] = static_cast<uint16_t>(t);
     }
-    void loop(int w, int W) {
-        pthread_setname_np(pthread_self(), "safe-swap");
-        uint64_t seen = 0;
-        for (;;) {
-            std::function<void(int, int)> fn;
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                cv_work_.wait(lk, [&] { return stop_ || epoch_ != seen; });
-                if (stop_) return;
-                seen = epoch_;
-                fn = fn_;
+    // One wave: its LDS instructions execute in issue order, so a lane sees what another lane wrote in an earlier statement
+    // without a barrier (the compiler keeps may-alias LDS accesses in program order; wave_barrier() only pins the schedule).
+    // No __syncthreads() in this kernel: its fence would also wait for the target loads that are kept in flight below.
+    __builtin_amdgcn_wave_barrier();
+    const uint32_t steps = k > 0 ? static_cast<uint32_t>(k - 1) : 0u;
+    // The targets of 1024 steps are staged in LDS; the next block's 16 targets per lane are loaded into registers before the
+    // block's 16 batches run and stored behind them, so a global-memory round trip is paid once per row, not once per batch.
+    // (Rows are 16-byte aligned and the buffer has a block of slack behind the last row: the last block may read past its row.)
+    const uint4 *src = reinterpret_cast<const uint4 *>(targets + q * width) + 2 * lane;
+    uint4 nx0 = src[0], nx1 = src[1];
+    for (uint32_t b0 = 0; b0 < steps; b0 += kReplayBlock) {
+        reinterpret_cast<uint4 *>(tb)[2 * lane] = nx0;
+        reinterpret_cast<uint4 *>(tb)[2 * lane + 1] = nx1;
+        __builtin_amdgcn_wave_barrier();
+        if (b0 + kReplayBlock < steps) {
+            src += kReplayBlock / 8;
+            nx0 = src[0];
+            nx1 = src[1];
+        }
+        const uint32_t b_end = min(steps, b0 + kReplayBlock);
+        for (uint32_t s0 = b0; s0 < b_end; s0 += 64) {
+            const uint32_t st = s0 + lane, batch = s0 >> 6;
+            const bool valid = st < steps;
+            const uint32_t i = valid ? static_cast<uint32_t>(k - 1) - st : 0u;
+            const uint32_t j = valid ? static_cast<uint32_t>(tb[st - b0]) : 0u;
+            const uint32_t stamp = ((0x03FFFFFFu - batch) << 6) | lane;
+            if (valid) {
+                atomicMin(&tag[i & hash_mask], stamp);
+                atomicMin(&tag[j & hash_mask], stamp);
             }
-            fn(w, W);
-            {
-                std::unique_lock<std::mutex> lk(mu_);
-                if (--pending_ == 0) cv_done_.notify_all();
+            __builtin_amdgcn_wave_barrier();
+            const bool mine = valid && tag[i & hash_mask] == stamp && tag[j & hash_mask] == stamp;
+            uint16_t x = 0, y = 0;
+            if (mine) {
+                x = a[i];
+                y = a[j];
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (mine) {
+                a[i] = y;
+                a[j] = x;
+            }
+            __builtin_amdgcn_wave_barrier();
+            // The other lanes, in lane order, without an LDS round trip per step: each reads its two values once (current with
+            // respect to the first phase), then the steps are replayed in REGISTERS -- step t broadcasts (i, j, x, y); a later lane
+            // whose position or target is step t's target now holds what t moved there; an earlier lane whose target is written
+            // again by t (as its target or as its own position) gives up that write.  One write of the survivors at the end.
+            const bool late = valid && !mine;
+            uint64_t later = __ballot(late);
+            if (later) {
+                uint32_t xr = 0, yr = 0;
+                if (late) {
+                    xr = a[i];
+                    yr = a[j];
+                }
+                bool write_j = late;
+                while (later) {                                        // (uniform)
+                    const int t = __builtin_ctzll(later);
+                    later &= later - 1ull;
+                    const uint32_t it = __builtin_amdgcn_readlane(i, t), jt = __builtin_amdgcn_readlane(j, t);
+                    const uint32_t xt = __builtin_amdgcn_readlane(xr, t);
+                    if (late && lane > static_cast<uint32_t>(t)) {   // (a later step's position or target can only meet jt: its i and j are < it)
+                        if (i == jt) xr = xt;
+                        if (j == jt) yr = xt;
+                    }
+                    if (lane < static_cast<uint32_t>(t) && (j == jt || j == it)) write_j = false;
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (late) {
+                    a[i] = static_cast<uint16_t>(yr);
+                    if (write_j) a[j] = static_cast<uint16_t>(xr);
+                }
+                __builtin_amdgcn_wave_barrier();
             }
         }
     }
-    std::mutex mu_;
-    std::condition_variable cv_work_, cv_done_;
-    std::vector<std::thread> threads_;
-    std::function<void(int, int)> fn_;
-    uint64_t epoch_ = 0;
-    int pending_ = 0;
-    bool stop_ = false;
-};
-
-// swaps of permutations [w, cnt) step W of one chunk -> row maps (host worker thread).
-// A shuffle is one dependent chain (load a[j], load a[i], store both: ~3 ns per swap through the store
-// buffer), so a thread replays NL permutations in lock step -- NL independent chains, 16-bit positions so
-// that all NL arrays stay in L1 -- and maps positions to rows only when it writes the row map.
-template <int NL>
-static void replay_lockstep(const safe_perms *p, const uint32_t *targets, int32_t *maps, const int64_t (&qs)[4], uint16_t *a) {
-    const int64_t k = p->k, stride = p->n + 1, width = std::max<int64_t>(k, 1), kpad = (k + 31) & ~int64_t(31);
-    const int32_t *mov = p->h_movable.data();
-    const uint32_t *j[NL];
-    uint16_t *ar[NL];
-    for (int r = 0; r < NL; ++r) {
-        j[r] = targets + qs[r] * width;
-        ar[r] = a + r * kpad;
-        for (int64_t t = 0; t < k; ++t) ar[r][t] = static_cast<uint16_t>(t);
+    __builtin_amdgcn_wave_barrier();
+    // the row map: rows that hold no value stay (entry n: the padding row); safe_extras.py:58: the row at indx_vals[t] is now
+    // old row indx_vals[position that ended at t]
+    int32_t *row = maps + q * (n + 1);
+#pragma unroll 4
+    for (int64_t r4 = 4 * lane; r4 < n; r4 += 256) {
+        const int4 p4 = *reinterpret_cast<const int4 *>(pos_of + r4);
+        const int32_t ps[4] = {p4.x, p4.y, p4.z, p4.w};
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (r4 + e < n) {
+                int32_t v = static_cast<int32_t>(r4 + e);
+                if (ps[e] >= 0) v = ROWIDS ? static_cast<int32_t>(a[ps[e]]) : mov[a[ps[e]]];
+                row[r4 + e] = v;
+            }
     }
-    for (int64_t i = k - 1, st = 0; i > 0; --i, ++st)                       // safe_extras.py:58 / legacy shuffle
-        for (int r = 0; r < NL; ++r) {
-            const uint32_t jj = j[r][st];
-            const uint16_t x = ar[r][i], y = ar[r][jj];
-            ar[r][i] = y;
-            ar[r][jj] = x;
+    if (lane == 0) row[n] = static_cast<int32_t>(n);
+}
+
+// k > 65535 movable rows (16-bit positions and LDS no longer hold a shuffle): the same replay, one lane per permutation on a
+// global-memory array.  Slow (a dependent global load per step) and never on a measured path; kept so that the library
+// has no size at which the stream leaves the device.
+__global__ __launch_bounds__(64) void k_replay_targets_big(const uint32_t *__restrict__ targets, int64_t width, int64_t n, int64_t k,
+                                                           const int32_t *__restrict__ mov, const int32_t *__restrict__ pos_of,
+                                                           int32_t *__restrict__ maps, int32_t *__restrict__ scratch) {
+    const int64_t q = blockIdx.x;
+    int32_t *a = scratch + q * k;
+    for (int64_t t = threadIdx.x; t < k; t += 64) a[t] = static_cast<int32_t>(t);
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const uint32_t *tg = targets + q * width;
+        for (int64_t i = k - 1, st = 0; i > 0; --i, ++st) {
+            const int64_t j = tg[st];
+            const int32_t x = a[i], y = a[j];
+            a[i] = y;
+            a[j] = x;
         }
-    for (int r = 0; r < NL; ++r) {
-        int32_t *m = maps + qs[r] * stride;
-        for (int64_t i = 0; i < stride; ++i) m[i] = static_cast<int32_t>(i);
-        for (int64_t t = 0; t < k; ++t) m[mov[t]] = mov[ar[r][t]];
+    }
+    __syncthreads();
+    int32_t *row = maps + q * (n + 1);
+    for (int64_t r = threadIdx.x; r <= n; r += 64) {
+        int32_t v = static_cast<int32_t>(r);
+        if (r < n) {
+            const int32_t t = pos_of[r];
+            if (t >= 0) v = mov[a[t]];
+        }
+        row[r] = v;
     }
 }
 
-static void swap_worker(const safe_perms *p, const uint32_t *targets, int32_t *maps, int64_t cnt, int w, int W) {
-    const int64_t k = p->k, stride = p->n + 1;
-    const int32_t *mov = p->h_movable.data();
-    if (k >= 2 && k < 65536) {
-        const int64_t kpad = (k + 31) & ~int64_t(31);
-        std::vector<uint16_t> a(4 * kpad);
-        for (int64_t q = w; q < cnt; q += 4 * W) {
-            int64_t qs[4];
-            int nl = 0;
-            for (int r = 0; r < 4; ++r)
-                if (q + r * W < cnt) qs[nl++] = q + r * W;
-            if (nl == 4) replay_lockstep<4>(p, targets, maps, qs, a.data());
-            else if (nl == 3) replay_lockstep<3>(p, targets, maps, qs, a.data());
-            else if (nl == 2) replay_lockstep<2>(p, targets, maps, qs, a.data());
-            else replay_lockstep<1>(p, targets, maps, qs, a.data());
-        }
-        return;
-    }
-    std::vector<int32_t> a(std::max<int64_t>(k, 1));
-    for (int64_t q = w; q < cnt; q += W) {
-        const uint32_t *j = targets + q * std::max<int64_t>(k, 1);
-        memcpy(a.data(), mov, k * sizeof(int32_t));
-        for (int64_t i = k - 1, st = 0; i > 0; --i, ++st) std::swap(a[i], a[j[st]]);     // safe_extras.py:58 / legacy shuffle
-        int32_t *m = maps + q * stride;
-        for (int64_t i = 0; i < stride; ++i) m[i] = static_cast<int32_t>(i);
-        for (int64_t t = 0; t < k; ++t) m[mov[t]] = a[t];
-    }
-}
+static size_t chunk_target_bytes(const safe_perms *p, int64_t cnt) { return static_cast<size_t>(cnt) * p->target_width * p->target_bytes; }
 
-// enqueue the GPU part of a chunk whose row maps are ready in h_maps[b]
+// enqueue the GPU part of a chunk whose swap targets are ready in h_stage[ci % kStage] (or come from the node's ring)
 static int enqueue_chunk(safe_perms *p, int64_t ci) {
     safe_ctx *ctx = p->ctx;
     hipStream_t gs = ctx->aux_stream;
-    const int64_t n = p->n, stride = n + 1;
+    const int64_t n = p->n, k = p->k, stride = n + 1;
     const int64_t q0 = stage_begin(p, ci), q1 = chunk_end(p, ci), cnt = q1 - q0;
-    const int b = static_cast<int>(ci & 1);
+    const int b = static_cast<int>(ci % safe_perms::kStage);
+    const size_t bytes = chunk_target_bytes(p, cnt);
     if (p->ring_consumer) {
-        // the node's producer drew and replayed this chunk: block until it is published, copy it into this rank's pinned
-        // staging buffer (free once the upload of two chunks ago has completed)
-        if (ci >= 2) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
-        SAFE_TRY(ring_fetch(p->ring, ci, p->h_maps[b], static_cast<size_t>(cnt) * stride * sizeof(int32_t), &p->ring_wait_ms));
+        // the node's producer drew this chunk: block until it is published, copy it into this rank's pinned staging buffer
+        // (free once the upload of kStage chunks ago has completed)
+        if (ci >= safe_perms::kStage) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
+        SAFE_TRY(ring_fetch(p->ring, ci, p->h_stage[b], bytes, &p->ring_wait_ms));
         safe_trace("  gen: chunk fetched from the node's stream");
-    } else {
-        SwapPool::get().wait();
-        {
-            std::lock_guard<std::mutex> lk(p->draw_mu);          // the chunk's target buffer may be drawn into again
-            p->consumed_chunks = std::max<int64_t>(p->consumed_chunks, ci + 1);
-        }
-        p->draw_cv.notify_all();
-        safe_trace("  gen: workers joined");
-        if (p->ring) SAFE_TRY(ring_publish(p->ring, ci, p->h_maps[b], static_cast<size_t>(cnt) * stride * sizeof(int32_t)));
+    } else if (p->ring) {
+        SAFE_TRY(ring_publish(p->ring, ci, p->h_stage[b], bytes));
     }
-    int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
-    SAFE_HIP_CHECK(hipMemcpyAsync(xa, p->h_maps[b], cnt * stride * sizeof(int32_t), hipMemcpyHostToDevice, gs));
+    SAFE_HIP_CHECK(hipMemcpyAsync(p->d_targets, p->h_stage[b], bytes, hipMemcpyHostToDevice, gs));
     SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
+    {
+        std::lock_guard<std::mutex> lk(p->draw_mu);                  // the draw thread may fill this buffer again once the upload is done
+        p->enqueued_chunks = std::max<int64_t>(p->enqueued_chunks, ci + 1);
+    }
+    p->draw_cv.notify_all();
+    int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
+    const int32_t *d_mov = p->d_movpos, *d_pos = p->d_movpos + ((n + 3) & ~int64_t(3));
+    if (k <= 65535) {
+        uint32_t hash_mask = 63u;                              // tag slots: the next power of two >= k (no aliasing), at most 8192 (4096 when the positions need most of the LDS)
+        while (hash_mask + 1 < static_cast<uint32_t>(k) && hash_mask < (k <= 32768 ? 8191u : 4095u)) hash_mask = 2 * hash_mask + 1;
+        const int64_t kpad = (std::max<int64_t>(k, 4) + 3) & ~int64_t(3);
+        const size_t lds = (static_cast<size_t>(hash_mask) + 1) * sizeof(uint32_t) + static_cast<size_t>(kReplayBlock + kpad) * sizeof(uint16_t);
+        auto kernel = n <= 65535 ? k_replay_targets<true> : k_replay_targets<false>;
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        hipLaunchKernelGGL(kernel, dim3(cnt), dim3(64), lds, gs, static_cast<const uint16_t *>(p->d_targets), p->target_width, n, k,
+                           d_mov, d_pos, xa, hash_mask);
+    } else {
+        if (!p->d_big) SAFE_TRY(dev_alloc(&p->d_big, static_cast<size_t>(kChunk) * p->n));
+        hipLaunchKernelGGL(k_replay_targets_big, dim3(cnt), dim3(64), 0, gs, static_cast<const uint32_t *>(p->d_targets),
+                           p->target_width, n, k, d_mov, d_pos, xa, p->d_big);
+    }
     const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), cnt), block(256);
     for (int64_t d = 1; d < cnt; d <<= 1) {
         hipLaunchKernelGGL(k_scan_round, grid, block, 0, gs, xa, xb, cnt, stride, d);
@@ -443,29 +500,34 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
 
 static void drawer_main(safe_perms *p) {
     pthread_setname_np(pthread_self(), "safe-draw");
-    const int64_t k = p->k, width = std::max<int64_t>(k, 1);
+    (void)hipSetDevice(p->ctx->device);
+    const int64_t k = p->k;
     const int64_t n_chunks = stage_count(p);
+    const int64_t steps = std::max<int64_t>(k - 1, 0);
+    uint32_t *h = p->h_local.data();
     for (int64_t c = 0; c < n_chunks; ++c) {
+        const int b = static_cast<int>(c % safe_perms::kStage);
         {
             std::unique_lock<std::mutex> lk(p->draw_mu);
-            p->draw_cv.wait(lk, [&] { return p->draw_stop || c < p->consumed_chunks + 2; });
+            p->draw_cv.wait(lk, [&] { return p->draw_stop || c < p->enqueued_chunks + safe_perms::kStage; });
             if (p->draw_stop) return;
         }
+        // the staging buffer's previous chunk (c - kStage) must have left for the device (its upload was queued: see the wait above)
+        if (c >= safe_perms::kStage && hipEventSynchronize(p->staged[b]) != hipSuccess) return;
         safe_trace("    drawer: buffer free, drawing");
         const int64_t q0 = stage_begin(p, c), cnt = chunk_end(p, c) - q0;
-        // draw into a buffer only this thread touches, then stream the chunk to the shared one
-        uint32_t *h = p->h_local.data();
         const double t_draw = wall_s();
+        char *dst = static_cast<char *>(p->h_stage[b]);
         for (int64_t q = 0; q < cnt; ++q) {
-            draw_stream_targets(p->stream, k, h + q * width);
+            draw_stream_targets(p->stream, k, h);                   // into a buffer that stays in L1, then packed onto the wire
+            if (p->target_bytes == 2) draws_pack_u16(reinterpret_cast<uint16_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps));
+            else memcpy(reinterpret_cast<uint32_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps) * sizeof(uint32_t));
             if ((q & 15) == 15) {
                 std::lock_guard<std::mutex> lk(p->draw_mu);
                 if (p->draw_stop) return;
             }
         }
         safe_trace("    drawer: chunk drawn");
-        draws_nt_copy(p->h_targets[c & 1].data(), h, static_cast<size_t>(cnt) * width * sizeof(uint32_t));
-        safe_trace("    drawer: chunk copied");
         {
             std::lock_guard<std::mutex> lk(p->draw_mu);
             p->drawn_chunks = c + 1;
@@ -477,7 +539,7 @@ static void drawer_main(safe_perms *p) {
 }
 
 static void drawer_start(safe_perms *p) {
-    p->drawn_chunks = p->consumed_chunks = 0;
+    p->drawn_chunks = p->enqueued_chunks = 0;
     p->draw_stop = false;
     if (p->count > 0 && !p->ring_consumer) p->drawer = std::thread(drawer_main, p);
 }
@@ -492,51 +554,21 @@ static void drawer_stop(safe_perms *p) {
     p->drawer.join();
 }
 
-// Pipeline per chunk c:  draw thread: targets(c+1)  ||  workers: swaps(c)  ||  GPU: scan(c-1).
-// On return every row < upto has been enqueued on ctx->aux_stream.
-// hands chunk ci (already drawn) to the swap workers
-static int submit_swaps(safe_perms *p, int64_t ci) {
-    const int64_t q0 = stage_begin(p, ci), q1 = chunk_end(p, ci), cnt = q1 - q0;
-    const int b = static_cast<int>(ci & 1);
-    // the pinned map buffer of two chunks ago must have been uploaded
-    if (ci >= 2) SAFE_HIP_CHECK(hipEventSynchronize(p->staged[b]));
-    safe_trace("  gen: staging buffer free");
-    const uint32_t *tg = p->h_targets[b].data();
-    int32_t *mp = p->h_maps[b];
-    SwapPool::get().submit([p, tg, mp, cnt](int w, int W) { swap_worker(p, tg, mp, cnt, w, W); });
-    p->swapping = q1;
-    return SAFE_OK;
-}
-
-// On return every row < upto has been enqueued on ctx->aux_stream.  The calling thread only
-// moves chunks along (drawn -> swap workers -> GPU); the draws themselves run on p->drawer.
+// Pipeline per chunk c:  draw thread: targets(c+1 ..)  ||  GPU: upload + replay + scan(c)  ||  enrichment kernels(c-1).
+// On return every row < upto has been enqueued on ctx->aux_stream.  The calling thread only moves chunks along
+// (drawn -> GPU); the draws themselves run on p->drawer.
 int perms_generate_until(safe_perms *p, int64_t upto) {
     upto = std::min<int64_t>(upto, p->count);
-    const int64_t n_chunks = stage_count(p);
     while (p->enqueued < upto) {
         const int64_t ci = chunk_of(p, p->enqueued);
-        if (p->ring_consumer) {                              // no draws, no swaps here: the chunk comes from the node's producer
-            SAFE_TRY(enqueue_chunk(p, ci));
-            continue;
-        }
-        if (p->swapping <= stage_begin(p, ci)) {          // its swaps have not been started yet
-            {
-                std::unique_lock<std::mutex> lk(p->draw_mu);
-                p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
-                p->generated = chunk_end(p, p->drawn_chunks - 1);
-            }
+        if (!p->ring_consumer) {                             // (a consumer's chunks come from the node's producer: no draws here)
+            std::unique_lock<std::mutex> lk(p->draw_mu);
+            p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
+            p->generated = chunk_end(p, p->drawn_chunks - 1);
+            lk.unlock();
             safe_trace("  gen: chunk drawn");
-            SAFE_TRY(submit_swaps(p, ci));
         }
-        SAFE_TRY(enqueue_chunk(p, ci));                      // joins the workers, frees the target buffer, queues the GPU part
-        if (ci + 1 < n_chunks) {                             // start the next chunk's swaps if its draws are already there
-            bool drawn;
-            {
-                std::lock_guard<std::mutex> lk(p->draw_mu);
-                drawn = p->drawn_chunks > ci + 1;
-            }
-            if (drawn) SAFE_TRY(submit_swaps(p, ci + 1));
-        }
+        SAFE_TRY(enqueue_chunk(p, ci));
     }
     return SAFE_OK;
 }
@@ -571,14 +603,16 @@ int perms_build_inverse(safe_perms *perms) {
 static void perms_free(safe_perms *p) {
     if (!p) return;
     drawer_stop(p);
-    if (!p->ring_consumer && !p->from_table && !p->device_gen) SwapPool::get().wait();
     if (p->ring) ring_end_call(p->ring);
     p->ring = nullptr;
-    for (int b = 0; b < 2; ++b) {
-        if (p->h_maps[b]) (void)hipHostFree(p->h_maps[b]);
+    for (int b = 0; b < safe_perms::kStage; ++b) {
+        if (p->h_stage[b]) (void)hipHostFree(p->h_stage[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
-        (void)hipFree(p->d_maps[b]);
     }
+    for (int b = 0; b < 2; ++b) (void)hipFree(p->d_maps[b]);
+    if (p->h_movpos) (void)hipHostFree(p->h_movpos);
+    (void)hipFree(p->d_targets);
+    (void)hipFree(p->d_big);
     for (hipEvent_t e : p->chunk_done)
         if (e) (void)hipEventDestroy(e);
     (void)hipFree(p->d_cur);
@@ -615,22 +649,27 @@ int safe_rng_permutations_host(uint32_t seed, const int64_t *values, int64_t n_i
     return SAFE_OK;
 }
 
+// the movable rows and their positions in that list, on the device (both the replay of a seeded stream and the device stream
+// write the row maps through them)
+static int upload_movpos(safe_perms *p) {
+    const int64_t n = p->n, k = p->k, n_pad = (n + 3) & ~int64_t(3);      // two halves of n_pad entries, padded with -1
+    int32_t *h = p->h_movpos;                                  // (the previous handle's upload has completed: destroy synchronises)
+    for (int64_t i = 0; i < 2 * n_pad; ++i) h[i] = -1;
+    for (int64_t t = 0; t < k; ++t) {
+        h[t] = p->h_movable[t];
+        h[n_pad + p->h_movable[t]] = static_cast<int32_t>(t);
+    }
+    SAFE_HIP_CHECK(hipMemcpyAsync(p->d_movpos, h, static_cast<size_t>(2 * n_pad) * sizeof(int32_t), hipMemcpyHostToDevice, p->ctx->aux_stream));
+    return SAFE_OK;
+}
+
 // whole table on the device (k_perms_device); every pipeline stage is complete once the kernel has run
 static int perms_generate_on_device(safe_perms *p, uint64_t key) {
     safe_ctx *ctx = p->ctx;
     const int64_t n = p->n, k = p->k, count = p->count;
     SAFE_REQUIRE(k <= 65535, "device permutation stream: %lld movable rows (16-bit positions hold 65535)", (long long)k);
-    if (!p->d_movpos) SAFE_TRY(dev_alloc(&p->d_movpos, static_cast<size_t>(2 * n)));      // (kept with the handle's other buffers)
-    int32_t *d_mov = p->d_movpos, *d_pos = p->d_movpos + n;
-    std::vector<int32_t> h(static_cast<size_t>(2 * n), -1);
-    for (int64_t t = 0; t < k; ++t) {
-        h[t] = p->h_movable[t];
-        h[n + p->h_movable[t]] = static_cast<int32_t>(t);
-    }
-    int32_t *staging = p->h_maps[0];                           // the handle's own pinned chunk buffer (128 x (n + 1) entries): unused otherwise
-    memcpy(staging, h.data(), h.size() * sizeof(int32_t));
+    int32_t *d_mov = p->d_movpos, *d_pos = p->d_movpos + ((n + 3) & ~int64_t(3));
     hipStream_t gs = ctx->aux_stream;
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_mov, staging, h.size() * sizeof(int32_t), hipMemcpyHostToDevice, gs));
     const int64_t kpad = (k + 1) & ~int64_t(1);
     const size_t lds = 64 * 64 * sizeof(uint32_t) + static_cast<size_t>(std::max<int64_t>(kpad, 2)) * sizeof(uint16_t);
     SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_perms_device), hipFuncAttributeMaxDynamicSharedMemorySize,
@@ -645,7 +684,7 @@ static int perms_generate_on_device(safe_perms *p, uint64_t key) {
         SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[c], gs));
     }
     SAFE_HIP_CHECK(hipMemcpyAsync(p->d_cur, p->table + (count - 1) * (n + 1), (n + 1) * sizeof(int32_t), hipMemcpyDeviceToDevice, gs));
-    p->generated = p->swapping = p->enqueued = count;
+    p->generated = p->enqueued = count;
     p->enqueued_all_ms = 1e3 * (wall_s() - p->t_created_s);
     return SAFE_OK;
 }
@@ -668,7 +707,8 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     safe_trace("perms_create: enter");
     // a shared call goes through the node's ring when a chunk fits it at least twice; every rank of the node decides this
     // from (n, ring capacity) alone, hence identically.  Otherwise (and for empty streams) this rank draws for itself.
-    const int64_t slot_bytes = kChunk * (n + 1) * static_cast<int64_t>(sizeof(int32_t));
+    // (a slot holds a chunk's swap targets; sized for k = n so that the decision does not depend on the rows' values)
+    const int64_t slot_bytes = kChunk * ((n + 7) & ~int64_t(7)) * (n <= 65535 ? 2 : 4);
     PermRing *ring = !device_gen && shared && ctx->ring && num_permutations > 0 && ring_slots_for(ctx->ring, slot_bytes) >= 2 ? ctx->ring : nullptr;
     safe_perms *p = nullptr;
     bool reused = false;
@@ -691,7 +731,7 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     p->ring_consumer = ring != nullptr && !ring_is_producer(ring);
     p->device_gen = device_gen;
     p->stream = (p->ring_consumer || device_gen) ? nullptr : draw_stream_new(has_seed ? seed : entropy_seed());
-    p->generated = p->swapping = p->enqueued = 0;
+    p->generated = p->enqueued = 0;
     p->stages = perms_stage_plan(num_permutations);
     if (device_gen) {
         // no host pipeline to follow: the whole table is there before the first launch, so the launches are even spans of
@@ -716,14 +756,20 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
             if ((rc = dev_alloc(&p->d_cur, stride)) != SAFE_OK) break;
             if ((rc = dev_alloc(&p->d_maps[0], kChunk * stride)) != SAFE_OK) break;
             if ((rc = dev_alloc(&p->d_maps[1], kChunk * stride)) != SAFE_OK) break;
+            if ((rc = dev_alloc(&p->d_movpos, static_cast<size_t>(2 * n + 8))) != SAFE_OK) break;
+            // staging of a chunk's swap targets, sized for k = n (a reused handle may see another set of movable rows)
+            p->stage_bytes = static_cast<size_t>(slot_bytes);
+            if ((rc = dev_alloc(reinterpret_cast<char **>(&p->d_targets), p->stage_bytes + 2 * kReplayBlock * sizeof(uint16_t))) != SAFE_OK) break;   // (+ a block of slack: see k_replay_targets)
         }
+        p->target_bytes = k <= 65535 ? 2 : 4;
+        p->target_width = (std::max<int64_t>(k - 1, 1) + 7) & ~int64_t(7);
         hipError_t e = hipSuccess;
-        for (int b = 0; b < 2 && e == hipSuccess; ++b) {
-            if (!p->ring_consumer) p->h_targets[b].resize(kChunk * std::max<int64_t>(k, 1) + 16);
-            if (!p->h_maps[b]) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_maps[b]), kChunk * stride * sizeof(int32_t), hipHostMallocDefault);
+        if (!p->h_movpos) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_movpos), static_cast<size_t>(2 * n + 8) * sizeof(int32_t), hipHostMallocDefault);
+        for (int b = 0; b < safe_perms::kStage && e == hipSuccess; ++b) {
+            if (!p->h_stage[b] && !device_gen) e = hipHostMalloc(&p->h_stage[b], p->stage_bytes, hipHostMallocDefault);
             if (e == hipSuccess && !p->staged[b]) e = hipEventCreateWithFlags(&p->staged[b], safe_event_flags(hipEventDisableTiming));
         }
-        if (!p->ring_consumer) p->h_local.resize(kChunk * std::max<int64_t>(k, 1) + 16);
+        if (!p->ring_consumer && !device_gen) p->h_local.resize(std::max<int64_t>(k, 1) + 64);
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
             e = hipGetLastError();
@@ -744,6 +790,7 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
             if (rc != SAFE_OK) p->ring = nullptr;            // (no call is open on the ring: nothing to end)
         }
     } while (0);
+    if (rc == SAFE_OK) rc = upload_movpos(p);
     if (rc == SAFE_OK && device_gen && num_permutations > 0) rc = perms_generate_on_device(p, device_key);
     if (rc != SAFE_OK) {
         perms_free(p);
@@ -809,7 +856,7 @@ static int perms_table_handle(safe_ctx *ctx, int64_t n, int64_t count, const int
     p->count = count;
     p->from_table = true;
     p->k = n;
-    p->generated = p->swapping = p->enqueued = count;
+    p->generated = p->enqueued = count;
     int rc = SAFE_OK;
     do {
         if ((rc = dev_alloc(&p->table, static_cast<size_t>(rows) * stride)) != SAFE_OK) break;
@@ -891,6 +938,10 @@ int safe_perms_slice(safe_perms *perms, int64_t p0, int64_t p1, safe_perms **out
     *out = nullptr;
     safe_ctx *ctx = perms->ctx;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    // The node's producer publishes chunks as it enqueues them.  A producer that only needs [p0, p1) for itself would leave the
+    // consumers (whose ranges lie further down the stream) waiting until its handle is destroyed, i.e. until its own kernels are
+    // done: the split would run one rank after the other.  So it moves the WHOLE stream along before it takes its slice.
+    if (perms->ring && !perms->ring_consumer) SAFE_TRY(perms_generate_until(perms, perms->count));
     SAFE_TRY(perms_wait(perms, p1, ctx->aux_stream));
     return perms_table_handle(ctx, perms->n, p1 - p0, perms->table + p0 * (perms->n + 1), hipMemcpyDeviceToDevice, "safe_perms_slice", out);
 }
@@ -910,7 +961,6 @@ int safe_perms_destroy(safe_perms *perms) {
     if (perms->ring && !perms->ring_consumer)             // the node's producer publishes the WHOLE stream, whatever it used itself
         rc = perms_generate_until(perms, perms->count);
     drawer_stop(perms);
-    if (!perms->ring_consumer && !perms->device_gen) SwapPool::get().wait();
     if (perms->ring) ring_end_call(perms->ring);
     perms->ring = nullptr;
     perms->ring_consumer = false;

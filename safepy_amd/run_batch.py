@@ -48,7 +48,7 @@ def main(argv=None):
     os.environ.setdefault('GPU_MAX_HW_QUEUES', '8')
     import safepy_amd
     from safepy_amd import sharding, backend
-    # ranks of one node share the host: swap workers within this rank's share of the CPUs, sleeping host waits when the share
+    # ranks of one node share the host: sleeping host waits when the share
     # is under three cores; the permutation stream itself is drawn once per node (sharding.ensure_shared_stream)
     backend.configure_host_for_ranks(int(os.environ.get('LOCAL_WORLD_SIZE', str(world))))
     if world > 1:

@@ -32,7 +32,7 @@ def _device_count():
 
 def _run_ranks(world, backend, tmp_path, timeout=900, stream='shared'):
     port = _free_port()
-    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', SAFE_HIP_SWAP_THREADS='1', GPU_MAX_HW_QUEUES='8',
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0', OMP_NUM_THREADS='1', GPU_MAX_HW_QUEUES='8',
                SAFE_HIP_RING_TIMEOUT_S='300')
     # every rank writes to its own file: a rank blocked on a full pipe inside a collective would stall all of them
     logs = [open(tmp_path / ('rank%d.log' % r), 'w+') for r in range(world)]
