@@ -34,8 +34,10 @@ HBM_PEAK_GBS = 8000.0          # MI355X_MICROARCH.md: HBM3E 8 TB/s spec
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=2)
+    # (200 steps: 0.7 s of timed work -- a pre-empted host thread costs one step ~5 ms about once in 500 steps on the shared bench
+    # hosts, tools/probe/trace_outlier.py; with 20 steps one such step moved the mean by 7 %)
+    ap.add_argument('--steps', type=int, default=200)
+    ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--perms', type=int, default=1000)
     ap.add_argument('--nodes', type=int, default=3971)
     ap.add_argument('--attrs', type=int, default=4373)
@@ -345,6 +347,63 @@ class Workload:
         self.units_per_step = float(self.n) * self.m_total * self.P          # node-attribute enrichments per step, all ranks
 
 
+class StepProbe:
+    """What happened to the process during each timed step, sampled after the step (a few microseconds): minor / major page
+    faults, involuntary context switches (getrusage), CFS throttling of the container (cgroup cpu.stat nr_throttled /
+    throttled_usec), device allocations made by the library (safe_alloc_count).  report() keeps the totals and the rows of the
+    slowest steps, so that an outlier in `step_ms` comes with its cause."""
+
+    def __init__(self):
+        import resource
+        self._resource = resource
+        self._cg = None
+        for path in ('/sys/fs/cgroup/cpu.stat', '/sys/fs/cgroup/cpu/cpu.stat'):
+            if os.path.exists(path):
+                self._cg = path
+                break
+        self.rows = []
+        self._last = self._read()
+
+    def _read(self):
+        ru = self._resource.getrusage(self._resource.RUSAGE_SELF)
+        thr, thr_us = 0, 0
+        if self._cg:
+            try:
+                with open(self._cg) as f:
+                    for line in f:
+                        kv = line.split()
+                        if kv[0] == 'nr_throttled':
+                            thr = int(kv[1])
+                        elif kv[0] in ('throttled_usec', 'throttled_time'):
+                            thr_us = int(kv[1]) // (1000 if kv[0] == 'throttled_time' else 1)
+            except (OSError, ValueError, IndexError):
+                pass
+        allocs = 0
+        try:
+            from safepy_amd import backend as be
+            allocs = be.device_alloc_count()
+        except Exception:
+            pass
+        return (ru.ru_minflt, ru.ru_majflt, ru.ru_nivcsw, ru.ru_nvcsw, thr, thr_us, allocs)
+
+    def sample(self):
+        now = self._read()
+        self.rows.append(tuple(a - b for a, b in zip(now, self._last)))
+        self._last = now
+
+    def report(self, step_ms, timings=None):
+        keys = ('minor_faults', 'major_faults', 'involuntary_switches', 'voluntary_switches', 'cfs_throttled_periods', 'cfs_throttled_us', 'device_allocations')
+        total = {k: int(sum(r[i] for r in self.rows)) for i, k in enumerate(keys)}
+        order = sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3]
+        slow = [dict({'step': int(i), 'ms': float(step_ms[i])}, **{k: int(self.rows[i][j]) for j, k in enumerate(keys)}) for i in order if i < len(self.rows)]
+        if timings and len(timings) == len(step_ms):            # where the step's own clocks put the time: host stream vs kernels
+            for row in slow:
+                t = timings[row['step']]
+                row.update({'tables_enqueued_ms': t.get('tables_enqueued_ms'), 'draw_busy_ms': t.get('draw_busy_ms'),
+                            'gpu_kernel_busy_ms': t.get('gpu_kernel_busy_ms'), 'gpu_kernel_sum_ms': t.get('gpu_kernel_ms')})
+        return {'totals_over_timed_steps': total, 'slowest_steps': slow, 'gc': 'frozen + disabled inside the timed region'}
+
+
 def thread_cpu_ms():
     """CPU milliseconds (user + system) of every thread of this process so far, by (tid, name): /proc/self/task/*/stat."""
     out = {}
@@ -390,7 +449,7 @@ def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, d
             dist.barrier()
         torch.cuda.synchronize()
 
-    def timed(k, fn):
+    def timed(k, fn, probe=None):
         fence()
         t_begin = time.perf_counter()
         per_step = []
@@ -398,6 +457,8 @@ def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, d
             ts = time.perf_counter()
             fn()
             per_step.append(1e3 * (time.perf_counter() - ts))     # (a step returns after its own stream synchronisation)
+            if probe is not None:
+                probe.sample()
         fence()
         seconds = time.perf_counter() - t_begin
         if dist is not None:                                       # the slowest rank's clock
@@ -409,10 +470,23 @@ def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, d
     for _ in range(n_warmup):
         step()
     timings.clear()
+    # measurement hygiene: no cyclic-GC pass inside the timed region (a generation-2 collection over torch's and NumPy's
+    # objects is a multi-millisecond pause in a 3 ms step); what the OS did to each step is recorded beside its duration
+    import gc
+    gc.collect()
+    gc.freeze()
+    gc_was_enabled = gc.isenabled()
+    gc.disable()
+    probe = StepProbe()
     cpu0 = time.process_time()
-    elapsed, step_ms = timed(n_steps, step)
+    try:
+        elapsed, step_ms = timed(n_steps, step, probe)
+    finally:
+        if gc_was_enabled:
+            gc.enable()
+        gc.unfreeze()
     res = {'elapsed': elapsed, 'step_ms': step_ms, 'host_cpu_ms': 1e3 * (time.process_time() - cpu0) / n_steps,
-           'timings': list(timings), 'kernel': ctx.last_kernel(), 'out': out}
+           'timings': list(timings), 'kernel': ctx.last_kernel(), 'out': out, 'step_probe': probe.report(step_ms, timings)}
     mean = lambda key: float(np.mean([t.get(key, 0.0) for t in timings])) if timings else 0.0      # noqa: E731
     mine = {'role': timings[-1].get('role', 'own'), 'host_stream_ms': mean('tables_enqueued_ms'), 'draw_busy_ms': mean('draw_busy_ms'),
             'waited_for_producer_ms': mean('waited_for_producer_ms'), 'gpu_kernel_ms': mean('gpu_kernel_ms'), 'gpu_kernel_busy_ms': mean('gpu_kernel_busy_ms'),
@@ -587,6 +661,7 @@ def main():
             'pinned_to_numa_node': numa_node,
             'step_ms_min_median_max': [float(np.min(res['step_ms'])), float(np.median(res['step_ms'])), float(np.max(res['step_ms']))],
             'step_ms_slowest3': [float(x) for x in sorted(res['step_ms'])[-3:]],
+            'step_probe': res['step_probe'],
         }
         if 'exchange_report' in res:
             line['exchange'] = res['exchange_report']

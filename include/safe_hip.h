@@ -363,6 +363,10 @@ int safe_allgather_cols(safe_comm *comm, const void *local_dev, size_t bytes_per
 /* Number of i8 slices the last matrix-core permutation test ran with (2 / 4 / 6: the bits its columns need
  * on their fixed-point grid; 0 if that kernel has not run) -- for roofline reporting. */
 int safe_last_mfma_slices(safe_ctx *ctx, int *slices);
+/* Diagnostics (bench.py's per-step probe): the number of hipMalloc / hipHostMalloc calls the library has made in this process.
+ * Buffers are cached per context and per handle shape, so a repeated call of the same shape is expected to add none
+ * (the reference allocates every [N, M] temporary anew on each pass: safe_extras.py:50-66). */
+int safe_alloc_count(int64_t *calls);
 
 /* Name and average duration (ms) of the dominant kernel of the last enrichment call,
  * measured with HIP events on the context stream (bench.py's roofline object). */

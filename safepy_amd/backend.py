@@ -572,6 +572,13 @@ def set_blocking_sync(on):
     check(lib.safe_set_blocking_sync(1 if on else 0))
 
 
+def device_alloc_count():
+    """hipMalloc / hipHostMalloc calls the library has made in this process so far (safe_alloc_count)."""
+    v = C.c_int64()
+    check(lib.safe_alloc_count(C.byref(v)))
+    return v.value
+
+
 def last_mfma_slices(ctx):
     """i8 slices the last matrix-core permutation test ran with (2 / 4 / 6; 0 = it has not run)."""
     v = C.c_int()

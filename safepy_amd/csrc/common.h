@@ -11,6 +11,7 @@
 #include <cstring>
 #include <condition_variable>
 #include <mutex>
+#include <atomic>
 #include <string>
 #include <thread>
 #include <vector>
@@ -28,6 +29,7 @@ void safe_trace(const char *what);
 hipError_t safe_stream_sync(hipStream_t s);
 // flags for events the host may wait on: adds hipEventBlockingSync while blocking waits are on
 unsigned safe_event_flags(unsigned base);
+bool safe_blocking_sync_selected();   // blocking (sleeping) host waits are on: do not spin
 
 #define SAFE_HIP_CHECK(expr)                                                                   \
     do {                                                                                       \
@@ -109,10 +111,14 @@ int ctx_block_alloc(safe_ctx *ctx, size_t bytes, void **out);
 void ctx_block_free(safe_ctx *ctx, void *p, size_t bytes);
 
 // RAII-less device buffer helper: all frees go through the owning handle's destroy.
+// calls of hipMalloc / hipHostMalloc made by the library so far (safe_alloc_count): a timed step is expected to make none
+extern std::atomic<long long> g_alloc_calls;
+
 template <typename T>
 static inline int dev_alloc(T **p, size_t count) {
     *p = nullptr;
     if (count == 0) count = 1;
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipMalloc(reinterpret_cast<void **>(p), count * sizeof(T));
     if (e != hipSuccess) {
         safe_set_error("hipMalloc(%zu bytes) failed: %s", count * sizeof(T), hipGetErrorString(e));
@@ -156,6 +162,9 @@ struct safe_nbr {
     uint16_t *sell_col2b = nullptr; // the same list in blocked order: 8 members of a lane adjacent (one 16-byte load per lane and block)
     std::vector<int32_t> h_slice_width;
     BitsTaskPlan bits_plan;         // (launch_bits' cache)
+    void *bits_plan_pinned = nullptr;              // the plan's task lists in pinned host memory (grow-only): uploaded from there every
+    size_t bits_plan_pinned_bytes = 0;             // pass -- an async copy from pageable memory pins the pages first (an ioctl that
+                                                   // was seen to take milliseconds once in a few hundred passes)
     std::vector<int64_t> h_slice_off;
     std::vector<int32_t> h_row_count;   // host copy of per-row counts
     double *dist = nullptr;         // optional [n][n]
@@ -273,6 +282,7 @@ struct safe_perms {
     std::mutex draw_mu;
     std::condition_variable draw_cv;
     int64_t drawn_chunks = 0;                      // chunks whose targets are complete in h_stage[c % kStage]
+    std::atomic<int64_t> drawn_chunks_pub{0};      // the same, readable without the mutex (the launcher spins on it)
     int64_t enqueued_chunks = 0;                   // chunks whose upload has been queued (staged[c % kStage] recorded)
     bool draw_stop = false;
     static constexpr int kStage = 3;

@@ -27,6 +27,7 @@ void safe_set_error(const char *fmt, ...) {
 // blocking waits switched on (safe_set_blocking_sync / SAFE_HIP_BLOCKING_SYNC=1: several ranks sharing few host cores) the
 // thread sleeps on an interrupt-backed event instead -- a few tens of microseconds later, no CPU meanwhile.
 static std::atomic<int> g_blocking_sync{-1};
+std::atomic<long long> g_alloc_calls{0};
 
 static bool blocking_sync_on() {
     int v = g_blocking_sync.load(std::memory_order_relaxed);
@@ -37,6 +38,8 @@ static bool blocking_sync_on() {
     }
     return v != 0;
 }
+
+bool safe_blocking_sync_selected() { return blocking_sync_on(); }
 
 unsigned safe_event_flags(unsigned base) { return blocking_sync_on() ? (base | hipEventBlockingSync) : base; }
 
@@ -63,6 +66,7 @@ int ctx_scratch(safe_ctx *ctx, int slot, size_t bytes, void **out) {
             ctx->scratch_bytes[slot] = 0;
         }
         const size_t want = bytes + bytes / 8;
+        g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         hipError_t e = hipMalloc(&ctx->scratch[slot], want);
         if (e != hipSuccess) {
             safe_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -84,6 +88,7 @@ int ctx_block_alloc(safe_ctx *ctx, size_t bytes, void **out) {
             ctx->block_cache.erase(ctx->block_cache.begin() + static_cast<std::ptrdiff_t>(i));
             return SAFE_OK;
         }
+    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
     hipError_t e = hipMalloc(out, want);
     if (e != hipSuccess) {
         safe_set_error("hipMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -124,6 +129,7 @@ int ctx_pinned(safe_ctx *ctx, size_t bytes, void **out) {
             ctx->pinned_bytes = 0;
         }
         const size_t want = bytes + bytes / 4 + 4096;
+        g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         hipError_t e = hipHostMalloc(&ctx->pinned, want, hipHostMallocDefault);
         if (e != hipSuccess) {
             safe_set_error("hipHostMalloc(%zu bytes) failed: %s", want, hipGetErrorString(e));
@@ -305,6 +311,12 @@ int safe_timer_stop_ms(safe_ctx *ctx, double *elapsed_ms) {
     float ms = 0.f;
     SAFE_HIP_CHECK(hipEventElapsedTime(&ms, ctx->t0, ctx->t1));
     *elapsed_ms = ms;
+    return SAFE_OK;
+}
+
+int safe_alloc_count(int64_t *calls) {
+    SAFE_REQUIRE(calls, "safe_alloc_count: NULL argument");
+    *calls = g_alloc_calls.load(std::memory_order_relaxed);
     return SAFE_OK;
 }
 

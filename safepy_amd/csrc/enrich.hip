@@ -2324,6 +2324,19 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             plan.launch_list[c] = static_cast<int64_t>(k);
         }
         plan.key = plan_key;
+        const size_t bytes = plan.tasks.size() * sizeof(int4);
+        if (nbr->bits_plan_pinned_bytes < bytes) {
+            SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // (an earlier pass may still be reading the old copy)
+            if (nbr->bits_plan_pinned) SAFE_HIP_CHECK(hipHostFree(nbr->bits_plan_pinned));
+            nbr->bits_plan_pinned = nullptr;
+            nbr->bits_plan_pinned_bytes = 0;
+            g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+            SAFE_HIP_CHECK(hipHostMalloc(&nbr->bits_plan_pinned, bytes + 4096, hipHostMallocDefault));
+            nbr->bits_plan_pinned_bytes = bytes + 4096;
+        } else {
+            SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+        }
+        memcpy(nbr->bits_plan_pinned, plan.tasks.data(), bytes);
     }
     const std::vector<int4> &tasks = plan.tasks;
     const std::vector<int64_t> &list_first = plan.list_first, &list_count = plan.list_count, &launch_list = plan.launch_list;
@@ -2340,7 +2353,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     }
     const int64_t n_pad = nbr->n_slices * 64;
     SAFE_TRY(ctx_scratch(ctx, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), reinterpret_cast<void **>(&d_gl)));
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, nbr->bits_plan_pinned, tasks.size() * sizeof(int4), hipMemcpyHostToDevice, ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_queue, 0, 8 * n_launch * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_gl, 0, static_cast<size_t>(n_pad) * mloc * sizeof(unsigned int), ctx->stream));
     safe_trace("launch_bits: buffers ready");

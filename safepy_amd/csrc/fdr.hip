@@ -302,6 +302,7 @@ int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m, int64_t n_per
         e = hipcub::DeviceSegmentedRadixSort::SortPairs(nullptr, temp_bytes, p_dev, keys_out, vals_in, vals_out,
                                                         static_cast<int>(batch_items), static_cast<int>(batch_rows), offsets,
                                                         offsets + 1, 0, 64, ctx->stream);
+        g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         if (e == hipSuccess) e = hipMalloc(&temp, std::max<size_t>(temp_bytes, 16));
     }
     for (int64_t r0 = 0; rc == SAFE_OK && e == hipSuccess && r0 < n; r0 += batch_rows) {

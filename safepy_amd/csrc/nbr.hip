@@ -372,6 +372,7 @@ static void nbr_free(safe_nbr *nbr) {
     (void)hipFree(nbr->at_ptr);
     (void)hipFree(nbr->at_col);
     nbr_free_blocks(nbr);
+    if (nbr->bits_plan_pinned) (void)hipHostFree(nbr->bits_plan_pinned);
     delete nbr;
 }
 

@@ -33,6 +33,11 @@
 #include "draws.h"
 #include "ring.h"
 
+static inline void cpu_relax() {
+#if defined(__x86_64__)
+    __builtin_ia32_pause();
+#endif
+}
 static double wall_s() { return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 
 static uint32_t entropy_seed() {
@@ -518,19 +523,25 @@ static void drawer_main(safe_perms *p) {
         const int64_t q0 = stage_begin(p, c), cnt = chunk_end(p, c) - q0;
         const double t_draw = wall_s();
         char *dst = static_cast<char *>(p->h_stage[b]);
+        static const bool prof = getenv("SAFE_HIP_DRAW_PROFILE") != nullptr;
+        double t_pack = 0.0;
         for (int64_t q = 0; q < cnt; ++q) {
             draw_stream_targets(p->stream, k, h);                   // into a buffer that stays in L1, then packed onto the wire
+            const double tp0 = prof ? wall_s() : 0.0;
             if (p->target_bytes == 2) draws_pack_u16(reinterpret_cast<uint16_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps));
             else memcpy(reinterpret_cast<uint32_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps) * sizeof(uint32_t));
+            if (prof) t_pack += wall_s() - tp0;
             if ((q & 15) == 15) {
                 std::lock_guard<std::mutex> lk(p->draw_mu);
                 if (p->draw_stop) return;
             }
         }
         safe_trace("    drawer: chunk drawn");
+        if (prof) fprintf(stderr, "draw chunk %lld: %lld perms, draw+pack %.1f us, pack %.1f us\n", (long long)c, (long long)cnt, 1e6 * (wall_s() - t_draw), 1e6 * t_pack);
         {
             std::lock_guard<std::mutex> lk(p->draw_mu);
             p->drawn_chunks = c + 1;
+            p->drawn_chunks_pub.store(c + 1, std::memory_order_release);
             p->draw_busy_ms += 1e3 * (wall_s() - t_draw);
             if (c + 1 == n_chunks) p->drawn_all_ms = 1e3 * (wall_s() - p->t_created_s);
         }
@@ -540,6 +551,7 @@ static void drawer_main(safe_perms *p) {
 
 static void drawer_start(safe_perms *p) {
     p->drawn_chunks = p->enqueued_chunks = 0;
+    p->drawn_chunks_pub.store(0, std::memory_order_release);
     p->draw_stop = false;
     if (p->count > 0 && !p->ring_consumer) p->drawer = std::thread(drawer_main, p);
 }
@@ -562,6 +574,14 @@ int perms_generate_until(safe_perms *p, int64_t upto) {
     while (p->enqueued < upto) {
         const int64_t ci = chunk_of(p, p->enqueued);
         if (!p->ring_consumer) {                             // (a consumer's chunks come from the node's producer: no draws here)
+            // The draw thread needs ~0.25 ms per chunk and this thread has nothing else to do meanwhile.  Sleeping on the
+            // condition variable costs a futex wake-up per chunk, and on a shared host that wake-up was seen to take 4-6 ms
+            // once in a few hundred steps (tools/probe/trace_outlier.py) -- so spin on the counter first (bounded; with
+            // blocking waits selected -- several ranks on few cores -- sleep at once).
+            if (!safe_blocking_sync_selected()) {
+                const double t_spin = wall_s();
+                while (p->drawn_chunks_pub.load(std::memory_order_acquire) <= ci && wall_s() - t_spin < 2e-3) cpu_relax();
+            }
             std::unique_lock<std::mutex> lk(p->draw_mu);
             p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
             p->generated = chunk_end(p, p->drawn_chunks - 1);
@@ -764,8 +784,10 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
         p->target_bytes = k <= 65535 ? 2 : 4;
         p->target_width = (std::max<int64_t>(k - 1, 1) + 7) & ~int64_t(7);
         hipError_t e = hipSuccess;
+        if (!p->h_movpos) g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         if (!p->h_movpos) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_movpos), static_cast<size_t>(2 * n + 8) * sizeof(int32_t), hipHostMallocDefault);
         for (int b = 0; b < safe_perms::kStage && e == hipSuccess; ++b) {
+            if (!p->h_stage[b] && !device_gen) g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
             if (!p->h_stage[b] && !device_gen) e = hipHostMalloc(&p->h_stage[b], p->stage_bytes, hipHostMallocDefault);
             if (e == hipSuccess && !p->staged[b]) e = hipEventCreateWithFlags(&p->staged[b], safe_event_flags(hipEventDisableTiming));
         }
