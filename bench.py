@@ -217,6 +217,126 @@ def hbm_kernels(ctx, torch, np, be):
     return out
 
 
+def dropin_extras(np, torch):
+    """SAFE.compute_pvalues() -- the call BASELINE.json's metric names (safe.py:432) -- as a notebook makes it: NumPy matrix on
+    the instance in, results on the instance out, at configs[1] (permutation test, seeded) and configs[3] (hypergeometric).
+    (a) the call alone: results stay on the device until they are read (lazy_outputs, the default); (b) the call + reading
+    `nes` and `nes_binary` as host float64 arrays.  The repeated call reuses the context's buffers and the membership's derived
+    structures; `first_call_after_define_ms` is the first compute_pvalues after a new define_neighborhoods (it also builds them)."""
+    import safepy_amd
+    from safepy_amd import backend as be, workloads
+    out = {}
+
+    def measure(tag, graph, metric, b, kw, reps):
+        sf = safepy_amd.SAFE(verbose=False)
+        sf.random_seed = 0
+        sf.graph = graph
+        sf.define_neighborhoods(node_distance_metric=metric, neighborhood_radius=0.1)
+        sf.node2attribute = b
+        import logging
+        logging.disable(logging.WARNING)
+        t0 = time.perf_counter()
+        sf.compute_pvalues(**kw)
+        first = 1e3 * (time.perf_counter() - t0)
+        sf.compute_pvalues(**kw)
+        call = []
+        for _ in range(reps):                                   # (a) the call alone: the previous results were never read, their
+            t0 = time.perf_counter()                            #     device buffers go back to the context's pool
+            sf.compute_pvalues(**kw)
+            call.append(1e3 * (time.perf_counter() - t0))
+        both, read, release = [], [], []
+        for _ in range(reps):                                   # (b) the call + nes and nes_binary as host arrays
+            t0 = time.perf_counter()
+            sf.nes = None                                       # what a repeated call also pays: the previous call's host arrays
+            sf.nes_binary = None                                # (2 x 8NM bytes) go back to the OS
+            t1 = time.perf_counter()
+            sf.compute_pvalues(**kw)
+            t2 = time.perf_counter()
+            nes, nb = np.asarray(sf.nes), np.asarray(sf.nes_binary)
+            t3 = time.perf_counter()
+            release.append(1e3 * (t1 - t0))
+            both.append(1e3 * (t3 - t1))
+            read.append(1e3 * (t3 - t2))
+            del nes, nb
+        ctx = be.Context.default(0)
+        t0 = time.perf_counter()
+        attr = be.Attributes.from_host(ctx, b)
+        ctx.sync()
+        up = 1e3 * (time.perf_counter() - t0)
+        attr.close()
+        logging.disable(logging.NOTSET)
+        n, m = b.shape
+        out[tag] = {'compute_pvalues_ms': float(np.median(call)), 'compute_pvalues_ms_min_max': [float(min(call)), float(max(call))],
+                    'read_nes_and_nes_binary_ms': float(np.median(read)), 'call_plus_read_ms': float(np.median(both)),
+                    'release_previous_host_results_ms': float(np.median(release)),
+                    'first_call_after_define_ms': first, 'calls_timed': reps,
+                    'phases': {'upload_attributes_ms': up, 'upload_bytes': int(b.nbytes), 'download_bytes': int(2 * 8 * n * m),
+                               'kernel_ms_last_call': float(ctx.last_kernel()[1] * max(int(ctx.last_kernel()[2]), 1)), 'kernel': ctx.last_kernel()[0]},
+                    'shape': [int(n), int(m)], 'kwargs': kw}
+        del sf
+
+    data = workloads.costanzo_surrogate(seed=0)
+    measure('configs1_randomization', safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length']),
+            'shortpath_weighted_layout', data['attributes'], dict(how='randomization', num_permutations=1000), 10)
+    del data
+    n, m = 20000, 10000
+    b = (np.random.default_rng(5).uniform(size=(n, m)) < 0.01).astype(np.float32)
+    measure('configs3_hypergeometric', safepy_amd.LayoutGraph(workloads.uniform_layout(4, n)), 'euclidean', b, {}, 3)
+    return out
+
+
+def example3_extra(np, cpu_leg):
+    """The reference's only published number (examples/Example_3_Scatterplot_annotation.ipynb:73,104,147-153: 16 s for
+    compute_pvalues(num_permutations=10000) on the 1586-node YeastPhenome UMAP scatter, one quantitative attribute, hardware
+    not stated) on a surrogate of that shape, through the same calls: load_network(.scatter) -> define_neighborhoods('euclidean',
+    0.06) -> load_attributes(DataFrame) -> compute_pvalues(num_permutations=10000); seeded (NumPy-compatible stream) and with
+    the notebook's default random_seed=None.  The oracle's full run is timed beside it when the CPU leg is on."""
+    import tempfile
+    import logging
+    import safepy_amd
+    from safepy_amd import workloads
+    out = {'published': {'seconds': 16.0, 'permutations_per_s': 599.8, 'source': 'Example_3_Scatterplot_annotation.ipynb cell 11 (tqdm line), hardware not stated'}}
+    with tempfile.TemporaryDirectory() as tmp:
+        path = os.path.join(tmp, 'surrogate_UMAP_1586.scatter')
+        keys, xy, att = workloads.example3_scatter(path)
+        logging.disable(logging.WARNING)
+        for seed, tag in ((0, 'seeded'), (None, 'unseeded_default')):
+            best = None
+            for rep in range(3):
+                sf = safepy_amd.SAFE(verbose=False)
+                sf.random_seed = seed
+                t = [time.perf_counter()]
+                sf.load_network(network_file=path, node_key_attribute='key')
+                t.append(time.perf_counter())
+                sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.06)
+                t.append(time.perf_counter())
+                sf.load_attributes(attribute_file=att)
+                t.append(time.perf_counter())
+                sf.compute_pvalues(num_permutations=10000)
+                nes = np.asarray(sf.nes)
+                t.append(time.perf_counter())
+                row = {'load_network_ms': 1e3 * (t[1] - t[0]), 'define_neighborhoods_ms': 1e3 * (t[2] - t[1]), 'load_attributes_ms': 1e3 * (t[3] - t[2]),
+                       'compute_pvalues_and_read_nes_ms': 1e3 * (t[4] - t[3]), 'enriched_neighborhoods': int(np.asarray(sf.nes_binary).sum())}
+                if best is None or row['compute_pvalues_and_read_nes_ms'] < best['compute_pvalues_and_read_nes_ms']:
+                    best = row
+                del sf, nes
+            out[tag] = best
+        logging.disable(logging.NOTSET)
+        if cpu_leg:
+            from oracle import safe_oracle as orc
+            a = orc.neighborhoods_euclidean(xy, 0.06)
+            b = att.to_numpy(dtype=np.float64)
+            t0 = time.perf_counter()
+            orc.compute_pvalues(a, b.copy(), enrichment_type='auto', num_permutations=10000, random_seed=0)
+            cpu_s = time.perf_counter() - t0
+            out['cpu_oracle'] = {'compute_pvalues_s': cpu_s, 'cores': effective_cores(), 'kind': 'port',
+                                 'sample': 'the full call: 1586 nodes x 1 attribute x 10000 permutations, NumPy/SciPy oracle'}
+            out['speedup_vs_cpu_oracle_seeded'] = cpu_s / (1e-3 * out['seeded']['compute_pvalues_and_read_nes_ms'])
+            out['speedup_vs_published_seeded'] = 16.0 / (1e-3 * out['seeded']['compute_pvalues_and_read_nes_ms'])
+    out['workload'] = '1586-node clustered scatter surrogate (safe-data is not available offline), euclidean r=0.06, 1 quantitative attribute (12 % NaN), 10000 permutations'
+    return out
+
+
 MFMA_I8_PEAK_TOPS = 5000.0     # MI355X_MICROARCH.md: dense i8 MFMA = 2x the 2.5 PF bf16 rate
 
 
@@ -726,6 +846,8 @@ def main():
             del wl
             line['hbm_bound_kernels'] = hbm_kernels(ctx, torch, np, be)
             line['mfma_bound_kernels'] = mfma_kernel(ctx, np, be)
+            line['dropin_compute_pvalues'] = dropin_extras(np, torch)
+            line['example3_published_shape'] = example3_extra(np, args.cpu_perms > 0)
     # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe): tear the group down and flush every
     # rank's C buffers first, so that rank 0's JSON line is the LAST line of the job's output
     if dist is not None:

@@ -2532,6 +2532,19 @@ static bool lds_f64_applicable(const safe_nbr *nbr, const safe_perms *perms) {
            ldsf64_bytes(nbr->n, perms->stride16) <= 160 * 1024;
 }
 
+// A NARROW block of quantitative columns (the reference's own Example 3 tests ONE attribute with 10 000 permutations,
+// examples/Example_3_Scatterplot_annotation.ipynb:104,147): the matrix-core kernel pads the block to 32 columns and its launches
+// are latency-bound (0.67 ms per 128 permutations whatever the width up to ~256 columns), the LDS-resident f64 kernel is bound
+// by its 4-column tiles -- 2-2.6 x faster until n x columns ~ 2e5 (tools/probe/narrow_paths.py: 1586 x 1: 2.85 vs 5.59 ms per
+// 2000 permutations; 3971 x 32: 2.55 vs 3.78; 3971 x 64: 4.16 vs 3.78).
+static bool narrow_block_prefers_lds(const safe_nbr *nbr, const safe_perms *perms, int64_t mloc) {
+    const char *force = getenv("SAFE_HIP_FORCE_PATH");
+    if (force && !strcmp(force, "mfma")) return false;
+    const char *knob = getenv("SAFE_HIP_NARROW_LDS");                  // =0: A/B, and the matrix-core tests at small sizes
+    const bool off = knob && !strcmp(knob, "0");
+    return !off && lds_f64_applicable(nbr, perms) && nbr->n * mloc <= 204800;
+}
+
 // general f64 permutation test with LDS-resident tiles (k_permtest_lds), pipelined over spans like launch_bits
 static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
                           bool z, const PermOut &out_in) {
@@ -2870,7 +2883,7 @@ int safe_permtest_counts(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_per
                                    : launch_scatter(ctx, nbr, attr, perms, col0, col1, out));
         return finish_kernel_timing(ctx);
     }
-    if (mfma_applicable(ctx, nbr, attr, perms, z)) {
+    if (mfma_applicable(ctx, nbr, attr, perms, z) && !narrow_block_prefers_lds(nbr, perms, col1 - col0)) {
         bool declined = false;
         SAFE_TRY(launch_mfma(ctx, nbr, attr, perms, col0, col1, z, out, &declined));
         if (!declined) return finish_kernel_timing(ctx);
@@ -2916,7 +2929,7 @@ int safe_randomization(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     unsigned int *d_enr = nullptr;
     Tiles tiles;
     const PermPath path = choose_path(ctx, nbr, attr, P, z);
-    bool mfma = path == PATH_GATHER && mfma_applicable(ctx, nbr, attr, perms, z);
+    bool mfma = path == PATH_GATHER && mfma_applicable(ctx, nbr, attr, perms, z) && !narrow_block_prefers_lds(nbr, perms, mloc);
     const bool lds64 = path == PATH_GATHER && lds_f64_applicable(nbr, perms);
     void *small = nullptr;                           // NES table f64 [P + 1] | enriched counters u32 [mloc + 16] (grow-only scratch)
     int rc = ctx_scratch(ctx, 10, static_cast<size_t>(P + 1) * sizeof(double) + static_cast<size_t>(mloc + 16) * sizeof(unsigned int), &small);

@@ -75,3 +75,24 @@ def quantitative_attributes(seed, n, m, nan_row_frac=0.05, nan_frac=0.01, dtype=
     b[rng.uniform(size=(n, m)) < nan_frac] = np.nan
     b[rng.choice(n, size=int(nan_row_frac * n), replace=False)] = np.nan
     return b
+
+
+def example3_scatter(path, seed=3, n=1586, nan_frac=0.12):
+    """The shape of the reference's only published timing (examples/Example_3_Scatterplot_annotation.ipynb:73,104,147-153:
+    `networks/YeastPhenome_UMAP_1586.scatter`, euclidean r = 0.06, ONE quantitative attribute, 10 000 permutations, 16 s):
+    writes a 1586-node `.scatter` file (tab-separated key / x / y / label, safe_io.py:271-285) of a UMAP-like clustered
+    layout to `path` and returns (keys, xy, attribute DataFrame indexed by key).  The attribute is a normalised-phenotype-like
+    column: N(0, 1) values kept to 10 fractional bits -- every neighborhood sum is then exact in f64 whatever the order of
+    summation, so the permutation counts of any two correct implementations are EQUAL, not just close -- with ~12 % NaN."""
+    import pandas as pd
+    rng = np.random.default_rng(seed)
+    xy = clustered_layout(rng, n, n_blobs=14, spread=0.025, background=0.35) * 20.0 - 10.0          # UMAP-like coordinates
+    keys = np.array(['Y%s%03d%s' % ('ABCDEFGHIJKLMNOP'[i % 16], i // 16, 'WC'[i % 2]) for i in range(n)])
+    labels = np.array(['G%04d' % i for i in range(n)])
+    pd.DataFrame({'key': keys, 'x': xy[:, 0], 'y': xy[:, 1], 'label': labels}).to_csv(path, sep='\t', index=False)
+    # (the loader parses the decimal text back: use what it will read)
+    xy = pd.read_csv(path, sep='\t')[['x', 'y']].to_numpy(dtype=np.float64)
+    values = np.round(rng.normal(size=n) * 1024.0) / 1024.0
+    values[rng.uniform(size=n) < nan_frac] = np.nan
+    att = pd.DataFrame({'NPV hap alpha | growth (spot assay) | standard | YPG [3%] (surrogate)': values}, index=pd.Index(keys, name='Gene systematic name'))
+    return keys, xy, att

@@ -21,6 +21,14 @@ def ctx(amd):
     return amd.Context.default(0)
 
 
+@pytest.fixture(autouse=True)
+def narrow_blocks_stay_on_the_matrix_cores(monkeypatch):
+    """These tests exercise the matrix-core kernel at small sizes; the product sends such narrow blocks (n x columns <= 2e5)
+    to the LDS-resident f64 kernel (enrich.hip narrow_block_prefers_lds), which tests/test_gpu_example3.py and the f64-kernel
+    tests cover."""
+    monkeypatch.setenv('SAFE_HIP_NARROW_LDS', '0')
+
+
 def _quant(rng, n, m, dtype=np.float64, order='C', nan_rows=0, nan_frac=0.0):
     b = rng.normal(size=(n, m)).astype(dtype)
     if nan_frac:

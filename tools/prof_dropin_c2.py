@@ -1,25 +1,25 @@
-"""cProfile of the drop-in SAFE.compute_pvalues() / define_neighborhoods() at configs[1] (host-side overheads)."""
 import os, sys, time, cProfile, pstats
 import numpy as np
 sys.path.insert(0, os.environ.get('GRAFT_REPO_ROOT', '/root/repo'))
 import safepy_amd
 from safepy_amd import workloads
-data = workloads.costanzo_surrogate(seed=0)
-graph = safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length'])
-b = data['attributes']
+which = sys.argv[1] if len(sys.argv) > 1 else 'c2'
+if which == 'c2':
+    data = workloads.costanzo_surrogate(seed=0)
+    graph = safepy_amd.LayoutGraph(data['xy'], data['edge_u'], data['edge_v'], length=data['length'])
+    b = data['attributes']; kw = dict(how='randomization', num_permutations=1000); metric = 'shortpath_weighted_layout'
+else:
+    n, m = 20000, 10000
+    graph = safepy_amd.LayoutGraph(workloads.uniform_layout(4, n))
+    b = (np.random.default_rng(5).uniform(size=(n, m)) < 0.01).astype(np.float32); kw = {}; metric = 'euclidean'
 sf = safepy_amd.SAFE(verbose=False)
 sf.random_seed = 0
 sf.graph = graph
-for it in range(2):
-    sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.1)
-    sf.node2attribute = b
-    sf.compute_pvalues(how='randomization', num_permutations=1000)
+sf.define_neighborhoods(node_distance_metric=metric, neighborhood_radius=0.1)
+sf.node2attribute = b
+import logging; logging.disable(logging.WARNING)
+for _ in range(3): sf.compute_pvalues(**kw)
 pr = cProfile.Profile(); pr.enable()
-t = time.perf_counter()
-sf.define_neighborhoods(node_distance_metric='shortpath_weighted_layout', neighborhood_radius=0.1)
-t1 = time.perf_counter()
-sf.compute_pvalues(how='randomization', num_permutations=1000)
-t2 = time.perf_counter()
+for _ in range(5): sf.compute_pvalues(**kw)
 pr.disable()
-print('define_neighborhoods %.2f ms, compute_pvalues %.2f ms' % (1e3 * (t1 - t), 1e3 * (t2 - t1)))
-pstats.Stats(pr).sort_stats('cumulative').print_stats(28)
+pstats.Stats(pr).sort_stats('tottime').print_stats(14)
