@@ -70,6 +70,14 @@ def test_three_ranks_one_gpu_uneven_split(tmp_path):
     _run_ranks(3, 'gloo', tmp_path)
 
 
+def test_eight_ranks_one_gpu_seven_consumers(tmp_path):
+    """The rank count of the driver's scaling run: one producer of the node's permutation stream, SEVEN consumers on the ring,
+    columns split eight ways (np.array_split sizes), sharded == unsharded == oracle on every rank."""
+    if _device_count() < 1:
+        pytest.skip('needs a HIP device')
+    _run_ranks(8, 'gloo', tmp_path, timeout=1200)
+
+
 def test_two_ranks_rccl_sharded_equals_unsharded_equals_oracle(tmp_path):
     if _device_count() < 2:
         pytest.skip('RCCL with 2 ranks needs 2 devices (one GPU per rank)')
@@ -94,6 +102,39 @@ def test_bench_starts_its_own_ranks():
                         '--cpu-perms', '0', '--extras', '0'])
     assert line['n_gpus'] == 2 and line['scaling'] == 'weak' and line['value'] > 0
     assert line['exchange']['d2h_only_ms_per_step'] > 0 and line['exchange']['all_gather_ms_per_step'] > 0
+
+
+def test_bench_eight_ranks_rehearsal_on_one_gpu():
+    """What the driver's `bench.py --gpus 8` does, rehearsed on one GPU (SAFE_BENCH_SHARE_DEVICE=1: every rank on device 0, the
+    exchange staged through gloo) under the bench hosts' 16-CPU quota: the launcher-less start, eight ranks, the shared stream
+    with seven consumers, and the multi_gpu_configs extras (configs[2] strong scaling seeded and unseeded, one configs[4] rank
+    share) run to the end well inside ten minutes and the line is complete.  (The GPU is time-shared: `value` means nothing.)"""
+    if _device_count() < 1:
+        pytest.skip('needs a HIP device')
+    import shutil
+    import time
+    pre = ['taskset', '-c', '0-15'] if shutil.which('taskset') and (os.cpu_count() or 1) >= 16 else []
+    t0 = time.time()
+    res = subprocess.run(pre + [sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '8', '--steps', '5', '--warmup', '1', '--cpu-perms', '0'],
+                         env=dict(os.environ, SAFE_BENCH_SHARE_DEVICE='1'), stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True,
+                         timeout=900, cwd=ROOT)
+    wall = time.time() - t0
+    assert res.returncode == 0, res.stderr[-4000:]
+    assert 'not published' not in res.stderr and 'Traceback' not in res.stderr, res.stderr[-4000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith('{')]
+    assert len(lines) == 1, res.stdout[-2000:]
+    line = json.loads(lines[0])
+    assert wall < 600, wall
+    assert line['n_gpus'] == 8 and len(line['per_rank']) == 8
+    roles = [r['role'] for r in line['per_rank']]
+    assert roles.count('producer') == 1 and roles.count('consumer') == 7, roles
+    extras = line['multi_gpu_configs']
+    assert set(extras) == {'configs2_strong_scaling', 'configs2_strong_scaling_unseeded', 'configs4_rank_share'}
+    assert all(r['role'] == 'device' for r in extras['configs2_strong_scaling_unseeded']['per_rank'])
+    assert extras['configs2_strong_scaling']['attributes_per_gpu'] in (546, 547)
+    # the producer rank's host CPU per step stays within 1.3 x the step (sleeping waits: 2 cores per rank)
+    x = line['exchange']
+    assert max(x['host_cpu_ms_per_step_no_exchange_per_rank']) <= 1.3 * x['no_exchange_ms_per_step'], x
 
 
 def test_bench_single_rank_rccl_group_reports_the_exchange():
