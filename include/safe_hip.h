@@ -291,9 +291,11 @@ int safe_hypergeom(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, double enrichm
  * (zero p-values become 1/num_permutations inside the logarithm, sign_mode combines the two
  * sides); num_permutations == 0: hypergeometric form (nes = -log10 pvalues_pos; pvalues_neg_dev
  * may be NULL).  A row needs all of its attributes: under attribute sharding this runs after the
- * p-value blocks have been gathered.  num_permutations > 0 also PROMISES that every p-value is
- * count / num_permutations (what safe_randomization and safe_outputs_from_* write): those rows are
- * adjusted from their histogram over the counts, without a sort; any other value -> SAFE_E_VALUE. */
+ * p-value blocks have been gathered.  With num_permutations > 0 the p-values are normally
+ * count / num_permutations (what safe_randomization and safe_outputs_from_* write): both matrices are
+ * checked read-only, and if every entry is such a ratio the rows are adjusted from their histogram
+ * over the counts, without a sort; otherwise (a caller's own values) they are sorted like the
+ * hypergeometric form.  Nothing is modified before the form is chosen. */
 int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_permutations, int sign_mode,
                     double enrichment_threshold, double *pvalues_neg_dev, double *pvalues_pos_dev, double *nes_dev,
                     double *nes_binary_dev, double *num_enriched_dev);

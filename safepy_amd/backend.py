@@ -422,6 +422,10 @@ class Permutations:
         h = C.c_void_p()
         self.device_key = None
         if seed is None and device_stream_enabled() and int(movable.sum()) <= 65535:
+            if shared and device_key is None:
+                # a collective call: a key drawn here would differ from rank to rank and so would the tables
+                raise ValueError('Permutations(seed=None, shared=True) needs a device_key the ranks agreed on '
+                                 '(sharding.agree_on_seed / reduce_flags_and_stats)')
             self.device_key = int.from_bytes(os.urandom(8), 'little') if device_key is None else int(device_key) & 0xFFFFFFFFFFFFFFFF
             check(lib.safe_perms_create_device(ctx.handle, self.n, _ptr(movable), self.count, C.c_uint64(self.device_key), C.byref(h)))
         else:

@@ -29,7 +29,10 @@ void safe_trace(const char *what);
 hipError_t safe_stream_sync(hipStream_t s);
 // flags for events the host may wait on: adds hipEventBlockingSync while blocking waits are on
 unsigned safe_event_flags(unsigned base);
-bool safe_blocking_sync_selected();   // blocking (sleeping) host waits are on: do not spin
+bool safe_blocking_sync_selected();
+// A diagnostic switch that makes a kernel skip work (timing experiments: SAFE_HIP_BITS_DBG, SAFE_HIP_MFMA_DBG*) is in effect: says so
+// on stderr, once per switch -- results of such a run are WRONG by construction and must not be mistaken for the product's.
+void safe_warn_diagnostic(const char *name);   // blocking (sleeping) host waits are on: do not spin
 
 #define SAFE_HIP_CHECK(expr)                                                                   \
     do {                                                                                       \

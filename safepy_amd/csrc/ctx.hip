@@ -16,6 +16,16 @@ void safe_trace(const char *what) {
             std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count(), what);
 }
 
+void safe_warn_diagnostic(const char *name) {
+    static std::mutex mu;
+    static std::vector<std::string> seen;
+    std::lock_guard<std::mutex> lk(mu);
+    for (const std::string &n : seen)
+        if (n == name) return;
+    seen.emplace_back(name);
+    fprintf(stderr, "[safe_hip] WARNING: diagnostic switch %s is set: kernels skip work, the results of this process are INVALID\n", name);
+}
+
 void safe_set_error(const char *fmt, ...) {
     va_list ap;
     va_start(ap, fmt);

@@ -2375,6 +2375,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
     if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 31;
+    if (dbg) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");
     const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
                          : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)

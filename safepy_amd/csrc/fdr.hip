@@ -204,6 +204,20 @@ __global__ __launch_bounds__(256) void k_fdr_row_counts(double *__restrict__ pva
     for (int64_t e = t; e < m; e += 256) p[e] = adj[static_cast<int>(rint(p[e] * P))];
 }
 
+// read-only: is every non-NaN entry a count ratio c / P, c in [0, P]?  (what the histogram form needs; anything else is sorted)
+__global__ __launch_bounds__(256) void k_fdr_check_ratio(const double *__restrict__ p, int64_t total, double P, unsigned int *__restrict__ flag) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    bool bad = false;
+    if (i < total) {
+        const double v = p[i];
+        if (v == v) {
+            const double cf = rint(v * P);
+            bad = !(cf >= 0.0 && cf <= P) || cf / P != v;
+        }
+    }
+    if (__ballot(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1u);
+}
+
 // NES / binarisation from (adjusted) p-values; n_perm == 0: hypergeometric form nes = -log10(p_pos)
 __global__ __launch_bounds__(256) void k_nes_from_pvalues(const double *__restrict__ p_neg, const double *__restrict__ p_pos,
                                                           int64_t n, int64_t m, double inv_perm, int sign_mode,
@@ -259,8 +273,7 @@ int fdr_matrix(safe_ctx *ctx, double *p_dev, int64_t n, int64_t m, int64_t n_per
         SAFE_HIP_CHECK(hipMemcpyAsync(pinned, d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
         SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
         if (*static_cast<unsigned int *>(pinned) == 0u) return SAFE_OK;
-        // some entry is not a count ratio: rows the kernel left untouched are sorted below; rows it already adjusted hold
-        // values that are not count ratios any more either -- refuse rather than adjust twice
+        // (cannot happen: safe_fdr_adjust validated the matrix before it chose this form)
         safe_set_error("safe_fdr_adjust: num_permutations = %lld but a p-value is not a multiple of 1 / num_permutations",
                        (long long)n_perm);
         return SAFE_E_VALUE;
@@ -339,8 +352,27 @@ extern "C" int safe_fdr_adjust(safe_ctx *ctx, int64_t n, int64_t m, int64_t num_
     SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_fdr_adjust: bad sign_mode %d", sign_mode);
     SAFE_REQUIRE(enrichment_threshold > 0.0 && enrichment_threshold < 1.0, "safe_fdr_adjust: enrichment_threshold must be in (0,1)");
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    if (num_permutations > 0) SAFE_TRY(fdr_matrix(ctx, pvalues_neg_dev, n, m, num_permutations));
-    SAFE_TRY(fdr_matrix(ctx, pvalues_pos_dev, n, m, num_permutations));
+    // The library's own empirical p-values are count ratios c / num_permutations and need no sort (k_fdr_row_counts).  A caller may
+    // hand over other values with num_permutations > 0 (only the 0 -> 1 / P rule of the NES depends on it): both matrices are
+    // checked READ-ONLY first, and anything that is not a count ratio goes through the sort like the hypergeometric form.
+    int64_t hist_perm = 0;
+    if (num_permutations > 0 && (num_permutations + 1) * 12 <= 60 * 1024 && !getenv("SAFE_HIP_FDR_SORT")) {
+        unsigned int *d_flag = nullptr;
+        SAFE_TRY(ctx_scratch(ctx, 10, sizeof(unsigned int), reinterpret_cast<void **>(&d_flag)));
+        SAFE_HIP_CHECK(hipMemsetAsync(d_flag, 0, sizeof(unsigned int), ctx->stream));
+        const int64_t total = n * m;
+        for (const double *mat : {static_cast<const double *>(pvalues_neg_dev), static_cast<const double *>(pvalues_pos_dev)})
+            hipLaunchKernelGGL(k_fdr_check_ratio, dim3(ceil_div(total, 256)), dim3(256), 0, ctx->stream, mat, total,
+                               static_cast<double>(num_permutations), d_flag);
+        SAFE_HIP_CHECK(hipGetLastError());
+        void *pinned = nullptr;
+        SAFE_TRY(ctx_pinned(ctx, sizeof(unsigned int), &pinned));
+        SAFE_HIP_CHECK(hipMemcpyAsync(pinned, d_flag, sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+        SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+        if (*static_cast<unsigned int *>(pinned) == 0u) hist_perm = num_permutations;
+    }
+    if (num_permutations > 0) SAFE_TRY(fdr_matrix(ctx, pvalues_neg_dev, n, m, hist_perm));
+    SAFE_TRY(fdr_matrix(ctx, pvalues_pos_dev, n, m, hist_perm));
     unsigned int *d_enr = nullptr;
     SAFE_TRY(dev_alloc(&d_enr, m));
     SAFE_HIP_CHECK(hipMemsetAsync(d_enr, 0, m * sizeof(unsigned int), ctx->stream));

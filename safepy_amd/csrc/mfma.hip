@@ -1007,6 +1007,7 @@ int build_blocks(safe_nbr *nbr) {
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!kbs.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_kb, kbs.data(), kbs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!bits.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS")) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG_NOMEMBERS");
     if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS") && !bits.empty())          // diagnostic: every piece empty -> no MFMA is issued (wrong results)
         SAFE_HIP_CHECK(hipMemset(nbr->bs_bits, 0, bits.size() * sizeof(uint32_t)));
     nbr->blocks_ready = true;
@@ -1622,6 +1623,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         if (long_launches && c >= 1) SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev[2 * (c - 1) + 1], 0));
         SAFE_TRY(perms_wait(perms, p_limit, ks));
         static const int dbg_window = getenv("SAFE_HIP_MFMA_DBG_WINDOW") ? atoi(getenv("SAFE_HIP_MFMA_DBG_WINDOW")) : 0;
+        if (dbg_window > 0) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG_WINDOW");
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
                            p_base, d_src[c & 1], dbg_window);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
@@ -1632,6 +1634,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
             double *ns_c = c == 0 ? out.ns : static_cast<double *>(nullptr);
             HypLookup no_lookup{};
             static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
+            if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
             no_lookup.dbg = mfma_dbg;        // 1: no transposes / LDS stores of the gathered rows, 4: no barrier per super-step, 8: no score completion
             void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,

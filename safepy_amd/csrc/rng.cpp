@@ -692,6 +692,10 @@ static int perms_generate_on_device(safe_perms *p, uint64_t key) {
     hipStream_t gs = ctx->aux_stream;
     const int64_t kpad = (k + 1) & ~int64_t(1);
     const size_t lds = 64 * 64 * sizeof(uint32_t) + static_cast<size_t>(std::max<int64_t>(kpad, 2)) * sizeof(uint16_t);
+    int lds_limit = 0;
+    SAFE_HIP_CHECK(hipDeviceGetAttribute(&lds_limit, hipDeviceAttributeMaxSharedMemoryPerBlock, ctx->device));
+    SAFE_REQUIRE(lds <= static_cast<size_t>(lds_limit), "device permutation stream: %lld movable rows need %zu bytes of LDS, a workgroup of this "
+                 "device gets %d (gfx950: 160 KiB); use the NumPy-compatible stream (SAFE_HIP_DEVICE_STREAM=0)", (long long)k, lds, lds_limit);
     SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_perms_device), hipFuncAttributeMaxDynamicSharedMemorySize,
                                        static_cast<int>(lds)));
     hipLaunchKernelGGL(k_perms_device, dim3(count), dim3(64), lds, gs, n, k, count, static_cast<uint32_t>(key),

@@ -84,7 +84,7 @@ def reduce_flags_and_stats(local_flags, local_stats, group=None, random_seed=0):
     # that gets the whole process throttled for the rest of the scheduler period
     mine = np.empty(n + 4, dtype=np.int64)
     mine[:n] = np.asarray(local_flags, dtype=np.int64)
-    seed = int.from_bytes(__import__('os').urandom(4), 'little') if random_seed is None else int(random_seed)
+    seed = _entropy63() if random_seed is None else int(random_seed)
     mine[n:] = (int(local_stats['n_other']), int(local_stats['n_non_integer']), int(local_stats['max_nan_col']), seed)
     mine = torch.from_numpy(mine).to(dev)
     table = torch.empty(world * (n + 4), dtype=torch.int64, device=dev)     # flat: gloo wants 1-D buffers
@@ -96,11 +96,18 @@ def reduce_flags_and_stats(local_flags, local_stats, group=None, random_seed=0):
     return flags, stats
 
 
+def _entropy63():
+    """63 bits of OS entropy (fits the int64 tensors the ranks exchange): the key of an unseeded run's device stream.  Where such a
+    run falls back to the NumPy-compatible stream (more than 65535 movable rows, SAFE_HIP_DEVICE_STREAM=0) its low 32 bits seed it."""
+    import os
+    return int.from_bytes(os.urandom(8), 'little') >> 1
+
+
 def agree_on_seed(random_seed, group=None):
     """The seed every rank uses: `random_seed` when given, else rank 0's draw from OS entropy."""
     import torch
     dist = _dist()
-    seed = int.from_bytes(__import__('os').urandom(4), 'little') if random_seed is None else int(random_seed)
+    seed = _entropy63() if random_seed is None else int(random_seed)
     t = torch.tensor([seed], dtype=torch.int64, device=_device_for(group))
     dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
     return int(t.item())
@@ -138,7 +145,10 @@ def ensure_shared_stream(ctx, group=None):
     dist.broadcast(token, src=0)
     try:
         ok = ctx.share_stream('%014x' % int(token.item()), local_rank, local_world)
-    except Exception:                                  # no /dev/shm, no room, a local rank 0 that never showed up ...
+    except Exception as err:                           # no /dev/shm, no room, a local rank 0 that never showed up ...
+        import logging
+        logging.warning('safepy_amd: rank %d could not join the node\'s shared permutation stream (%s); every rank of the job '
+                        'draws its own stream from now on', dist.get_rank(), err)
         ok = False
     # all or nothing: a node whose ring could not be set up falls back to one stream per rank -- on EVERY rank, or the
     # collective calls that follow would disagree about who draws
@@ -300,6 +310,8 @@ def _call_permutations(ctx, n, flags, num_permutations, random_seed, unseeded, a
     if unseeded and be.device_stream_enabled() and int(np.count_nonzero(flags)) <= 65535:
         return be.Permutations(ctx, n, flags, num_permutations, None, device_key=random_seed)
     shared = (not alone) and ensure_shared_stream(ctx, group)        # one draw thread per node, not per rank
+    if unseeded and random_seed is not None:
+        random_seed = int(random_seed) & 0xFFFFFFFF                  # (the agreed entropy value is wider than an MT19937 seed)
     return be.Permutations(ctx, n, flags, num_permutations, random_seed, shared=shared)
 
 

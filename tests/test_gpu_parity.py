@@ -1155,17 +1155,20 @@ def test_fdr_without_a_sort_equals_fdrcorrection(amd, nperm, m):
     assert np.isnan(t[0].cpu().numpy()[5]).all()
 
 
-def test_fdr_without_a_sort_refuses_other_values(amd):
-    """num_permutations > 0 promises p = counts / num_permutations; anything else is refused, not adjusted wrongly."""
+def test_fdr_with_values_that_are_not_count_ratios(amd):
+    """num_permutations > 0 with p-values that are NOT counts / num_permutations (a caller's own matrices): checked read-only
+    first and adjusted through the sort -- nothing is refused and nothing is adjusted twice."""
     import torch
     from safepy_amd import backend as be
     ctx = amd.Context.default(0)
     n, m, nperm = 4, 33, 20
     p = np.random.default_rng(1).integers(0, nperm + 1, size=(n, m)).astype(np.float64) / nperm
     p[2, 7] = 0.123456
-    t = [torch.from_numpy(p.copy()).to('cuda'), torch.from_numpy(p.copy()).to('cuda'),
+    q = np.random.default_rng(2).uniform(size=(n, m))
+    t = [torch.from_numpy(p.copy()).to('cuda'), torch.from_numpy(q.copy()).to('cuda'),
          torch.empty((n, m), dtype=torch.float64, device='cuda'), torch.empty((n, m), dtype=torch.float64, device='cuda'),
          torch.empty((m,), dtype=torch.float64, device='cuda')]
     torch.cuda.synchronize()
-    with pytest.raises(Exception, match='num_permutations'):
-        be.fdr_adjust(ctx, n, m, nperm, 'both', 0.05, [x.data_ptr() for x in t])
+    be.fdr_adjust(ctx, n, m, nperm, 'both', 0.05, [x.data_ptr() for x in t])
+    np.testing.assert_array_equal(t[0].cpu().numpy(), orc.fdr_rows(p))
+    np.testing.assert_array_equal(t[1].cpu().numpy(), orc.fdr_rows(q))

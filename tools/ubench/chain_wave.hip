@@ -10,6 +10,11 @@
 // behind the accept that completes the level and the rest of the trip is redone under the next mask.
 // Output: the word offset at which every permutation starts -- checked against the scalar rule on the host.
 //
+// Measured on MI355X (round 4): k = 3789: 19.3 ms per 1000 permutations (3.6 ns per word, 202 ns = ~430 clocks per 64-word trip;
+// 28.8 ms with the words loaded from global memory two trips ahead instead of staged through LDS); k = 20000: 86 ms per 1000.
+// The product's host thread (draws.cpp: AVX-512, the same batch rule) needs 1.65 ms per 1000 at k = 3789 on the bench host's
+// EPYC 9575F -- a lone wave issues one dependent instruction every few clocks at 2.1-2.4 GHz, the CPU core four to six per clock
+// at 5 GHz.  The chain therefore stays on the host; what the device takes over is everything downstream of it (rng.cpp).
 // build: hipcc --offload-arch=gfx950 -O3 chain_wave.hip -o chain_wave ; run: ./chain_wave [k] [P]
 #include <hip/hip_runtime.h>
 #include <chrono>
@@ -34,13 +39,33 @@ __device__ __forceinline__ uint32_t prefix_count(uint64_t x) {      // set bits 
     return __builtin_amdgcn_mbcnt_hi(static_cast<uint32_t>(x >> 32), __builtin_amdgcn_mbcnt_lo(static_cast<uint32_t>(x), 0u));
 }
 
+// Words are staged through LDS in blocks of 1024 (16 trips): the block after the current one is loaded into registers while
+// the current one is consumed and stored behind it, so no trip waits for global memory; a trip's word is one ds_read away,
+// requested a trip ahead.
+constexpr int BLK = 1024;
 __global__ __launch_bounds__(64) void k_chain(const uint32_t *__restrict__ words, int k, int P, unsigned long long *__restrict__ starts,
                                               unsigned long long *__restrict__ trips_out) {
+    __shared__ uint32_t tb[2 * BLK];
     const uint32_t lane = threadIdx.x;
     unsigned long long base = 0, trips = 0;
     uint32_t s0 = 0;                                                 // first lane of the trip that has not been consumed
-    // three batches in flight: the loads of batch b + 2 are issued while batch b is resolved
-    uint32_t w = words[lane], w1 = words[64 + lane], w2 = words[128 + lane];
+    const uint4 *src = reinterpret_cast<const uint4 *>(words) + 4 * lane;      // this lane's 16 words of a block
+    uint4 n0 = src[0], n1 = src[1], n2 = src[2], n3 = src[3];
+    auto stage = [&](unsigned long long blk) {                      // block `blk` (in registers) -> LDS half blk & 1; request block blk + 1
+        uint4 *dst = reinterpret_cast<uint4 *>(tb + (blk & 1) * BLK) + 4 * lane;
+        dst[0] = n0; dst[1] = n1; dst[2] = n2; dst[3] = n3;
+        src += BLK / 4;
+        n0 = src[0]; n1 = src[1]; n2 = src[2]; n3 = src[3];
+    };
+    stage(0);
+    stage(1);
+    uint32_t w = tb[lane], wn = tb[64 + lane];
+    auto advance = [&]() {                                           // next trip: its word was requested a trip ago
+        base += 64;
+        if ((base & (BLK - 1)) == 0) stage(base / BLK + 1);          // entering a block: the one after it goes to the other half
+        w = wn;
+        wn = tb[(base + 64) & (2 * BLK - 1) & ~63u | lane];
+    };
     for (int q = 0; q < P; ++q) {
         if (lane == 0) starts[q] = base + s0;
         int y = k - 1;
@@ -70,15 +95,13 @@ __global__ __launch_bounds__(64) void k_chain(const uint32_t *__restrict__ words
                     y = ylo - 1;
                     if (s0 == 64) {
                         s0 = 0;
-                        base += 64;
-                        w = w1; w1 = w2; w2 = words[base + 128 + lane];
+                        advance();
                     }
                     break;
                 }
                 y -= cnt;
                 s0 = 0;
-                base += 64;
-                w = w1; w1 = w2; w2 = words[base + 128 + lane];
+                advance();
             }
         }
     }
@@ -91,7 +114,7 @@ int main(int argc, char **argv) {
     double mu = 0;
     for (int i = k - 1; i >= 1; --i) mu += double(mask_of(i) + 1.0) / (i + 1.0);
     const size_t n_words = size_t(mu * P * 1.05) + 100000;
-    std::vector<uint32_t> words(n_words + 256);
+    std::vector<uint32_t> words(n_words + 4096);
     for (auto &v : words) v = rng.next();
     std::vector<unsigned long long> ref(P + 1);
     auto t0 = std::chrono::steady_clock::now();
