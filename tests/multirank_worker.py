@@ -145,7 +145,7 @@ def main():
         os.environ['SAFE_HIP_DEVICE_STREAM'] = '0'
         out = sharding.sharded_compute_pvalues(ctx, nbr, np.ascontiguousarray(b[:, c0:c1]), m, enrichment_type='randomization',
                                                num_permutations=40, random_seed=None, gather=('nes',))
-        sf.random_seed = out['stats']['random_seed']
+        sf.random_seed = out['stats']['random_seed'] & 0xFFFFFFFF       # (the agreed value has 63 bits: its low 32 seed MT19937)
         sf.load_attributes(attribute_file=b.copy())
         sf.compute_pvalues(how='randomization', num_permutations=40, neighborhood_score_type='sum', multiple_testing=False)
         assert np.array_equal(out['full_nes'], sf.nes, equal_nan=True)

@@ -760,10 +760,11 @@ def test_f64_kernel_forms_agree(amd, ctx, golden_enr, monkeypatch, score):
 # -------------------------------------------- integer exchange of the sharded result ----
 
 @pytest.mark.parametrize('kind', ['binary', 'quantitative'])
-def test_nes_from_gathered_packed_counts(amd, ctx, kind):
+def test_nes_from_gathered_packed_counts(amd, ctx, kind, monkeypatch):
     """What sharding.gather_nes does after the all-gather, with the gather simulated on one GPU:
     two column blocks computed separately, their packed counters laid end to end (one padded to
     the widest block), NES derived from the concatenation == NES of the unsharded run."""
+    monkeypatch.setenv('SAFE_HIP_NARROW_LDS', '0')      # (blocks this narrow normally run on the f64 kernel, which leaves no integer counters)
     import torch
     from safepy_amd import backend as be, sharding
     rng = np.random.default_rng(3)
@@ -808,9 +809,10 @@ def test_nes_from_gathered_packed_counts(amd, ctx, kind):
 
 
 @pytest.mark.parametrize('kind', ['binary', 'quantitative'])
-def test_every_output_from_gathered_packed_counts(amd, ctx, kind):
+def test_every_output_from_gathered_packed_counts(amd, ctx, kind, monkeypatch):
     """safe_outputs_from_packed_counts: pvalues_neg, pvalues_pos, nes and nes_binary [N, M] from the concatenated integer
     counters of two column blocks == the unsharded call's matrices (safe.py:532-554, 468-472), any subset of them."""
+    monkeypatch.setenv('SAFE_HIP_NARROW_LDS', '0')      # (blocks this narrow normally run on the f64 kernel, which leaves no integer counters)
     import torch
     from safepy_amd import backend as be, sharding
     rng = np.random.default_rng(5)
