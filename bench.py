@@ -136,6 +136,18 @@ def pmc_traffic(kernel_name, with_stamp=False):
     return val, {'profiled_at_commit': stamp.get('commit'), 'stale': _stamp_is_stale(dict(stamp, kernel=kernel_name), kernel_name)}
 
 
+def mfma_pipe_busy(kernel_name):
+    """Fraction of the matrix-core pipes' cycles the kernel kept busy, from the committed PMC pass (profiles/pmc_mfma.json:
+    SQ_VALU_MFMA_BUSY_CYCLES over GRBM_GUI_ACTIVE x SIMDs; tools/pmc_mfma.sh + tools/update_profiles.py), with its stamp; None
+    when there is no such file."""
+    path = os.path.join(ROOT, 'profiles', 'pmc_mfma.json')
+    if not os.path.exists(path):
+        return None
+    d = json.load(open(path))
+    return {'sum': d.get('mfma_pipe_busy_sum'), 'z_score': d.get('mfma_pipe_busy_zscore'), 'stale': _stamp_is_stale(d, None),
+            'commit': d.get('commit'), 'source': d.get('_source')}
+
+
 def binding_resources(num_cu, kernel_name=None):
     """Utilisation of the resources that actually bound the dominant kernel (it is neither HBM- nor MFMA-bound), from the
     committed PMC passes of this bench command (profiles/pmc_bits.json; counters cannot be read inside the timed process):
@@ -154,6 +166,20 @@ def binding_resources(num_cu, kernel_name=None):
                 'source': c['_source'], 'profiled_at_commit': c.get('commit'),
                 'stale': _stamp_is_stale(c, kernel_name)}
     except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
+
+
+def gpu_clocks():
+    """Current engine / memory clocks of device 0 as rocm-smi reports them (the streaming kernels' rates differ by +-10 % from box
+    to box: the clocks they ran at belong beside them); None when rocm-smi is not usable."""
+    import subprocess
+    try:
+        txt = subprocess.run(['rocm-smi', '-d', '0', '--showclocks', '--json'], capture_output=True, text=True, timeout=20).stdout
+        d = json.loads(txt[txt.index('{'):])
+        card = d[sorted(d)[0]]
+        pick = lambda key: next((v for k, v in card.items() if key in k.lower()), None)       # noqa: E731
+        return {'sclk': pick('sclk'), 'mclk': pick('mclk'), 'fclk': pick('fclk')}
+    except Exception:
         return None
 
 
@@ -214,6 +240,7 @@ def hbm_kernels(ctx, torch, np, be):
                  'enrichments_per_s_call': n * m / (call_ms * 1e-3)}
     attr.close()
     nbr.close()
+    out['clocks_right_after'] = gpu_clocks()
     return out
 
 
@@ -366,18 +393,23 @@ def mfma_kernel(ctx, np, be):
         name, ms, launches = ctx.last_kernel()
         res = (name, ms, launches, dt)
     name, ms, launches, dt = res
-    blocks = be.block_count(nbr)
+    blocks, pieces = be.block_count(nbr), be.piece_count(nbr)
     slices = be.last_mfma_slices(ctx)
-    ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
+    # EXECUTED operations: the kernel issues MFMAs only for the 32 x 32 pieces of the stored blocks that hold a member
+    # (safe_nbr_piece_count); the stored-block figure (what rounds 1-3 reported) is kept beside it
+    ops = 2.0 * pieces * 32 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
+    stored_ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
     tops = ops / (ms * launches * 1e-3) / 1e12
     out = {name: {'bound': 'mfma', 'workload': 'configs[4], one rank of 8: N=%d x M=%d quantitative f64 attributes x %d permutations, '
                                               '%d members per neighborhood on average' % (n, m, nperm, int(nbr.nnz / n)),
                   'kernel_ms': ms * launches, 'call_ms': 1e3 * dt, 'algorithmic_ops': ops, 'achieved': tops,
                   'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS, 'i8_slices': slices,
                   'membership_blocks_256x32': blocks, 'block_fill': nbr.nnz / (blocks * 256.0 * 32.0),
-                  # the executed-block rate above counts whole 256 x 32 blocks (27 % fill; since round 3 the kernel skips the
-                  # 32 x 32 pieces without a member, so part of those ops is no longer executed at all); the USEFUL rate counts
-                  # one multiply-add per membership entry, column, permutation and slice
+                  'pieces_32x32_multiplied': pieces, 'pieces_skipped_frac': 1.0 - pieces / (8.0 * blocks),
+                  'stored_block_ops': stored_ops, 'stored_block_frac_of_peak': stored_ops / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                  'mfma_pipe_busy_pmc': mfma_pipe_busy(name),
+                  # `achieved` / `frac` count the pieces really multiplied; the USEFUL rate counts one multiply-add per membership entry,
+                  # column, permutation and slice
                   'useful_ops': 2.0 * float(nbr.nnz) * m * slices * (nperm + 1),
                   'useful_frac_of_peak': 2.0 * float(nbr.nnz) * m * slices * (nperm + 1) / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                   'enrichments_per_s': float(n) * m * nperm / dt,
@@ -666,12 +698,12 @@ def roofline_of(wl, res, ctx, np, be):
     span = int(np.ceil(P / launches))                       # permutations per launch
     if kname.startswith('k_permtest_mfma'):
         blocks, slices = be.block_count(wl.nbr), be.last_mfma_slices(ctx)
-        ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * slices * (P + 1) / launches
+        ops = 2.0 * be.piece_count(wl.nbr) * 32 * 32 * (32 * ((m + 31) // 32)) * slices * (P + 1) / launches      # executed pieces only
         useful = 2.0 * float(wl.nbr.nnz) * m * slices * (P + 1) / launches
         tops = ops / (k_ms * 1e-3) / 1e12
         return {'bound': 'mfma', 'kernel': kname, 'achieved': tops, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS,
                 'traffic': None, 'kernel_ms': k_ms, 'launches_per_step': launches, 'kernel_busy_ms_per_step': k_busy,
-                'algorithmic_ops': ops, 'i8_slices': slices,
+                'algorithmic_ops': ops, 'i8_slices': slices, 'mfma_pipe_busy_pmc': mfma_pipe_busy(kname),
                 'useful_mac_frac': useful / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                 'block_fill': float(wl.nbr.nnz) / (blocks * 256.0 * 32.0)}
     # Algorithmic HBM bytes of ONE launch: SURVEY 8(d) compulsory traffic = one read of the

@@ -114,6 +114,10 @@ int safe_nbr_set_layout(safe_nbr *nbr, const double *xy_host);
  * matrix-core permutation kernel (0 until that kernel has run once on the handle): the
  * algorithmic GEMM size for roofline reporting. */
 int safe_nbr_block_count(const safe_nbr *nbr, int64_t *blocks);
+/* Of those blocks' 32-row x 32-column pieces (8 per block), the ones that hold at least one member: the kernel issues
+ * matrix-core instructions for these only, so the EXECUTED operation count of a call is pieces x 32 x 32 x columns x slices
+ * x (permutations + 1) x 2 (roofline reporting; 0 until the kernel has run once on the handle). */
+int safe_nbr_piece_count(const safe_nbr *nbr, int64_t *pieces);
 int safe_nbr_destroy(safe_nbr *nbr);
 int safe_nbr_info(const safe_nbr *nbr, int64_t *n, int64_t *nnz, int64_t *max_row_count);
 /* self.neighborhoods in the reference layout: int64 [n,n] row-major (safe.py:430). */

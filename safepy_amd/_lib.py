@@ -89,6 +89,7 @@ PROTOTYPES = {
     'safe_nbr_from_dense_i64': (C.c_int, [_vp, _vp, _i64, _pp]),
     'safe_nbr_set_layout': (C.c_int, [_vp, _vp]),
     'safe_nbr_block_count': (C.c_int, [_vp, _pi64]),
+    'safe_nbr_piece_count': (C.c_int, [_vp, C.POINTER(C.c_int64)]),
     'safe_nbr_destroy': (C.c_int, [_vp]),
     'safe_nbr_info': (C.c_int, [_vp, _pi64, _pi64, _pi64]),
     'safe_nbr_to_dense_i64': (C.c_int, [_vp, _vp]),

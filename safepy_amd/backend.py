@@ -695,6 +695,13 @@ def block_count(nbr):
     return c.value
 
 
+def piece_count(nbr):
+    """32 x 32 pieces of the stored membership blocks that hold a member: the ones the matrix-core kernel multiplies (safe_nbr_piece_count)."""
+    v = C.c_int64()
+    check(lib.safe_nbr_piece_count(nbr.handle, C.byref(v)))
+    return v.value
+
+
 def fdr_adjust(ctx, n, m, num_permutations, attribute_sign, enrichment_threshold, out_ptrs):
     """multiple_testing=True: out_ptrs = (pvalues_neg or None, pvalues_pos, nes, nes_binary, num_enriched);
     num_permutations = 0 selects the hypergeometric form."""

@@ -182,6 +182,7 @@ struct safe_nbr {
     bool blocks_ready = false;
     int64_t bs_groups = 0;          // number of 256-row groups
     int64_t bs_blocks = 0;          // stored blocks (every group padded to a multiple of 4)
+    int64_t bs_pieces = 0;          // 32-row x 32-column pieces of the stored blocks that hold at least one member (the only ones multiplied)
     int64_t bs_src = 0;             // length of a source-row map: (ceil(n/32)+1)*32, the last block is padding
     int32_t *bs_order = nullptr;    // [bs_src] node at ordered position u (n = padding -> zero attribute row)
     int32_t *bs_rowmap = nullptr;   // [bs_groups*256] node at ordered row u, -1 = padding

@@ -994,6 +994,12 @@ int build_blocks(safe_nbr *nbr) {
     }
     nbr->bs_groups = n_groups;
     nbr->bs_blocks = static_cast<int64_t>(kbs.size());
+    nbr->bs_pieces = 0;                                                   // (a wave skips the MFMAs of a 32 x 32 piece without members)
+    for (size_t piece = 0; piece + 32 <= bits.size(); piece += 32) {
+        uint32_t any = 0;
+        for (int r = 0; r < 32; ++r) any |= bits[piece + r];
+        nbr->bs_pieces += any != 0;
+    }
     nbr->bs_src = n_src;
     nbr->h_bs_ptr = ptr;
     nbr->h_bs_rowmap = h_rowmap;

@@ -539,6 +539,12 @@ int safe_nbr_block_count(const safe_nbr *nbr, int64_t *blocks) {
     return SAFE_OK;
 }
 
+int safe_nbr_piece_count(const safe_nbr *nbr, int64_t *pieces) {
+    SAFE_REQUIRE(nbr && pieces, "safe_nbr_piece_count: NULL argument");
+    *pieces = nbr->blocks_ready ? nbr->bs_pieces : 0;
+    return SAFE_OK;
+}
+
 int safe_nbr_set_layout(safe_nbr *nbr, const double *xy_host) {
     SAFE_REQUIRE(nbr && xy_host, "safe_nbr_set_layout: NULL argument");
     nbr->h_xy.assign(xy_host, xy_host + 2 * nbr->n);
