@@ -170,17 +170,23 @@ def binding_resources(num_cu, kernel_name=None):
 
 
 def gpu_clocks():
-    """Current engine / memory clocks of device 0 as rocm-smi reports them (the streaming kernels' rates differ by +-10 % from box
-    to box: the clocks they ran at belong beside them); None when rocm-smi is not usable."""
-    import subprocess
-    try:
-        txt = subprocess.run(['rocm-smi', '-d', '0', '--showclocks', '--json'], capture_output=True, text=True, timeout=20).stdout
-        d = json.loads(txt[txt.index('{'):])
-        card = d[sorted(d)[0]]
-        pick = lambda key: next((v for k, v in card.items() if key in k.lower()), None)       # noqa: E731
-        return {'sclk': pick('sclk'), 'mclk': pick('mclk'), 'fclk': pick('fclk')}
-    except Exception:
-        return None
+    """Current engine / memory clock levels of the GPUs as the amdgpu driver exposes them in sysfs (pp_dpm_sclk / pp_dpm_mclk: the
+    line marked '*').  The streaming kernels' rates differ by +-10 % from box to box: the clocks they ran at belong beside them.
+    (No rocm-smi child process: a process that has initialised the GPU must not exec.)  None when sysfs is not readable."""
+    import glob
+    out = {}
+    for path in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
+        dev = os.path.dirname(path)
+        entry = {}
+        for key in ('sclk', 'mclk', 'fclk'):
+            try:
+                with open(os.path.join(dev, 'pp_dpm_' + key)) as f:
+                    cur = [ln.split(':', 1)[1].strip().rstrip('*').strip() for ln in f if ln.strip().endswith('*')]
+                entry[key] = cur[0] if cur else None
+            except OSError:
+                entry[key] = None
+        out[os.path.basename(os.path.dirname(dev))] = entry
+    return out or None
 
 
 def hbm_kernels(ctx, torch, np, be):

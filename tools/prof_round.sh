@@ -23,6 +23,8 @@ timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o r -- $CMD
 python3 $ROOT/tools/rocpd_counters.py $OUT/fetch/r_results.db > $OUT/pmc_traffic.txt
 python3 $ROOT/tools/rocpd_counters.py $OUT/write/r_results.db >> $OUT/pmc_traffic.txt
 rm -rf $OUT/trace $OUT/fetch $OUT/write
+bash $ROOT/tools/pmc_mfma.sh $TAG/mfma_sum sum > /dev/null 2>&1
+bash $ROOT/tools/pmc_mfma.sh $TAG/mfma_z z-score > /dev/null 2>&1
 bash $ROOT/tools/pmc_bits.sh $TAG/bits
 rm -rf $OUT/bits/pmc1 $OUT/bits/pmc2 $OUT/bits/pmc3 $OUT/bits/pmc4 $OUT/bits/pmc5
 head -30 $OUT/kernel_stats.txt

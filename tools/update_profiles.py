@@ -127,5 +127,26 @@ doc['valu_wave_insts_per_clock_per_simd_sustained'] = 0.43
 doc['_source'] = 'profiles/%s_pmc_permtest_bits.txt (rocprofv3 --pmc, tools/pmc_bits.sh), tools/ubench/valu_issue.hip' % rnd
 doc.update(stamp)
 json.dump(doc, open(os.path.join(ROOT, 'profiles', 'pmc_bits.json'), 'w'), indent=1)
+# ---- matrix-core kernel: pipe-busy fraction (tools/pmc_mfma.sh <tag>/mfma_sum sum ; <tag>/mfma_z z-score)
+mf = dict(stamp)
+txt_all = ''
+for key, sub in (('mfma_pipe_busy_sum', 'mfma_sum'), ('mfma_pipe_busy_zscore', 'mfma_z')):
+    path = os.path.join(src_dir, sub, 'pmc_summary.txt')
+    if not os.path.exists(path):
+        continue
+    c = counters(path)
+    busy, gui, n_mfma = get(c, 'k_permtest_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES'), get(c, 'k_permtest_mfma', 'GRBM_GUI_ACTIVE'), get(c, 'k_permtest_mfma', 'SQ_INSTS_MFMA')
+    if busy and gui:
+        # GRBM_GUI_ACTIVE sums the 8 XCDs' active clocks; the busy cycles sum over the 1024 SIMDs' matrix pipes
+        mf[key] = busy[0] / (gui[0] / 8.0 * 1024.0)
+        mf[key + '_counters'] = {'SQ_VALU_MFMA_BUSY_CYCLES': busy[0], 'GRBM_GUI_ACTIVE': gui[0], 'SQ_INSTS_MFMA': n_mfma[0] if n_mfma else None}
+    txt_all += '## %s\n' % sub + open(path).read()
+if txt_all:
+    mf['_source'] = 'profiles/%s_pmc_permtest_mfma.txt (rocprofv3 --pmc, tools/pmc_mfma.sh: python3 tools/bench_big.py quant 1024 128 sum|z-score)' % rnd
+    json.dump(mf, open(os.path.join(ROOT, 'profiles', 'pmc_mfma.json'), 'w'), indent=1)
+    open(os.path.join(ROOT, 'profiles', '%s_pmc_permtest_mfma.txt' % rnd), 'w').write(
+        '# rocprofv3 --pmc (four separate passes, --kernel-trace only) -- python3 tools/bench_big.py quant 1024 128 <sum|z-score> (tools/pmc_mfma.sh; round %s, '
+        'commit %s, MI355X)\n' % (rnd, commit) + txt_all)
+    print('mfma pipe busy', {k: round(v, 3) for k, v in mf.items() if k.startswith('mfma_pipe_busy') and isinstance(v, float)})
 print({k: round(v['hbm_bytes_per_launch'] / 1e6, 1) for k, v in out.items() if isinstance(v, dict) and 'hbm_bytes_per_launch' in v})
 print('LDS conflict share', doc.get('SQ_LDS_BANK_CONFLICT', 0) / max(doc.get('SQ_LDS_IDX_ACTIVE', 1), 1))
