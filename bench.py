@@ -169,24 +169,63 @@ def binding_resources(num_cu, kernel_name=None):
         return None
 
 
-def gpu_clocks():
-    """Current engine / memory clock levels of the GPUs as the amdgpu driver exposes them in sysfs (pp_dpm_sclk / pp_dpm_mclk: the
-    line marked '*').  The streaming kernels' rates differ by +-10 % from box to box: the clocks they ran at belong beside them.
-    (No rocm-smi child process: a process that has initialised the GPU must not exec.)  None when sysfs is not readable."""
-    import glob
-    out = {}
-    for path in sorted(glob.glob('/sys/class/drm/card*/device/pp_dpm_sclk')):
-        dev = os.path.dirname(path)
-        entry = {}
-        for key in ('sclk', 'mclk', 'fclk'):
-            try:
-                with open(os.path.join(dev, 'pp_dpm_' + key)) as f:
-                    cur = [ln.split(':', 1)[1].strip().rstrip('*').strip() for ln in f if ln.strip().endswith('*')]
-                entry[key] = cur[0] if cur else None
-            except OSError:
-                entry[key] = None
-        out[os.path.basename(os.path.dirname(dev))] = entry
-    return out or None
+class ClockSampler:
+    """Engine / memory clock of THIS GPU while a kernel loop runs, from the amdgpu driver's sysfs files (pp_dpm_sclk / pp_dpm_mclk: the
+    level marked '*'), sampled every 2 ms on a thread of its own.  The streaming kernels' rates differ by +-10 % from box to box:
+    the clocks they ran at belong beside them.  (No rocm-smi child process: a process that has initialised the GPU must not exec.)
+    The card is found by its PCI address; without it (or without sysfs) the report is None."""
+
+    def __init__(self, torch):
+        import glob
+        self.dev = None
+        try:
+            p = torch.cuda.get_device_properties(torch.cuda.current_device())
+            want = '%04x:%02x:%02x.0' % (p.pci_domain_id, p.pci_bus_id, p.pci_device_id)
+            for path in glob.glob('/sys/class/drm/card*/device'):
+                if os.path.basename(os.path.realpath(path)) == want and os.path.exists(os.path.join(path, 'pp_dpm_sclk')):
+                    self.dev = path
+        except Exception:
+            self.dev = None
+        self.samples = {'sclk': [], 'mclk': []}
+        self._stop = False
+        self._thread = None
+
+    def _read(self, key):
+        try:
+            with open(os.path.join(self.dev, 'pp_dpm_' + key)) as f:
+                for ln in f:
+                    if ln.strip().endswith('*'):
+                        return int(''.join(ch for ch in ln.split(':', 1)[1] if ch.isdigit()))
+        except (OSError, ValueError, IndexError):
+            pass
+        return None
+
+    def __enter__(self):
+        if self.dev is not None:
+            import threading
+
+            def loop():
+                while not self._stop:
+                    for key in self.samples:
+                        v = self._read(key)
+                        if v is not None:
+                            self.samples[key].append(v)
+                    time.sleep(0.002)
+            self._thread = threading.Thread(target=loop, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        self._stop = True
+        if self._thread is not None:
+            self._thread.join()
+
+    def report(self):
+        if self.dev is None or not self.samples['sclk']:
+            return None
+        s = self.samples
+        return {'sclk_mhz_max': max(s['sclk']), 'sclk_mhz_median': sorted(s['sclk'])[len(s['sclk']) // 2],
+                'mclk_mhz_max': max(s['mclk']) if s['mclk'] else None, 'samples': len(s['sclk'])}
 
 
 def hbm_kernels(ctx, torch, np, be):
@@ -205,15 +244,20 @@ def hbm_kernels(ctx, torch, np, be):
     nr = 0.1 * (xy[:, 0].max() - xy[:, 0].min())
     for _ in range(2):
         ctx.euclidean_dense(t_xy.data_ptr(), n, nr, t_mask.data_ptr(), None)
-    ctx.timer_start()
-    reps = 5
-    for _ in range(reps):
-        ctx.euclidean_dense(t_xy.data_ptr(), n, nr, t_mask.data_ptr(), None)
-    ms = ctx.timer_stop_ms() / reps
+    with ClockSampler(torch) as clk:                  # (50 launches while sampling, the first 5 timed as before)
+        ctx.timer_start()
+        reps = 5
+        for _ in range(reps):
+            ctx.euclidean_dense(t_xy.data_ptr(), n, nr, t_mask.data_ptr(), None)
+        ms = ctx.timer_stop_ms() / reps
+        for _ in range(45):
+            ctx.euclidean_dense(t_xy.data_ptr(), n, nr, t_mask.data_ptr(), None)
+        ctx.sync()
     alg = 16 * n + 8 * n * n
     out['k_euclid_dense'] = {'bound': 'hbm', 'workload': 'N=%d, int64 [N,N] membership (reference layout)' % n,
                              'kernel_ms': ms, 'algorithmic_bytes': alg, 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS,
-                             'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic('k_euclid_dense')}
+                             'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic('k_euclid_dense'),
+                             'clocks_while_running': clk.report()}
     del t_mask
     m = 10000                                # configs[3]: 20 000 nodes x 10 000 binary attributes
     b = (rng.uniform(size=(n, m)) < 0.01).astype(np.float32)
@@ -225,11 +269,15 @@ def hbm_kernels(ctx, torch, np, be):
     be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
     be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
     ctx.sync()
-    t0 = time.perf_counter()
-    be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
-    ctx.sync()
-    call_ms = 1e3 * (time.perf_counter() - t0)
-    name, ms, _ = ctx.last_kernel()
+    with ClockSampler(torch) as clk:
+        t0 = time.perf_counter()
+        be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
+        ctx.sync()
+        call_ms = 1e3 * (time.perf_counter() - t0)
+        name, ms, _ = ctx.last_kernel()
+        for _ in range(10):
+            be.hypergeom(ctx, nbr, attr, 0.05, ptrs)
+        ctx.sync()
     if name == 'k_hyp_emit':                   # split form: streams p, nes, nes_binary out; reads the packed u16 counts (12 B per 6 elements per row position)
         n_pos = 256 * ((n + 255) // 256)
         alg = n * m * 8 * 3 + n_pos * ((m + 191) // 192) * 384
@@ -243,10 +291,9 @@ def hbm_kernels(ctx, torch, np, be):
                                              % (n, m, int(nbr.nnz / n)),
                  'kernel_ms': ms, 'algorithmic_bytes': alg, 'achieved': alg / ms / 1e6, 'peak': HBM_PEAK_GBS,
                  'unit': 'GB/s', 'frac': alg / ms / 1e6 / HBM_PEAK_GBS, 'traffic': pmc_traffic(name), 'compute_pvalues_call_ms': call_ms,
-                 'enrichments_per_s_call': n * m / (call_ms * 1e-3)}
+                 'enrichments_per_s_call': n * m / (call_ms * 1e-3), 'clocks_while_running': clk.report()}
     attr.close()
     nbr.close()
-    out['clocks_right_after'] = gpu_clocks()
     return out
 
 
@@ -430,11 +477,13 @@ def mfma_kernel(ctx, np, be):
     dtz = time.perf_counter() - t0
     perms.close()
     zname, zms, zlaunches = ctx.last_kernel()
-    zops = 2.0 * blocks * 256 * 32 * (32 * ((m + 15) // 16)) * 7 * (nperm + 1)
+    zops = 2.0 * pieces * 32 * 32 * (32 * ((m + 15) // 16)) * 7 * (nperm + 1)                 # executed pieces, as above
+    zstored = 2.0 * blocks * 256 * 32 * (32 * ((m + 15) // 16)) * 7 * (nperm + 1)
     out[zname + '<z-score>'] = {'bound': 'mfma', 'workload': 'the same share, z-scores', 'kernel_ms': zms * zlaunches, 'call_ms': 1e3 * dtz,
                                 'algorithmic_ops': zops, 'achieved': zops / (zms * zlaunches * 1e-3) / 1e12, 'peak': MFMA_I8_PEAK_TOPS,
                                 'unit': 'TOP/s', 'frac': zops / (zms * zlaunches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 'i8_slices': 7,
-                                'enrichments_per_s': float(n) * m * nperm / dtz}
+                                'stored_block_frac_of_peak': zstored / (zms * zlaunches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                                'mfma_pipe_busy_pmc': mfma_pipe_busy(zname), 'enrichments_per_s': float(n) * m * nperm / dtz}
     for o in outs:
         o.free()
     attr.close()
