@@ -191,7 +191,10 @@ int safe_attr_set_row_flags(safe_attr *attr, const uint8_t *flags_host);
  * of np.random.permutation(indx_vals) (masked-rejection Fisher-Yates), applied
  * cumulatively; movable_host[i] != 0 marks indx_vals.  has_seed == 0 seeds from OS
  * entropy (random_seed=None).  The result is the composed table cur[p][i] with
- * permuted_matrix_p = B[cur[p]], resident on the device. */
+ * permuted_matrix_p = B[cur[p]], resident on the device.  Split of the work: one host thread runs
+ * MT19937 and the rejection chain (how many words a shuffle consumes depends on its rejections:
+ * the one sequential part) and ships the accepted swap targets; the swaps are replayed and the
+ * tables composed on the device, chunk by chunk, while the enrichment kernels of earlier chunks run. */
 int safe_perms_create(safe_ctx *ctx, int64_t n, const uint8_t *movable_host,
                       int64_t num_permutations, int has_seed, uint32_t seed, safe_perms **out);
 int safe_perms_destroy(safe_perms *perms);
@@ -224,11 +227,11 @@ int safe_perms_create_device(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
  * safepy/safe.py:489-519, 1339-1353).  The stream of safe_extras.py:46-58 is sequential, so a rank cannot draw "its part":
  * safe_ctx_share_stream attaches the context to a shared-memory ring named `name` (the same string on every rank of the
  * node, unique per job; capacity_bytes of chunk slots), local rank 0 being the node's producer.  safe_perms_create_shared
- * then behaves exactly like safe_perms_create -- same arguments, same tables -- but only the producer draws and replays
- * swaps; it publishes each pipeline chunk's row maps and the other ranks block (futex, no CPU) until a chunk is there,
- * copy it and upload it.  The call is COLLECTIVE over the ranks of the node: same n, movable rows and permutation count,
+ * then behaves exactly like safe_perms_create -- same arguments, same tables -- but only the producer runs the draw
+ * thread; it publishes each pipeline chunk's accepted swap targets (2 bytes each) and the other ranks block (futex, no CPU)
+ * until a chunk is there, copy it and upload it; every rank replays the swaps and composes the tables on its own device.  The call is COLLECTIVE over the ranks of the node: same n, movable rows and permutation count,
  * same order of calls (checked: SAFE_E_VALUE otherwise; waits time out after SAFE_HIP_RING_TIMEOUT_S, default 120 s).  The
- * seed is the producer's.  When a chunk (128 x (n + 1) x 4 bytes) does not fit the ring twice, or the context shares no
+ * seed is the producer's.  When a chunk (128 x n x 2 bytes; 4 beyond 65535 rows) does not fit the ring twice, or the context shares no
  * stream, every rank silently draws for itself (decided from n and the capacity alone, hence identically everywhere). */
 int safe_ctx_share_stream(safe_ctx *ctx, const char *name, int local_rank, int local_world, int64_t capacity_bytes);
 int safe_ctx_unshare_stream(safe_ctx *ctx);

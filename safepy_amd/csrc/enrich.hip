@@ -2243,7 +2243,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     if (const char *e = getenv("SAFE_HIP_BITS_OCC")) occ5 = occ5 && atoi(e) >= 5;
     else occ5 = false;                                   // (experimental: opt-in)
     int tasks_per_slot = 2;                              // queue depth per workgroup slot: balance against the per-task costs (T reload, counter flush);
-                                                         // 2 measured best of 1..6 once the host stream stopped being the bottleneck (tools/step_sweep2.sh)
+                                                         // 2 measured best of 1..6 once the host stream stopped being the bottleneck (round-3 sweep, CHANGELOG.md)
     if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
     const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
     // One task list per DISTINCT launch size: the stream's stages are 32, 96, 128 ... and short last ones, and a list cut for 128
@@ -2436,7 +2436,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
             // workgroup to finish.  A few CUs are therefore left out of the grid (SAFE_HIP_BITS_SPARE, default 8 of 256):
-            // the median step shrinks by ~3 % at 1000 permutations, ~6 % at 10 000 (tools/step_sweep.sh)
+            // the median step shrinks by ~3 % at 1000 permutations, ~6 % at 10 000 (round-3 sweep, CHANGELOG.md)
             int spare = std::min(16, ctx->num_cu / 8);        // (8 until the kernels got faster than k_permute_cols on 8 CUs: 10 000-permutation step 27.1 -> 26.3 ms with 16)
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
