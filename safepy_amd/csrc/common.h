@@ -91,6 +91,12 @@ struct safe_ctx {
     int packed_layout = -1;
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
+    // large device-to-host copies into pageable memory (safe_memcpy_d2h): a ring of pinned slots the DMA engine fills while host
+    // threads copy finished slots into the destination (and take its first-touch page faults in parallel)
+    static constexpr int D2H_SLOTS = 8;
+    static constexpr size_t D2H_SLOT_BYTES = size_t(4) << 20;
+    void *d2h_ring = nullptr;
+    hipEvent_t d2h_events[D2H_SLOTS] = {};
     std::vector<hipEvent_t> ev_timing, ev_plain;   // reused per-launch events (creating 20 per call costs ~0.1 ms)
     std::vector<std::pair<size_t, void *>> block_cache;   // small device blocks of destroyed handles (ctx_block_alloc)
     static constexpr int N_SCRATCH = 12;

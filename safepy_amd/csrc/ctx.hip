@@ -5,6 +5,7 @@
 #include <atomic>
 #include <chrono>
 #include <map>
+#include <thread>
 
 static thread_local char g_error[1024] = "";
 
@@ -228,6 +229,9 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->ring) ring_close(ctx->ring);
     ctx->ring = nullptr;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
+    if (ctx->d2h_ring) (void)hipHostFree(ctx->d2h_ring);
+    for (hipEvent_t e : ctx->d2h_events)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_timing) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_plain) (void)hipEventDestroy(e);
     for (int i = 0; i < safe_ctx::N_SCRATCH; ++i)
@@ -299,10 +303,81 @@ int safe_memcpy_h2d(safe_ctx *ctx, void *dev, const void *host, size_t bytes) {
     return SAFE_OK;
 }
 
+// A result matrix read back into a fresh NumPy array (SAFE.nes and its siblings: 139 MB each at configs[1], 1.6 GB at configs[3])
+// is bound by the host side of a pageable copy: one thread takes every first-touch page fault and does the copy out of the
+// runtime's staging buffer (8.2 ms per 139 MB = 17 GB/s measured).  Here the DMA engine fills a ring of pinned 4 MB slots
+// (~50 GB/s) and a few host threads copy finished slots into the destination -- faults and copies in parallel.
+static int d2h_pipelined(safe_ctx *ctx, char *host, const char *dev, size_t bytes, int workers) {
+    constexpr int R = safe_ctx::D2H_SLOTS;
+    constexpr size_t S = safe_ctx::D2H_SLOT_BYTES;
+    if (!ctx->d2h_ring) {
+        g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+        SAFE_HIP_CHECK(hipHostMalloc(&ctx->d2h_ring, R * S, hipHostMallocDefault));
+        for (int i = 0; i < R; ++i) SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->d2h_events[i], hipEventDisableTiming));
+    }
+    const int64_t n_chunks = static_cast<int64_t>((bytes + S - 1) / S);
+    std::atomic<int64_t> issued{0};                       // chunks whose copy into their slot has been queued (event recorded)
+    std::atomic<int64_t> slot_done[R];                    // per slot: the last chunk copied out of it, + 1
+    for (auto &d : slot_done) d.store(0, std::memory_order_relaxed);
+    std::atomic<int> failed{0};
+    char *ring = static_cast<char *>(ctx->d2h_ring);
+    const int device = ctx->device;
+    auto work = [&](int w) {
+        (void)hipSetDevice(device);
+        for (int64_t c = w; c < n_chunks; c += workers) {
+            while (issued.load(std::memory_order_acquire) <= c) {
+                if (failed.load(std::memory_order_relaxed)) return;
+#if defined(__x86_64__)
+                __builtin_ia32_pause();
+#endif
+            }
+            const int s = static_cast<int>(c % R);
+            if (hipEventSynchronize(ctx->d2h_events[s]) != hipSuccess) {
+                failed.store(1);
+                return;
+            }
+            const size_t off = static_cast<size_t>(c) * S, len = std::min(S, bytes - off);
+            memcpy(host + off, ring + static_cast<size_t>(s) * S, len);
+            slot_done[s].store(c + 1, std::memory_order_release);
+        }
+    };
+    std::vector<std::thread> pool;
+    for (int w = 0; w < workers; ++w) pool.emplace_back(work, w);
+    hipError_t e = hipSuccess;
+    for (int64_t c = 0; c < n_chunks && e == hipSuccess; ++c) {
+        const int s = static_cast<int>(c % R);
+        while (c >= R && slot_done[s].load(std::memory_order_acquire) < c - R + 1) {      // the slot's previous chunk has been copied out
+            if (failed.load(std::memory_order_relaxed)) break;
+#if defined(__x86_64__)
+            __builtin_ia32_pause();
+#endif
+        }
+        if (failed.load(std::memory_order_relaxed)) break;
+        const size_t off = static_cast<size_t>(c) * S, len = std::min(S, bytes - off);
+        e = hipMemcpyAsync(ring + static_cast<size_t>(s) * S, dev + off, len, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipEventRecord(ctx->d2h_events[s], ctx->stream);
+        if (e == hipSuccess) issued.store(c + 1, std::memory_order_release);
+    }
+    if (e != hipSuccess) failed.store(1);
+    for (std::thread &t : pool) t.join();
+    if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
+    if (e != hipSuccess || failed.load()) {
+        safe_set_error("safe_memcpy_d2h: %s", e != hipSuccess ? hipGetErrorString(e) : "a copy thread failed");
+        return SAFE_E_HIP;
+    }
+    return SAFE_OK;
+}
+
 int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes) {
     SAFE_REQUIRE(ctx != nullptr && (bytes == 0 || (dev && host)), "safe_memcpy_d2h: NULL argument");
     if (bytes == 0) return SAFE_OK;
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    // SAFE_HIP_D2H_THREADS=0: the plain copy; default: 4 copy threads for 64 MB and more (2 when blocking waits are selected: a rank
+    // that has few cores to itself).  tools/probe/d2h_threads.py: 139 MB 7.7 -> 3.6 ms, 1.6 GB 93 -> 36 ms (4 threads; more do not
+    // help); a 17 MB copy into recycled memory runs at 55 GB/s as it is and stays on the plain path.
+    int workers = safe_blocking_sync_selected() ? 2 : 4;
+    if (const char *env = getenv("SAFE_HIP_D2H_THREADS")) workers = atoi(env);
+    if (workers > 0 && bytes >= (size_t(64) << 20)) return d2h_pipelined(ctx, static_cast<char *>(host), static_cast<const char *>(dev), bytes, std::min(workers, 16));
     SAFE_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;
