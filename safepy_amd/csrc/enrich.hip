@@ -1024,13 +1024,35 @@ __device__ __forceinline__ void vripple_lv(uint32_t (&s)[LV], uint32_t t8) {
     }
 }
 
+// The same in two stages (classes of eight and more levels): a carry into the eights almost never travels past the thirty-twos on
+// sparse annotations, so levels 3 and 4 are rippled first and the rest only when some lane still carries.
+template <int LV>
+__device__ __forceinline__ uint32_t vripple_low(uint32_t (&s)[LV], uint32_t t8) {
+#pragma unroll
+    for (int l = 3; l < 5 && l < LV; ++l) {
+        uint32_t c;
+        asm("v_and_b32 %0, %1, %2\n\tv_xor_b32 %1, %1, %2" : "=&v"(c), "+v"(s[l]) : "v"(t8));
+        t8 = c;
+    }
+    return t8;
+}
+template <int LV>
+__device__ __forceinline__ void vripple_high(uint32_t (&s)[LV], uint32_t t32) {
+#pragma unroll
+    for (int l = 5; l < LV; ++l) {
+        uint32_t c;
+        asm("v_and_b32 %0, %1, %2\n\tv_xor_b32 %1, %1, %2" : "=&v"(c), "+v"(s[l]) : "v"(t32));
+        t32 = c;
+    }
+}
+
 // ids: this lane's blocks (uint4 = 8 x u16), 64 uint4 apart; SHIFT = 2 turns the resident 2*id list into 8*id.
 // The id words are fetched TWO blocks ahead into two register quads that swap roles (no copies): a block's adds take
 // 100-200 cycles, a load from L2 / MALL several hundred -- one block of look-ahead left every wave waiting at vmcnt(0)
 // at the top of each block (the lists have a tail of two blocks, so the look-ahead never leaves the buffer).
 // GATHER: 1 = the real thing; 0 = no LDS reads (diagnostic); 2 = LDS reads at conflict-free addresses (diagnostic: bits 3..7 of
 // every address replaced by the lane's number mod 32 -- the same number of gathers, every bank pair used once per lane group)
-template <int LV, int SHIFT, int GATHER>
+template <int LV, int SHIFT, int GATHER, bool RIP2 = false>
 __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ refill, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     uint32_t a[8];
     a[0] = (c.x & 0xFFFFu) << SHIFT;
@@ -1062,12 +1084,20 @@ __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ ref
     const uint32_t e0 = vadd8_lv<LV>(s0, x0);
     const uint32_t e1 = vadd8_lv<LV>(s1, x1);
     if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
-        vripple_lv<LV>(s0, e0);
-        vripple_lv<LV>(s1, e1);
+        if constexpr (RIP2 && LV >= 8) {
+            const uint32_t c0 = vripple_low<LV>(s0, e0), c1 = vripple_low<LV>(s1, e1);
+            if (__builtin_amdgcn_ballot_w64((c0 | c1) != 0)) {
+                vripple_high<LV>(s0, c0);
+                vripple_high<LV>(s1, c1);
+            }
+        } else {
+            vripple_lv<LV>(s0, e0);
+            vripple_lv<LV>(s1, e1);
+        }
     }
 }
 
-template <int LV, int SHIFT, int GATHER>
+template <int LV, int SHIFT, int GATHER, bool RIP2 = false>
 __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     // `ids` is the slice's first block, the same for the whole wave (scalar registers); the lane is the offset
 #pragma unroll
@@ -1077,10 +1107,10 @@ __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane,
     int b = 0;
     constexpr int STEP = GATHER == 3 ? 0 : 128;            // GATHER 3 (diagnostic): every id load re-reads the slice's first blocks (L1 hits)
     for (; b + 1 < nblk; b += 2, pc += STEP) {
-        blk_add8<LV, SHIFT, GATHER>(ca, pc, s0, s1);
-        blk_add8<LV, SHIFT, GATHER>(cb, pc + 64, s0, s1);
+        blk_add8<LV, SHIFT, GATHER, RIP2>(ca, pc, s0, s1);
+        blk_add8<LV, SHIFT, GATHER, RIP2>(cb, pc + 64, s0, s1);
     }
-    if (b < nblk) blk_add8<LV, SHIFT, GATHER>(ca, pc, s0, s1);
+    if (b < nblk) blk_add8<LV, SHIFT, GATHER, RIP2>(ca, pc, s0, s1);
 }
 
 // one wave, one task: observed sums, then every permutation of the task's range; counters come back in g / l
@@ -1120,7 +1150,7 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
             if (p & 1) blk_add8<LV, 0, GATHER>(cb, ahead, s0, s1);
             else blk_add8<LV, 0, GATHER>(ca, ahead, s0, s1);
         } else
-        blk_sum<LV, 0, GATHER>(perm_ids, lane, nblk, s0, s1);
+        blk_sum<LV, 0, GATHER, (DBG & 32) == 0>(perm_ids, lane, nblk, s0, s1);
         if (DBG & 4) {
             g0[0] ^= s0[0] ^ s0[LV - 1];
             g1[0] ^= s1[0] ^ s1[LV - 1];
@@ -2374,8 +2404,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 31;
-    if (dbg) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 63;
+    if (dbg & 31) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
     const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
                          : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
@@ -2383,6 +2413,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
                          : dbg == 8 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>)
                          : dbg == 16 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>)
+                         : dbg == 32 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 32>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {
