@@ -2272,8 +2272,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     bool occ5 = 5 * lds_T <= 160 * 1024;
     if (const char *e = getenv("SAFE_HIP_BITS_OCC")) occ5 = occ5 && atoi(e) >= 5;
     else occ5 = false;                                   // (experimental: opt-in)
-    int tasks_per_slot = 2;                              // queue depth per workgroup slot: balance against the per-task costs (T reload, counter flush);
-                                                         // 2 measured best of 1..6 once the host stream stopped being the bottleneck (round-3 sweep, CHANGELOG.md)
+    int tasks_per_slot = 1;                              // queue depth per workgroup slot: every task reloads T and flushes its counters (64 wave-atomics
+                                                         // + two 32 x 32 bit transposes per wave: 11 % of the kernel at depth 2, tools/bits_ablate.py dbg=2), so
+                                                         // as few tasks as fill the chip once -- depth 1 vs 2: seeded step 3.52 -> 3.41 ms, 10 000 unseeded
+                                                         // permutations 25.8 -> 24.4 ms (tools/exp_ab.sh; round 3 had chosen 2 while the host stream bound the step)
     if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
     const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
     // One task list per DISTINCT launch size: the stream's stages are 32, 96, 128 ... and short last ones, and a list cut for 128
