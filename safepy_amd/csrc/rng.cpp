@@ -759,11 +759,14 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     p->stages = perms_stage_plan(num_permutations);
     if (device_gen) {
         // no host pipeline to follow: the whole table is there before the first launch, so the launches are even spans of
-        // 128 permutations (the short first stages of the host plan cost 6.5 us per permutation against 3.2 in a full launch)
+        // 200 permutations -- a task of the bit-sliced kernel counts up to 255 permutations before it must flush its counters,
+        // and fewer, longer tasks flush less (tools/probe/span_sweep.py: 10 000 permutations 24.8 ms at 128 per launch, 24.1 at
+        // 200, 24.3 at 250, 25.3 at 334 where a launch's tasks are split again)
+        const int64_t even = 200;
         p->stages.clear();
-        for (int64_t q = 0; q < num_permutations; q += kChunk) p->stages.push_back(q);
+        for (int64_t q = 0; q < num_permutations; q += even) p->stages.push_back(q);
         p->stages.push_back(num_permutations);
-        if (p->stages.size() >= 3 && num_permutations - p->stages[p->stages.size() - 2] < kChunk / 4)
+        if (p->stages.size() >= 3 && num_permutations - p->stages[p->stages.size() - 2] < even / 4)
             p->stages.erase(p->stages.end() - 2);                        // a short tail joins its predecessor
     }
     p->t_created_s = wall_s();
