@@ -988,7 +988,9 @@ __global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
 //     past w, so a wave whose slice is <= 8 / 56 / 248 members wide runs with 4 / 6 / 8 levels instead of 10
 //     (rows are sorted by size: most slices are narrow) -- shorter compare chains, fewer live registers;
 //   * DBG (diagnostics, tools/bits_ablate.py): bit 0 skips the LDS gathers, bit 1 the counter flush,
-//     bit 2 the compare / count step -- wrong results, used to see what the time goes to.
+//     bit 2 the compare / count step, bit 6 flushes with plain stores instead of atomics -- wrong results, used to see what the
+//     time goes to.  (Round 4: the no-flush build is 9 % faster, the plain-store build is not: with the flush gone the compiler also
+//     drops the upper counter levels and their ripples as dead code -- the atomics themselves cost nothing measurable.)
 // --------------------------------------------------------------------------------------
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
@@ -1268,7 +1270,7 @@ __global__ __launch_bounds__(256) void k_bits_observed(int64_t n, const int32_t 
 // #less levels -> word b = less << 16 | greater of attribute b -- and adds them to the totals [attribute][SELL position]
 // (the 64 lanes of a wave update one contiguous 256-byte run).  The address walks down the attributes in a vector
 // register pair: 64 scalar base addresses held at once do not fit the scalar file.
-template <int CL>
+template <int CL, bool PLAIN_STORE = false>
 __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const uint32_t (&g1)[CL], const uint32_t (&l0)[CL],
                                                const uint32_t (&l1)[CL], unsigned int *__restrict__ gl_counts, int64_t col0,
                                                int64_t mloc, int64_t n_pad, int64_t spos, bool active) {
@@ -1289,7 +1291,9 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
 #pragma unroll
         for (int bit = 0; bit < 32; ++bit) {
             asm volatile("" : "+v"(off));
-            if (bit < n_valid && active && m[bit]) atomicAdd(gl_counts + off, m[bit]);
+            if (PLAIN_STORE) {                                    // (diagnostic, wrong results: what the atomics themselves cost)
+                if (bit < n_valid && active && m[bit]) gl_counts[off] = m[bit];
+            } else if (bit < n_valid && active && m[bit]) atomicAdd(gl_counts + off, m[bit]);
             off += n_pad;
         }
     }
@@ -1372,7 +1376,7 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
 
         const int64_t spos = s * 64 + lane;
         if (!(DBG & 2)) {
-            if (np > 0) flush_counters<CL>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, active);
+            if (np > 0) flush_counters<CL, (DBG & 64) != 0>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, active);
         } else if (active && (g0[0] | g1[0] | l0[0] | l1[0]) == 0xDEADBEEFu) {
             gl_counts[spos] = g0[1] ^ l0[1];                              // (keeps the counters alive in the diagnostic build)
         }
@@ -2406,8 +2410,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 63;
-    if (dbg & 31) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 127;
+    if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
     const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
                          : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
@@ -2416,6 +2420,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 8 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>)
                          : dbg == 16 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>)
                          : dbg == 32 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 32>)
+                         : dbg == 64 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 64>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {

@@ -233,7 +233,12 @@ __global__ __launch_bounds__(64) void k_perms_device(int64_t n, int64_t k, int64
 // --------------------------------------------------------------------------------------
 // chunked generation
 // --------------------------------------------------------------------------------------
-static const int64_t kChunk = 128;      // permutations per host/GPU pipeline stage
+// permutations per host/GPU pipeline stage (SAFE_HIP_CHUNK for A/B)
+static const int64_t kChunk = [] {
+    const char *e = getenv("SAFE_HIP_CHUNK");
+    const long long v = e ? atoll(e) : 128;
+    return static_cast<int64_t>(v >= 32 && v <= 255 ? v : 128);
+}();
 static const int64_t kFirst = 64;       // the first stage is short so that the first kernel starts early (32: the launch that covers it
                                         // costs twice as much per permutation; kernels 2.86 -> 2.67 ms per 1000, tools/exp_stages.sh)
 
