@@ -1,6 +1,8 @@
 """HIP path (through the C ABI) against the round-3 reference vectors: `multiple_testing=True` run through the UNSTUBBED
 reference with the real statsmodels (tests/golden/fdr.npz) and the second size, N = 1200 x 300 permutations
 (tests/golden/big.npz) -- every permutation-kernel family against the reference ITSELF, not only the pinned oracle."""
+import ast
+
 import numpy as np
 import pytest
 
@@ -39,7 +41,7 @@ def test_multiple_testing_vs_reference(amd, golden_fdr, monkeypatch, tag, sort):
     if sort != 'auto':                                           # 'auto': the sort-free histogram form where p = counts / P
         monkeypatch.setenv('SAFE_HIP_FDR_SORT', sort)
     g = golden_fdr
-    kw = eval(str(g[tag + '_kwargs']))                           # a dict literal written by make_golden.py
+    kw = ast.literal_eval(str(g[tag + "_kwargs"]))                           # a dict literal written by make_golden.py
     attrs = {k: kw.pop(k) for k in ('attribute_sign', 'random_seed') if k in kw}
     sf = _safe(amd, g, **attrs)
     sf.neighborhoods = g['A'].astype(np.int64)

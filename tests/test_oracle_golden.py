@@ -1,5 +1,7 @@
 """Pin the CPU oracle against vectors produced by the real reference
 (tests/golden/make_golden.py).  CPU only."""
+import ast
+
 import numpy as np
 import pytest
 
@@ -159,7 +161,7 @@ def test_compute_pvalues_with_multiple_testing_equals_reference(golden_fdr):
     a = g['A'].astype(np.int64)
     assert len(g['cases']) == 18
     for tag in g['cases']:
-        kw = eval(str(g[tag + '_kwargs']))                     # a dict literal written by make_golden.py
+        kw = ast.literal_eval(str(g[tag + "_kwargs"]))                     # a dict literal written by make_golden.py
         mat = g[str(g[tag + '_input'])].copy()
         got = orc.compute_pvalues(a, mat, enrichment_type=kw.get('how', 'auto'),
                                   neighborhood_score_type=kw.get('neighborhood_score_type', 'sum'),
