@@ -73,6 +73,7 @@ struct safe_ctx {
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;           // permutation-table generation (overlaps the enrichment kernels)
     hipStream_t side_stream = nullptr;          // second enrichment stream: consecutive spans overlap their tails
+    hipStream_t more_streams[2] = {nullptr, nullptr};   // third and fourth (bit-sliced kernel: deeper overlap of consecutive launches)
     int num_cu = 0;
     int64_t hbm_bytes = 0;
     char arch[64] = {0};
@@ -99,7 +100,7 @@ struct safe_ctx {
     hipEvent_t d2h_events[D2H_SLOTS] = {};
     std::vector<hipEvent_t> ev_timing, ev_plain;   // reused per-launch events (creating 20 per call costs ~0.1 ms)
     std::vector<std::pair<size_t, void *>> block_cache;   // small device blocks of destroyed handles (ctx_block_alloc)
-    static constexpr int N_SCRATCH = 12;
+    static constexpr int N_SCRATCH = 16;
     void *scratch[N_SCRATCH] = {};
     size_t scratch_bytes[N_SCRATCH] = {};
 };

@@ -209,6 +209,7 @@ int safe_ctx_create(int device, safe_ctx **out) {
         SAFE_HIP_CHECK(hipStreamCreateWithPriority(&ctx->aux_stream, hipStreamNonBlocking, hi));
     }
     SAFE_HIP_CHECK(hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+    for (hipStream_t &ms : ctx->more_streams) SAFE_HIP_CHECK(hipStreamCreateWithFlags(&ms, hipStreamNonBlocking));
     SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->t0, safe_event_flags(hipEventDefault)));
     SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->t1, safe_event_flags(hipEventDefault)));
     SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->k0, safe_event_flags(hipEventDefault)));
@@ -239,6 +240,8 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     for (auto &b : ctx->block_cache) (void)hipFree(b.second);
     if (ctx->aux_stream) (void)hipStreamDestroy(ctx->aux_stream);
     if (ctx->side_stream) (void)hipStreamDestroy(ctx->side_stream);
+    for (hipStream_t ms : ctx->more_streams)
+        if (ms) (void)hipStreamDestroy(ms);
     if (ctx->own_stream) (void)hipStreamDestroy(ctx->own_stream);
     delete ctx;
     return SAFE_OK;

@@ -1299,6 +1299,13 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
     }
 }
 
+// Diagnostic (SAFE_HIP_BITS_DBG bit 7, results stay correct): every wave records (task slot, wave, start, end, block-iterations) of
+// each task it ran in this buffer -- s_memtime clocks (100 MHz) -- and launch_bits prints, per launch, how long the tasks took and
+// how much of the launch the workgroup slots sat idle.
+constexpr int BLK_TRACE_MAX = 1 << 17;
+__device__ unsigned long long g_blk_trace[BLK_TRACE_MAX * 4];
+__device__ unsigned int g_blk_trace_n;
+
 // WPS = waves per SIMD the kernel is built for: 4 (128 registers; every class keeps its observed sums in registers and counts
 // with CL levels) or 5 (96 registers: the classes of more than 56 members count with five levels -- their tasks hold at most
 // 31 permutations -- and re-read the observed sums; five workgroups per CU when T fits five times).
@@ -1350,6 +1357,8 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
         int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end < p_begin || !active) p_end = p_begin;                  // (nothing to do for this wave; it still joins the barriers)
 
+        unsigned long long t_begin = 0;
+        if (DBG & 128) t_begin = __builtin_readcyclecounter();
         load_word_column(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
         const int64_t my_blk = (active ? slice_off[s] : 0) / 8;             // in uint4 units (slice offsets are multiples of 512); wave-uniform
         const int wdt = __builtin_amdgcn_readfirstlane(active ? slice_width[s] : 0);
@@ -1379,6 +1388,15 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
             if (np > 0) flush_counters<CL, (DBG & 64) != 0>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, active);
         } else if (active && (g0[0] | g1[0] | l0[0] | l1[0]) == 0xDEADBEEFu) {
             gl_counts[spos] = g0[1] ^ l0[1];                              // (keeps the counters alive in the diagnostic build)
+        }
+        if ((DBG & 128) && lane == 0) {
+            const unsigned int at = atomicAdd(&g_blk_trace_n, 1u);
+            if (at < BLK_TRACE_MAX) {
+                g_blk_trace[4 * at] = (static_cast<unsigned long long>(blockIdx.x) << 32) | (static_cast<unsigned long long>(slot) << 2) | wave;
+                g_blk_trace[4 * at + 1] = t_begin;
+                g_blk_trace[4 * at + 2] = __builtin_readcyclecounter();
+                g_blk_trace[4 * at + 3] = (static_cast<unsigned long long>(nblk) << 32) | static_cast<unsigned int>(np);
+            }
         }
         __syncthreads();                                                  // before T is overwritten by the next task
     }
@@ -2241,6 +2259,51 @@ int kernel_stat_from_events(safe_ctx *ctx, hipEvent_t *ev, int64_t n_launch) {
     return SAFE_OK;
 }
 
+// SAFE_HIP_BITS_DBG=128: what the waves of the last call's launches did (g_blk_trace), on stderr
+static void blk_trace_dump(int n_launch) {
+    unsigned int cnt = 0;
+    if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_blk_trace_n), sizeof(cnt)) != hipSuccess) return;
+    cnt = std::min<unsigned int>(cnt, BLK_TRACE_MAX);
+    std::vector<unsigned long long> rec(static_cast<size_t>(cnt) * 4);
+    if (cnt && hipMemcpyFromSymbol(rec.data(), HIP_SYMBOL(g_blk_trace), rec.size() * sizeof(unsigned long long)) != hipSuccess) return;
+    const unsigned int zero = 0;
+    (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_trace_n), &zero, sizeof(zero));
+    if (!cnt) return;
+    // one line per (workgroup): first start, last end, busy time of wave 0..3; then a summary
+    unsigned long long t0 = ~0ull, t1 = 0;
+    for (unsigned int i = 0; i < cnt; ++i) {
+        t0 = std::min(t0, rec[4 * i + 1]);
+        t1 = std::max(t1, rec[4 * i + 2]);
+    }
+    const double tick_us = 0.01;                                         // s_memtime: 100 MHz
+    double busy = 0.0, work = 0.0;
+    std::vector<double> dur;
+    for (unsigned int i = 0; i < cnt; ++i) {
+        const double d = static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]) * tick_us;
+        busy += d;
+        dur.push_back(d);
+        work += static_cast<double>(rec[4 * i + 3] >> 32) * static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
+    }
+    std::sort(dur.begin(), dur.end());
+    fprintf(stderr, "[blk trace] %u wave-tasks over %d launches, wall %.1f us; wave-task duration min %.1f median %.1f p90 %.1f max %.1f us; "
+            "sum of durations %.0f us (= %.1f waves busy on average); %.3g block-iterations -> %.1f ns per block-iteration per wave\n",
+            cnt, n_launch, static_cast<double>(t1 - t0) * tick_us, dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(), busy,
+            busy / (static_cast<double>(t1 - t0) * tick_us), work, 1e3 * busy / std::max(work, 1.0));
+    // duration per block-iteration by slice width class
+    double cls_busy[5] = {0, 0, 0, 0, 0}, cls_work[5] = {0, 0, 0, 0, 0};
+    for (unsigned int i = 0; i < cnt; ++i) {
+        const double nb = static_cast<double>(rec[4 * i + 3] >> 32), np = static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
+        const int c = nb <= 1 ? 0 : nb <= 7 ? 1 : nb <= 31 ? 2 : nb <= 63 ? 3 : 4;
+        cls_busy[c] += static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]) * tick_us;
+        cls_work[c] += std::max(nb, 1.0) * np;
+    }
+    const char *names[5] = {"1 block", "2-7 blocks", "8-31 blocks", "32-63 blocks", ">= 64 blocks"};
+    for (int c = 0; c < 5; ++c)
+        if (cls_work[c] > 0)
+            fprintf(stderr, "[blk trace]   slices of %-12s: %.0f us of wave time, %.3g block-iterations, %.1f ns each\n", names[c], cls_busy[c], cls_work[c],
+                    1e3 * cls_busy[c] / cls_work[c]);
+}
+
 static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
                        const PermOut &out) {
     const int64_t n = nbr->n, mloc = col1 - col0, n_wg = ceil_div(mloc, 64), P = perms->count;
@@ -2400,17 +2463,23 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
     const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
     const int64_t entries_pad = (nbr->sell_entries + 1024 + 255) / 256 * 256;    // tail: the kernels fetch ids two blocks (2 x 512) ahead
-    uint16_t *d_ids[2] = {nullptr, nullptr};
+    // consecutive launches run on NS streams (SAFE_HIP_BITS_STREAMS, 2..4; default 2): a launch is as long as its longest task, the
+    // next one fills the slots its short tasks leave.  Three or four launches in flight measure WORSE (unseeded 1000-permutation
+    // step 3.01 -> 3.19 -> 3.43 ms, tools/exp_ab.sh): the later launches' workgroups take slots from the long tasks of the first
+    int NS = 2;
+    if (const char *e = getenv("SAFE_HIP_BITS_STREAMS")) NS = std::min(4, std::max(2, atoi(e)));
+    uint16_t *d_ids[4] = {nullptr, nullptr, nullptr, nullptr};
     if (pre)
-        for (int b = 0; b < 2; ++b)
-            SAFE_TRY(ctx_scratch(ctx, 4 + b, static_cast<size_t>(span) * entries_pad * sizeof(uint16_t),
+        for (int b = 0; b < NS; ++b)
+            SAFE_TRY(ctx_scratch(ctx, b < 2 ? 4 + b : 10 + b, static_cast<size_t>(span) * entries_pad * sizeof(uint16_t),
                                  reinterpret_cast<void **>(&d_ids[b])));
+    hipStream_t kstreams[4] = {ctx->stream, ctx->side_stream, ctx->more_streams[0], ctx->more_streams[1]};
     const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 127;
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 255;
     if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
     const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
@@ -2421,6 +2490,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 16 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>)
                          : dbg == 32 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 32>)
                          : dbg == 64 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 64>)
+                         : dbg == 128 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 128>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {
@@ -2451,25 +2521,25 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
-    SAFE_TRY(ctx_events(ctx, false, 2, &plain));
+    SAFE_TRY(ctx_events(ctx, false, 4, &plain));
     // consecutive spans alternate between two streams so the tail of one launch (a few long
     // tasks) overlaps the head of the next; both wait for the inputs prepared on ctx->stream
-    hipEvent_t ready = plain[0], side_done = plain[1];
+    hipEvent_t ready = plain[0];
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
-    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
+    for (int b = 1; b < NS; ++b) SAFE_HIP_CHECK(hipStreamWaitEvent(kstreams[b], ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
         const int64_t p_base = starts[c], p_limit = starts[c + 1];
         const int64_t n_tasks = list_count[launch_list[c]];                 // this launch size's task list
         const int4 *d_tasks = d_task_lists + list_first[launch_list[c]];
         const int64_t blocks = std::min<int64_t>(n_tasks, slots);
-        hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
+        hipStream_t ks = kstreams[c % NS];
         SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
         safe_trace("launch_bits: span tables enqueued");
         if (pre) {
             hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
                                static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
                                perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
-                               p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c & 1]);
+                               p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c % NS]);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
@@ -2480,7 +2550,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
             if (blk) {
-                const uint16_t *ids_c = d_ids[c & 1];
+                const uint16_t *ids_c = d_ids[c % NS];
                 unsigned int *queue_c = d_queue + 8 * c;
                 BitsQueues bq = list_queues[launch_list[c]];
                 void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
@@ -2491,15 +2561,15 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                                           std::max<size_t>(1, std::min<size_t>(occ5 ? 5 : 4, (160 * 1024) / lds_pre)));   // 4 (5): the register file holds 16 (20) waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
             } else if (narrow)
-                hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
+                hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
             else if (wide)
-                hipLaunchKernelGGL(k_permtest_bits_pre<16>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
+                hipLaunchKernelGGL(k_permtest_bits_pre<16>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
             else
-                hipLaunchKernelGGL(k_permtest_bits_pre<10>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c & 1], entries_pad,
+                hipLaunchKernelGGL(k_permtest_bits_pre<10>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
             SAFE_HIP_CHECK(hipGetLastError());
@@ -2520,8 +2590,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
     }
-    SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
-    SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
+    for (int b = 1; b < NS; ++b) {
+        SAFE_HIP_CHECK(hipEventRecord(plain[b], kstreams[b]));
+        SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, plain[b], 0));
+    }
     SAFE_TRY(enrich_finalize_counts(ctx, d_gl, n_pad, nbr->sell_row, mloc, P, out, nullptr));
     ctx->packed_counts = d_gl;
     ctx->packed_n_pad = n_pad;
@@ -2535,6 +2607,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));    // tasks (host vector) and temporaries
     safe_trace("launch_bits: synced");
     SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
+    if (dbg == 128) blk_trace_dump(static_cast<int>(n_launch));
     return SAFE_OK;
 }
 
