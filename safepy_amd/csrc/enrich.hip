@@ -1300,8 +1300,8 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
 }
 
 // Diagnostic (SAFE_HIP_BITS_DBG bit 7, results stay correct): every wave records (task slot, wave, start, end, block-iterations) of
-// each task it ran in this buffer -- s_memtime clocks (100 MHz) -- and launch_bits prints, per launch, how long the tasks took and
-// how much of the launch the workgroup slots sat idle.
+// each task it ran in this buffer -- s_memtime: shader clocks on gfx9 -- and launch_bits prints how long the tasks took, in clocks
+// per block-iteration and by slice width (clocks of different XCDs are not synchronised: only durations are used).
 constexpr int BLK_TRACE_MAX = 1 << 17;
 __device__ unsigned long long g_blk_trace[BLK_TRACE_MAX * 4];
 __device__ unsigned int g_blk_trace_n;
@@ -2269,39 +2269,29 @@ static void blk_trace_dump(int n_launch) {
     const unsigned int zero = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_trace_n), &zero, sizeof(zero));
     if (!cnt) return;
-    // one line per (workgroup): first start, last end, busy time of wave 0..3; then a summary
-    unsigned long long t0 = ~0ull, t1 = 0;
-    for (unsigned int i = 0; i < cnt; ++i) {
-        t0 = std::min(t0, rec[4 * i + 1]);
-        t1 = std::max(t1, rec[4 * i + 2]);
-    }
-    const double tick_us = 0.01;                                         // s_memtime: 100 MHz
     double busy = 0.0, work = 0.0;
     std::vector<double> dur;
     for (unsigned int i = 0; i < cnt; ++i) {
-        const double d = static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]) * tick_us;
+        const double d = static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]);
         busy += d;
         dur.push_back(d);
-        work += static_cast<double>(rec[4 * i + 3] >> 32) * static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
+        work += std::max<double>(1.0, static_cast<double>(rec[4 * i + 3] >> 32)) * static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
     }
     std::sort(dur.begin(), dur.end());
-    fprintf(stderr, "[blk trace] %u wave-tasks over %d launches, wall %.1f us; wave-task duration min %.1f median %.1f p90 %.1f max %.1f us; "
-            "sum of durations %.0f us (= %.1f waves busy on average); %.3g block-iterations -> %.1f ns per block-iteration per wave\n",
-            cnt, n_launch, static_cast<double>(t1 - t0) * tick_us, dur.front(), dur[dur.size() / 2], dur[dur.size() * 9 / 10], dur.back(), busy,
-            busy / (static_cast<double>(t1 - t0) * tick_us), work, 1e3 * busy / std::max(work, 1.0));
-    // duration per block-iteration by slice width class
+    fprintf(stderr, "[blk trace] %u wave-tasks over %d launches; wave-task duration min %.0f median %.0f p90 %.0f max %.0f kclk; "
+            "%.3g block-iterations, %.0f clocks per block-iteration per wave (4 waves share a SIMD)\n",
+            cnt, n_launch, dur.front() / 1e3, dur[dur.size() / 2] / 1e3, dur[dur.size() * 9 / 10] / 1e3, dur.back() / 1e3, work, busy / std::max(work, 1.0));
     double cls_busy[5] = {0, 0, 0, 0, 0}, cls_work[5] = {0, 0, 0, 0, 0};
     for (unsigned int i = 0; i < cnt; ++i) {
         const double nb = static_cast<double>(rec[4 * i + 3] >> 32), np = static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
         const int c = nb <= 1 ? 0 : nb <= 7 ? 1 : nb <= 31 ? 2 : nb <= 63 ? 3 : 4;
-        cls_busy[c] += static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]) * tick_us;
+        cls_busy[c] += static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]);
         cls_work[c] += std::max(nb, 1.0) * np;
     }
     const char *names[5] = {"1 block", "2-7 blocks", "8-31 blocks", "32-63 blocks", ">= 64 blocks"};
     for (int c = 0; c < 5; ++c)
         if (cls_work[c] > 0)
-            fprintf(stderr, "[blk trace]   slices of %-12s: %.0f us of wave time, %.3g block-iterations, %.1f ns each\n", names[c], cls_busy[c], cls_work[c],
-                    1e3 * cls_busy[c] / cls_work[c]);
+            fprintf(stderr, "[blk trace]   slices of %-12s: %.3g block-iterations, %.0f clocks each\n", names[c], cls_work[c], cls_busy[c] / cls_work[c]);
 }
 
 static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
