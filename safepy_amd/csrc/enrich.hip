@@ -805,7 +805,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
 __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict__ cur16, int64_t stride16,
                                                       const uint16_t *__restrict__ sell_col2, int64_t entries,
                                                       int64_t entries_pad, int64_t p0, int64_t count, uint32_t pad_off,
-                                                      uint16_t *__restrict__ out) {
+                                                      uint16_t *__restrict__ out, int diag_banks = 0) {
     // one permutation row (<= 16 KB) staged in LDS per block, 4096 member entries per block: the
     // random 2-byte reads hit LDS instead of L2 sectors
     extern __shared__ uint16_t row[];
@@ -824,8 +824,16 @@ __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict
         uint4 o;
         if (e + 8 <= entries) {
             const uint4 c = *reinterpret_cast<const uint4 *>(sell_col2 + e);
-            const uint32_t a0 = row[(c.x & 0xFFFFu) >> 1], a1 = row[c.x >> 17], a2 = row[(c.y & 0xFFFFu) >> 1], a3 = row[c.y >> 17];
-            const uint32_t a4 = row[(c.z & 0xFFFFu) >> 1], a5 = row[c.z >> 17], a6 = row[(c.w & 0xFFFFu) >> 1], a7 = row[c.w >> 17];
+            uint32_t a0 = row[(c.x & 0xFFFFu) >> 1], a1 = row[c.x >> 17], a2 = row[(c.y & 0xFFFFu) >> 1], a3 = row[c.y >> 17];
+            uint32_t a4 = row[(c.z & 0xFFFFu) >> 1], a5 = row[c.z >> 17], a6 = row[(c.w & 0xFFFFu) >> 1], a7 = row[c.w >> 17];
+            if (diag_banks) {
+                // diagnostic (WRONG results): the low five bits of every member's row become the lane's -- in each gather instruction
+                // the 32 lanes of a half-wave then hit 32 different bank pairs: what would conflict-free gathers be worth?
+                const uint32_t lb = static_cast<uint32_t>((e >> 3) & 31);
+                auto fix = [&](uint32_t a) { return (a & ~31u) | lb; };
+                a0 = fix(a0), a1 = fix(a1), a2 = fix(a2), a3 = fix(a3);
+                a4 = fix(a4), a5 = fix(a5), a6 = fix(a6), a7 = fix(a7);
+            }
             o.x = (a0 << 3) | (a1 << 19);
             o.y = (a2 << 3) | (a3 << 19);
             o.z = (a4 << 3) | (a5 << 19);
@@ -2458,6 +2466,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // step 3.01 -> 3.19 -> 3.43 ms, tools/exp_ab.sh): the later launches' workgroups take slots from the long tasks of the first
     int NS = 2;
     if (const char *e = getenv("SAFE_HIP_BITS_STREAMS")) NS = std::min(4, std::max(2, atoi(e)));
+    const int diag_banks = getenv("SAFE_HIP_BITS_DIAG_BANKS") ? 1 : 0;      // (wrong results: conflict-free gather addresses, see k_permute_cols)
+    if (diag_banks) safe_warn_diagnostic("SAFE_HIP_BITS_DIAG_BANKS");
     uint16_t *d_ids[4] = {nullptr, nullptr, nullptr, nullptr};
     if (pre)
         for (int b = 0; b < NS; ++b)
@@ -2529,7 +2539,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
                                static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
                                perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
-                               p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c % NS]);
+                               p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c % NS], diag_banks);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
