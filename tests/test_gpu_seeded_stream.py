@@ -41,7 +41,7 @@ def numpy_tables(n, flags, nperm, seed):
 @pytest.mark.parametrize('n,k_fixed,nperm,seed', [
     (1, 0, 5, 0), (1, 1, 5, 0), (2, 0, 40, 1), (3, 1, 40, 2), (5, 4, 6, 3), (4, 4, 3, 4),
     (17, 0, 300, 5), (64, 0, 130, 6), (65, 1, 130, 7), (66, 0, 130, 8), (129, 3, 200, 9), (300, 17, 500, 10),
-    (1000, 0, 385, 11), (3971, 182, 300, 0), (3971, 182, 1000, 12345), (8193, 1, 40, 13), (20000, 1000, 150, 14),
+    (1000, 0, 385, 11), (3971, 182, 300, 0), (3971, 182, 1000, 12345), (3971, 182, 10000, 99), (2500, 0, 2555, 4294967295), (8193, 1, 40, 13), (20000, 1000, 150, 14),
     (32769, 0, 12, 15), (65535, 0, 6, 16), (65536, 0, 5, 17)])
 def test_tables_equal_numpy(amd, ctx, n, k_fixed, nperm, seed):
     from safepy_amd import backend as be
