@@ -2349,13 +2349,16 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int64_t min_ppt = 16, target_min = 256;              // floors of a task's size: permutations, block-permutations
     if (const char *e = getenv("SAFE_HIP_BITS_MINPPT")) min_ppt = std::max(1, atoi(e));
     if (const char *e = getenv("SAFE_HIP_BITS_TARGETMIN")) target_min = std::max(1, atoi(e));
+    int64_t max_ppt = 0;                                 // SAFE_HIP_BITS_MAXPPT: cap on a task's permutations (A/B: long launches with short tasks)
+    if (const char *e = getenv("SAFE_HIP_BITS_MAXPPT")) max_ppt = std::max(0, atoi(e));
     struct TaskCost { int4 t; int64_t cost; };
     auto build_tasks = [&](int64_t span_c) {
         const int64_t target = std::max<int64_t>(target_min, blocks_per_perm * span_c / tasks_per_wg);    // block-permutations per task
         std::vector<TaskCost> tc;
         for (int64_t g = 0; g < n_sg; ++g) {
             const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
-            const int64_t ppt_cap = !occ5 ? 255 : (bl * 8 > 56 ? 31 : 63);      // counter levels of the task's class: 8, or 5 / 6
+            int64_t ppt_cap = !occ5 ? 255 : (bl * 8 > 56 ? 31 : 63);            // counter levels of the task's class: 8, or 5 / 6
+            if (max_ppt > 0) ppt_cap = std::min<int64_t>(ppt_cap, max_ppt);
             int64_t ppt = std::min<int64_t>(std::min<int64_t>(span_c, ppt_cap), std::max<int64_t>(min_ppt, target / bl));
             const int64_t chunks = ceil_div(span_c, ppt);
             ppt = ceil_div(span_c, chunks);
@@ -2399,7 +2402,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     };
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     // the lists only depend on the handle and on these numbers: the handle keeps the last plan
-    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch};
+    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch, max_ppt};
     plan_key.insert(plan_key.end(), starts.begin(), starts.end());
     BitsTaskPlan &plan = nbr->bits_plan;
     if (plan.key != plan_key) {
@@ -2693,6 +2696,8 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     int64_t min_ppt = 16, target_min = 256;              // floors of a task's size: permutations, block-permutations
     if (const char *e = getenv("SAFE_HIP_BITS_MINPPT")) min_ppt = std::max(1, atoi(e));
     if (const char *e = getenv("SAFE_HIP_BITS_TARGETMIN")) target_min = std::max(1, atoi(e));
+    int64_t max_ppt = 0;                                 // SAFE_HIP_BITS_MAXPPT: cap on a task's permutations (A/B: long launches with short tasks)
+    if (const char *e = getenv("SAFE_HIP_BITS_MAXPPT")) max_ppt = std::max(0, atoi(e));
     struct TaskCost { int4 t; int64_t cost; };
     std::vector<TaskCost> tc;
     for (int64_t g = 0; g < n_sg; ++g) {
