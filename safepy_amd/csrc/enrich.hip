@@ -2679,7 +2679,12 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
 #undef PREP
     }
     int64_t span = 1;
-    const std::vector<int64_t> starts = perm_launch_starts(perms, &span);
+    // a narrow block (the reference's Example 3: ONE attribute, 10 000 permutations) gives a launch almost nothing to do: its 128
+    // permutations take 0.25 ms of launch and tail latency whatever the width, so after the start-up stages a launch covers
+    // eight pipeline stages (SAFE_HIP_LDS_MERGE; 11.6 -> 7 ms at the Example-3 shape)
+    int merge = n * mloc <= 204800 ? 8 : 1;
+    if (const char *e = getenv("SAFE_HIP_LDS_MERGE")) merge = std::max(1, atoi(e));
+    const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
     const size_t lds_bytes = ldsf64_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
