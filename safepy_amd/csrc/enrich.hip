@@ -2681,7 +2681,8 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     int64_t span = 1;
     // a narrow block (the reference's Example 3: ONE attribute, 10 000 permutations) gives a launch almost nothing to do: its 128
     // permutations take 0.25 ms of launch and tail latency whatever the width, so after the start-up stages a launch covers
-    // eight pipeline stages (SAFE_HIP_LDS_MERGE; 11.6 -> 7 ms at the Example-3 shape)
+    // eight pipeline stages (SAFE_HIP_LDS_MERGE; at the Example-3 shape 7.5 -> 2.0 ms unseeded, 11.6 -> 10.5 ms seeded, where the
+    // host draws of 10 000 short shuffles are then the bound)
     int merge = n * mloc <= 204800 ? 8 : 1;
     if (const char *e = getenv("SAFE_HIP_LDS_MERGE")) merge = std::max(1, atoi(e));
     const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
