@@ -1107,6 +1107,69 @@ __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ ref
     }
 }
 
+// The stream form of blk_add8 (k_permtest_bits_blk's permutation loop).  The two id quads live in v[112:115] (Q = 0) and
+// v[116:119] (Q = 1), registers the compiler does not know about: the kernel is built with 112 registers (amdgpu_num_vgpr) and the
+// clobber lists below make the allocation 120 (not 128: at 4 x 120 registers a SIMD keeps room for a wave of the table kernels of
+// the next pipeline stage next to this kernel's four; with 4 x 128 they queued behind it and the seeded step got slower).  A quad is refilled IN PLACE with the block after next right after its ids were
+// extracted, and the wait is ours: the quads are fetched in block order, so when block g is due exactly one younger fetch (block
+// g + 1's) may still be in flight -- vmcnt(1); whatever else the compiler has in flight only makes that wait stricter (vmcnt
+// retires in order).  As C++ values (`c = *refill`, blk_add8) the compiler loaded the refill into fresh registers and copied them
+// over at the loop latch behind `s_waitcnt vmcnt(0)`: every second block waited for ids requested one block earlier -- an L2 round
+// trip against a block's 160-600 clocks -- and a quad written by an asm statement is no better: the allocator copies it around
+// BEFORE the wait.  `base` is wave-uniform (scalar registers), `lane_off` the block's byte offset plus the lane's.
+template <int Q>
+__device__ __forceinline__ void stream_fetch(const u32x4 *base, uint32_t lane_off) {
+    if (Q == 0) asm volatile("global_load_dwordx4 v[112:115], %0, %1" : : "v"(lane_off), "s"(base) : "v112", "v113", "v114", "v115");
+    else asm volatile("global_load_dwordx4 v[116:119], %0, %1" : : "v"(lane_off), "s"(base) : "v116", "v117", "v118", "v119");
+}
+
+template <int LV, int GATHER, bool RIP2, int Q>
+__device__ __forceinline__ void blk_add8s(const u32x4 *base, uint32_t lane_off, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
+    uint32_t a[8];
+    if (Q == 0)
+        asm volatile("s_waitcnt vmcnt(1)\n\tv_and_b32 %0, 0xffff, v112\n\tv_lshrrev_b32 %1, 16, v112\n\tv_and_b32 %2, 0xffff, v113\n\t"
+                     "v_lshrrev_b32 %3, 16, v113\n\tv_and_b32 %4, 0xffff, v114\n\tv_lshrrev_b32 %5, 16, v114\n\t"
+                     "v_and_b32 %6, 0xffff, v115\n\tv_lshrrev_b32 %7, 16, v115"
+                     : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]));
+    else
+        asm volatile("s_waitcnt vmcnt(1)\n\tv_and_b32 %0, 0xffff, v116\n\tv_lshrrev_b32 %1, 16, v116\n\tv_and_b32 %2, 0xffff, v117\n\t"
+                     "v_lshrrev_b32 %3, 16, v117\n\tv_and_b32 %4, 0xffff, v118\n\tv_lshrrev_b32 %5, 16, v118\n\t"
+                     "v_and_b32 %6, 0xffff, v119\n\tv_lshrrev_b32 %7, 16, v119"
+                     : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]), "=v"(a[4]), "=v"(a[5]), "=v"(a[6]), "=v"(a[7]));
+    stream_fetch<Q>(base, lane_off);
+    if (GATHER == 2) {
+        const uint32_t lane_bits = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 31u) << 3;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) a[u] = (a[u] & 0xFF00u) | lane_bits;
+    }
+    uint32_t x0[8], x1[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+        if (GATHER) {
+            const u32x2 w = *(lds_u2_ptr)(uintptr_t)(a[u]);
+            x0[u] = w.x;
+            x1[u] = w.y;
+        } else {
+            x0[u] = a[u];
+            x1[u] = a[u] >> 3;
+        }
+    }
+    const uint32_t e0 = vadd8_lv<LV>(s0, x0);
+    const uint32_t e1 = vadd8_lv<LV>(s1, x1);
+    if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+        if constexpr (RIP2 && LV >= 8) {
+            const uint32_t c0 = vripple_low<LV>(s0, e0), c1 = vripple_low<LV>(s1, e1);
+            if (__builtin_amdgcn_ballot_w64((c0 | c1) != 0)) {
+                vripple_high<LV>(s0, c0);
+                vripple_high<LV>(s1, c1);
+            }
+        } else {
+            vripple_lv<LV>(s0, e0);
+            vripple_lv<LV>(s1, e1);
+        }
+    }
+}
+
 template <int LV, int SHIFT, int GATHER, bool RIP2 = false>
 __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     // `ids` is the slice's first block, the same for the whole wave (scalar registers); the lane is the offset
@@ -1143,28 +1206,44 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
         }
     }
     uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
-    // one-block slices (17 of 63 on the bench network): blk_sum requests three blocks per permutation and uses one, and waits for it
-    // at once.  Here the ids of the permutation after next are requested while this one is added: two quads that swap roles.
+    constexpr bool STREAM = (DBG & 256) == 0;                         // (the five-waves build passes bit 8: it has no registers 112-119)
+    // STREAM (the default): the task's blocks -- permutation after permutation -- are ONE stream through two id quads that are
+    // refilled IN PLACE with the block after next (blk_add8s), so a permutation's first blocks were requested while the previous
+    // permutation was still being added.  !STREAM (SAFE_HIP_BITS_DBG=256, the form of rounds 2-4, same results): every permutation
+    // starts its own look-ahead (blk_sum) and waits for its first block's ids -- an L2 round trip per permutation and slice.
     u32x4 ca{}, cb{};
-    const bool single = LV == 4 && nblk == 1 && GATHER != 3;
+    const bool single = !STREAM && LV == 4 && nblk == 1 && GATHER != 3;
     if (single) {
         ca = perm_ids[lane];
         cb = perm_ids[(np > 1 ? perm_stride : 0) + lane];
     }
-    for (int p = 0; p < np; ++p, perm_ids += perm_stride) {
-        uint32_t s0[LV], s1[LV];
-        if (single) {
-#pragma unroll
-            for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
-            const u32x4 *ahead = perm_ids + (p + 2 < np ? 2 * perm_stride : 0) + lane;
-            if (p & 1) blk_add8<LV, 0, GATHER>(cb, ahead, s0, s1);
-            else blk_add8<LV, 0, GATHER>(ca, ahead, s0, s1);
-        } else
-        blk_sum<LV, 0, GATHER, (DBG & 32) == 0>(perm_ids, lane, nblk, s0, s1);
+    // the stream's fetch position, two blocks ahead of the block being added: a wave-uniform byte offset from the task's first
+    // block (scalar registers; the id lists of one launch are far below 4 GB), added to the lane's own offset per fetch
+    const uint32_t pf_hi = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<uint64_t>(perm_ids) >> 32)));
+    const uint32_t pf_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<uint64_t>(perm_ids))));
+    const u32x4 *pf_base = reinterpret_cast<const u32x4 *>((static_cast<uint64_t>(pf_hi) << 32) | static_cast<uint64_t>(pf_lo));
+    uint32_t pf = 0;
+    int pf_b = 0, pf_p = 0;
+    const uint32_t pf_stride = static_cast<uint32_t>(perm_stride) * 16u, pf_wrap = pf_stride - static_cast<uint32_t>(nblk) * 1024u;
+    const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+    auto pf_next = [&]() __attribute__((always_inline)) {
+        if (GATHER == 3) return;
+        pf += 1024u;
+        if (++pf_b == nblk) {
+            pf_b = 0;
+            pf += pf_wrap;
+            if (++pf_p == np) {                                              // past the task's end: the last permutation's blocks again (never used)
+                pf_p = np - 1;
+                pf -= pf_stride;
+            }
+        }
+    };
+    // what follows a permutation's sums: compare with the observed sums, count
+    auto settle = [&](int p, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) __attribute__((always_inline)) {
         if (DBG & 4) {
             g0[0] ^= s0[0] ^ s0[LV - 1];
             g1[0] ^= s1[0] ^ s1[LV - 1];
-            continue;
+            return;
         }
         uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
 #pragma unroll
@@ -1187,11 +1266,80 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
             vflush<CLT>(l0, lp0);
             vflush<CLT>(l1, lp1);
         }
+    };
+    if (STREAM) {
+        // Blocks alternate between the quads (block g of the stream sits in quad g & 1), in straight-line code: an `if (quad)` around
+        // one block body made the two arms keep the sums in different registers, ten moves per block.  A slice of an even number of
+        // blocks is pairs all the way; with an odd number two permutations make one period: pairs, A | B, pairs.
+        constexpr bool R2 = (DBG & 32) == 0;
+        stream_fetch<0>(pf_base, pf + lane_off);
+        pf_next();
+        stream_fetch<1>(pf_base, pf + lane_off);
+        pf_next();
+        const int pairs = nblk >> 1;
+        auto add_pairs = [&](uint32_t (&s0)[LV], uint32_t (&s1)[LV]) __attribute__((always_inline)) {
+            for (int i = 0; i < pairs; ++i) {
+                blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
+                pf_next();
+                blk_add8s<LV, GATHER, R2, 1>(pf_base, pf + lane_off, s0, s1);
+                pf_next();
+            }
+        };
+        if (nblk & 1) {
+            int p = 0;
+            for (; p + 1 < np; p += 2) {
+                uint32_t s0[LV], s1[LV];
+#pragma unroll
+                for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+                add_pairs(s0, s1);
+                blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
+                pf_next();
+                settle(p, s0, s1);
+#pragma unroll
+                for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+                blk_add8s<LV, GATHER, R2, 1>(pf_base, pf + lane_off, s0, s1);
+                pf_next();
+                add_pairs(s0, s1);
+                settle(p + 1, s0, s1);
+            }
+            if (p < np) {
+                uint32_t s0[LV], s1[LV];
+#pragma unroll
+                for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+                add_pairs(s0, s1);
+                blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
+                pf_next();
+                settle(p, s0, s1);
+            }
+        } else {
+            for (int p = 0; p < np; ++p) {
+                uint32_t s0[LV], s1[LV];
+#pragma unroll
+                for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+                add_pairs(s0, s1);
+                settle(p, s0, s1);
+            }
+        }
+    } else {
+        for (int p = 0; p < np; ++p, perm_ids += perm_stride) {
+            uint32_t s0[LV], s1[LV];
+            if (single) {
+#pragma unroll
+                for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
+                const u32x4 *ahead = perm_ids + (p + 2 < np ? 2 * perm_stride : 0) + lane;
+                if (p & 1) blk_add8<LV, 0, GATHER>(cb, ahead, s0, s1);
+                else blk_add8<LV, 0, GATHER>(ca, ahead, s0, s1);
+            } else
+                blk_sum<LV, 0, GATHER, (DBG & 32) == 0>(perm_ids, lane, nblk, s0, s1);
+            settle(p, s0, s1);
+        }
     }
     vflush<CLT>(g0, gp0);
     vflush<CLT>(g1, gp1);
     vflush<CLT>(l0, lp0);
     vflush<CLT>(l1, lp1);
+    // (the two fetches past the stream's end: landed before anything else is asked of the vector-memory counter)
+    if (STREAM) asm volatile("s_waitcnt vmcnt(0)" : : : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
 }
 
 template <int LV, int CL, int DBG, int CLT = CL, bool OBSMEM = false>
@@ -1317,8 +1465,9 @@ __device__ unsigned int g_blk_trace_n;
 // WPS = waves per SIMD the kernel is built for: 4 (128 registers; every class keeps its observed sums in registers and counts
 // with CL levels) or 5 (96 registers: the classes of more than 56 members count with five levels -- their tasks hold at most
 // 31 permutations -- and re-read the observed sums; five workgroups per CU when T fits five times).
-template <int CL, int DBG, int WPS = 4>
-__global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
+template <int CL, int DBG, int WPS>
+__device__ __forceinline__ void bits_blk_body(
+
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
     const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, BitsQueues qs,
@@ -1408,6 +1557,31 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk(
         }
         __syncthreads();                                                  // before T is overwritten by the next task
     }
+}
+
+// The two builds of the body.  The default one holds the id stream's two quads in registers 112-119 behind the compiler's back
+// (blk_add8s): it is compiled with 112 registers (the attribute counts in pairs on gfx90a and later: 56), and the clobber lists of the
+// stream's asm statements make the allocation 120.
+// The plain one (five waves per SIMD, SAFE_HIP_BITS_DBG bit 8) runs without the stream.
+template <int CL, int DBG>
+__global__ __launch_bounds__(256, 4) __attribute__((amdgpu_num_vgpr(56))) void k_permtest_bits_blk(
+
+    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, BitsQueues qs,
+    const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_pad) {
+    bits_blk_body<CL, DBG & ~256, 4>(n, ids_p, entries_pad, sell_row, slice_off, slice_width, obs, n_slices, bbits, qs, tasks, p_base, p_limit, queue, mloc, gl_counts, n_pad);
+}
+template <int CL, int DBG, int WPS>
+__global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk_plain(
+
+    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint32_t *__restrict__ obs, int64_t n_slices, const uint2 *__restrict__ bbits, BitsQueues qs,
+    const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_pad) {
+    bits_blk_body<CL, DBG | 256, WPS>(n, ids_p, entries_pad, sell_row, slice_off, slice_width, obs, n_slices, bbits, qs, tasks, p_base, p_limit, queue, mloc, gl_counts, n_pad);
 }
 
 // counts -> everything compute_pvalues derives from them (safe.py:528-554, 468-472).
@@ -2482,9 +2656,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 255;
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 511;
     if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
-    const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0, 5>)
+    const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
                          : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
                          : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>)
@@ -2494,6 +2668,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 32 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 32>)
                          : dbg == 64 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 64>)
                          : dbg == 128 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 128>)
+                         : dbg == 256 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 256, 4>)
+                         : dbg == 384 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 384, 4>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {
@@ -2610,7 +2786,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));    // tasks (host vector) and temporaries
     safe_trace("launch_bits: synced");
     SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
-    if (dbg == 128) blk_trace_dump(static_cast<int>(n_launch));
+    if (dbg & 128) blk_trace_dump(static_cast<int>(n_launch));
     return SAFE_OK;
 }
 
