@@ -1170,6 +1170,88 @@ __device__ __forceinline__ void blk_add8s(const u32x4 *base, uint32_t lane_off, 
     }
 }
 
+// The stream's block in two halves, the LDS gathers ONE HALF AHEAD of the adds: when the adds of a block's first four members
+// run the gathers of its last four are in flight, and the gathers of the NEXT block's first four (X0 / X1, carried into the next
+// call) are issued before the last four are added -- a wave no longer sits out a whole LDS round trip per block (the diagnostic
+// build without gathers ran as fast with eight more vector operations per block: that round trip was what the gathers cost).
+// Q = the quad of this block; the next block's is the other one, waited for (vmcnt(1), as in blk_add8s) when its first half is due.
+constexpr int HALF_MAX_LV = 8;            // (the classes of nine and ten levels have no registers for the second set of gathered words)
+template <int Q>
+__device__ __forceinline__ void stream_ids_lo(uint32_t (&a)[4]) {             // ids 0..3 of quad Q, after waiting for its fetch
+    if (Q == 0)
+        asm volatile("s_waitcnt vmcnt(1)\n\tv_and_b32 %0, 0xffff, v112\n\tv_lshrrev_b32 %1, 16, v112\n\tv_and_b32 %2, 0xffff, v113\n\t"
+                     "v_lshrrev_b32 %3, 16, v113" : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]));
+    else
+        asm volatile("s_waitcnt vmcnt(1)\n\tv_and_b32 %0, 0xffff, v116\n\tv_lshrrev_b32 %1, 16, v116\n\tv_and_b32 %2, 0xffff, v117\n\t"
+                     "v_lshrrev_b32 %3, 16, v117" : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]));
+}
+template <int Q>
+__device__ __forceinline__ void stream_ids_hi(uint32_t (&a)[4]) {             // ids 4..7 (the quad has landed: its first half was used)
+    if (Q == 0)
+        asm volatile("v_and_b32 %0, 0xffff, v114\n\tv_lshrrev_b32 %1, 16, v114\n\tv_and_b32 %2, 0xffff, v115\n\t"
+                     "v_lshrrev_b32 %3, 16, v115" : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]));
+    else
+        asm volatile("v_and_b32 %0, 0xffff, v118\n\tv_lshrrev_b32 %1, 16, v118\n\tv_and_b32 %2, 0xffff, v119\n\t"
+                     "v_lshrrev_b32 %3, 16, v119" : "=v"(a[0]), "=v"(a[1]), "=v"(a[2]), "=v"(a[3]));
+}
+template <int GATHER>
+__device__ __forceinline__ void gather4(uint32_t (&a)[4], uint32_t (&x0)[4], uint32_t (&x1)[4]) {
+    if (GATHER == 2) {
+        const uint32_t lane_bits = (__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u)) & 31u) << 3;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) a[u] = (a[u] & 0xFF00u) | lane_bits;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        if (GATHER) {
+            const u32x2 w = *(lds_u2_ptr)(uintptr_t)(a[u]);
+            x0[u] = w.x;
+            x1[u] = w.y;
+        } else {
+            x0[u] = a[u];
+            x1[u] = a[u] >> 3;
+        }
+    }
+}
+// four members into the sums: the carry into the fours comes back
+template <int LV>
+__device__ __forceinline__ uint32_t vadd4_lv(uint32_t (&s)[LV], const uint32_t (&x)[4]) {
+    const uint32_t t2a = maj3(s[0], x[0], x[1]);
+    s[0] = xor3(s[0], x[0], x[1]);
+    const uint32_t t2b = maj3(s[0], x[2], x[3]);
+    s[0] = xor3(s[0], x[2], x[3]);
+    const uint32_t t4 = maj3(s[1], t2a, t2b);
+    s[1] = xor3(s[1], t2a, t2b);
+    return t4;
+}
+template <int LV, int GATHER, bool RIP2, int Q>
+__device__ __forceinline__ void blk_step(const u32x4 *base, uint32_t lane_off, uint32_t (&s0)[LV], uint32_t (&s1)[LV], uint32_t (&X0)[4],
+                                         uint32_t (&X1)[4]) {
+    uint32_t a[4], Y0[4], Y1[4];
+    stream_ids_hi<Q>(a);
+    stream_fetch<Q>(base, lane_off);                                         // the block after next, into this block's quad
+    gather4<GATHER>(a, Y0, Y1);
+    const uint32_t f0 = vadd4_lv<LV>(s0, X0), f1 = vadd4_lv<LV>(s1, X1);
+    stream_ids_lo<1 - Q>(a);
+    gather4<GATHER>(a, X0, X1);                                              // the next block's first half
+    const uint32_t h0 = vadd4_lv<LV>(s0, Y0), h1 = vadd4_lv<LV>(s1, Y1);
+    const uint32_t e0 = maj3(s0[2], f0, h0), e1 = maj3(s1[2], f1, h1);
+    s0[2] = xor3(s0[2], f0, h0);
+    s1[2] = xor3(s1[2], f1, h1);
+    if (__builtin_amdgcn_ballot_w64((e0 | e1) != 0)) {
+        if constexpr (RIP2 && LV >= 8) {
+            const uint32_t c0 = vripple_low<LV>(s0, e0), c1 = vripple_low<LV>(s1, e1);
+            if (__builtin_amdgcn_ballot_w64((c0 | c1) != 0)) {
+                vripple_high<LV>(s0, c0);
+                vripple_high<LV>(s1, c1);
+            }
+        } else {
+            vripple_lv<LV>(s0, e0);
+            vripple_lv<LV>(s1, e1);
+        }
+    }
+}
+
 template <int LV, int SHIFT, int GATHER, bool RIP2 = false>
 __device__ __forceinline__ void blk_sum(const u32x4 *__restrict__ ids, int lane, int nblk, uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
     // `ids` is the slice's first block, the same for the whole wave (scalar registers); the lane is the offset
@@ -1272,17 +1354,32 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
         // one block body made the two arms keep the sums in different registers, ten moves per block.  A slice of an even number of
         // blocks is pairs all the way; with an odd number two permutations make one period: pairs, A | B, pairs.
         constexpr bool R2 = (DBG & 32) == 0;
+        constexpr bool HALF = (DBG & 512) == 0 && LV <= HALF_MAX_LV;        // (bit 9: the gathers of a block all at its start, as before)
         stream_fetch<0>(pf_base, pf + lane_off);
         pf_next();
         stream_fetch<1>(pf_base, pf + lane_off);
         pf_next();
+        uint32_t X0[4] = {0, 0, 0, 0}, X1[4] = {0, 0, 0, 0};
+        if (HALF) {
+            uint32_t a[4];
+            stream_ids_lo<0>(a);
+            gather4<GATHER>(a, X0, X1);
+        }
+        auto blockA = [&](uint32_t (&s0)[LV], uint32_t (&s1)[LV]) __attribute__((always_inline)) {
+            if (HALF) blk_step<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1, X0, X1);
+            else blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
+            pf_next();
+        };
+        auto blockB = [&](uint32_t (&s0)[LV], uint32_t (&s1)[LV]) __attribute__((always_inline)) {
+            if (HALF) blk_step<LV, GATHER, R2, 1>(pf_base, pf + lane_off, s0, s1, X0, X1);
+            else blk_add8s<LV, GATHER, R2, 1>(pf_base, pf + lane_off, s0, s1);
+            pf_next();
+        };
         const int pairs = nblk >> 1;
         auto add_pairs = [&](uint32_t (&s0)[LV], uint32_t (&s1)[LV]) __attribute__((always_inline)) {
             for (int i = 0; i < pairs; ++i) {
-                blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
-                pf_next();
-                blk_add8s<LV, GATHER, R2, 1>(pf_base, pf + lane_off, s0, s1);
-                pf_next();
+                blockA(s0, s1);
+                blockB(s0, s1);
             }
         };
         if (nblk & 1) {
@@ -1292,13 +1389,11 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
 #pragma unroll
                 for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
                 add_pairs(s0, s1);
-                blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
-                pf_next();
+                blockA(s0, s1);
                 settle(p, s0, s1);
 #pragma unroll
                 for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
-                blk_add8s<LV, GATHER, R2, 1>(pf_base, pf + lane_off, s0, s1);
-                pf_next();
+                blockB(s0, s1);
                 add_pairs(s0, s1);
                 settle(p + 1, s0, s1);
             }
@@ -1307,8 +1402,7 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
 #pragma unroll
                 for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
                 add_pairs(s0, s1);
-                blk_add8s<LV, GATHER, R2, 0>(pf_base, pf + lane_off, s0, s1);
-                pf_next();
+                blockA(s0, s1);
                 settle(p, s0, s1);
             }
         } else {
@@ -2656,7 +2750,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 511;
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 1023;
     if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
     const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 0, 5>)
                          : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
@@ -2670,6 +2764,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                          : dbg == 128 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 128>)
                          : dbg == 256 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 256, 4>)
                          : dbg == 384 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 384, 4>)
+                         : dbg == 512 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 512>)
+                         : dbg == 640 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 640>)
                                     : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
     uint32_t *d_obs = nullptr;
     if (blk) {
