@@ -37,7 +37,7 @@ def parse():
     # (200 steps: 0.7 s of timed work -- a pre-empted host thread costs one step ~5 ms about once in 500 steps on the shared bench
     # hosts, tools/probe/trace_outlier.py; with 20 steps one such step moved the mean by 7 %)
     ap.add_argument('--steps', type=int, default=200)
-    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--warmup', type=int, default=50)        # the first ~50 steps of a fresh process run 0.1 ms slower (step_ms_mean_by_quarter_of_run)
     ap.add_argument('--perms', type=int, default=1000)
     ap.add_argument('--nodes', type=int, default=3971)
     ap.add_argument('--attrs', type=int, default=4373)
@@ -869,6 +869,8 @@ def main():
             'pinned_to_numa_node': numa_node,
             'step_ms_min_median_max': [float(np.min(res['step_ms'])), float(np.median(res['step_ms'])), float(np.max(res['step_ms']))],
             'step_ms_slowest3': [float(x) for x in sorted(res['step_ms'])[-3:]],
+            'step_ms_deciles': [round(float(x), 3) for x in np.percentile(res['step_ms'], list(range(10, 100, 10)))],
+            'step_ms_mean_by_quarter_of_run': [round(float(np.mean(q)), 3) for q in np.array_split(np.asarray(res['step_ms']), 4)],
             'step_probe': res['step_probe'],
         }
         if 'exchange_report' in res:
