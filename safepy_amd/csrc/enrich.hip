@@ -1305,17 +1305,19 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
     const uint32_t pf_lo = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(reinterpret_cast<uint64_t>(perm_ids))));
     const u32x4 *pf_base = reinterpret_cast<const u32x4 *>((static_cast<uint64_t>(pf_hi) << 32) | static_cast<uint64_t>(pf_lo));
     uint32_t pf = 0;
-    int pf_b = 0, pf_p = 0;
+    int pf_left = nblk, pf_perms = np;                                      // blocks left in the fetch position's permutation, permutations left
     const uint32_t pf_stride = static_cast<uint32_t>(perm_stride) * 16u, pf_wrap = pf_stride - static_cast<uint32_t>(nblk) * 1024u;
     const uint32_t lane_off = static_cast<uint32_t>(lane) * 16u;
+    // (the wrap is a real branch -- the empty asm statement keeps the compiler from turning it into a dozen scalar selects per block)
     auto pf_next = [&]() __attribute__((always_inline)) {
         if (GATHER == 3) return;
         pf += 1024u;
-        if (++pf_b == nblk) {
-            pf_b = 0;
+        if (__builtin_expect(--pf_left == 0, 0)) {
+            asm volatile("");
+            pf_left = nblk;
             pf += pf_wrap;
-            if (++pf_p == np) {                                              // past the task's end: the last permutation's blocks again (never used)
-                pf_p = np - 1;
+            if (--pf_perms == 0) {                                           // past the task's end: the last permutation's blocks again (never used)
+                pf_perms = 1;
                 pf -= pf_stride;
             }
         }
