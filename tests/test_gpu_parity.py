@@ -645,13 +645,22 @@ def test_integer_forms_large_support_and_many_permutations(amd, monkeypatch, pat
     assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
 
 
-@pytest.mark.parametrize('kernel,nperm', [('blk', 40), ('blk', 300), ('pre', 40), ('barrier', 40)])
+@pytest.mark.parametrize('kernel,nperm', [('blk', 40), ('blk', 300), ('blk', 1), ('blk', 2), ('blk', 3), ('blk', 41), ('blk', 257), ('blk-plain', 41),
+                                          ('blk-unpipelined', 41), ('pre', 40), ('barrier', 40)])
 def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
     """The three bit-sliced kernels (blocked member lists = default, pre-permuted lists, permutation row in LDS) on a
     membership whose SELL slices fall into every width class of the blocked kernel (<= 8, <= 56, <= 248, <= 504, > 504 members:
     4 / 6 / 8 / 9 / 10 levels of the vertical sums), with columns dense enough that the sums really reach the top
-    levels, an empty neighborhood, a ragged last word group; 300 permutations carry the counters past their low levels."""
+    levels, an empty neighborhood, a ragged last word group; 300 permutations carry the counters past their low levels.  Odd and
+    tiny permutation counts walk the blocked kernel's id stream through its tails (a slice of an odd number of blocks takes two
+    permutations per period); 'blk-plain' is the form without the stream (SAFE_HIP_BITS_DBG=256, also the five-waves build's),
+    'blk-unpipelined' the stream with a block's gathers all at its start (bit 9)."""
     monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'bits')
+    if kernel == 'blk-plain':
+        monkeypatch.setenv('SAFE_HIP_BITS_DBG', '256')
+    elif kernel == 'blk-unpipelined':
+        monkeypatch.setenv('SAFE_HIP_BITS_DBG', '512')
+    kernel = kernel.split('-')[0]
     if kernel == 'pre':
         monkeypatch.setenv('SAFE_HIP_BITS_KERNEL', 'pre')
     elif kernel == 'barrier':
