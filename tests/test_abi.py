@@ -71,3 +71,43 @@ def test_product_never_imports_the_oracle():
             if f.endswith(('.py', '.hip', '.cpp', '.h')):
                 text = open(os.path.join(dirpath, f), errors='replace').read()
                 assert 'safe_oracle' not in text and 'import oracle' not in text and 'from oracle' not in text, f
+
+
+def test_id_stream_registers_stay_hidden_from_the_compiler(tmp_path):
+    """k_permtest_bits_blk keeps its two id quads in v[112:119] behind the compiler's back (enrich.hip, blk_add8s / blk_step: the
+    kernel is compiled with 112 registers, the asm clobber lists make the allocation 120).  If a compiler ever placed a value of
+    its own in one of those registers the prefetches would overwrite it silently -- so the SHIPPED code object is disassembled
+    here and every instruction of those kernels that names v112..v119 must be one of the stream's own: the fetch
+    (global_load_dwordx4 into a whole quad) or an id extraction (v_and_b32 0xffff / v_lshrrev_b32 16 reading one of them)."""
+    import glob
+    import shutil
+    import subprocess
+    from safepy_amd import _lib
+    objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
+    if not os.path.exists(objdump):
+        pytest.skip('no llvm-objdump in this image')
+    lib = str(tmp_path / 'lib.so')
+    shutil.copy(_lib.LIB_PATH, lib)
+    subprocess.run([objdump, '--offloading', lib], capture_output=True, cwd=str(tmp_path), check=True)
+    named = re.compile(r'\bv11[2-9]\b|v\[\d+:11[2-9]\]|v\[11[2-9]:\d+\]')
+    own = re.compile(r'^(global_load_dwordx4 v\[11[26]:11[59]\], v\d+, s\[\d+:\d+\]'
+                     r'|v_and_b32_e32 v\d+, 0xffff, v11[2-9]'
+                     r'|v_lshrrev_b32_e32 v\d+, 16, v11[2-9])\s*(//.*)?$')
+    kernels, uses, foreign = set(), 0, []
+    for co in sorted(glob.glob(str(tmp_path / 'lib.so.*gfx950'))):
+        text = subprocess.run([objdump, '-d', '--no-show-raw-insn', co], capture_output=True, text=True, check=True).stdout
+        if 'k_permtest_bits_blkILi8E' not in text:
+            continue
+        sym = None
+        for line in text.split('\n'):
+            m = re.match(r'^[0-9a-f]+ <(.+)>:$', line)
+            if m:
+                sym = m.group(1)
+                continue
+            if sym and sym.startswith('_Z19k_permtest_bits_blkILi8E') and named.search(line.split('//')[0]):
+                kernels.add(sym)
+                uses += 1
+                if not own.match(line.strip()):
+                    foreign.append((sym[:48], line.strip()))
+    assert kernels and uses > 1000, 'the stream kernels were not found in the library'
+    assert not foreign, foreign[:5]
