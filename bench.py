@@ -148,7 +148,10 @@ def mfma_pipe_busy(kernel_name):
             'commit': d.get('commit'), 'source': d.get('_source')}
 
 
-def binding_resources(num_cu, kernel_name=None):
+VALU_PEAK_WAVE_INSTR_PER_SIMD_US = 830.0     # measured: tools/ubench/valu_banks.hip (v_bitop3_b32, two and four waves per SIMD, any operand banks)
+
+
+def binding_resources(num_cu, kernel_name=None, busy_ms=None):
     """Utilisation of the resources that actually bound the dominant kernel (it is neither HBM- nor MFMA-bound), from the
     committed PMC passes of this bench command (profiles/pmc_bits.json; counters cannot be read inside the timed process):
     LDS pipe busy cycles per CU and VALU issue cycles per SIMD over the kernel's GPU cycles.  Stamped with the commit and
@@ -157,7 +160,19 @@ def binding_resources(num_cu, kernel_name=None):
         with open(os.path.join(ROOT, 'profiles', 'pmc_bits.json')) as f:
             c = json.load(f)
         gpu_cycles = c['GRBM_GUI_ACTIVE'] / 8.0               # the counter is summed over the 8 XCDs
-        return {'kernel': c['kernel'],
+        wall = {}
+        if busy_ms:
+            # the launches of a step overlap on two streams, so fractions over the SUM of their durations (below) understate how
+            # busy the chip is while the kernel runs: the same instruction counts over the union of the launch intervals of THIS run
+            steps = float(c.get('steps_profiled', 1))
+            rate = c['SQ_INSTS_VALU'] / steps / (4 * num_cu) / (busy_ms * 1e3)
+            wall = {'valu_wave_instr_per_step': c['SQ_INSTS_VALU'] / steps,
+                    'valu_wave_instr_per_simd_and_us_while_busy': rate,
+                    'valu_issue_frac_of_measured_peak_while_busy': rate / VALU_PEAK_WAVE_INSTR_PER_SIMD_US,
+                    'lds_wave_instr_per_cu_and_us_while_busy': c['SQ_INSTS_LDS'] / steps / num_cu / (busy_ms * 1e3),
+                    'note': 'diagnostic builds (DESIGN.md 4, K5a): without any LDS gather the kernel takes the same time; the bound is the issue '
+                            'rate of four in-order waves per SIMD (a lone wave issues one instruction per ~6 clocks)'}
+        return {'kernel': c['kernel'], **wall,
                 'lds_pipe_busy_frac': c['SQ_LDS_IDX_ACTIVE'] / num_cu / gpu_cycles,
                 'lds_bank_conflict_share_of_busy': c['SQ_LDS_BANK_CONFLICT'] / c['SQ_LDS_IDX_ACTIVE'],
                 'valu_issue_frac': c['SQ_INSTS_VALU'] / (4 * num_cu) / c['valu_wave_insts_per_clock_per_simd_sustained'] / gpu_cycles,
@@ -775,12 +790,12 @@ def roofline_of(wl, res, ctx, np, be):
         alg_bytes = n * m * 4 + P * (n + 1) * 4 + nnz * 4 + 5 * n * m * 8
     achieved = alg_bytes / (k_ms * 1e-3) / 1e9
     traffic, traffic_stamp = pmc_traffic(kname, with_stamp=True)
-    binding = binding_resources(ctx.num_cu, kname)
+    binding = binding_resources(ctx.num_cu, kname, k_busy)
     roof = {}
     if binding is not None and kname.startswith('k_permtest_bits'):
         # what actually bounds the kernel (PMC passes of this same command, profiles/): the busier of its two pipes
-        roof.update({'binding_resource': 'VALU issue + LDS gather', 'binding_unit': 'fraction of issue slots',
-                     'binding_frac': max(binding['valu_issue_frac'], binding['lds_pipe_busy_frac']),
+        roof.update({'binding_resource': 'VALU issue (four in-order waves per SIMD)', 'binding_unit': 'fraction of the measured issue peak, over the time the kernel is running',
+                     'binding_frac': binding.get('valu_issue_frac_of_measured_peak_while_busy', max(binding['valu_issue_frac'], binding['lds_pipe_busy_frac'])),
                      'binding_resource_utilisation': binding})
     roof.update({'bound': 'hbm', 'kernel': kname, 'achieved': achieved, 'peak': HBM_PEAK_GBS, 'unit': 'GB/s',
                  'frac': achieved / HBM_PEAK_GBS, 'traffic': traffic, 'traffic_source': traffic_stamp, 'kernel_ms': k_ms,
