@@ -239,11 +239,12 @@ static const int64_t kChunk = [] {
     const long long v = e ? atoll(e) : 128;
     return static_cast<int64_t>(v >= 32 && v <= 255 ? v : 128);
 }();
-static const int64_t kFirst = 64;       // the first stage is short so that the first kernel starts early (32: the launch that covers it
-                                        // costs twice as much per permutation; kernels 2.86 -> 2.67 ms per 1000, tools/exp_stages.sh)
-
-// Stage boundaries of the host / GPU pipeline for `count` permutations: [0, 64), [64, 128), [128, 256), ... and a SHORT last
-// stage: the final stages are cut to <= 72 and 32 permutations (what the last stage holds runs after the draws have ended).
+// Stage boundaries of the host / GPU pipeline for `count` permutations: a ramp [0, 16), [16, 64), [64, 192), then 128-permutation
+// stages, and a SHORT last stage (the final stages are cut to <= 96 and 32 permutations: what the last stage holds runs after the
+// draws have ended).  The ramp: the first kernel launch waits for the first stage's draws, replay and scan, so it is short; the
+// launch that covers a short stage costs more per permutation, so the next ones grow quickly.  Seeded step at configs[1], medians
+// on one box (tools/exp_ab.sh): 64 | 128 ... 3.28-3.32 ms; 32 | 128 ... 3.22-3.24; 16 | 64 | 192 ... 3.18-3.21; 16 | 48 | 128 3.31-3.36;
+// 8 | 32 | 96 | 224 3.38.
 std::vector<int64_t> perms_stage_plan(int64_t count) {
     std::vector<int64_t> b;
     b.push_back(0);
@@ -259,16 +260,12 @@ std::vector<int64_t> perms_stage_plan(int64_t count) {
                 if (v > (h.empty() ? 0 : h.back())) h.push_back(v);
                 c = *end ? end + 1 : end;
             }
+        if (h.empty()) h = {16, 64, 192};
         return h;
     }();
-    if (!head.empty()) {
-        for (int64_t q : head)
-            if (q < count) b.push_back(q);
-        for (int64_t q = head.back() + kChunk; q < count; q += kChunk) b.push_back(q);
-    } else {
-        if (count > kFirst) b.push_back(kFirst);
-        for (int64_t q = kChunk; q < count; q += kChunk) b.push_back(q);
-    }
+    for (int64_t q : head)
+        if (q < count) b.push_back(q);
+    for (int64_t q = head.back() + kChunk; q < count; q += kChunk) b.push_back(q);
     const int64_t last = b.back();
     static const int tail_rule = getenv("SAFE_HIP_TAIL_STAGE") ? atoi(getenv("SAFE_HIP_TAIL_STAGE")) : 1;
     if (tail_rule == 1 && count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
