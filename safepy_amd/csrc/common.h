@@ -302,7 +302,11 @@ struct safe_perms {
     size_t stage_bytes = 0;                        // capacity of each staging buffer (sized for k = n)
     int target_bytes = 2;                          // bytes per swap target on the wire (2 when k <= 65535)
     int64_t target_width = 0;                      // targets per permutation row: k - 1 rounded up to 8
-    void *d_targets = nullptr;                     // device copy of the chunk being replayed
+    void *d_targets = nullptr;                     // device copy of the chunk being replayed (even chunks)
+    void *d_targets_odd = nullptr;                 // ... odd chunks: a chunk's upload and replay run beside its predecessor's scan
+    int32_t *d_maps_odd[2] = {nullptr, nullptr};   // row maps / scan ping-pong of the odd chunks
+    hipEvent_t replayed[2] = {nullptr, nullptr};   // by chunk parity: the replay has written its row maps (recorded on the replay stream)
+    hipEvent_t movpos_ready = nullptr;             // d_movpos uploaded (aux stream) -- the replay stream waits for it once per handle
     int32_t *d_big = nullptr;                      // k > 65535 only: [chunk][k] position arrays of the global-memory replay
     int32_t *h_movpos = nullptr;                   // pinned [2n]: staging of d_movpos
     int32_t *d_maps[2] = {nullptr, nullptr};       // [chunk][n+1] row maps / scan ping-pong

@@ -462,14 +462,26 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     } else if (p->ring) {
         SAFE_TRY(ring_publish(p->ring, ci, p->h_stage[b], bytes));
     }
-    SAFE_HIP_CHECK(hipMemcpyAsync(p->d_targets, p->h_stage[b], bytes, hipMemcpyHostToDevice, gs));
-    SAFE_HIP_CHECK(hipEventRecord(p->staged[b], gs));
+    // Two streams: upload + replay of chunk c on the replay stream, scan + emit on the table stream.  The replays are independent
+    // of each other (only the scan composes with the previous chunk's last row), so chunk c's upload and replay run beside chunk
+    // c - 1's scan: in the ramp of the pipeline (stages of 16 / 48 / 128 permutations, each waiting for its draws) the tables of the
+    // second and third stage are ready 65-85 us earlier.  Buffers alternate by the chunk's parity.
+    static const bool one_stream = getenv("SAFE_HIP_REPLAY_STREAM") && atoi(getenv("SAFE_HIP_REPLAY_STREAM")) == 0;      // (A/B)
+    const int par = one_stream ? 0 : static_cast<int>(ci & 1);
+    hipStream_t rs = one_stream ? gs : ctx->more_streams[0];
+    void *d_tg = par ? p->d_targets_odd : p->d_targets;
+    if (!one_stream) {
+        if (ci == 0) SAFE_HIP_CHECK(hipStreamWaitEvent(rs, p->movpos_ready, 0));
+        if (ci >= 2) SAFE_HIP_CHECK(hipStreamWaitEvent(rs, p->chunk_done[ci - 2], 0));       // this parity's row maps are free again
+    }
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tg, p->h_stage[b], bytes, hipMemcpyHostToDevice, rs));
+    SAFE_HIP_CHECK(hipEventRecord(p->staged[b], rs));
     {
         std::lock_guard<std::mutex> lk(p->draw_mu);                  // the draw thread may fill this buffer again once the upload is done
         p->enqueued_chunks = std::max<int64_t>(p->enqueued_chunks, ci + 1);
     }
     p->draw_cv.notify_all();
-    int32_t *xa = p->d_maps[0], *xb = p->d_maps[1];
+    int32_t *xa = par ? p->d_maps_odd[0] : p->d_maps[0], *xb = par ? p->d_maps_odd[1] : p->d_maps[1];
     const int32_t *d_mov = p->d_movpos, *d_pos = p->d_movpos + ((n + 3) & ~int64_t(3));
     if (k <= 65535) {
         uint32_t hash_mask = 63u;                              // tag slots: the next power of two >= k (no aliasing), at most 8192 (4096 when the positions need most of the LDS)
@@ -478,12 +490,16 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
         const size_t lds = (static_cast<size_t>(hash_mask) + 1) * sizeof(uint32_t) + static_cast<size_t>(kReplayBlock + kpad) * sizeof(uint16_t);
         auto kernel = n <= 65535 ? k_replay_targets<true> : k_replay_targets<false>;
         SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
-        hipLaunchKernelGGL(kernel, dim3(cnt), dim3(64), lds, gs, static_cast<const uint16_t *>(p->d_targets), p->target_width, n, k,
+        hipLaunchKernelGGL(kernel, dim3(cnt), dim3(64), lds, rs, static_cast<const uint16_t *>(d_tg), p->target_width, n, k,
                            d_mov, d_pos, xa, hash_mask);
     } else {
         if (!p->d_big) SAFE_TRY(dev_alloc(&p->d_big, static_cast<size_t>(kChunk) * p->n));
-        hipLaunchKernelGGL(k_replay_targets_big, dim3(cnt), dim3(64), 0, gs, static_cast<const uint32_t *>(p->d_targets),
+        hipLaunchKernelGGL(k_replay_targets_big, dim3(cnt), dim3(64), 0, rs, static_cast<const uint32_t *>(d_tg),
                            p->target_width, n, k, d_mov, d_pos, xa, p->d_big);
+    }
+    if (!one_stream) {
+        SAFE_HIP_CHECK(hipEventRecord(p->replayed[par], rs));
+        SAFE_HIP_CHECK(hipStreamWaitEvent(gs, p->replayed[par], 0));
     }
     const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), cnt), block(256);
     for (int64_t d = 1; d < cnt; d <<= 1) {
@@ -631,7 +647,13 @@ static void perms_free(safe_perms *p) {
         if (p->h_stage[b]) (void)hipHostFree(p->h_stage[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
     }
-    for (int b = 0; b < 2; ++b) (void)hipFree(p->d_maps[b]);
+    for (int b = 0; b < 2; ++b) {
+        (void)hipFree(p->d_maps[b]);
+        (void)hipFree(p->d_maps_odd[b]);
+        if (p->replayed[b]) (void)hipEventDestroy(p->replayed[b]);
+    }
+    if (p->movpos_ready) (void)hipEventDestroy(p->movpos_ready);
+    (void)hipFree(p->d_targets_odd);
     if (p->h_movpos) (void)hipHostFree(p->h_movpos);
     (void)hipFree(p->d_targets);
     (void)hipFree(p->d_big);
@@ -682,6 +704,7 @@ static int upload_movpos(safe_perms *p) {
         h[n_pad + p->h_movable[t]] = static_cast<int32_t>(t);
     }
     SAFE_HIP_CHECK(hipMemcpyAsync(p->d_movpos, h, static_cast<size_t>(2 * n_pad) * sizeof(int32_t), hipMemcpyHostToDevice, p->ctx->aux_stream));
+    if (p->movpos_ready) SAFE_HIP_CHECK(hipEventRecord(p->movpos_ready, p->ctx->aux_stream));
     return SAFE_OK;
 }
 
@@ -790,11 +813,21 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
             p->stage_bytes = static_cast<size_t>(slot_bytes);
             if ((rc = dev_alloc(reinterpret_cast<char **>(&p->d_targets), p->stage_bytes + 2 * kReplayBlock * sizeof(uint16_t))) != SAFE_OK) break;   // (+ a block of slack: see k_replay_targets)
         }
+        if (!device_gen) {                                   // the odd chunks' buffers (a handle first used with the device stream has none yet)
+            if (!p->d_maps_odd[0] && (rc = dev_alloc(&p->d_maps_odd[0], kChunk * stride)) != SAFE_OK) break;
+            if (!p->d_maps_odd[1] && (rc = dev_alloc(&p->d_maps_odd[1], kChunk * stride)) != SAFE_OK) break;
+            if (!p->d_targets_odd &&
+                (rc = dev_alloc(reinterpret_cast<char **>(&p->d_targets_odd), p->stage_bytes + 2 * kReplayBlock * sizeof(uint16_t))) != SAFE_OK)
+                break;
+        }
         p->target_bytes = k <= 65535 ? 2 : 4;
         p->target_width = (std::max<int64_t>(k - 1, 1) + 7) & ~int64_t(7);
         hipError_t e = hipSuccess;
         if (!p->h_movpos) g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
         if (!p->h_movpos) e = hipHostMalloc(reinterpret_cast<void **>(&p->h_movpos), static_cast<size_t>(2 * n + 8) * sizeof(int32_t), hipHostMallocDefault);
+        for (int b = 0; b < 2 && e == hipSuccess; ++b)
+            if (!p->replayed[b]) e = hipEventCreateWithFlags(&p->replayed[b], safe_event_flags(hipEventDisableTiming));
+        if (e == hipSuccess && !p->movpos_ready) e = hipEventCreateWithFlags(&p->movpos_ready, safe_event_flags(hipEventDisableTiming));
         for (int b = 0; b < safe_perms::kStage && e == hipSuccess; ++b) {
             if (!p->h_stage[b] && !device_gen) g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
             if (!p->h_stage[b] && !device_gen) e = hipHostMalloc(&p->h_stage[b], p->stage_bytes, hipHostMallocDefault);
