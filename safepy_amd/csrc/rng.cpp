@@ -77,6 +77,24 @@ __global__ __launch_bounds__(256) void k_emit_rows(const int32_t *__restrict__ x
     }
 }
 
+// the last scan round and the emit in one launch (a chunk's chain is launch-latency bound: every launch less is ~6 us
+// sooner for the tables of the pipeline's first stages)
+__global__ __launch_bounds__(256) void k_scan_emit(const int32_t *__restrict__ xin, int64_t d, const int32_t *__restrict__ cur_base,
+                                                   int64_t cnt, int64_t n, int32_t *__restrict__ table,
+                                                   uint16_t *__restrict__ table16, int64_t stride16) {
+    const int64_t i = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    const int64_t q = blockIdx.y, stride = n + 1;
+    if (i < stride) {
+        int32_t v = xin[q * stride + i];
+        if (q >= d) v = xin[(q - d) * stride + v];
+        v = cur_base[v];
+        table[q * stride + i] = v;
+        if (table16) table16[q * stride16 + i] = static_cast<uint16_t>(v);
+    } else if (table16 && i < stride16) {
+        table16[q * stride16 + i] = static_cast<uint16_t>(n);
+    }
+}
+
 // 16-bit copy of a caller-supplied table, rows padded with the padding row's id
 __global__ __launch_bounds__(256) void k_table16(const int32_t *__restrict__ table, int64_t stride, uint16_t *__restrict__ table16,
                                                   int64_t stride16, int64_t n) {
@@ -489,7 +507,12 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
         const int64_t kpad = (std::max<int64_t>(k, 4) + 3) & ~int64_t(3);
         const size_t lds = (static_cast<size_t>(hash_mask) + 1) * sizeof(uint32_t) + static_cast<size_t>(kReplayBlock + kpad) * sizeof(uint16_t);
         auto kernel = n <= 65535 ? k_replay_targets<true> : k_replay_targets<false>;
-        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+        static std::atomic<size_t> lds_set[2][16] = {};              // by kernel form and device (the attribute call costs ~3 us of the launcher's time per chunk)
+        std::atomic<size_t> &set = lds_set[n <= 65535 ? 1 : 0][ctx->device & 15];
+        if (set.load(std::memory_order_relaxed) < lds) {
+            SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds)));
+            set.store(lds, std::memory_order_relaxed);
+        }
         hipLaunchKernelGGL(kernel, dim3(cnt), dim3(64), lds, rs, static_cast<const uint16_t *>(d_tg), p->target_width, n, k,
                            d_mov, d_pos, xa, hash_mask);
     } else {
@@ -502,16 +525,24 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
         SAFE_HIP_CHECK(hipStreamWaitEvent(gs, p->replayed[par], 0));
     }
     const dim3 grid(ceil_div(std::max<int64_t>(stride, p->stride16), 256), cnt), block(256);
-    for (int64_t d = 1; d < cnt; d <<= 1) {
-        hipLaunchKernelGGL(k_scan_round, grid, block, 0, gs, xa, xb, cnt, stride, d);
-        std::swap(xa, xb);
+    // the base of this chunk's compositions = the last row of the previous chunk, read where it lies in the table (the identity
+    // for the first chunk: d_cur)
+    const int32_t *cur_base = q0 > 0 ? p->table + (q0 - 1) * stride : p->d_cur;
+    int32_t *t_rows = p->table + q0 * stride;
+    uint16_t *t16_rows = p->table16 ? p->table16 + q0 * p->stride16 : nullptr;
+    if (cnt == 1) {
+        hipLaunchKernelGGL(k_emit_rows, grid, block, 0, gs, xa, cur_base, cnt, n, t_rows, t16_rows, p->stride16);
+    } else {
+        for (int64_t d = 1; d < cnt; d <<= 1) {
+            if (2 * d >= cnt) {                                          // the last round carries the emit
+                hipLaunchKernelGGL(k_scan_emit, grid, block, 0, gs, xa, d, cur_base, cnt, n, t_rows, t16_rows, p->stride16);
+            } else {
+                hipLaunchKernelGGL(k_scan_round, grid, block, 0, gs, xa, xb, cnt, stride, d);
+                std::swap(xa, xb);
+            }
+        }
     }
-    hipLaunchKernelGGL(k_emit_rows, grid, block, 0, gs, xa, p->d_cur, cnt, n, p->table + q0 * stride,
-                       p->table16 ? p->table16 + q0 * p->stride16 : nullptr, p->stride16);
     SAFE_HIP_CHECK(hipGetLastError());
-    // the last row of the chunk is the base of the next one
-    SAFE_HIP_CHECK(hipMemcpyAsync(p->d_cur, p->table + (q1 - 1) * stride, stride * sizeof(int32_t),
-                                  hipMemcpyDeviceToDevice, gs));
     if (static_cast<int64_t>(p->chunk_done.size()) <= ci) p->chunk_done.resize(ci + 1, nullptr);
     if (!p->chunk_done[ci]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&p->chunk_done[ci], safe_event_flags(hipEventDisableTiming)));
     SAFE_HIP_CHECK(hipEventRecord(p->chunk_done[ci], gs));
