@@ -690,16 +690,21 @@ def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, d
             seconds = float(t.item())
         return seconds, per_step
 
-    for _ in range(n_warmup):
-        step()
-    timings.clear()
     # measurement hygiene: no cyclic-GC pass inside the timed region (a generation-2 collection over torch's and NumPy's
-    # objects is a multi-millisecond pause in a 3 ms step); what the OS did to each step is recorded beside its duration
+    # objects is a multi-millisecond pause in a 3 ms step); what the OS did to each step is recorded beside its duration.
+    # The collection runs BEFORE the last warm-up steps: the step right after it re-faults what the allocator gave back
+    # (seen as ~3800 minor faults and a 10 ms step at the start of the timed region).
     import gc
+    n_tail = min(n_warmup, 5)
+    for _ in range(n_warmup - n_tail):
+        step()
     gc.collect()
     gc.freeze()
     gc_was_enabled = gc.isenabled()
     gc.disable()
+    for _ in range(n_tail):
+        step()
+    timings.clear()
     probe = StepProbe()
     cpu0 = time.process_time()
     try:
