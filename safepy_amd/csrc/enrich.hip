@@ -1107,6 +1107,9 @@ __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ ref
     }
 }
 
+// (the clobber lists below name registers that are RESERVED in the stream kernels -- that is the point: see the next comment; the
+// check that the compiler keeps out of them is tests/test_abi.py's disassembly of the shipped code object)
+#pragma clang diagnostic ignored "-Winline-asm"
 // The stream form of blk_add8 (k_permtest_bits_blk's permutation loop).  The two id quads live in v[112:115] (Q = 0) and
 // v[116:119] (Q = 1), registers the compiler does not know about: the kernel is built with 112 registers (amdgpu_num_vgpr) and the
 // clobber lists below make the allocation 120 (not 128: at 4 x 120 registers a SIMD keeps room for a wave of the table kernels of
@@ -2973,11 +2976,6 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
     const int64_t tasks_per_tile = std::max<int64_t>(1, ceil_div(6 * slots, n_tiles));
     const int64_t target = std::max<int64_t>(256, blocks_per_perm * span / tasks_per_tile);
-    int64_t min_ppt = 16, target_min = 256;              // floors of a task's size: permutations, block-permutations
-    if (const char *e = getenv("SAFE_HIP_BITS_MINPPT")) min_ppt = std::max(1, atoi(e));
-    if (const char *e = getenv("SAFE_HIP_BITS_TARGETMIN")) target_min = std::max(1, atoi(e));
-    int64_t max_ppt = 0;                                 // SAFE_HIP_BITS_MAXPPT: cap on a task's permutations (A/B: long launches with short tasks)
-    if (const char *e = getenv("SAFE_HIP_BITS_MAXPPT")) max_ppt = std::max(0, atoi(e));
     struct TaskCost { int4 t; int64_t cost; };
     std::vector<TaskCost> tc;
     for (int64_t g = 0; g < n_sg; ++g) {
