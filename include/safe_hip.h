@@ -372,6 +372,11 @@ int safe_allgather_cols(safe_comm *comm, const void *local_dev, size_t bytes_per
 /* Number of i8 slices the last matrix-core permutation test ran with (2 / 4 / 6: the bits its columns need
  * on their fixed-point grid; 0 if that kernel has not run) -- for roofline reporting. */
 int safe_last_mfma_slices(safe_ctx *ctx, int *slices);
+/* The filtered form of that kernel (six-slice columns of 'sum' scores, np.dot of safepy/safe_extras.py:15 inside the
+ * loop of :56-66): *core_slices = slices the matrix cores multiplied (3 when the filter ran: only the high digits; the
+ * compares they cannot decide are settled exactly from the low digits), *undecided = how many compares that was
+ * (negative: their list overflowed and the call was repeated with all six slices).  Counts are identical either way. */
+int safe_last_mfma_filter(safe_ctx *ctx, int *core_slices, int64_t *undecided);
 /* Diagnostics (bench.py's per-step probe): the number of hipMalloc / hipHostMalloc calls the library has made in this process.
  * Buffers are cached per context and per handle shape, so a repeated call of the same shape is expected to add none
  * (the reference allocates every [N, M] temporary anew on each pass: safe_extras.py:50-66). */

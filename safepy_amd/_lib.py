@@ -127,6 +127,7 @@ PROTOTYPES = {
     'safe_last_kernel_stats': (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), _pi64]),
     'safe_last_kernel_busy_ms': (C.c_int, [_vp, C.POINTER(C.c_double)]),
     'safe_last_mfma_slices': (C.c_int, [_vp, C.POINTER(C.c_int)]),
+    'safe_last_mfma_filter': (C.c_int, [_vp, C.POINTER(C.c_int), _pi64]),
     'safe_alloc_count': (C.c_int, [C.POINTER(C.c_int64)]),
     'safe_perms_create_from_table': (C.c_int, [_vp, _i64, _i64, _vp, _pp]),
     'safe_perms_slice': (C.c_int, [_vp, _i64, _i64, _pp]),

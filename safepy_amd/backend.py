@@ -590,6 +590,14 @@ def last_mfma_slices(ctx):
     return v.value
 
 
+def last_mfma_filter(ctx):
+    """(slices the matrix cores multiplied, compares settled from the low digits) of the last matrix-core permutation test;
+    a negative second value: the undecided list overflowed and the call was repeated with all six slices."""
+    s, u = C.c_int(), C.c_int64()
+    check(lib.safe_last_mfma_filter(ctx.handle, C.byref(s), C.byref(u)))
+    return s.value, u.value
+
+
 def rng_permutations_host(seed, values, count):
     """Host-only: `count` successive np.random.permutation(values) draws after np.random.seed(seed)."""
     values = np.ascontiguousarray(values, dtype=np.int64)

@@ -81,6 +81,8 @@ struct safe_ctx {
     hipEvent_t k0 = nullptr, k1 = nullptr;      // dominant-kernel timing
     KernelStat last_kernel;
     int last_slices = 0;                        // i8 slices of the last matrix-core permutation test (2 / 4 / 6)
+    int last_core_slices = 0;                   // slices its matrix-core kernel multiplied (3 of 6 in the filtered form)
+    int64_t last_undecided = 0;                 // filtered form: compares decided by k_mfma_resolve (negative: list overflow, six-slice rerun)
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)
     struct safe_perms *perm_cache = nullptr;    // buffers of the last destroyed permutation handle, reused by the next
     struct PermRing *ring = nullptr;            // node-shared permutation stream (safe_ctx_share_stream), or NULL
@@ -193,6 +195,7 @@ struct safe_nbr {
     int64_t bs_src = 0;             // length of a source-row map: (ceil(n/32)+1)*32, the last block is padding
     int32_t *bs_order = nullptr;    // [bs_src] node at ordered position u (n = padding -> zero attribute row)
     int32_t *bs_rowmap = nullptr;   // [bs_groups*256] node at ordered row u, -1 = padding
+    int32_t *bs_rowcnt = nullptr;   // [bs_groups*256] members of that node's neighborhood (0 = padding)
     int32_t *bs_ptr = nullptr;      // [bs_groups+1] first block of a group
     int32_t *bs_kb = nullptr;       // [bs_blocks] ordered column block of a stored block
     uint32_t *bs_bits = nullptr;    // [bs_blocks][256] membership bits of the block's 256 rows
@@ -296,6 +299,7 @@ struct safe_perms {
     std::atomic<int64_t> drawn_chunks_pub{0};      // the same, readable without the mutex (the launcher spins on it)
     int64_t enqueued_chunks = 0;                   // chunks whose upload has been queued (staged[c % kStage] recorded)
     bool draw_stop = false;
+    bool draw_failed = false;        // the draw thread gave up (under draw_mu): waiters return an error instead of waiting for ever
     static constexpr int kStage = 3;
     void *h_stage[kStage] = {nullptr, nullptr, nullptr};   // pinned: accepted swap targets of a chunk, [chunk][target_width] u16 (k <= 65535) or u32
     hipEvent_t staged[kStage] = {nullptr, nullptr, nullptr};

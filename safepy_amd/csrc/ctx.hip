@@ -414,6 +414,13 @@ int safe_last_mfma_slices(safe_ctx *ctx, int *slices) {
     return SAFE_OK;
 }
 
+int safe_last_mfma_filter(safe_ctx *ctx, int *core_slices, int64_t *undecided) {
+    SAFE_REQUIRE(ctx && core_slices && undecided, "safe_last_mfma_filter: NULL argument");
+    *core_slices = ctx->last_core_slices;
+    *undecided = ctx->last_undecided;
+    return SAFE_OK;
+}
+
 int safe_last_kernel_stats(safe_ctx *ctx, char *name, size_t name_len, double *avg_ms, int64_t *launches) {
     SAFE_REQUIRE(ctx != nullptr, "safe_last_kernel_stats: ctx is NULL");
     if (name && name_len) snprintf(name, name_len, "%s", ctx->last_kernel.name.c_str());

@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
                                                     int64_t col0, int64_t mloc, int64_t n_ct, const int *__restrict__ shift,
                                                     const unsigned long long *__restrict__ maxbits, const int *__restrict__ need,
                                                     unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
-                                                    unsigned int *__restrict__ n_small_rounded) {
+                                                    unsigned int *__restrict__ n_small_rounded, int64_t split_off) {
     __shared__ double tile[32][33];
     __shared__ unsigned int s_small[32], s_rounded[32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -211,7 +211,10 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
     // "small": more than 2^20 below the column maximum -- held to fewer than 26 significant bits on a rounding grid
     const double small_below = j < mloc ? ldexp(__longlong_as_double(static_cast<long long>(maxbits[j])), -20) : 0.0;
     const int ns = mfma_slices_for(*need);
-    const int64_t row_bytes = ns * 32, tile_bytes = (n + 1) * row_bytes;         // tile-major: bs[column tile][row][slice][32]
+    // split form (split_off != 0 and six slices: the filtered permutation test): digits 0-2 and digits 3-5 are two matrices of
+    // three slices each, the high one split_off bytes behind the low one
+    const bool split = split_off != 0 && ns == MF_NS;
+    const int64_t row_bytes = (split ? MF_NS / 2 : ns) * 32, tile_bytes = (n + 1) * row_bytes;   // tile-major: bs[column tile][row][slice][32]
     const long long bias = ns == 2 ? 0x8080ll : ns == 4 ? 0x80808080ll : 0x808080808080ll;
     unsigned int k_small = 0, k_rounded = 0;
     for (int i = 0; i < 4; ++i) {
@@ -231,7 +234,9 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
         unsigned char *dst = bs + ct * tile_bytes + r * row_bytes + tx;
 #pragma unroll
         for (int t = 0; t < MF_NS; ++t)
-            if (t < ns) dst[t * 32] = static_cast<unsigned char>(((u >> (8 * t)) & 0xFFu) ^ 0x80u);
+            if (t < ns)
+                dst[(split && t >= MF_NS / 2 ? split_off + (t - MF_NS / 2) * 32 : t * 32)] =
+                    static_cast<unsigned char>(((u >> (8 * t)) & 0xFFu) ^ 0x80u);
     }
     if (k_small) atomicAdd(&s_small[tx], k_small);
     if (k_rounded) atomicAdd(&s_rounded[tx], k_rounded);
@@ -400,14 +405,38 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
 // EPI (counts form only): which epilogue this instantiation carries -- 0 = packed u16 counts for k_hyp_emit (the default split
 // form), 1 = plain counts, 2 = table lookup fused into the epilogue.  One kernel with all three kept the fused form's pipelined
 // table values (16 x double2 + nodes + slab offsets) in the register budget of the main loop: 60 VGPRs spilled.
-template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0, bool PREF = true>
+// FM (filtered permutation test of six-slice columns, the exact counts with half the matrix work):
+// every value is q = hi * 2^24 + lo with hi = digits 3-5 and lo = digits 0-2 (|lo| <= MF_LO_MAX), so a score is
+// v = 2^24 V_hi + V_lo with |V_lo| <= members * MF_LO_MAX.  The matrix cores only form V_hi; against the EXACT observed
+// score O (two observe passes, FM = 1: one over the low and one over the high digits) a permuted score is
+//   certainly smaller   when V_hi <  T0          T0 = floor((O - B) / 2^24),  B = members * MF_LO_MAX
+//   certainly greater   when V_hi >  T0 + W      W  = floor(2 B / 2^24) + 1
+// and otherwise (a window of ~members units of 2^24 against a spread of ~2^25 sqrt(members): ~1e-5 of the compares on
+// N(0,1) data) it is appended to a list and decided EXACTLY by k_mfma_resolve, which sums the low digits of the
+// neighborhood's members.  Counters therefore equal the six-slice kernel's bit for bit.
+//   FM = 0  classic (all slices on the matrix cores, exact compare in the kernel)
+//   FM = 1  observe: n_q = 1, the completed score is stored (shift 0) or added (<< shift) to obs64[column][row]
+//   FM = 2  filter: every q is a permutation; thresholds from obs64 at the start of the task
+constexpr long long MF_LO_MAX = 128ll * (1ll + 256ll + 65536ll);          // |digits 0-2 of a balanced base-256 number|
+struct MfmaFilt {
+    long long *obs64 = nullptr;               // [column][padded row] exact observed scores (fixed point)
+    const int32_t *rowcnt = nullptr;          // [padded row] members of the row's neighborhood (0: padding)
+    ulonglong2 *amb = nullptr;                // undecided compares: {row | column << 32, V_hi << 16 | permutation}
+    unsigned int *amb_count = nullptr;
+    unsigned int amb_cap = 0;
+    int obs_shift = 0;
+    int p_base = 0;                           // the launch's first permutation
+};
+
+template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0, bool PREF = true, int FM = 0>
 __global__ __launch_bounds__(512) void k_permtest_mfma(
     const unsigned char *__restrict__ bs, int64_t row_bytes, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint32_t *__restrict__ blk_bits,
     const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
-    const double *__restrict__ col_scale, double *__restrict__ ns_out, HypLookup hl) {
+    const double *__restrict__ col_scale, double *__restrict__ ns_out, HypLookup hl, MfmaFilt fa) {
     static_assert(!Z || (NS == MF_NS + 1 && !COUNTS), "z-scores: six value slices + the not-NaN slice");
+    static_assert(FM == 0 || (NS == MF_NS / 2 && !COUNTS && !Z), "filtered form: three slices of 'sum' scores");
     constexpr int KS = NS * MF_SS, BUF = 4 * KS;                            // LDS bytes per k-step / per super-step buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] + kb list
     __shared__ int slot_box;
@@ -472,6 +501,22 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             uint32_t cnt[16];
 #pragma unroll
             for (int r = 0; r < 16; ++r) cnt[r] = 0;
+            // filter: this lane's thresholds -- T0 in the LDS slot of the observed score, the window width in a register
+            // (0xFFFFFFFF: padding row / column or an empty neighborhood: nothing is counted, nothing recorded)
+            uint32_t win[FM == 2 ? 16 : 1];
+            if constexpr (FM == 2) {
+                const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int32_t members = fa.rowcnt[u];
+                    const bool live = colf < mloc && members > 0;
+                    const long long bound = static_cast<long long>(members) * MF_LO_MAX;
+                    const long long o = live ? fa.obs64[colf * n_padr + u] : 0ll;
+                    obs[r * 512] = live ? (o - bound) >> 24 : 0ll;
+                    win[r] = live ? static_cast<uint32_t>((2 * bound) >> 24) + 1u : 0xFFFFFFFFu;
+                }
+            }
 
             auto load_src = [&](int q, int t) -> int4 {
                 q = q < n_q ? q : n_q - 1;                           // (look-ahead past the task's end: a valid row of indices, never used)
@@ -603,6 +648,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 if constexpr (COUNTS) {
                     // (the counts are written once, after the loop)
                 } else if (t == S - 1 && !(hl.dbg & 8)) {            // a score is complete
+                    uint32_t undecided = 0;                                 // (filter) outputs the high digits leave open
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
                         constexpr int NV = Z ? MF_NS : NS;                  // value slices
@@ -626,14 +672,53 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                                 const double o = __longlong_as_double(obs[r * 512]);
                                 cnt[r] += (static_cast<uint32_t>(zs >= o) << 16) | static_cast<uint32_t>(zs <= o);
                             }
+                        } else if constexpr (FM == 1) {
+                            const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
+                            if (colf < mloc) {
+                                long long *dst = fa.obs64 + colf * n_padr + static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                *dst = fa.obs_shift ? *dst + (v << fa.obs_shift) : v;
+                            }
+                        } else if constexpr (FM == 2) {
+                            const long long x = v - obs[r * 512];
+                            const bool below = x < 0;
+                            const bool above = static_cast<unsigned long long>(x) > static_cast<unsigned long long>(win[FM == 2 ? r : 0]);
+                            cnt[r] += below ? (1u << 16) : (above ? 1u : 0u);         // certainly smaller / certainly greater
+                            undecided |= (!below && !above && win[FM == 2 ? r : 0] != 0xFFFFFFFFu) ? (1u << r) : 0u;
                         } else if (q == 0) {
                             obs[r * 512] = v;
                         } else {
                             const long long o = obs[r * 512];
                             cnt[r] += (static_cast<uint32_t>(v < o) << 16) | static_cast<uint32_t>(v > o);
                         }
+                        if constexpr (FM != 2) {
 #pragma unroll
-                        for (int s = 0; s < NS; ++s) acc[s][r] = 0;
+                            for (int s = 0; s < NS; ++s) acc[s][r] = 0;
+                        }
+                    }
+                    if constexpr (FM == 2) {
+                        // rare (~1e-5 of the compares): the low digits decide (k_mfma_resolve)
+                        if (__builtin_expect(undecided != 0u, 0)) {
+                            // a per-lane loop over the set bits with a DYNAMIC element index (a select chain over the sixteen
+                            // accumulator elements): unrolled over r the sixteen copies of this block cost the main loop 100
+                            // spilled registers although it almost never runs
+                            const unsigned long long colf = static_cast<unsigned long long>(static_cast<int64_t>(ct) * 32 + col_in_tile);
+                            const unsigned long long u0 = static_cast<unsigned long long>(static_cast<int64_t>(g) * MF_R + wave * 32 + 4 * h);
+                            for (uint32_t left = undecided; left;) {
+                                const int r = __builtin_ctz(left);
+                                left &= left - 1u;
+                                const unsigned int at = atomicAdd(fa.amb_count, 1u);
+                                if (at >= fa.amb_cap) continue;
+                                long long v = static_cast<long long>(acc[NS - 1][r]);
+                                for (int s = NS - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
+                                const unsigned long long u = u0 + static_cast<unsigned long long>((r & 3) + 8 * (r >> 2));
+                                fa.amb[at] = make_ulonglong2(u | (colf << 32), (static_cast<unsigned long long>(v) << 16) |
+                                                                                   static_cast<unsigned long long>(fa.p_base + q));
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[s][r] = 0;
                     }
                 }
 #pragma unroll
@@ -754,13 +839,13 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             }
             // ---- task epilogue: observed scores (first span only) and the counters
             const int64_t col = Z ? colz : static_cast<int64_t>(ct) * 32 + col_in_tile;
-            if (!COUNTS && col < mloc && !(Z && (col_in_tile & 16))) {
+            if (!COUNTS && FM != 1 && col < mloc && !(Z && (col_in_tile & 16))) {
                 const double sc = (ns_out && !Z) ? col_scale[col] : 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
                     const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (cnt[r]) atomicAdd(&gl_counts[col * n_padr + u], cnt[r]);
-                    if (ns_out) {
+                    if (FM == 0 && ns_out) {
                         const int32_t node = rowmap[u];
                         if (node >= 0)
                             ns_out[static_cast<int64_t>(node) * mloc + col] =
@@ -867,10 +952,11 @@ int build_blocks(safe_nbr *nbr) {
     for (int64_t u = 0; u < n; ++u) pos[order[u]] = static_cast<int32_t>(u);
 
     const int64_t n_groups = ceil_div(n, MF_R), n_kb = ceil_div(n, 32), n_src = (n_kb + 1) * 32;
-    std::vector<int32_t> h_order(n_src, static_cast<int32_t>(n)), h_rowmap(n_groups * MF_R, -1);
+    std::vector<int32_t> h_order(n_src, static_cast<int32_t>(n)), h_rowmap(n_groups * MF_R, -1), h_rowcnt(n_groups * MF_R, 0);
     for (int64_t u = 0; u < n; ++u) {
         h_order[u] = order[u];
         h_rowmap[u] = order[u];
+        h_rowcnt[u] = row_ptr[order[u] + 1] - row_ptr[order[u]];
     }
     // row groups are independent: built by a few host threads into per-group lists, then laid end to end
     std::vector<int32_t> ptr(n_groups + 1, 0), kbs;
@@ -1005,11 +1091,13 @@ int build_blocks(safe_nbr *nbr) {
     nbr->h_bs_rowmap = h_rowmap;
     SAFE_TRY(dev_alloc(&nbr->bs_order, n_src));
     SAFE_TRY(dev_alloc(&nbr->bs_rowmap, n_groups * MF_R));
+    SAFE_TRY(dev_alloc(&nbr->bs_rowcnt, n_groups * MF_R));
     SAFE_TRY(dev_alloc(&nbr->bs_ptr, n_groups + 1));
     SAFE_TRY(dev_alloc(&nbr->bs_kb, kbs.size()));
     SAFE_TRY(dev_alloc(&nbr->bs_bits, bits.size()));
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_order, h_order.data(), n_src * sizeof(int32_t), hipMemcpyHostToDevice));
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_rowmap, h_rowmap.data(), h_rowmap.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    SAFE_HIP_CHECK(hipMemcpy(nbr->bs_rowcnt, h_rowcnt.data(), h_rowcnt.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!kbs.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_kb, kbs.data(), kbs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!bits.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
@@ -1323,7 +1411,7 @@ void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const Hy
     hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN, false, true, EPI>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs,      \
                        cs.row_bytes, static_cast<int64_t>(MF_CN * 32), cs.d_src, cs.n_src, 1, nbr->bs_ptr, nbr->bs_kb, nbr->bs_bits,    \
                        cs.d_tasks, cs.d_qoff, cs.d_qctr, cs.mloc, static_cast<unsigned int *>(nullptr), nbr->bs_groups * MF_R,           \
-                       nbr->bs_rowmap, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), hl)
+                       nbr->bs_rowmap, static_cast<const double *>(nullptr), static_cast<double *>(nullptr), hl, MfmaFilt{})
     if (hl.cnt16) COUNTS_LAUNCH(0);                 // packed counts for k_hyp_emit
     else if (!hl.tab) COUNTS_LAUNCH(1);             // plain counts
     else COUNTS_LAUNCH(2);                          // table lookup in the epilogue
@@ -1462,9 +1550,71 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     return SAFE_OK;
 }
 
+namespace {
+// ---------------------------------------------------------------------------------------
+// filtered form: the compares the high digits could not decide, and the observed scores
+// ---------------------------------------------------------------------------------------
+// One wave per undecided compare {row u, column, permutation, V_hi}: V_lo = sum over the members of the row's neighborhood of
+// the low digits (0-2) of the permuted attribute row, then the EXACT sign of v - o = (V_hi << 24) + V_lo - O.
+// Undecided compares of one task share a column tile, so the slice rows they gather are the ones the task kept in its L2.
+__global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restrict__ amb, const unsigned int *__restrict__ amb_count,
+                                                      unsigned int amb_cap, const long long *__restrict__ obs64, int64_t n_padr,
+                                                      const int32_t *__restrict__ rowmap, const int32_t *__restrict__ row_ptr,
+                                                      const int32_t *__restrict__ col_idx, const int32_t *__restrict__ table, int64_t n,
+                                                      const unsigned char *__restrict__ bs_lo, int64_t tile_bytes,
+                                                      unsigned int *__restrict__ gl_counts) {
+    const unsigned int count = min(*amb_count, amb_cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    constexpr int64_t row_bytes = (MF_NS / 2) * 32;
+    for (unsigned int rec = wave0; rec < count; rec += n_waves) {
+        const ulonglong2 w = amb[rec];
+        const int64_t u = static_cast<int64_t>(w.x & 0xFFFFFFFFull), col = static_cast<int64_t>(w.x >> 32);
+        const int64_t perm = static_cast<int64_t>(w.y & 0xFFFFull);
+        const long long v_hi = static_cast<long long>(w.y) >> 16;
+        const int32_t node = rowmap[u];
+        const int32_t e0 = row_ptr[node], e1 = row_ptr[node + 1];
+        const unsigned char *base = bs_lo + (col >> 5) * tile_bytes + (col & 31);
+        const int32_t *cur = table + perm * (n + 1);
+        long long s = 0;
+        for (int32_t e = e0 + lane; e < e1; e += 64) {
+            const signed char *d = reinterpret_cast<const signed char *>(base + static_cast<int64_t>(cur[col_idx[e]]) * row_bytes);
+            s += static_cast<long long>(static_cast<int>(d[0]) + 256 * static_cast<int>(d[32]) + 65536 * static_cast<int>(d[64]));
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) {
+            const long long diff = (v_hi << 24) - obs64[col * n_padr + u] + s;          // v - o, exactly
+            const unsigned int add = diff < 0 ? (1u << 16) : diff > 0 ? 1u : 0u;
+            if (add) atomicAdd(&gl_counts[col * n_padr + u], add);
+        }
+    }
+}
+
+// ns[node][column] = observed score (safe.py:496-499): obs64 is [column][padded row]
+__global__ __launch_bounds__(256) void k_mfma_obs_ns(const long long *__restrict__ obs64, int64_t n_padr, const int32_t *__restrict__ rowmap,
+                                                     const double *__restrict__ col_scale, int64_t mloc, double *__restrict__ ns) {
+    __shared__ double tile[32][33];
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int64_t u0 = static_cast<int64_t>(blockIdx.x) * 32, c0 = static_cast<int64_t>(blockIdx.y) * 32;
+    for (int i = 0; i < 4; ++i) {
+        const int64_t c = c0 + ty + 8 * i;
+        tile[ty + 8 * i][tx] = c < mloc ? static_cast<double>(obs64[c * n_padr + u0 + tx]) * col_scale[c] : 0.0;
+    }
+    __syncthreads();
+    for (int i = 0; i < 4; ++i) {
+        const int32_t node = rowmap[u0 + ty + 8 * i];
+        const int64_t c = c0 + tx;
+        if (node >= 0 && c < mloc) ns[static_cast<int64_t>(node) * mloc + c] = tile[tx][ty + 8 * i];
+    }
+}
+}  // namespace
+
 void nbr_free_blocks(safe_nbr *nbr) {
     (void)hipFree(nbr->bs_order);
     (void)hipFree(nbr->bs_rowmap);
+    (void)hipFree(nbr->bs_rowcnt);
+    nbr->bs_rowcnt = nullptr;
     (void)hipFree(nbr->bs_ptr);
     (void)hipFree(nbr->bs_kb);
     (void)hipFree(nbr->bs_bits);
@@ -1490,9 +1640,10 @@ bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *
 // Runs the permutation test of columns [col0, col1) on the MFMA path.  *declined = true (and
 // SAFE_OK) when the attribute values cannot be represented on the fixed-point grid without a
 // rounding that could matter; the caller then uses the f64 kernels.
-int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1, bool z,
-                const PermOut &out_in, bool *declined) {
+static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1, bool z,
+                           const PermOut &out_in, bool *declined, bool allow_filter, bool *overflowed) {
     *declined = false;
+    *overflowed = false;
     SAFE_TRY(build_blocks(nbr));
     PermOut out = out_in;
     const int64_t n = nbr->n, mloc = col1 - col0, P = perms->count;
@@ -1501,6 +1652,11 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     int64_t row_bytes = n_ct * (z ? MF_NS + 1 : MF_NS) * 32;   // (the largest form; the call's slice count is known after the column statistics)
     const int64_t n_padr = nbr->bs_groups * MF_R;
     const bool f32 = attr->dtype == SAFE_DTYPE_F32;
+
+    // ---- the filtered form (six-slice 'sum' columns: three slices on the matrix cores, see k_permtest_mfma)
+    const char *filt_env = getenv("SAFE_HIP_MFMA_FILTER");                // =0: all six slices on the matrix cores
+    const bool want_filter = allow_filter && !z && nbr->max_count < (1 << 20) && !(filt_env && !strcmp(filt_env, "0"));
+    const int64_t split_off = want_filter ? n_ct * (n + 1) * (MF_NS / 2) * 32 : 0;   // high digits behind the low digits
 
     // ---- column scales and slices
     int n_slices = MF_NS;                        // i8 slices of this call: 2 / 4 / 6 by the bits its columns need (k_mfma_colfinish)
@@ -1541,10 +1697,10 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
                                    attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero);
         } else if (f32)
             hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded);
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off);
         else
             hipLaunchKernelGGL(k_mfma_slice<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded);
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off);
         hipLaunchKernelGGL(k_mfma_colcheck, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_cnt, d_small, d_rounded,
                            z ? d_zero : static_cast<unsigned int *>(nullptr), d_inexact, mloc, d_bad);
         SAFE_HIP_CHECK(hipGetLastError());
@@ -1559,6 +1715,10 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         n_slices = z ? MF_NS + 1 : mfma_slices_for(verdict[1]);
         row_bytes = static_cast<int64_t>(n_slices) * 32;          // tile-major: a row of a tile is n_slices x 32 bytes, tiles (n + 1) rows apart
     }
+    const bool filt = want_filter && n_slices == MF_NS;
+    const int core_slices = filt ? MF_NS / 2 : n_slices;         // slices the matrix cores multiply
+    if (filt) row_bytes = static_cast<int64_t>(core_slices) * 32;
+    const unsigned char *d_bs_lo = d_bs, *d_bs_hi = d_bs + split_off;
 
     // ---- tasks: (row group, column tile), one queue per XCD keyed by column tile so the slice
     //      rows of a tile are pulled into one L2; inside a queue tile-major, heavy groups first
@@ -1578,7 +1738,7 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     const std::vector<int64_t> starts = perm_launch_starts(perms, &span);
     const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
     void *ws = nullptr;
-    SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + (8 * n_launch + 8) * sizeof(unsigned int), &ws));
+    SAFE_TRY(ctx_scratch(ctx, 3, tasks.size() * sizeof(int2) + 16 * sizeof(int32_t) + (8 * n_launch + 8 + 16) * sizeof(unsigned int), &ws));
     int2 *d_tasks = static_cast<int2 *>(ws);
     int32_t *d_qoff = reinterpret_cast<int32_t *>(d_tasks + tasks.size());
     unsigned int *d_qctr = reinterpret_cast<unsigned int *>(d_qoff + 16);
@@ -1589,19 +1749,43 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         SAFE_TRY(ctx_scratch(ctx, 4 + b, static_cast<size_t>(span + 1) * n_src * sizeof(int32_t), reinterpret_cast<void **>(&d_src[b])));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_tasks, tasks.data(), tasks.size() * sizeof(int2), hipMemcpyHostToDevice, ctx->stream));
     SAFE_HIP_CHECK(hipMemcpyAsync(d_qoff, q_off, sizeof(q_off), hipMemcpyHostToDevice, ctx->stream));
-    SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, (8 * n_launch + 8) * sizeof(unsigned int), ctx->stream));
+    SAFE_HIP_CHECK(hipMemsetAsync(d_qctr, 0, (8 * n_launch + 8 + 16) * sizeof(unsigned int), ctx->stream));
     SAFE_HIP_CHECK(hipMemsetAsync(d_counts, 0, static_cast<size_t>(n_padr) * mloc * sizeof(unsigned int), ctx->stream));
+    // filtered form: exact observed scores, the undecided compares of a launch (one list per stream parity), their counters
+    long long *d_obs64 = nullptr;
+    ulonglong2 *d_amb[2] = {nullptr, nullptr};
+    int32_t *d_src_id = nullptr;
+    unsigned int *d_amb_cnt = nullptr;
+    unsigned int amb_cap = 0;
+    if (filt) {
+        SAFE_TRY(ctx_scratch(ctx, 12, static_cast<size_t>(n_padr) * mloc * sizeof(long long), reinterpret_cast<void **>(&d_obs64)));
+        const double per_launch = static_cast<double>(n) * static_cast<double>(mloc) * static_cast<double>(span);
+        amb_cap = static_cast<unsigned int>(std::min(67108864.0, std::max(1048576.0, per_launch / 512.0)));
+        if (const char *e = getenv("SAFE_HIP_MFMA_FILTER_CAP")) amb_cap = static_cast<unsigned int>(std::max(1, atoi(e)));   // (tests: force the fall-back)
+        for (int b = 0; b < 2; ++b)
+            SAFE_TRY(ctx_scratch(ctx, 13 + b, static_cast<size_t>(amb_cap) * sizeof(ulonglong2), reinterpret_cast<void **>(&d_amb[b])));
+        void *small = nullptr;
+        SAFE_TRY(ctx_scratch(ctx, 15, static_cast<size_t>(n_src) * sizeof(int32_t) + static_cast<size_t>(n_launch) * sizeof(unsigned int), &small));
+        d_src_id = static_cast<int32_t *>(small);
+        d_amb_cnt = reinterpret_cast<unsigned int *>(d_src_id + n_src);
+        SAFE_HIP_CHECK(hipMemsetAsync(d_amb_cnt, 0, static_cast<size_t>(n_launch) * sizeof(unsigned int), ctx->stream));
+    }
 
-    const size_t lds_bytes = 2 * static_cast<size_t>(4 * n_slices * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    const size_t lds_bytes = 2 * static_cast<size_t>(4 * core_slices * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
     const char *pref_env = getenv("SAFE_HIP_MFMA_PREF");
     const bool pref = !(pref_env && !strcmp(pref_env, "0"));
+    const void *kfn_obs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 1>);
     const void *kfn = z               ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>)
+                      : filt          ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 2>)
                       : !pref && n_slices == 6 ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS, false, true, 0, false>)
                       : n_slices == 2 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
                       : n_slices == 4 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 4>)
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    if (filt) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_obs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     ctx->last_slices = n_slices;
+    ctx->last_core_slices = core_slices;
+    ctx->last_undecided = 0;
     // The kernel is persistent and takes a CU whole (256 VGPRs x 2 waves per SIMD): table kernels of the next span that are
     // queued while it runs (aux stream: scan rounds, row emission) get a CU only as its workgroups retire and trickle through
     // the whole tail of the launch -- harmless for the result, but they then show launch-long durations in a kernel trace
@@ -1621,6 +1805,32 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
     SAFE_TRY(ctx_events(ctx, false, 2, &plain));
     hipEvent_t ready = plain[0], side_done = plain[1];
+    static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
+    if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
+    if (filt) {
+        // the exact observed scores: low digits stored, high digits added << 24 (two short launches over the identity map)
+        hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
+                           static_cast<const int32_t *>(nullptr), 0, d_src_id, 0);
+        for (int pass = 0; pass < 2; ++pass) {
+            const unsigned char *bs_p = pass ? d_bs_hi : d_bs_lo;
+            const int32_t *src_c = d_src_id;
+            int n_q = 1;
+            unsigned int *qctr_c = d_qctr + 8 * n_launch + 8 + 8 * pass;
+            double *ns_c = nullptr;
+            HypLookup no_lookup{};
+            MfmaFilt fa;
+            fa.obs64 = d_obs64;
+            fa.obs_shift = pass ? 24 : 0;
+            void *args[] = {(void *)&bs_p, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+                            (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
+                            (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup, (void *)&fa};
+            SAFE_HIP_CHECK(hipLaunchKernel(kfn_obs, dim3(blocks), dim3(512), args, lds_bytes, ctx->stream));
+        }
+        if (out.ns)
+            hipLaunchKernelGGL(k_mfma_obs_ns, dim3(n_padr / 32, ceil_div(mloc, 32)), dim3(256), 0, ctx->stream, d_obs64, n_padr, nbr->bs_rowmap,
+                               d_scale, mloc, out.ns);
+        SAFE_HIP_CHECK(hipGetLastError());
+    }
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
@@ -1634,27 +1844,44 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
                            p_base, d_src[c & 1], dbg_window);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
         {
-            const int32_t *src_c = d_src[c & 1];
-            int n_q = static_cast<int>(cnt + 1);
+            // classic: row 0 of the source maps is the identity (the observed score is formed once per task); filtered form:
+            // the observed scores are in d_obs64 and every q is a permutation
+            const int32_t *src_c = filt ? d_src[c & 1] + n_src : d_src[c & 1];
+            int n_q = static_cast<int>(filt ? cnt : cnt + 1);
             unsigned int *qctr_c = d_qctr + 8 * c;
-            double *ns_c = c == 0 ? out.ns : static_cast<double *>(nullptr);
+            double *ns_c = (c == 0 && !filt) ? out.ns : static_cast<double *>(nullptr);
             HypLookup no_lookup{};
-            static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
-            if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
             no_lookup.dbg = mfma_dbg;        // 1: no transposes / LDS stores of the gathered rows, 4: no barrier per super-step, 8: no score completion
-            void *args[] = {(void *)&d_bs, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+            MfmaFilt fa;
+            if (filt) {
+                fa.obs64 = d_obs64;
+                fa.rowcnt = nbr->bs_rowcnt;
+                fa.amb = d_amb[c & 1];
+                fa.amb_count = d_amb_cnt + c;
+                fa.amb_cap = amb_cap;
+                fa.p_base = static_cast<int>(p_base);
+            }
+            const unsigned char *bs_main = filt ? d_bs_hi : d_bs;
+            void *args[] = {(void *)&bs_main, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
-                            (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup};
+                            (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup, (void *)&fa};
             SAFE_HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(512), args, lds_bytes, ks));
         }
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
+        if (filt) {
+            hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
+                               nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, d_counts);
+            SAFE_HIP_CHECK(hipGetLastError());
+        }
         if (c >= 1) {
             // the source-map buffer of span c-1 is reused by span c+1: same stream, ordered
         }
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
+    std::vector<unsigned int> amb_seen(filt ? n_launch : 0, 0u);
+    if (filt) SAFE_HIP_CHECK(hipMemcpyAsync(amb_seen.data(), d_amb_cnt, amb_seen.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_padr, nbr->bs_rowmap, mloc, P, out, z ? out.ns : nullptr));
     if (!z) {                                                 // (z-score counters depend on NaN observed scores: not exported)
         ctx->packed_counts = d_counts;
@@ -1667,5 +1894,24 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
+    for (unsigned int seen : amb_seen) {
+        ctx->last_undecided += seen;
+        if (seen > amb_cap) *overflowed = true;          // a launch left more undecided compares than its list holds
+    }
+    return SAFE_OK;
+}
+
+int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1, bool z,
+                const PermOut &out_in, bool *declined) {
+    bool overflowed = false;
+    SAFE_TRY(launch_mfma_run(ctx, nbr, attr, perms, col0, col1, z, out_in, declined, true, &overflowed));
+    if (overflowed) {
+        // data with many (near-)equal scores: the filter decides too little -- the whole call again with all slices on the
+        // matrix cores (counters, scores and outputs are rewritten from scratch)
+        safe_trace("matrix-core filter: too many undecided compares, running the six-slice form");
+        const int64_t undecided = ctx->last_undecided;
+        SAFE_TRY(launch_mfma_run(ctx, nbr, attr, perms, col0, col1, z, out_in, declined, false, &overflowed));
+        ctx->last_undecided = -undecided;                // (negative: the filtered pass was abandoned)
+    }
     return SAFE_OK;
 }

@@ -289,7 +289,15 @@ std::vector<int64_t> perms_stage_plan(int64_t count) {
     if (tail_rule == 1 && count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
     if (tail_rule == 2 && b.size() >= 3 && count - last < 64) b.pop_back();                   // a short tail joins its predecessor
     b.push_back(count);
-    return b;
+    // every per-stage buffer (pinned staging, ring slot, row maps, targets) holds kChunk permutations: whatever SAFE_HIP_CHUNK,
+    // SAFE_HIP_STAGES and the tail rules asked for, no stage may be longer
+    std::vector<int64_t> cut;
+    cut.push_back(0);
+    for (size_t i = 1; i < b.size(); ++i) {
+        while (b[i] - cut.back() > kChunk) cut.push_back(cut.back() + kChunk);
+        cut.push_back(b[i]);
+    }
+    return cut;
 }
 static int64_t stage_begin(const safe_perms *p, int64_t ci) { return p->stages[std::min<size_t>(ci, p->stages.size() - 1)]; }
 static int64_t stage_count(const safe_perms *p) { return static_cast<int64_t>(p->stages.size()) - 1; }
@@ -471,6 +479,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     const int64_t q0 = stage_begin(p, ci), q1 = chunk_end(p, ci), cnt = q1 - q0;
     const int b = static_cast<int>(ci % safe_perms::kStage);
     const size_t bytes = chunk_target_bytes(p, cnt);
+    SAFE_REQUIRE(cnt <= kChunk, "pipeline stage of %lld permutations exceeds the stage buffers (%lld)", (long long)cnt, (long long)kChunk);
     if (p->ring_consumer) {
         // the node's producer drew this chunk: block until it is published, copy it into this rank's pinned staging buffer
         // (free once the upload of kStage chunks ago has completed)
@@ -567,9 +576,17 @@ static void drawer_main(safe_perms *p) {
             if (p->draw_stop) return;
         }
         // the staging buffer's previous chunk (c - kStage) must have left for the device (its upload was queued: see the wait above)
-        if (c >= safe_perms::kStage && hipEventSynchronize(p->staged[b]) != hipSuccess) return;
-        safe_trace("    drawer: buffer free, drawing");
         const int64_t q0 = stage_begin(p, c), cnt = chunk_end(p, c) - q0;
+        if ((c >= safe_perms::kStage && hipEventSynchronize(p->staged[b]) != hipSuccess) || cnt > kChunk) {
+            // the launcher waits on draw_cv for this chunk: tell it, or it waits for ever
+            {
+                std::lock_guard<std::mutex> lk(p->draw_mu);
+                p->draw_failed = true;
+            }
+            p->draw_cv.notify_all();
+            return;
+        }
+        safe_trace("    drawer: buffer free, drawing");
         const double t_draw = wall_s();
         char *dst = static_cast<char *>(p->h_stage[b]);
         static const bool prof = getenv("SAFE_HIP_DRAW_PROFILE") != nullptr;
@@ -602,6 +619,7 @@ static void drawer_start(safe_perms *p) {
     p->drawn_chunks = p->enqueued_chunks = 0;
     p->drawn_chunks_pub.store(0, std::memory_order_release);
     p->draw_stop = false;
+    p->draw_failed = false;
     if (p->count > 0 && !p->ring_consumer) p->drawer = std::thread(drawer_main, p);
 }
 
@@ -632,7 +650,12 @@ int perms_generate_until(safe_perms *p, int64_t upto) {
                 while (p->drawn_chunks_pub.load(std::memory_order_acquire) <= ci && wall_s() - t_spin < 2e-3) cpu_relax();
             }
             std::unique_lock<std::mutex> lk(p->draw_mu);
-            p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci; });
+            p->draw_cv.wait(lk, [&] { return p->drawn_chunks > ci || p->draw_failed; });
+            if (p->drawn_chunks <= ci) {
+                lk.unlock();
+                safe_set_error("the draw thread of the seeded stream stopped (staging buffer wait failed)");
+                return SAFE_E_HIP;
+            }
             p->generated = chunk_end(p, p->drawn_chunks - 1);
             lk.unlock();
             safe_trace("  gen: chunk drawn");

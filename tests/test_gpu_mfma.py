@@ -412,3 +412,90 @@ def test_zscore_sparse_inexact_column_is_left_to_the_f64_kernels(amd, ctx):
     np.testing.assert_array_equal(cn, cn_w)
     np.testing.assert_array_equal(cp, cp_w)
     nbr.close()
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the filtered form: three of the six slices on the matrix cores, undecided compares settled from the low digits
+# ---------------------------------------------------------------------------------------------------------------------
+def _filter_case(seed, n=700, m=45):
+    rng = np.random.default_rng(seed)
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    b = _quant(rng, n, m, np.float64, 'C', nan_rows=n // 25, nan_frac=0.01)
+    return xy, a, b
+
+
+def test_filtered_form_runs_three_slices_and_equals_the_six_slice_form_and_the_oracle(amd, ctx, monkeypatch):
+    from safepy_amd import backend as be
+    xy, a, b = _filter_case(101)
+    nperm, seed = 120, 4
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    ns_w = orc.compute_neighborhood_score(a, b, 'sum')
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma' and be.last_mfma_slices(ctx) == 6
+    core, undecided = be.last_mfma_filter(ctx)
+    assert core == 3 and undecided >= 0
+    np.testing.assert_allclose(ns, ns_w, rtol=1e-9, atol=1e-12)
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    monkeypatch.setenv('SAFE_HIP_MFMA_FILTER', '0')
+    ns6, cn6, cp6, _ = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert be.last_mfma_filter(ctx)[0] == 6
+    np.testing.assert_array_equal(ns, ns6)                            # the same exact integer sums, the same scale
+    np.testing.assert_array_equal(cn, cn6)
+    np.testing.assert_array_equal(cp, cp6)
+    nbr.close()
+
+
+def test_filtered_form_when_the_high_digits_decide_nothing(amd, ctx):
+    """Columns whose values differ only in their LOW digits (a large common offset plus small noise; one column is the
+    same value everywhere: every compare a tie): the high digits of every permuted sum equal the observed ones, so every
+    compare goes through the exact resolve kernel -- counts still equal the oracle's."""
+    from safepy_amd import backend as be
+    rng = np.random.default_rng(7)
+    n, m, nperm, seed = 320, 32, 40, 3
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.12)
+    # 2^40 + integers below 2^22: exactly representable (41 bits: six slices), high digits (bits 24+) all equal
+    b = (2.0 ** 40 + rng.integers(0, 1 << 22, size=(n, m))).astype(np.float64)
+    b[:, 5] = 2.0 ** 40 + 12345.0
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.12))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    assert name == 'k_permtest_mfma' and be.last_mfma_slices(ctx) == 6
+    core, undecided = be.last_mfma_filter(ctx)
+    assert core == 3 and undecided > 0.5 * n * m * nperm                # (every row is present: all sums of a neighborhood share their high digits)
+    np.testing.assert_array_equal(ns, orc.compute_neighborhood_score(a, b, 'sum'))
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_filtered_form_falls_back_to_six_slices_when_its_list_overflows(amd, ctx, monkeypatch):
+    from safepy_amd import backend as be
+    xy, a, b = _filter_case(33, n=400, m=33)
+    b[:, 3] = np.round(b[:, 3] * 4) / 4 + 2.0 ** 30                    # a column with many exactly equal sums (ties are undecided)
+    nperm, seed = 30, 8
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    monkeypatch.setenv('SAFE_HIP_MFMA_FILTER_CAP', '4')
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed)
+    core, undecided = be.last_mfma_filter(ctx)
+    assert core == 6 and undecided < 0                                  # the filtered pass was abandoned
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
+
+
+def test_filtered_form_column_shards_and_launch_spans(amd, ctx):
+    """A column shard that starts inside a tile, more permutations than one launch holds."""
+    xy, a, b = _filter_case(9, n=520, m=70)
+    nperm, seed = 300, 21
+    cn_w, cp_w = orc.run_permutations(a, b, 'sum', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.1))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, col0=13, col1=61)
+    assert name == 'k_permtest_mfma'
+    np.testing.assert_array_equal(cn, cn_w[:, 13:61])
+    np.testing.assert_array_equal(cp, cp_w[:, 13:61])
+    nbr.close()
