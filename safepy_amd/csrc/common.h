@@ -195,7 +195,10 @@ struct safe_nbr {
     int64_t bs_src = 0;             // length of a source-row map: (ceil(n/32)+1)*32, the last block is padding
     int32_t *bs_order = nullptr;    // [bs_src] node at ordered position u (n = padding -> zero attribute row)
     int32_t *bs_rowmap = nullptr;   // [bs_groups*256] node at ordered row u, -1 = padding
-    int32_t *bs_rowcnt = nullptr;   // [bs_groups*256] members of that node's neighborhood (0 = padding)
+    int32_t *bs_rowcnt = nullptr;   // [bs_groups*256] members of that node's neighborhood (-1 = padding row)
+    int32_t *bs_grpmax = nullptr;   // [bs_groups] largest neighborhood of the group's rows
+    uint4 *bs_bits4 = nullptr;      // the membership bits again, [super-step of 4 blocks][256 rows][4]: one 16-byte load per row and super-step
+    int64_t bs_max_group_blocks = 0;   // blocks of the longest group
     int32_t *bs_ptr = nullptr;      // [bs_groups+1] first block of a group
     int32_t *bs_kb = nullptr;       // [bs_blocks] ordered column block of a stored block
     uint32_t *bs_bits = nullptr;    // [bs_blocks][256] membership bits of the block's 256 rows

@@ -867,6 +867,262 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 }
 
 // ---------------------------------------------------------------------------------------
+// the filtered form's own kernel (FM = 2 above is the same arithmetic in the general kernel's shape)
+// ---------------------------------------------------------------------------------------
+// What the general kernel's shape costs once only three slices are multiplied: every wave reads the whole operand tile from
+// LDS for its 32 rows (1 KB per MFMA), 320 of its 512 threads repeat gather loads they do not need, the membership words of a
+// k-step arrive as four scalar-width loads, and all eight waves meet at one barrier per 128 gathered rows.  Here
+//   * a workgroup is FOUR waves of 64 rows (two 32 x 32 pieces per wave: every LDS operand read feeds two MFMAs, 96
+//     accumulator registers), and TWO workgroups share a CU -- the other workgroup's matrix work covers this one's barrier,
+//     gather and score completion;
+//   * the membership words of a super-step are one 16-byte load per piece (blk_bits4: [super-step][row][4 k-steps]);
+//   * threads without a gather role load the zero row (one cache line per instruction) instead of repeating a neighbour's rows;
+//   * the thresholds are 32-bit: y = floor(V_hi / 16) against Y0 = floor((O - B') / 2^28), B' = B + 15 * 2^24, with one window
+//     width per task (from the group's largest neighborhood: neighborhoods below 2048 members); what the test leaves open is
+//     appended for k_mfma_resolve, which forms that score from all six digits (the record carries no partial sum);
+//   * <= / >= counters are 8-bit fields (two outputs per register), flushed to memory every 255 permutations.
+constexpr int MF_F_MAXBLK = 2048;         // column blocks per row group this kernel can index from LDS (else the general kernel)
+__global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
+    const unsigned char *__restrict__ bs, int64_t tile_bytes, int64_t zrow, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
+    const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint4 *__restrict__ blk_bits4,
+    const int32_t *__restrict__ grp_maxcnt, const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off,
+    unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa, int dbg) {
+    constexpr int NS = MF_NS / 2, KS = NS * MF_SS, BUF = 4 * KS;
+    constexpr int64_t row_bytes = NS * 32;
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] | kb list | Y0 [32][256]
+    __shared__ int slot_box;
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lam = lane & 31, h = lane >> 5;
+    int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * BUF);
+    int32_t *y0s = reinterpret_cast<int32_t *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t)) + tid;
+    constexpr int CH = 2 * NS, GT = 4 * 8 * CH;                               // 192 gather threads = waves 0-2
+    const bool gth = tid < GT;
+    const int gt = gth ? tid : 0;
+    const int chunk = gt % CH, rq = (gt / CH) % 8, ks_g = gt / (8 * CH);
+    const int s_g = chunk >> 1, half_g = chunk & 1;
+    const uint32_t w_base = static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
+    const uint32_t r_base = static_cast<uint32_t>(h * 512 + lam * 16);
+    const int col_in_tile = 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
+    const int32_t row_keep = gth ? -1 : 0, row_else = gth ? 0 : static_cast<int32_t>(zrow);   // non-gather threads: the zero row
+
+    const int home = blockIdx.x & 7;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int qx = (home + attempt) & 7;
+        const int q_begin = q_off[qx], q_len = q_off[qx + 1] - q_begin;
+        for (;;) {
+            if (tid == 0) slot_box = static_cast<int>(atomicAdd(&q_ctr[qx], 1u));
+            __syncthreads();
+            const int slot = slot_box;
+            __syncthreads();
+            if (slot >= q_len) break;
+            const int2 task = tasks[q_begin + slot];
+            const int g = task.x, ct = task.y;
+            const int b0 = blk_ptr[g], nb = blk_ptr[g + 1] - b0, S = nb >> 2;
+            if (S == 0) continue;
+            for (int i = tid; i < nb; i += 256) kb_list[i] = blk_kb[b0 + i];
+
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + (gth ? chunk * 16 : 0);
+            const uint4 *bits_w = blk_bits4 + static_cast<int64_t>(b0 >> 2) * MF_R + wave * 64 + lam;
+            const int total = n_q * S;
+            const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
+            const int64_t u_lane = static_cast<int64_t>(g) * MF_R + wave * 64 + 4 * h;     // + 32 p + (r & 3) + 8 (r >> 2)
+
+            // thresholds of this lane's 32 outputs (32-bit, in LDS); the window width is one number per task
+            const long long b_max = static_cast<long long>(grp_maxcnt[g]) * MF_LO_MAX;
+            const uint32_t wc = static_cast<uint32_t>((2 * b_max + (15ll << 24)) >> 28) + 2u;
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                long long o64[16];
+                int32_t members[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t u = u_lane + 32 * p + (r & 3) + 8 * (r >> 2);
+                    members[r] = fa.rowcnt[u];
+                    o64[r] = colf < mloc ? fa.obs64[colf * n_padr + u] : 0ll;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long bp = static_cast<long long>(members[r]) * MF_LO_MAX + (15ll << 24);
+                    // padding rows (-1 members) and padding columns only ever form y = 0: Y0 = 1 counts them "smaller" without any
+                    // further test (their counters are never read); an EMPTY neighborhood of a real row takes the general rule
+                    // (every compare a tie: undecided, settled as "equal" by the resolve kernel)
+                    y0s[(16 * p + r) * 256] = (colf < mloc && members[r] >= 0) ? static_cast<int32_t>((o64[r] - bp) >> 28) : 1;
+                }
+            }
+            __syncthreads();                                         // kb_list
+
+            v16i acc[2][NS];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
+            uint32_t cnt[16];                                        // outputs r (piece 0) and 16 + r (piece 1): 8-bit fields #< | #>
+#pragma unroll
+            for (int r = 0; r < 16; ++r) cnt[r] = 0;
+            int since_flush = 0;
+
+            auto flush = [&]() __attribute__((always_inline)) {
+                if (colf < mloc) {
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+#pragma unroll
+                        for (int p = 0; p < 2; ++p) {
+                            const uint32_t f = cnt[r] >> (16 * p);
+                            const uint32_t add = ((f & 0xFF00u) << 8) | (f & 0xFFu);
+                            if (add) atomicAdd(&gl_counts[colf * n_padr + u_lane + 32 * p + (r & 3) + 8 * (r >> 2)], add);
+                        }
+                        cnt[r] = 0;
+                    }
+                }
+            };
+            auto load_src = [&](int q, int t) -> int4 {
+                q = q < n_q ? q : n_q - 1;
+                const int kb = kb_list[4 * t + ks_g];
+                return *reinterpret_cast<const int4 *>(srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + 4 * rq);
+            };
+            auto load_rows = [&](const int4 &src, uint4 (&L)[4]) {
+                L[0] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.x & row_keep) | row_else) * row_bytes);
+                L[1] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.y & row_keep) | row_else) * row_bytes);
+                L[2] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.z & row_keep) | row_else) * row_bytes);
+                L[3] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.w & row_keep) | row_else) * row_bytes);
+            };
+            auto store_quarter = [&](const uint4 (&L)[4], int cw, int buf) {
+                unsigned char *dst = lds + buf * BUF + w_base;
+                const uint32_t w[4] = {cw == 0 ? L[0].x : cw == 1 ? L[0].y : cw == 2 ? L[0].z : L[0].w,
+                                       cw == 0 ? L[1].x : cw == 1 ? L[1].y : cw == 2 ? L[1].z : L[1].w,
+                                       cw == 0 ? L[2].x : cw == 1 ? L[2].y : cw == 2 ? L[2].z : L[2].w,
+                                       cw == 0 ? L[3].x : cw == 1 ? L[3].y : cw == 2 ? L[3].z : L[3].w};
+                uint32_t o[4];
+                transpose4(w, o);
+#pragma unroll
+                for (int b = 0; b < 4; ++b) *reinterpret_cast<uint32_t *>(dst + (b + 8 * cw) * 16) = o[b];
+            };
+            auto advance = [&](int &qq, int &tt) {
+                if (++tt == S) {
+                    tt = 0;
+                    ++qq;
+                }
+            };
+
+            // the pipeline of k_permtest_mfma: rows of super-step it + 2 requested at the top of iteration it, transposed into
+            // the other buffer during it + 1; their source indices one iteration earlier still
+            uint4 L_a[4], L_b[4];
+            int4 src_a = make_int4(0, 0, 0, 0), src_b = make_int4(0, 0, 0, 0);
+            int q1 = 0, t1 = 0, q2, t2, q3, t3;
+            advance(q1, t1);
+            q2 = q1, t2 = t1;
+            advance(q2, t2);
+            {
+                const int4 s0 = load_src(0, 0);
+                load_rows(s0, L_b);
+                const int4 s1 = load_src(q1, t1);
+                load_rows(s1, L_a);
+                src_a = load_src(q2, t2);
+                if (gth) {
+#pragma unroll
+                    for (int cw = 0; cw < 4; ++cw) store_quarter(L_b, cw, 0);
+                }
+            }
+            uint4 aw[2];
+#pragma unroll
+            for (int p = 0; p < 2; ++p) aw[p] = bits_w[32 * p];
+            __syncthreads();
+
+            int q = 0, t = 0;
+            auto body = [&](int it, uint4 (&L_store)[4], uint4 (&L_load)[4], const int4 &src_use, int4 &src_load)
+                            __attribute__((always_inline)) {
+                const int buf = it & 1;
+                q3 = q2, t3 = t2;
+                advance(q3, t3);
+                const bool more1 = it + 1 < total;
+                uint4 aw_next[2];
+#pragma unroll
+                for (int p = 0; p < 2; ++p) aw_next[p] = bits_w[static_cast<int64_t>(t1) * MF_R + 32 * p];
+                src_load = load_src(q3, t3);
+                load_rows(src_use, L_load);
+
+                const unsigned char *bbuf = lds + buf * BUF + r_base;
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    // (one operand set, read right before its MFMAs: the SIMD's other wave -- of the CU's other workgroup -- covers
+                    // the LDS latency; a second set, read one k-step ahead, costs 12 registers this kernel does not have)
+                    v4i b_cur[NS];
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t word = k == 0 ? aw[p].x : k == 1 ? aw[p].y : k == 2 ? aw[p].z : aw[p].w;
+                        if (__builtin_amdgcn_ballot_w64(word != 0u) != 0ull && !(dbg & 2)) {   // (a piece without members is skipped)
+                            v4i a;
+                            a[0] = static_cast<int>(expand4(word, 16 * h));
+                            a[1] = static_cast<int>(expand4(word, 16 * h + 4));
+                            a[2] = static_cast<int>(expand4(word, 16 * h + 8));
+                            a[3] = static_cast<int>(expand4(word, 16 * h + 12));
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) acc[p][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[p][s], 0, 0, 0);
+                        }
+                    }
+                    if (gth && more1 && !(dbg & 1)) store_quarter(L_store, k, buf ^ 1);
+                }
+
+                if (t == S - 1 && !(dbg & 8)) {                      // the scores of permutation q are complete
+                    uint32_t open = 0;                                // outputs the coarse test leaves undecided
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) {
+                            const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);   // floor(V_hi / 16)
+                            const int32_t d = y - y0s[(16 * p + r) * 256];
+                            const bool below = d < 0, above = static_cast<uint32_t>(d) >= wc;
+                            cnt[r] += (below ? 256u : (above ? 1u : 0u)) << (16 * p);
+                            open |= (!below && !above) ? (1u << (16 * p + r)) : 0u;
+                        }
+                    if (__builtin_expect(open != 0u, 0)) {
+                        // rare (~1e-5 of the compares): the resolve kernel forms the exact score from all six digits.  (Nothing here
+                        // touches the accumulators: a per-lane loop that indexed them dynamically moved all 96 of them to scratch
+                        // memory, unrolled copies cost the main loop its registers.)
+                        for (uint32_t left = open; left;) {
+                            const int o = __builtin_ctz(left);
+                            left &= left - 1u;
+                            const unsigned int at = atomicAdd(fa.amb_count, 1u);
+                            if (at < fa.amb_cap) {
+                                const int64_t u = u_lane + 32 * (o >> 4) + (o & 3) + 8 * ((o & 15) >> 2);
+                                fa.amb[at] = make_ulonglong2(static_cast<unsigned long long>(u) | (static_cast<unsigned long long>(colf) << 32),
+                                                             (1ull << 63) | static_cast<unsigned long long>(fa.p_base + q));
+                            }
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
+                    if (++since_flush == 255) {
+                        flush();
+                        since_flush = 0;
+                    }
+                }
+#pragma unroll
+                for (int p = 0; p < 2; ++p) aw[p] = aw_next[p];
+                if (!(dbg & 4)) __syncthreads();
+                q = q1, t = t1;
+                q1 = q2, t1 = t2;
+                q2 = q3, t2 = t3;
+            };
+            for (int it = 0; it < total; it += 2) {
+                body(it, L_a, L_b, src_a, src_b);
+                if (it + 1 < total) body(it + 1, L_b, L_a, src_b, src_a);
+            }
+            flush();
+            __syncthreads();                                         // kb_list / buffers / thresholds are reused by the next task
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------
 // host: node order, block structure
 // ---------------------------------------------------------------------------------------
 uint64_t hilbert_index(uint32_t x, uint32_t y, int bits) {
@@ -952,7 +1208,7 @@ int build_blocks(safe_nbr *nbr) {
     for (int64_t u = 0; u < n; ++u) pos[order[u]] = static_cast<int32_t>(u);
 
     const int64_t n_groups = ceil_div(n, MF_R), n_kb = ceil_div(n, 32), n_src = (n_kb + 1) * 32;
-    std::vector<int32_t> h_order(n_src, static_cast<int32_t>(n)), h_rowmap(n_groups * MF_R, -1), h_rowcnt(n_groups * MF_R, 0);
+    std::vector<int32_t> h_order(n_src, static_cast<int32_t>(n)), h_rowmap(n_groups * MF_R, -1), h_rowcnt(n_groups * MF_R, -1);
     for (int64_t u = 0; u < n; ++u) {
         h_order[u] = order[u];
         h_rowmap[u] = order[u];
@@ -1078,6 +1334,16 @@ int build_blocks(safe_nbr *nbr) {
         std::copy(g_kbs[g].begin(), g_kbs[g].end(), kbs.begin() + ptr[g]);
         std::copy(g_bits[g].begin(), g_bits[g].end(), bits.begin() + static_cast<size_t>(ptr[g]) * MF_R);
     }
+    // the same bits with the four blocks of a super-step side by side, and the largest neighborhood of every group
+    std::vector<uint32_t> bits4(bits.size());
+    for (size_t b = 0; b < kbs.size(); ++b)
+        for (int r = 0; r < MF_R; ++r) bits4[((b >> 2) * MF_R + r) * 4 + (b & 3)] = bits[b * MF_R + r];
+    std::vector<int32_t> h_grpmax(n_groups, 0);
+    nbr->bs_max_group_blocks = 0;
+    for (int64_t g = 0; g < n_groups; ++g) {
+        for (int r = 0; r < MF_R; ++r) h_grpmax[g] = std::max(h_grpmax[g], h_rowcnt[g * MF_R + r]);
+        nbr->bs_max_group_blocks = std::max<int64_t>(nbr->bs_max_group_blocks, ptr[g + 1] - ptr[g]);
+    }
     nbr->bs_groups = n_groups;
     nbr->bs_blocks = static_cast<int64_t>(kbs.size());
     nbr->bs_pieces = 0;                                                   // (a wave skips the MFMAs of a 32 x 32 piece without members)
@@ -1093,6 +1359,10 @@ int build_blocks(safe_nbr *nbr) {
     SAFE_TRY(dev_alloc(&nbr->bs_rowmap, n_groups * MF_R));
     SAFE_TRY(dev_alloc(&nbr->bs_rowcnt, n_groups * MF_R));
     SAFE_TRY(dev_alloc(&nbr->bs_ptr, n_groups + 1));
+    SAFE_TRY(dev_alloc(&nbr->bs_grpmax, n_groups));
+    SAFE_TRY(dev_alloc(&nbr->bs_bits4, bits4.size() / 4));
+    SAFE_HIP_CHECK(hipMemcpy(nbr->bs_grpmax, h_grpmax.data(), h_grpmax.size() * sizeof(int32_t), hipMemcpyHostToDevice));
+    if (!bits4.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits4, bits4.data(), bits4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     SAFE_TRY(dev_alloc(&nbr->bs_kb, kbs.size()));
     SAFE_TRY(dev_alloc(&nbr->bs_bits, bits.size()));
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_order, h_order.data(), n_src * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1103,7 +1373,10 @@ int build_blocks(safe_nbr *nbr) {
     if (!bits.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS")) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG_NOMEMBERS");
     if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS") && !bits.empty())          // diagnostic: every piece empty -> no MFMA is issued (wrong results)
+    {
         SAFE_HIP_CHECK(hipMemset(nbr->bs_bits, 0, bits.size() * sizeof(uint32_t)));
+        SAFE_HIP_CHECK(hipMemset(nbr->bs_bits4, 0, bits.size() * sizeof(uint32_t)));
+    }
     nbr->blocks_ready = true;
     (void)ctx;
     return SAFE_OK;
@@ -1561,7 +1834,7 @@ __global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restri
                                                       unsigned int amb_cap, const long long *__restrict__ obs64, int64_t n_padr,
                                                       const int32_t *__restrict__ rowmap, const int32_t *__restrict__ row_ptr,
                                                       const int32_t *__restrict__ col_idx, const int32_t *__restrict__ table, int64_t n,
-                                                      const unsigned char *__restrict__ bs_lo, int64_t tile_bytes,
+                                                      const unsigned char *__restrict__ bs_lo, int64_t tile_bytes, int64_t hi_off,
                                                       unsigned int *__restrict__ gl_counts) {
     const unsigned int count = min(*amb_count, amb_cap);
     const int lane = threadIdx.x & 63;
@@ -1571,7 +1844,8 @@ __global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restri
         const ulonglong2 w = amb[rec];
         const int64_t u = static_cast<int64_t>(w.x & 0xFFFFFFFFull), col = static_cast<int64_t>(w.x >> 32);
         const int64_t perm = static_cast<int64_t>(w.y & 0xFFFFull);
-        const long long v_hi = static_cast<long long>(w.y) >> 16;
+        const bool full = (w.y >> 63) != 0ull;                                       // no partial sum: all six digits are summed here
+        const long long v_hi = full ? 0ll : static_cast<long long>(w.y) >> 16;
         const int32_t node = rowmap[u];
         const int32_t e0 = row_ptr[node], e1 = row_ptr[node + 1];
         const unsigned char *base = bs_lo + (col >> 5) * tile_bytes + (col & 31);
@@ -1580,6 +1854,10 @@ __global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restri
         for (int32_t e = e0 + lane; e < e1; e += 64) {
             const signed char *d = reinterpret_cast<const signed char *>(base + static_cast<int64_t>(cur[col_idx[e]]) * row_bytes);
             s += static_cast<long long>(static_cast<int>(d[0]) + 256 * static_cast<int>(d[32]) + 65536 * static_cast<int>(d[64]));
+            if (full) {
+                const signed char *dh = d + hi_off;
+                s += static_cast<long long>(static_cast<int>(dh[0]) + 256 * static_cast<int>(dh[32]) + 65536 * static_cast<int>(dh[64])) << 24;
+            }
         }
 #pragma unroll
         for (int o = 32; o >= 1; o >>= 1) s += __shfl_xor(s, o);
@@ -1614,7 +1892,10 @@ void nbr_free_blocks(safe_nbr *nbr) {
     (void)hipFree(nbr->bs_order);
     (void)hipFree(nbr->bs_rowmap);
     (void)hipFree(nbr->bs_rowcnt);
-    nbr->bs_rowcnt = nullptr;
+    (void)hipFree(nbr->bs_grpmax);
+    (void)hipFree(nbr->bs_bits4);
+    nbr->bs_rowcnt = nbr->bs_grpmax = nullptr;
+    nbr->bs_bits4 = nullptr;
     (void)hipFree(nbr->bs_ptr);
     (void)hipFree(nbr->bs_kb);
     (void)hipFree(nbr->bs_bits);
@@ -1716,6 +1997,10 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         row_bytes = static_cast<int64_t>(n_slices) * 32;          // tile-major: a row of a tile is n_slices x 32 bytes, tiles (n + 1) rows apart
     }
     const bool filt = want_filter && n_slices == MF_NS;
+    // its own kernel (64 rows per wave, two workgroups per CU) unless a group is too long for its LDS list / a neighborhood too
+    // large for its 32-bit thresholds; SAFE_HIP_MFMA_FORM=general: the general kernel's FM = 2 (A/B)
+    const char *form_env = getenv("SAFE_HIP_MFMA_FORM");
+    const bool filt_own = filt && nbr->bs_max_group_blocks <= MF_F_MAXBLK && nbr->max_count < 2048 && !(form_env && !strcmp(form_env, "general"));
     const int core_slices = filt ? MF_NS / 2 : n_slices;         // slices the matrix cores multiply
     if (filt) row_bytes = static_cast<int64_t>(core_slices) * 32;
     const unsigned char *d_bs_lo = d_bs, *d_bs_hi = d_bs + split_off;
@@ -1783,6 +2068,9 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     if (filt) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_obs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    const size_t lds_own = 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t);
+    if (filt_own)
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma_f), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_own)));
     ctx->last_slices = n_slices;
     ctx->last_core_slices = core_slices;
     ctx->last_undecided = 0;
@@ -1862,16 +2150,22 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                 fa.p_base = static_cast<int>(p_base);
             }
             const unsigned char *bs_main = filt ? d_bs_hi : d_bs;
+            if (filt_own) {
+                const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
+                hipLaunchKernelGGL(k_permtest_mfma_f, dim3(blocks_own), dim3(256), lds_own, ks, bs_main, tile_bytes, n, src_c, n_src, n_q, nbr->bs_ptr,
+                                   nbr->bs_kb, nbr->bs_bits4, nbr->bs_grpmax, d_tasks, d_qoff, qctr_c, mloc, d_counts, n_padr, fa, mfma_dbg);
+            } else {
             void *args[] = {(void *)&bs_main, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
                             (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup, (void *)&fa};
             SAFE_HIP_CHECK(hipLaunchKernel(kfn, dim3(blocks), dim3(512), args, lds_bytes, ks));
+            }
         }
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
         if (filt) {
             hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
-                               nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, d_counts);
+                               nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_counts);
             SAFE_HIP_CHECK(hipGetLastError());
         }
         if (c >= 1) {

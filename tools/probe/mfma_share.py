@@ -20,8 +20,9 @@ attr = be.Attributes.from_host(ctx, b)
 del b
 outs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
 keep = None
-for variant in os.environ.get('VARIANTS', '1,1,0').split(','):
-    os.environ['SAFE_HIP_MFMA_FILTER'] = variant
+for variant in os.environ.get('VARIANTS', 'own,own,general,six').split(','):
+    os.environ['SAFE_HIP_MFMA_FILTER'] = '0' if variant == 'six' else '1'
+    os.environ['SAFE_HIP_MFMA_FORM'] = 'general' if variant == 'general' else 'own'
     perms = be.Permutations(ctx, n, attr.row_flags(), nperm, 0)
     ctx.sync()
     t0 = time.perf_counter()
