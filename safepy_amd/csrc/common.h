@@ -81,6 +81,7 @@ struct safe_ctx {
     hipEvent_t k0 = nullptr, k1 = nullptr;      // dominant-kernel timing
     KernelStat last_kernel;
     int last_slices = 0;                        // i8 slices of the last matrix-core permutation test (2 / 4 / 6)
+    void *diag_prof = nullptr;                  // (diagnostic builds) per-phase cycle counters of the matrix-core kernel
     int last_core_slices = 0;                   // slices its matrix-core kernel multiplied (3 of 6 in the filtered form)
     int64_t last_undecided = 0;                 // filtered form: compares decided by k_mfma_resolve (negative: list overflow, six-slice rerun)
     // grow-only scratch buffers reused across calls (hipMalloc of >100 MB costs milliseconds)

@@ -426,6 +426,7 @@ struct MfmaFilt {
     unsigned int amb_cap = 0;
     int obs_shift = 0;
     int p_base = 0;                           // the launch's first permutation
+    unsigned long long *prof = nullptr;       // (diagnostic build 512) cycles per phase, summed over waves: [wave 0-3][8]
 };
 
 template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0, bool PREF = true, int FM = 0>
@@ -448,6 +449,10 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     long long *obs = reinterpret_cast<long long *>(lds + 2 * BUF + MF_MAXBLK * sizeof(int32_t)) + threadIdx.x;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lam = lane & 31, h = lane >> 5;
+    // this wave's 32 rows of the group: waves w and w + 4 share a SIMD (a workgroup's waves go round the four SIMDs) and own the
+    // ADJACENT pieces 2 (w & 3) and 2 (w & 3) + 1 -- the pairing build_blocks balances, and the one k_permtest_mfma_f's
+    // 64-row waves have
+    const int wrow = (2 * (wave & 3) + (wave >> 2)) * 32;
     // gather role: thread -> (k-step of the super-step, row quad, 16-byte chunk of the row segment)
     constexpr int CH = 2 * NS, GT = 4 * 8 * CH;
     const bool gth = tid < GT;
@@ -482,7 +487,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             __syncthreads();
 
             const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + chunk * 16;
-            const uint32_t *bits_w = blk_bits + static_cast<int64_t>(b0) * MF_R + wave * 32 + lam;
+            const uint32_t *bits_w = blk_bits + static_cast<int64_t>(b0) * MF_R + wrow + lam;
             const int total = n_q * S;
 
             // z-scores: this lane's attribute column and the power-of-two scales of its sum / sum of squares
@@ -508,7 +513,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int64_t u = static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int32_t members = fa.rowcnt[u];
                     const bool live = colf < mloc && members > 0;
                     const long long bound = static_cast<long long>(members) * MF_LO_MAX;
@@ -675,7 +680,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                         } else if constexpr (FM == 1) {
                             const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
                             if (colf < mloc) {
-                                long long *dst = fa.obs64 + colf * n_padr + static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                                long long *dst = fa.obs64 + colf * n_padr + static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
                                 *dst = fa.obs_shift ? *dst + (v << fa.obs_shift) : v;
                             }
                         } else if constexpr (FM == 2) {
@@ -702,7 +707,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                             // accumulator elements): unrolled over r the sixteen copies of this block cost the main loop 100
                             // spilled registers although it almost never runs
                             const unsigned long long colf = static_cast<unsigned long long>(static_cast<int64_t>(ct) * 32 + col_in_tile);
-                            const unsigned long long u0 = static_cast<unsigned long long>(static_cast<int64_t>(g) * MF_R + wave * 32 + 4 * h);
+                            const unsigned long long u0 = static_cast<unsigned long long>(static_cast<int64_t>(g) * MF_R + wrow + 4 * h);
                             for (uint32_t left = undecided; left;) {
                                 const int r = __builtin_ctz(left);
                                 left &= left - 1u;
@@ -744,7 +749,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 if constexpr (EPI != 0) {
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
-                        node[EPI == 0 ? 0 : r] = rowmap[static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h];
+                        node[EPI == 0 ? 0 : r] = rowmap[static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h];
 #pragma unroll
                     for (int r = 0; r < 16; ++r)
                         slab[EPI == 0 ? 0 : r] = (EPI == 2 && node[EPI == 0 ? 0 : r] >= 0)
@@ -762,7 +767,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     static_assert(NS == 6, "packed counts hold six tiles");
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        const int64_t u = static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
                         unsigned int *dst = hl.cnt16 + ((static_cast<int64_t>(ct) * n_padr + u) * 32 + col_in_tile) * 3;
                         uint3 w;
                         w.x = static_cast<uint32_t>(acc[0][r]) | (static_cast<uint32_t>(acc[1][r]) << 16);
@@ -843,7 +848,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 const double sc = (ns_out && !Z) ? col_scale[col] : 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
-                    const int64_t u = static_cast<int64_t>(g) * MF_R + wave * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int64_t u = static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
                     if (cnt[r]) atomicAdd(&gl_counts[col * n_padr + u], cnt[r]);
                     if (FM == 0 && ns_out) {
                         const int32_t node = rowmap[u];
@@ -881,20 +886,35 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 //     width per task (from the group's largest neighborhood: neighborhoods below 2048 members); what the test leaves open is
 //     appended for k_mfma_resolve, which forms that score from all six digits (the record carries no partial sum);
 //   * <= / >= counters are 8-bit fields (two outputs per register), flushed to memory every 255 permutations.
+// (diagnostic builds) keeps a value -- and the loads / MFMAs that produce it -- alive without using it
+__device__ __forceinline__ void mf_keep(uint32_t x) { asm volatile("" ::"v"(x)); }
+__device__ __forceinline__ void mf_keep(const uint4 &x) { asm volatile("" ::"v"(x.x), "v"(x.y), "v"(x.z), "v"(x.w)); }
+__device__ __forceinline__ void mf_keep(const v4i &x) { asm volatile("" ::"v"(x[0]), "v"(x[1]), "v"(x[2]), "v"(x[3])); }
 constexpr int MF_F_MAXBLK = 2048;         // column blocks per row group this kernel can index from LDS (else the general kernel)
+// DBG: diagnostic builds that skip work (WRONG results; only instantiated with -DSAFE_HIP_DIAG, selected by SAFE_HIP_MFMA_DBG):
+// 1 no transposes / LDS stores, 2 no MFMAs, 4 no barrier per super-step, 8 no score completion, 16 no membership-word loads,
+// 32 no source-index loads, 64 no row gathers, 128 always the same LDS buffer, 256 no LDS operand reads.  A template parameter:
+// as a kernel argument the tests cost the main loop 16 spilled registers and made it three times slower.
+template <int DBG>
 __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
     const unsigned char *__restrict__ bs, int64_t tile_bytes, int64_t zrow, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint4 *__restrict__ blk_bits4,
     const int32_t *__restrict__ grp_maxcnt, const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off,
-    unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa, int dbg) {
+    unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa) {
+    constexpr int dbg = DBG;
     constexpr int NS = MF_NS / 2, KS = NS * MF_SS, BUF = 4 * KS;
     constexpr int64_t row_bytes = NS * 32;
-    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] | kb list | Y0 [32][256]
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] | kb list | Y0 [32][256] | counters [8][256]
     __shared__ int slot_box;
     const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
     const int lam = lane & 31, h = lane >> 5;
     int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * BUF);
     int32_t *y0s = reinterpret_cast<int32_t *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t)) + tid;
+    // counters: ONE 8-bit field per output in LDS ([8][256] words; output o = 16 p + r in word r & 7, byte 2 p + (r >> 3)) that counts
+    // the permutations NOT certainly greater than the observed score; flushed every 255 permutations as
+    // (#smaller << 16 | #greater) = (field << 16 | permutations - field).  An undecided compare is counted "smaller" and taken back
+    // at once (a rare global atomic of -(1 << 16)); k_mfma_resolve then adds what it really was
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t)) + tid;
     constexpr int CH = 2 * NS, GT = 4 * 8 * CH;                               // 192 gather threads = waves 0-2
     const bool gth = tid < GT;
     const int gt = gth ? tid : 0;
@@ -922,7 +942,7 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
             for (int i = tid; i < nb; i += 256) kb_list[i] = blk_kb[b0 + i];
 
             const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + (gth ? chunk * 16 : 0);
-            const uint4 *bits_w = blk_bits4 + static_cast<int64_t>(b0 >> 2) * MF_R + wave * 64 + lam;
+            const uint4 *bits_w = blk_bits4 + static_cast<int64_t>(b0 >> 2) * MF_R + wave * 64 + lane;   // lane l: row l of the wave's 64
             const int total = n_q * S;
             const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
             const int64_t u_lane = static_cast<int64_t>(g) * MF_R + wave * 64 + 4 * h;     // + 32 p + (r & 3) + 8 (r >> 2)
@@ -958,30 +978,32 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 for (int s = 0; s < NS; ++s)
 #pragma unroll
                     for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
-            uint32_t cnt[16];                                        // outputs r (piece 0) and 16 + r (piece 1): 8-bit fields #< | #>
 #pragma unroll
-            for (int r = 0; r < 16; ++r) cnt[r] = 0;
+            for (int j = 0; j < 8; ++j) cnts[j * 256] = 0;
             int since_flush = 0;
+            unsigned long long prof_acc[5] = {0, 0, 0, 0, 0};
 
             auto flush = [&]() __attribute__((always_inline)) {
-                if (colf < mloc) {
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t w = cnts[j * 256];
+                    cnts[j * 256] = 0;
+                    if (colf < mloc) {
 #pragma unroll
-                        for (int p = 0; p < 2; ++p) {
-                            const uint32_t f = cnt[r] >> (16 * p);
-                            const uint32_t add = ((f & 0xFF00u) << 8) | (f & 0xFFu);
-                            if (add) atomicAdd(&gl_counts[colf * n_padr + u_lane + 32 * p + (r & 3) + 8 * (r >> 2)], add);
+                        for (int f = 0; f < 4; ++f) {                    // byte f: piece f >> 1, accumulator element j + 8 (f & 1)
+                            const uint32_t smaller = (w >> (8 * f)) & 0xFFu;
+                            const int r = j + 8 * (f & 1);
+                            atomicAdd(&gl_counts[colf * n_padr + u_lane + 32 * (f >> 1) + (r & 3) + 8 * (r >> 2)],
+                                      (smaller << 16) | (static_cast<uint32_t>(since_flush) - smaller));
                         }
-                        cnt[r] = 0;
                     }
                 }
             };
-            auto load_src = [&](int q, int t) -> int4 {
+            auto load_src_kb = [&](int q, int kb) -> int4 {
                 q = q < n_q ? q : n_q - 1;
-                const int kb = kb_list[4 * t + ks_g];
                 return *reinterpret_cast<const int4 *>(srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + 4 * rq);
             };
+            auto load_src = [&](int q, int t) -> int4 { return load_src_kb(q, kb_list[4 * t + ks_g]); };
             auto load_rows = [&](const int4 &src, uint4 (&L)[4]) {
                 L[0] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.x & row_keep) | row_else) * row_bytes);
                 L[1] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.y & row_keep) | row_else) * row_bytes);
@@ -1025,9 +1047,25 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                     for (int cw = 0; cw < 4; ++cw) store_quarter(L_b, cw, 0);
                 }
             }
+            // membership words of a super-step: lane l loads the four words of row l; v_permlane32_swap then gives every lane the
+            // words of row (l & 31) of piece 0 and of piece 1 (one 16-byte load per lane instead of two)
+            auto split_rows = [&](const uint4 &raw, uint4 (&w)[2]) __attribute__((always_inline)) {
+                typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+                const v2u x = __builtin_amdgcn_permlane32_swap(raw.x, raw.x, false, false);
+                const v2u y = __builtin_amdgcn_permlane32_swap(raw.y, raw.y, false, false);
+                const v2u z = __builtin_amdgcn_permlane32_swap(raw.z, raw.z, false, false);
+                const v2u ww = __builtin_amdgcn_permlane32_swap(raw.w, raw.w, false, false);
+                w[0] = make_uint4(x[0], y[0], z[0], ww[0]);
+                w[1] = make_uint4(x[1], y[1], z[1], ww[1]);
+            };
             uint4 aw[2];
-#pragma unroll
-            for (int p = 0; p < 2; ++p) aw[p] = bits_w[32 * p];
+            split_rows(bits_w[0], aw);
+            int kb_next;                                             // column block of the source indices requested next (read one iteration early)
+            {
+                int q3p = q2, t3p = t2;
+                advance(q3p, t3p);
+                kb_next = kb_list[4 * t3p + ks_g];
+            }
             __syncthreads();
 
             int q = 0, t = 0;
@@ -1037,23 +1075,46 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 q3 = q2, t3 = t2;
                 advance(q3, t3);
                 const bool more1 = it + 1 < total;
-                uint4 aw_next[2];
-#pragma unroll
-                for (int p = 0; p < 2; ++p) aw_next[p] = bits_w[static_cast<int64_t>(t1) * MF_R + 32 * p];
-                src_load = load_src(q3, t3);
-                load_rows(src_use, L_load);
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                if (dbg & 512) c0 = __builtin_amdgcn_s_memtime();
+                uint4 aw_raw = aw[0];
+                if (!(dbg & 16)) aw_raw = bits_w[static_cast<int64_t>(t1) * MF_R];
+                if (!(dbg & 32)) src_load = load_src_kb(q3, kb_next);
+                {
+                    int q4 = q3, t4 = t3;
+                    advance(q4, t4);
+                    kb_next = kb_list[4 * t4 + ks_g];                // (consumed at the top of the next iteration: no wait here)
+                }
+                // the four row loads of the gather are issued one per k-step below: right after the barrier all four waves of the
+                // workgroup (and often the CU's other workgroup) would queue 24 of them at once -- a wave spent ~450 cycles per
+                // super-step getting its six loads accepted
+                const int32_t row_of[4] = {(src_use.x & row_keep) | row_else, (src_use.y & row_keep) | row_else,
+                                           (src_use.z & row_keep) | row_else, (src_use.w & row_keep) | row_else};
 
-                const unsigned char *bbuf = lds + buf * BUF + r_base;
+                const unsigned char *bbuf = lds + ((dbg & 128) ? 0 : buf * BUF) + r_base;
+                if (dbg & 512) c1 = __builtin_amdgcn_s_memtime();
+                // two operand sets: the slices of k-step k + 1 are read before the MFMAs of k-step k are issued
+                v4i b_cur[NS], b_nxt[NS];
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+                    if (!(dbg & 256)) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
-                    // (one operand set, read right before its MFMAs: the SIMD's other wave -- of the CU's other workgroup -- covers
-                    // the LDS latency; a second set, read one k-step ahead, costs 12 registers this kernel does not have)
-                    v4i b_cur[NS];
+                    if (k < 3) {
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+                        for (int s = 0; s < NS; ++s)
+                            if (!(dbg & 256)) b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
+                    }
+                    if (!(dbg & 64)) L_load[k] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(row_of[k]) * row_bytes);
+                    __builtin_amdgcn_sched_barrier(0);               // the reads and the row load stay ahead of this k-step's MFMAs
 #pragma unroll
                     for (int p = 0; p < 2; ++p) {
                         const uint32_t word = k == 0 ? aw[p].x : k == 1 ? aw[p].y : k == 2 ? aw[p].z : aw[p].w;
+                        if (dbg & 2) {
+                            mf_keep(word);
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) mf_keep(b_cur[s]);
+                        }
                         if (__builtin_amdgcn_ballot_w64(word != 0u) != 0ull && !(dbg & 2)) {   // (a piece without members is skipped)
                             v4i a;
                             a[0] = static_cast<int>(expand4(word, 16 * h));
@@ -1065,20 +1126,36 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                         }
                     }
                     if (gth && more1 && !(dbg & 1)) store_quarter(L_store, k, buf ^ 1);
+                    if ((dbg & 1) && k == 3) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) mf_keep(L_store[i]);
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
                 }
+                uint4 aw_next[2];
+                split_rows(aw_raw, aw_next);
 
+                if (dbg & 512) c2 = __builtin_amdgcn_s_memtime();
                 if (t == S - 1 && !(dbg & 8)) {                      // the scores of permutation q are complete
-                    uint32_t open = 0;                                // outputs the coarse test leaves undecided
+                    uint32_t open = 0;                                // outputs the test leaves undecided
+                    const int32_t wcs = static_cast<int32_t>(wc);
 #pragma unroll
-                    for (int p = 0; p < 2; ++p)
+                    for (int j = 0; j < 8; ++j) {                     // the four outputs of counter word j; their thresholds read together
+                        int32_t y0v[4];
 #pragma unroll
-                        for (int r = 0; r < 16; ++r) {
+                        for (int f = 0; f < 4; ++f) y0v[f] = y0s[(16 * (f >> 1) + j + 8 * (f & 1)) * 256];
+                        uint32_t inc = 0;
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {
+                            const int p = f >> 1, r = j + 8 * (f & 1);
                             const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);   // floor(V_hi / 16)
-                            const int32_t d = y - y0s[(16 * p + r) * 256];
-                            const bool below = d < 0, above = static_cast<uint32_t>(d) >= wc;
-                            cnt[r] += (below ? 256u : (above ? 1u : 0u)) << (16 * p);
-                            open |= (!below && !above) ? (1u << (16 * p + r)) : 0u;
+                            const int32_t d = y - y0v[f];
+                            inc |= (d < wcs) ? (1u << (8 * f)) : 0u;               // not certainly greater (d < 0: certainly smaller)
+                            open |= (static_cast<uint32_t>(d) < wc) ? (1u << (16 * p + r)) : 0u;
                         }
+                        if (inc) __hip_atomic_fetch_add(&cnts[j * 256], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                    }
                     if (__builtin_expect(open != 0u, 0)) {
                         // rare (~1e-5 of the compares): the resolve kernel forms the exact score from all six digits.  (Nothing here
                         // touches the accumulators: a per-lane loop that indexed them dynamically moved all 96 of them to scratch
@@ -1086,12 +1163,12 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                         for (uint32_t left = open; left;) {
                             const int o = __builtin_ctz(left);
                             left &= left - 1u;
+                            const int64_t u = u_lane + 32 * (o >> 4) + (o & 3) + 8 * ((o & 15) >> 2);
+                            atomicAdd(&gl_counts[colf * n_padr + u], 0xFFFF0000u);       // it was counted "smaller" above: taken back
                             const unsigned int at = atomicAdd(fa.amb_count, 1u);
-                            if (at < fa.amb_cap) {
-                                const int64_t u = u_lane + 32 * (o >> 4) + (o & 3) + 8 * ((o & 15) >> 2);
+                            if (at < fa.amb_cap)
                                 fa.amb[at] = make_ulonglong2(static_cast<unsigned long long>(u) | (static_cast<unsigned long long>(colf) << 32),
                                                              (1ull << 63) | static_cast<unsigned long long>(fa.p_base + q));
-                            }
                         }
                     }
 #pragma unroll
@@ -1107,7 +1184,20 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 }
 #pragma unroll
                 for (int p = 0; p < 2; ++p) aw[p] = aw_next[p];
+                if (dbg & 512) {
+                    mf_keep(aw[0]);                                  // (the wait for the membership words belongs to this phase)
+                    mf_keep(aw[1]);
+                    c3 = __builtin_amdgcn_s_memtime();
+                }
                 if (!(dbg & 4)) __syncthreads();
+                if (dbg & 512) {
+                    const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+                    prof_acc[0] += c1 - c0;                          // issue of the look-ahead loads
+                    prof_acc[1] += c2 - c1;                          // operand reads, MFMAs, transposed stores
+                    prof_acc[2] += c3 - c2;                          // score completion (+ the wait for the next membership words)
+                    prof_acc[3] += c4 - c3;                          // barrier
+                    prof_acc[4] += 1;
+                }
                 q = q1, t = t1;
                 q1 = q2, t1 = t2;
                 q2 = q3, t2 = t3;
@@ -1116,7 +1206,22 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 body(it, L_a, L_b, src_a, src_b);
                 if (it + 1 < total) body(it + 1, L_b, L_a, src_b, src_a);
             }
-            flush();
+            if ((dbg & 512) && lane == 0 && fa.prof) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    atomicAdd(&fa.prof[wave * 8 + i], prof_acc[i]);
+                    prof_acc[i] = 0;
+                }
+            }
+            if (since_flush) flush();
+            if (dbg & 8) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mf_keep(static_cast<uint32_t>(acc[p][s][r]));
+            }
             __syncthreads();                                         // kb_list / buffers / thresholds are reused by the next task
         }
     }
@@ -1256,8 +1361,8 @@ int build_blocks(safe_nbr *nbr) {
                 }
             }
             for (int32_t kb : touched) slot[kb] = -1;
-            // The kernel works through a group four blocks (one super-step) at a time, every wave on its own 32 rows, and skips
-            // the pieces that hold no member; waves w and w + 4 share a SIMD's matrix pipe and all waves meet at a barrier
+            // The kernel works through a group four blocks (one super-step) at a time, every wave on its own 32 (or 64) rows, and skips
+            // the pieces that hold no member; the pieces 2k and 2k + 1 share a SIMD's matrix pipe and all waves meet at a barrier
             // after every super-step.  Deal the blocks into super-steps so that the busiest SIMD of each has as little to do as
             // possible (greedy, heaviest blocks first): at configs[4] 4.98 instead of 5.83 multiply steps per super-step on the
             // critical SIMD (8 without the skip; tools/notes/mfma_subtile_stats.py).  The sum over a group's blocks does not
@@ -1272,7 +1377,7 @@ int build_blocks(safe_nbr *nbr) {
                         uint32_t any = 0;
                         for (int r = 0; r < 32; ++r) any |= bit_out[i * MF_R + w * 32 + r];
                         if (any) {
-                            ++simd[i][w & 3];
+                            ++simd[i][w >> 1];                                   // pieces 2k and 2k + 1 share a SIMD (both kernels)
                             ++weight[i];
                         }
                     }
@@ -2068,9 +2173,17 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     if (filt) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_obs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
-    const size_t lds_own = 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t);
+    static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
+    if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
+    const void *kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
+#ifdef SAFE_HIP_DIAG
+#define MF_F_DIAG(D) if (mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<D>);
+    MF_F_DIAG(1) MF_F_DIAG(2) MF_F_DIAG(4) MF_F_DIAG(8) MF_F_DIAG(15) MF_F_DIAG(31) MF_F_DIAG(47) MF_F_DIAG(79) MF_F_DIAG(271) MF_F_DIAG(127) MF_F_DIAG(383) MF_F_DIAG(511) MF_F_DIAG(512)
+#undef MF_F_DIAG
+#endif
+    const size_t lds_own = 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t);
     if (filt_own)
-        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_mfma_f), hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_own)));
+        SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_own, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_own)));
     ctx->last_slices = n_slices;
     ctx->last_core_slices = core_slices;
     ctx->last_undecided = 0;
@@ -2093,8 +2206,6 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
     SAFE_TRY(ctx_events(ctx, false, 2, &plain));
     hipEvent_t ready = plain[0], side_done = plain[1];
-    static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
-    if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
     if (filt) {
         // the exact observed scores: low digits stored, high digits added << 24 (two short launches over the identity map)
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
@@ -2148,12 +2259,22 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                 fa.amb_count = d_amb_cnt + c;
                 fa.amb_cap = amb_cap;
                 fa.p_base = static_cast<int>(p_base);
+#ifdef SAFE_HIP_DIAG
+                if (mfma_dbg == 512) {
+                    if (!ctx->diag_prof) SAFE_HIP_CHECK(hipMalloc(&ctx->diag_prof, 64 * sizeof(unsigned long long)));
+                    if (c == 0) SAFE_HIP_CHECK(hipMemsetAsync(ctx->diag_prof, 0, 64 * sizeof(unsigned long long), ks));
+                    fa.prof = static_cast<unsigned long long *>(ctx->diag_prof);
+                }
+#endif
             }
             const unsigned char *bs_main = filt ? d_bs_hi : d_bs;
             if (filt_own) {
                 const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
-                hipLaunchKernelGGL(k_permtest_mfma_f, dim3(blocks_own), dim3(256), lds_own, ks, bs_main, tile_bytes, n, src_c, n_src, n_q, nbr->bs_ptr,
-                                   nbr->bs_kb, nbr->bs_bits4, nbr->bs_grpmax, d_tasks, d_qoff, qctr_c, mloc, d_counts, n_padr, fa, mfma_dbg);
+                int64_t zrow = n;
+                void *args[] = {(void *)&bs_main, (void *)&tile_bytes, (void *)&zrow, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+                                (void *)&nbr->bs_kb, (void *)&nbr->bs_bits4, (void *)&nbr->bs_grpmax, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c,
+                                (void *)&mloc, (void *)&d_counts, (void *)&n_padr, (void *)&fa};
+                SAFE_HIP_CHECK(hipLaunchKernel(kfn_own, dim3(blocks_own), dim3(256), args, lds_own, ks));
             } else {
             void *args[] = {(void *)&bs_main, (void *)&row_bytes, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                             (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
@@ -2167,6 +2288,19 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
             hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
                                nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_counts);
             SAFE_HIP_CHECK(hipGetLastError());
+            if (c == 0 && long_launches && n_launch > 1) {
+                // pilot: data with many equal scores (sparse columns, few distinct values) leaves the high digits little to
+                // decide -- if the first launch sent more than 2 in 1000 compares to the resolve kernel, stop here and let the
+                // caller run all six slices (a launch of this size is long: the wait is nothing beside it)
+                unsigned int seen0 = 0;
+                SAFE_HIP_CHECK(hipMemcpyAsync(&seen0, d_amb_cnt, sizeof(seen0), hipMemcpyDeviceToHost, ks));
+                SAFE_HIP_CHECK(safe_stream_sync(ks));
+                if (static_cast<double>(seen0) > 2e-3 * static_cast<double>(n) * static_cast<double>(mloc) * static_cast<double>(cnt)) {
+                    ctx->last_undecided = seen0;
+                    *overflowed = true;
+                    return SAFE_OK;
+                }
+            }
         }
         if (c >= 1) {
             // the source-map buffer of span c-1 is reused by span c+1: same stream, ordered
@@ -2188,6 +2322,17 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     SAFE_TRY(kernel_stat_from_events(ctx, ev, n_launch));
+#ifdef SAFE_HIP_DIAG
+    if (mfma_dbg == 512 && ctx->diag_prof) {
+        unsigned long long prof[64];
+        SAFE_HIP_CHECK(hipMemcpy(prof, ctx->diag_prof, sizeof(prof), hipMemcpyDeviceToHost));
+        for (int w = 0; w < 4; ++w) {
+            const double it = static_cast<double>(std::max<unsigned long long>(prof[w * 8 + 4], 1));
+            fprintf(stderr, "mfma_f wave %d: %.0f iterations; cycles per iteration: loads %.0f, k-loop %.0f, completion %.0f, barrier %.0f\n", w, it,
+                    prof[w * 8] / it, prof[w * 8 + 1] / it, prof[w * 8 + 2] / it, prof[w * 8 + 3] / it);
+        }
+    }
+#endif
     for (unsigned int seen : amb_seen) {
         ctx->last_undecided += seen;
         if (seen > amb_cap) *overflowed = true;          // a launch left more undecided compares than its list holds
@@ -2204,6 +2349,8 @@ int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms
         // matrix cores (counters, scores and outputs are rewritten from scratch)
         safe_trace("matrix-core filter: too many undecided compares, running the six-slice form");
         const int64_t undecided = ctx->last_undecided;
+        if (out_in.enriched)                                  // (the abandoned pass may have counted its hits already)
+            SAFE_HIP_CHECK(hipMemsetAsync(out_in.enriched, 0, static_cast<size_t>(col1 - col0) * sizeof(unsigned int), ctx->stream));
         SAFE_TRY(launch_mfma_run(ctx, nbr, attr, perms, col0, col1, z, out_in, declined, false, &overflowed));
         ctx->last_undecided = -undecided;                // (negative: the filtered pass was abandoned)
     }

@@ -499,3 +499,26 @@ def test_filtered_form_column_shards_and_launch_spans(amd, ctx):
     np.testing.assert_array_equal(cn, cn_w[:, 13:61])
     np.testing.assert_array_equal(cp, cp_w[:, 13:61])
     nbr.close()
+
+
+def test_filtered_form_fall_back_inside_compute_pvalues_counts_enriched_neighborhoods_once(amd, monkeypatch):
+    """The abandoned filtered pass has already added its hits to the per-attribute counters when the six-slice pass starts:
+    they are cleared (num_neighborhoods_enriched was doubled before)."""
+    monkeypatch.setenv('SAFE_HIP_MFMA_FILTER_CAP', '4')
+    monkeypatch.setenv('SAFE_HIP_FORCE_PATH', 'mfma')
+    rng = np.random.default_rng(12)
+    n, m, nperm = 600, 40, 50
+    xy = rng.uniform(size=(n, 2))
+    b = _quant(rng, n, m, np.float64, 'C', nan_rows=20, nan_frac=0.02)
+    a = orc.neighborhoods_euclidean(xy, 0.1)
+    want = orc.compute_pvalues(a, b.copy(), enrichment_type='randomization', num_permutations=nperm, random_seed=6)
+    sf = amd.SAFE(verbose=False)
+    sf.graph = amd.LayoutGraph(xy)
+    sf.random_seed = 6
+    sf.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.1)
+    sf.load_attributes(attribute_file=b.copy())
+    sf.compute_pvalues(num_permutations=nperm, verbose=False)
+    from safepy_amd import backend as be
+    assert be.last_mfma_filter(amd.Context.default(0))[1] < 0
+    np.testing.assert_array_equal(sf.nes_binary, want['nes_binary'])
+    np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['nes_binary'].sum(axis=0))
