@@ -464,23 +464,32 @@ def mfma_kernel(ctx, np, be):
     name, ms, launches, dt = res
     blocks, pieces = be.block_count(nbr), be.piece_count(nbr)
     slices = be.last_mfma_slices(ctx)
+    core, undecided = be.last_mfma_filter(ctx)
     # EXECUTED operations: the kernel issues MFMAs only for the 32 x 32 pieces of the stored blocks that hold a member
-    # (safe_nbr_piece_count); the stored-block figure (what rounds 1-3 reported) is kept beside it
-    ops = 2.0 * pieces * 32 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
-    stored_ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
+    # (safe_nbr_piece_count); the stored-block figure (what rounds 1-3 reported) is kept beside it.  The filtered form (round 5)
+    # multiplies only the three high digits (core = 3) -- the compares they cannot decide are settled exactly from the low
+    # digits by k_mfma_resolve -- so the same counts cost half the operations: `frac` prices the operations really executed,
+    # `six_slice_equivalent_frac` what the round-4 kernel would have needed for the same result in the same time
+    passes = (nperm + 2) if core < slices else (nperm + 1)
+    ops = 2.0 * pieces * 32 * 32 * (32 * ((m + 31) // 32)) * core * passes
+    stored_ops = 2.0 * blocks * 256 * 32 * (32 * ((m + 31) // 32)) * core * passes
+    six_ops = 2.0 * pieces * 32 * 32 * (32 * ((m + 31) // 32)) * slices * (nperm + 1)
     tops = ops / (ms * launches * 1e-3) / 1e12
     out = {name: {'bound': 'mfma', 'workload': 'configs[4], one rank of 8: N=%d x M=%d quantitative f64 attributes x %d permutations, '
                                               '%d members per neighborhood on average' % (n, m, nperm, int(nbr.nnz / n)),
                   'kernel_ms': ms * launches, 'call_ms': 1e3 * dt, 'algorithmic_ops': ops, 'achieved': tops,
                   'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS, 'i8_slices': slices,
+                  'i8_slices_multiplied': core, 'compares_resolved_from_low_digits': undecided,
+                  'compares_resolved_frac': (abs(undecided) / (float(n) * m * nperm)) if undecided else 0.0,
+                  'six_slice_equivalent_frac': six_ops / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                   'membership_blocks_256x32': blocks, 'block_fill': nbr.nnz / (blocks * 256.0 * 32.0),
                   'pieces_32x32_multiplied': pieces, 'pieces_skipped_frac': 1.0 - pieces / (8.0 * blocks),
                   'stored_block_ops': stored_ops, 'stored_block_frac_of_peak': stored_ops / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                   'mfma_pipe_busy_pmc': mfma_pipe_busy(name),
                   # `achieved` / `frac` count the pieces really multiplied; the USEFUL rate counts one multiply-add per membership entry,
                   # column, permutation and slice
-                  'useful_ops': 2.0 * float(nbr.nnz) * m * slices * (nperm + 1),
-                  'useful_frac_of_peak': 2.0 * float(nbr.nnz) * m * slices * (nperm + 1) / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
+                  'useful_ops': 2.0 * float(nbr.nnz) * m * core * passes,
+                  'useful_frac_of_peak': 2.0 * float(nbr.nnz) * m * core * passes / (ms * launches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                   'enrichments_per_s': float(n) * m * nperm / dt,
                   'config5_rank_share_seconds': dt}}
     # the same share with neighborhood_score_type='z-score' (safe_extras.py:19-31): 16-column tiles carrying value digits,
@@ -774,12 +783,17 @@ def roofline_of(wl, res, ctx, np, be):
     span = int(np.ceil(P / launches))                       # permutations per launch
     if kname.startswith('k_permtest_mfma'):
         blocks, slices = be.block_count(wl.nbr), be.last_mfma_slices(ctx)
-        ops = 2.0 * be.piece_count(wl.nbr) * 32 * 32 * (32 * ((m + 31) // 32)) * slices * (P + 1) / launches      # executed pieces only
-        useful = 2.0 * float(wl.nbr.nnz) * m * slices * (P + 1) / launches
+        core, undecided = be.last_mfma_filter(ctx)
+        # EXECUTED slices: the filtered form multiplies only the high digits (core = 3 of 6) over the permutations and forms the
+        # observed score in two extra passes of three slices; the six-slice form carries the observed pass in every launch
+        passes = (P + 2) if core < slices else (P + 1)
+        ops = 2.0 * be.piece_count(wl.nbr) * 32 * 32 * (32 * ((m + 31) // 32)) * core * passes / launches      # executed pieces only
+        useful = 2.0 * float(wl.nbr.nnz) * m * core * passes / launches
         tops = ops / (k_ms * 1e-3) / 1e12
         return {'bound': 'mfma', 'kernel': kname, 'achieved': tops, 'peak': MFMA_I8_PEAK_TOPS, 'unit': 'TOP/s', 'frac': tops / MFMA_I8_PEAK_TOPS,
                 'traffic': None, 'kernel_ms': k_ms, 'launches_per_step': launches, 'kernel_busy_ms_per_step': k_busy,
-                'algorithmic_ops': ops, 'i8_slices': slices, 'mfma_pipe_busy_pmc': mfma_pipe_busy(kname),
+                'algorithmic_ops': ops, 'i8_slices': slices, 'i8_slices_multiplied': core, 'compares_resolved_from_low_digits': undecided,
+                'mfma_pipe_busy_pmc': mfma_pipe_busy(kname),
                 'useful_mac_frac': useful / (k_ms * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                 'block_fill': float(wl.nbr.nnz) / (blocks * 256.0 * 32.0)}
     # Algorithmic HBM bytes of ONE launch: SURVEY 8(d) compulsory traffic = one read of the
@@ -843,7 +857,8 @@ def main():
     if share_device:
         local_rank = 0
     torch.cuda.set_device(local_rank)
-    numa_node = None if os.environ.get('SAFE_BENCH_NO_PIN') == '1' else be.pin_threads_to_device_numa(local_rank)
+    numa_node = None if os.environ.get('SAFE_BENCH_NO_PIN') == '1' else be.pin_threads_to_device_numa(
+        local_rank, reserve_draw_cores=int(os.environ.get('SAFE_BENCH_DRAW_CORES', '2')))
     torch.set_num_threads(1)      # no OpenMP spinning next to the host draw thread (container CPU quotas throttle it)
     ctx = be.Context.default(local_rank)          # (before the process group: see GPU_MAX_HW_QUEUES above)
     dist = None

@@ -75,6 +75,10 @@ int safe_set_blocking_sync(int on);
 int safe_ctx_set_stream(safe_ctx *ctx, void *hip_stream);
 int safe_ctx_sync(safe_ctx *ctx);
 int safe_ctx_info(safe_ctx *ctx, int *num_cu, int64_t *hbm_bytes, char *arch, size_t arch_len);
+/* How this library was built: the compiler version and the verdict of the build's disassembly check of the bit-sliced
+ * permutation kernel's hidden registers (the kernel behind run_permutations, safepy/safe_extras.py:36-70, keeps two id quads in
+ * registers the compiler does not allocate; a library built where the check could not run uses the form without them). */
+int safe_build_info(char *out, size_t out_len);
 int safe_dev_alloc(safe_ctx *ctx, size_t bytes, void **out_dev);
 int safe_dev_free(safe_ctx *ctx, void *dev);
 int safe_dev_memset(safe_ctx *ctx, void *dev, int value, size_t bytes);
@@ -381,6 +385,12 @@ int safe_last_mfma_filter(safe_ctx *ctx, int *core_slices, int64_t *undecided);
  * Buffers are cached per context and per handle shape, so a repeated call of the same shape is expected to add none
  * (the reference allocates every [N, M] temporary anew on each pass: safe_extras.py:50-66). */
 int safe_alloc_count(int64_t *calls);
+/* Host placement of the seeded stream's sequential part (np.random.seed / np.random.permutation, safepy/safe_extras.py:46,58):
+ * the CPUs the library's draw threads may run on (count = 0: wherever the process may).  For LAUNCHERS that place their own
+ * threads (bench.py, run_batch): keeping the draw thread off the hardware threads that share a core with the launcher's
+ * polling thread.  Applies to draw threads started after the call (one persistent thread per context, created at the
+ * first seeded call).  The library never re-pins its caller's threads. */
+int safe_set_draw_cpus(const int *cpus, int count);
 
 /* Name and average duration (ms) of the dominant kernel of the last enrichment call,
  * measured with HIP events on the context stream (bench.py's roofline object). */

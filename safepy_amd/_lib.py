@@ -129,6 +129,8 @@ PROTOTYPES = {
     'safe_last_mfma_slices': (C.c_int, [_vp, C.POINTER(C.c_int)]),
     'safe_last_mfma_filter': (C.c_int, [_vp, C.POINTER(C.c_int), _pi64]),
     'safe_alloc_count': (C.c_int, [C.POINTER(C.c_int64)]),
+    'safe_build_info': (C.c_int, [C.c_char_p, C.c_size_t]),
+    'safe_set_draw_cpus': (C.c_int, [C.POINTER(C.c_int), C.c_int]),
     'safe_perms_create_from_table': (C.c_int, [_vp, _i64, _i64, _vp, _pp]),
     'safe_perms_slice': (C.c_int, [_vp, _i64, _i64, _pp]),
     'safe_outputs_from_counts': (C.c_int, [_vp, _i64, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp]),

@@ -21,11 +21,37 @@ def _ptr(a):
     return C.c_void_p(a.ctypes.data) if a is not None else None
 
 
-def pin_threads_to_device_numa(device=0):
+def _split_off_cores(cpus, n_cores, slot=0):
+    """(CPUs of `n_cores` whole physical cores, the rest) of the CPU set `cpus`, or None when the topology cannot be read or
+    fewer than n_cores + 2 cores would be left."""
+    by_core = {}
+    for c in sorted(cpus):
+        try:
+            sib = set()
+            for part in open('/sys/devices/system/cpu/cpu%d/topology/thread_siblings_list' % c).read().strip().split(','):
+                lo, _, hi = part.partition('-')
+                sib.update(range(int(lo), int(hi or lo) + 1))
+        except OSError:
+            return None
+        if sib <= cpus:                                   # only cores whose hardware threads are all ours to use
+            by_core[min(sib)] = sib
+    cores = sorted(by_core)
+    if len(cores) < n_cores * (slot + 1) + 2:
+        return None
+    taken = set()
+    hi = len(cores) - n_cores * slot                      # (ranks of one node take different cores: slot = local rank)
+    for c in cores[hi - n_cores:hi]:
+        taken |= by_core[c]
+    return taken, set(cpus) - taken
+
+
+def pin_threads_to_device_numa(device=0, reserve_draw_cores=0):
     """Keep every thread this process has -- and those it starts later: the draw thread -- on the CPUs of the NUMA node the GPU hangs off.  A container may be scheduled on any CPU of a
     two-socket host; with the draw thread on the far socket a whole run is ~15-20 % slower (5.2 vs 5.4-6.2
     ms/step at configs[1]).  Returns the node, or None when the topology cannot be read (nothing is changed
-    then).  For launchers (bench.py, run_batch): a library does not re-pin its caller behind its back."""
+    then).  For launchers (bench.py, run_batch): a library does not re-pin its caller behind its back.
+    reserve_draw_cores = k > 0: k whole physical cores of that node are set aside for the library's draw thread
+    (safe_set_draw_cpus) and every other thread of the process is kept off them."""
     import os
     try:
         buf = C.create_string_buffer(32)
@@ -41,9 +67,18 @@ def pin_threads_to_device_numa(device=0):
         cpus &= os.sched_getaffinity(0)
         if not cpus:
             return None
+        mine = cpus
+        if reserve_draw_cores:
+            # whole physical cores for the library's draw thread: nothing else of this process then shares a core with it
+            # (a polling launcher on the sibling hardware thread slows the sequential draw chain by a third)
+            split = _split_off_cores(cpus, int(reserve_draw_cores), int(device))
+            if split is not None:
+                draw_cpus, mine = split
+                arr = (C.c_int * len(draw_cpus))(*sorted(draw_cpus))
+                check(lib.safe_set_draw_cpus(arr, len(draw_cpus)))
         for tid in os.listdir('/proc/self/task'):
             try:
-                os.sched_setaffinity(int(tid), cpus)
+                os.sched_setaffinity(int(tid), mine)
             except OSError:
                 pass
         return node
@@ -588,6 +623,13 @@ def last_mfma_slices(ctx):
     v = C.c_int()
     check(lib.safe_last_mfma_slices(ctx.handle, C.byref(v)))
     return v.value
+
+
+def build_info():
+    """Compiler version and build-time checks of the loaded library."""
+    buf = C.create_string_buffer(512)
+    check(lib.safe_build_info(buf, 512))
+    return buf.value.decode()
 
 
 def last_mfma_filter(ctx):

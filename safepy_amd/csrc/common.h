@@ -32,7 +32,8 @@ unsigned safe_event_flags(unsigned base);
 bool safe_blocking_sync_selected();
 // A diagnostic switch that makes a kernel skip work (timing experiments: SAFE_HIP_BITS_DBG, SAFE_HIP_MFMA_DBG*) is in effect: says so
 // on stderr, once per switch -- results of such a run are WRONG by construction and must not be mistaken for the product's.
-void safe_warn_diagnostic(const char *name);   // blocking (sleeping) host waits are on: do not spin
+void safe_warn_diagnostic(const char *name);
+bool safe_hidden_regs_checked();                // buildinfo.cpp: the build's disassembly check of the id-stream registers passed   // blocking (sleeping) host waits are on: do not spin
 
 #define SAFE_HIP_CHECK(expr)                                                                   \
     do {                                                                                       \
@@ -67,8 +68,24 @@ struct KernelStat {
     double busy_ms = 0.0;           // union of the launches' intervals (consecutive launches overlap on two streams); 0 = not measured
 };
 
+struct safe_perms;
+// The context's draw thread (rng.cpp): one persistent host thread runs the sequential part of every seeded stream of the
+// context (np.random.seed / np.random.permutation, safepy/safe_extras.py:46,58).  A thread created per call started on whatever
+// idle core the scheduler found -- clock and caches cold -- and one step in twenty drew 1.5-2 x slower; the persistent thread
+// spins briefly for its next job before it sleeps, so back-to-back calls never pay a wake-up either.
+struct DrawWorker {
+    std::thread th;
+    std::mutex mu;
+    std::condition_variable cv;                 // job posted / worker idle again
+    std::atomic<safe_perms *> job{nullptr};     // posted, not yet taken
+    bool busy = false;                          // (under mu) a job is running
+    bool quit = false;
+};
+void draw_worker_shutdown(safe_ctx *ctx);
+
 struct safe_ctx {
     int device = 0;
+    DrawWorker *draw_worker = nullptr;
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;           // permutation-table generation (overlaps the enrichment kernels)
@@ -100,6 +117,7 @@ struct safe_ctx {
     static constexpr int D2H_SLOTS = 8;
     static constexpr size_t D2H_SLOT_BYTES = size_t(4) << 20;
     void *d2h_ring = nullptr;
+    std::mutex d2h_mu;                          // the ring serves one read-back at a time
     hipEvent_t d2h_events[D2H_SLOTS] = {};
     std::vector<hipEvent_t> ev_timing, ev_plain;   // reused per-launch events (creating 20 per call costs ~0.1 ms)
     std::vector<std::pair<size_t, void *>> block_cache;   // small device blocks of destroyed handles (ctx_block_alloc)
@@ -296,7 +314,9 @@ struct safe_perms {
     std::vector<uint32_t> h_local;                 // the draw thread's private buffer: the targets of one shuffle (L1-resident)
     // the draw thread: runs the sequential MT19937 / rejection stream chunk by chunk into the pinned staging buffers, at most
     // kStage chunks ahead of the uploads, independent of the thread that launches kernels
-    std::thread drawer;
+    std::thread drawer;                            // a thread of its own (only when the context's draw worker is busy with another handle)
+    bool on_worker = false;                        // this handle's draws run (or ran) on ctx->draw_worker
+    bool worker_done = false;                      // (under the worker's mutex) ... and have ended
     std::mutex draw_mu;
     std::condition_variable draw_cv;
     int64_t drawn_chunks = 0;                      // chunks whose targets are complete in h_stage[c % kStage]

@@ -227,6 +227,7 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->k0) (void)hipEventDestroy(ctx->k0);
     if (ctx->k1) (void)hipEventDestroy(ctx->k1);
     perms_cache_drop(ctx);
+    draw_worker_shutdown(ctx);
     if (ctx->ring) ring_close(ctx->ring);
     ctx->ring = nullptr;
     if (ctx->pinned) (void)hipHostFree(ctx->pinned);
@@ -310,14 +311,31 @@ int safe_memcpy_h2d(safe_ctx *ctx, void *dev, const void *host, size_t bytes) {
 // is bound by the host side of a pageable copy: one thread takes every first-touch page fault and does the copy out of the
 // runtime's staging buffer (8.2 ms per 139 MB = 17 GB/s measured).  Here the DMA engine fills a ring of pinned 4 MB slots
 // (~50 GB/s) and a few host threads copy finished slots into the destination -- faults and copies in parallel.
-static int d2h_pipelined(safe_ctx *ctx, char *host, const char *dev, size_t bytes, int workers) {
+static int d2h_pipelined(safe_ctx *ctx, char *host, const char *dev, size_t bytes, int workers, bool *fallback) {
     constexpr int R = safe_ctx::D2H_SLOTS;
     constexpr size_t S = safe_ctx::D2H_SLOT_BYTES;
+    // one read-back at a time per context (ctypes releases the GIL: two Python threads may call safe_memcpy_d2h on one context)
+    std::lock_guard<std::mutex> ring_guard(ctx->d2h_mu);
     if (!ctx->d2h_ring) {
+        // published only when complete: a failed allocation or event leaves no half-made ring behind, and the caller takes the
+        // plain copy (*fallback)
+        void *ring_mem = nullptr;
+        hipEvent_t evs[R] = {};
         g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
-        SAFE_HIP_CHECK(hipHostMalloc(&ctx->d2h_ring, R * S, hipHostMallocDefault));
-        for (int i = 0; i < R; ++i) SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->d2h_events[i], hipEventDisableTiming));
+        bool ok = hipHostMalloc(&ring_mem, R * S, hipHostMallocDefault) == hipSuccess;
+        for (int i = 0; ok && i < R; ++i) ok = hipEventCreateWithFlags(&evs[i], safe_event_flags(hipEventDisableTiming)) == hipSuccess;
+        if (!ok) {
+            for (hipEvent_t e : evs)
+                if (e) (void)hipEventDestroy(e);
+            if (ring_mem) (void)hipHostFree(ring_mem);
+            (void)hipGetLastError();
+            *fallback = true;
+            return SAFE_OK;
+        }
+        for (int i = 0; i < R; ++i) ctx->d2h_events[i] = evs[i];
+        ctx->d2h_ring = ring_mem;
     }
+    const bool sleepy = safe_blocking_sync_selected();     // few cores per rank: the waits below yield instead of spinning
     const int64_t n_chunks = static_cast<int64_t>((bytes + S - 1) / S);
     std::atomic<int64_t> issued{0};                       // chunks whose copy into their slot has been queued (event recorded)
     std::atomic<int64_t> slot_done[R];                    // per slot: the last chunk copied out of it, + 1
@@ -330,8 +348,9 @@ static int d2h_pipelined(safe_ctx *ctx, char *host, const char *dev, size_t byte
         for (int64_t c = w; c < n_chunks; c += workers) {
             while (issued.load(std::memory_order_acquire) <= c) {
                 if (failed.load(std::memory_order_relaxed)) return;
+                if (sleepy) std::this_thread::yield();
 #if defined(__x86_64__)
-                __builtin_ia32_pause();
+                else __builtin_ia32_pause();
 #endif
             }
             const int s = static_cast<int>(c % R);
@@ -351,8 +370,9 @@ static int d2h_pipelined(safe_ctx *ctx, char *host, const char *dev, size_t byte
         const int s = static_cast<int>(c % R);
         while (c >= R && slot_done[s].load(std::memory_order_acquire) < c - R + 1) {      // the slot's previous chunk has been copied out
             if (failed.load(std::memory_order_relaxed)) break;
+            if (sleepy) std::this_thread::yield();
 #if defined(__x86_64__)
-            __builtin_ia32_pause();
+            else __builtin_ia32_pause();
 #endif
         }
         if (failed.load(std::memory_order_relaxed)) break;
@@ -380,7 +400,11 @@ int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes) {
     // help); a 17 MB copy into recycled memory runs at 55 GB/s as it is and stays on the plain path.
     int workers = safe_blocking_sync_selected() ? 2 : 4;
     if (const char *env = getenv("SAFE_HIP_D2H_THREADS")) workers = atoi(env);
-    if (workers > 0 && bytes >= (size_t(64) << 20)) return d2h_pipelined(ctx, static_cast<char *>(host), static_cast<const char *>(dev), bytes, std::min(workers, 16));
+    if (workers > 0 && bytes >= (size_t(64) << 20)) {
+        bool fallback = false;
+        const int rc = d2h_pipelined(ctx, static_cast<char *>(host), static_cast<const char *>(dev), bytes, std::min(workers, 16), &fallback);
+        if (rc != SAFE_OK || !fallback) return rc;          // (fallback: the pinned ring could not be made -- the plain copy below)
+    }
     SAFE_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
     SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
     return SAFE_OK;

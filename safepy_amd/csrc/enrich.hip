@@ -1109,6 +1109,7 @@ __device__ __forceinline__ void blk_add8(u32x4 &c, const u32x4 *__restrict__ ref
 
 // (the clobber lists below name registers that are RESERVED in the stream kernels -- that is the point: see the next comment; the
 // check that the compiler keeps out of them is tests/test_abi.py's disassembly of the shipped code object)
+#pragma clang diagnostic push
 #pragma clang diagnostic ignored "-Winline-asm"
 // The stream form of blk_add8 (k_permtest_bits_blk's permutation loop).  The two id quads live in v[112:115] (Q = 0) and
 // v[116:119] (Q = 1), registers the compiler does not know about: the kernel is built with 112 registers (amdgpu_num_vgpr) and the
@@ -1440,6 +1441,7 @@ __device__ __forceinline__ void blk_task_core(const uint32_t *__restrict__ obs, 
     // (the two fetches past the stream's end: landed before anything else is asked of the vector-memory counter)
     if (STREAM) asm volatile("s_waitcnt vmcnt(0)" : : : "v112", "v113", "v114", "v115", "v116", "v117", "v118", "v119");
 }
+#pragma clang diagnostic pop
 
 template <int LV, int CL, int DBG, int CLT = CL, bool OBSMEM = false>
 __device__ __forceinline__ void blk_task(const uint32_t *__restrict__ obs, const u32x4 *__restrict__ perm_ids, int64_t perm_stride,
@@ -2696,7 +2698,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             }
             plan.launch_list[c] = static_cast<int64_t>(k);
         }
-        plan.key = plan_key;
+        // (plan.key is set LAST, below: an allocation or a wait that fails on the way leaves no key, and the next call rebuilds
+        // the plan instead of uploading from a missing or stale pinned copy)
         const size_t bytes = plan.tasks.size() * sizeof(int4);
         if (nbr->bits_plan_pinned_bytes < bytes) {
             SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));                 // (an earlier pass may still be reading the old copy)
@@ -2710,6 +2713,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
         }
         memcpy(nbr->bits_plan_pinned, plan.tasks.data(), bytes);
+        plan.key = plan_key;
     }
     const std::vector<int4> &tasks = plan.tasks;
     const std::vector<int64_t> &list_first = plan.list_first, &list_count = plan.list_count, &launch_list = plan.launch_list;
@@ -2742,8 +2746,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // step 3.01 -> 3.19 -> 3.43 ms, tools/exp_ab.sh): the later launches' workgroups take slots from the long tasks of the first
     int NS = 2;
     if (const char *e = getenv("SAFE_HIP_BITS_STREAMS")) NS = std::min(4, std::max(2, atoi(e)));
+#ifdef SAFE_HIP_DIAG
     const int diag_banks = getenv("SAFE_HIP_BITS_DIAG_BANKS") ? 1 : 0;      // (wrong results: conflict-free gather addresses, see k_permute_cols)
     if (diag_banks) safe_warn_diagnostic("SAFE_HIP_BITS_DIAG_BANKS");
+#else
+    const int diag_banks = 0;
+#endif
     uint16_t *d_ids[4] = {nullptr, nullptr, nullptr, nullptr};
     if (pre)
         for (int b = 0; b < NS; ++b)
@@ -2754,24 +2762,42 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
     const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
+    // SAFE_HIP_BITS_DBG: variants of the blocked kernel.  32 / 128 / 256 / 384 / 512 / 640 give correct results (A/B: one-stage carry
+    // ripple, ..., 256 = no id stream = no hidden registers, 512 = no half-block gather pipeline); 1 / 2 / 4 / 8 / 16 / 64 skip work
+    // (WRONG results) and exist only in a library built with `make DIAG=1`.  Anything else is refused.
     int dbg = 0;
-    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e) & 1023;
-    if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");             // (bit 5 = a correct variant for A/B: the carry ripple in ONE stage as in rounds 2-3; two stages measure 1 % faster)
-    const void *blk_fn = dbg == 0 && occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 0, 5>)
-                         : dbg == 0 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>)
-                         : dbg == 1 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>)
-                         : dbg == 2 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>)
-                         : dbg == 4 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>)
-                         : dbg == 8 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>)
-                         : dbg == 16 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>)
-                         : dbg == 32 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 32>)
-                         : dbg == 64 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 64>)
-                         : dbg == 128 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 128>)
-                         : dbg == 256 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 256, 4>)
-                         : dbg == 384 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 384, 4>)
-                         : dbg == 512 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 512>)
-                         : dbg == 640 ? reinterpret_cast<const void *>(k_permtest_bits_blk<8, 640>)
-                                    : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>);
+    if (const char *e = getenv("SAFE_HIP_BITS_DBG")) dbg = atoi(e);
+    if (dbg == 0 && !occ5 && !safe_hidden_regs_checked()) {
+        // the build could not disassemble the stream kernels (no llvm-objdump): nothing vouches for the registers they hide from
+        // the compiler, so the form without them runs (the same counts, ~5 % slower)
+        static bool told = false;
+        if (!told) fprintf(stderr, "safepy_amd: this library was built without the hidden-register check; running k_permtest_bits_blk without the id stream\n");
+        told = true;
+        dbg = 256;
+    }
+    const void *blk_fn = nullptr;
+    switch (dbg) {
+        case 0: blk_fn = occ5 ? reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 0, 5>) : reinterpret_cast<const void *>(k_permtest_bits_blk<8, 0>); break;
+        case 32: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 32>); break;
+        case 128: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 128>); break;
+        case 256: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 256, 4>); break;
+        case 384: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk_plain<8, 384, 4>); break;
+        case 512: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 512>); break;
+        case 640: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 640>); break;
+#ifdef SAFE_HIP_DIAG
+        case 1: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1>); break;
+        case 2: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2>); break;
+        case 4: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 4>); break;
+        case 7: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 7>); break;
+        case 8: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>); break;
+        case 16: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>); break;
+        case 64: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 64>); break;
+#endif
+        default:
+            SAFE_REQUIRE(false, "SAFE_HIP_BITS_DBG=%d is not a variant of this build (correct variants: 0 32 128 256 384 512 640; the "
+                                "work-skipping ones 1 2 4 7 8 16 64 need a library built with make DIAG=1)", dbg);
+    }
+    if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");
     uint32_t *d_obs = nullptr;
     if (blk) {
         SAFE_HIP_CHECK(hipFuncSetAttribute(blk_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));

@@ -391,6 +391,13 @@ __device__ __forceinline__ void transpose4(const uint32_t (&in)[4], uint32_t (&o
     out[3] = __builtin_amdgcn_perm(hi23, hi01, 0x07060302u);
 }
 
+// (diagnostic switches of the general kernel -- SAFE_HIP_MFMA_DBG bits 1 / 4 / 8: no transposed stores / no barrier / no score
+// completion, WRONG results -- exist only in a library built with make DIAG=1)
+#ifdef SAFE_HIP_DIAG
+#define MF_DIAG(x) (x)
+#else
+#define MF_DIAG(x) false
+#endif
 // COUNTS = false: the permutation test (six i8 slices of ONE 32-column tile per task).
 // COUNTS = true : observed counts only, for 0/1 attributes (hypergeometric path, 'sum' scores): the six
 //                 planes of a task are six adjacent 32-column TILES with one plane each, n_q = 1, and
@@ -643,7 +650,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     }
                     // a quarter of the next super-step's tile goes to the other buffer while the
                     // matrix pipe works through this k-step
-                    if (gth && more1 && !(hl.dbg & 1)) store_quarter(L_store, k, buf ^ 1);
+                    if (gth && more1 && !MF_DIAG(hl.dbg & 1)) store_quarter(L_store, k, buf ^ 1);
                     if constexpr (PF) {
 #pragma unroll
                         for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[PF ? s : 0];
@@ -652,7 +659,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 
                 if constexpr (COUNTS) {
                     // (the counts are written once, after the loop)
-                } else if (t == S - 1 && !(hl.dbg & 8)) {            // a score is complete
+                } else if (t == S - 1 && !MF_DIAG(hl.dbg & 8)) {     // a score is complete
                     uint32_t undecided = 0;                                 // (filter) outputs the high digits leave open
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
@@ -728,7 +735,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) aw[k] = aw_next[k];
-                if (!(hl.dbg & 4)) __syncthreads();
+                if (!MF_DIAG(hl.dbg & 4)) __syncthreads();
                 q = q1, t = t1;
                 q1 = q2, t1 = t2;
                 q2 = q3, t2 = t3;
@@ -1476,12 +1483,14 @@ int build_blocks(safe_nbr *nbr) {
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_ptr, ptr.data(), ptr.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!kbs.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_kb, kbs.data(), kbs.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!bits.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits, bits.data(), bits.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+#ifdef SAFE_HIP_DIAG
     if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS")) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG_NOMEMBERS");
     if (getenv("SAFE_HIP_MFMA_DBG_NOMEMBERS") && !bits.empty())          // diagnostic: every piece empty -> no MFMA is issued (wrong results)
     {
         SAFE_HIP_CHECK(hipMemset(nbr->bs_bits, 0, bits.size() * sizeof(uint32_t)));
         SAFE_HIP_CHECK(hipMemset(nbr->bs_bits4, 0, bits.size() * sizeof(uint32_t)));
     }
+#endif
     nbr->blocks_ready = true;
     (void)ctx;
     return SAFE_OK;
@@ -2173,8 +2182,12 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     if (filt) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_obs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+#ifdef SAFE_HIP_DIAG
     static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
     if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
+#else
+    constexpr int mfma_dbg = 0;
+#endif
     const void *kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
 #ifdef SAFE_HIP_DIAG
 #define MF_F_DIAG(D) if (mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<D>);
@@ -2237,8 +2250,12 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         hipStream_t ks = (c & 1) ? ctx->side_stream : ctx->stream;
         if (long_launches && c >= 1) SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->aux_stream, ev[2 * (c - 1) + 1], 0));
         SAFE_TRY(perms_wait(perms, p_limit, ks));
+#ifdef SAFE_HIP_DIAG
         static const int dbg_window = getenv("SAFE_HIP_MFMA_DBG_WINDOW") ? atoi(getenv("SAFE_HIP_MFMA_DBG_WINDOW")) : 0;
         if (dbg_window > 0) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG_WINDOW");
+#else
+        constexpr int dbg_window = 0;
+#endif
         hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), cnt + 1), dim3(256), 0, ks, nbr->bs_order, n_src, n, perms->table,
                            p_base, d_src[c & 1], dbg_window);
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));

@@ -615,15 +615,120 @@ static void drawer_main(safe_perms *p) {
     }
 }
 
+// CPUs the draw threads of this process may run on (safe_set_draw_cpus; empty = wherever the process may)
+static std::mutex g_draw_cpu_mu;
+static std::vector<int> g_draw_cpus;
+
+int safe_set_draw_cpus(const int *cpus, int count) {
+    SAFE_REQUIRE(count == 0 || cpus, "safe_set_draw_cpus: NULL argument");
+    std::lock_guard<std::mutex> lk(g_draw_cpu_mu);
+    g_draw_cpus.assign(cpus, cpus + std::max(count, 0));
+    return SAFE_OK;
+}
+
+static void draw_thread_apply_cpus() {
+    std::lock_guard<std::mutex> lk(g_draw_cpu_mu);
+    if (g_draw_cpus.empty()) return;
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    for (int c : g_draw_cpus)
+        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+    (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);      // (best effort: a refused mask leaves the thread where it was)
+}
+
+static void draw_worker_main(safe_ctx *ctx) {
+    DrawWorker *w = ctx->draw_worker;
+    pthread_setname_np(pthread_self(), "safe-draw");
+    draw_thread_apply_cpus();
+    (void)hipSetDevice(ctx->device);
+    static const double spin_s = [] {
+        const char *e = getenv("SAFE_HIP_DRAW_IDLE_SPIN_US");              // how long the idle worker polls before it sleeps
+        return 1e-6 * (e ? std::max(0, atoi(e)) : 1500);
+    }();
+    for (;;) {
+        safe_perms *p = nullptr;
+        if (!safe_blocking_sync_selected()) {
+            const double t0 = wall_s();
+            while (!(p = w->job.exchange(nullptr, std::memory_order_acq_rel)) && wall_s() - t0 < spin_s) cpu_relax();
+        }
+        if (!p) {
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return w->quit || (p = w->job.exchange(nullptr, std::memory_order_acq_rel)) != nullptr; });
+            if (!p) return;                                                // quit
+        }
+        drawer_main(p);
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            p->worker_done = true;
+            w->busy = false;
+        }
+        w->cv.notify_all();
+    }
+}
+
+void draw_worker_shutdown(safe_ctx *ctx) {
+    DrawWorker *w = ctx->draw_worker;
+    if (!w) return;
+    {
+        std::lock_guard<std::mutex> lk(w->mu);
+        w->quit = true;
+    }
+    w->cv.notify_all();
+    if (w->th.joinable()) w->th.join();
+    delete w;
+    ctx->draw_worker = nullptr;
+}
+
 static void drawer_start(safe_perms *p) {
     p->drawn_chunks = p->enqueued_chunks = 0;
     p->drawn_chunks_pub.store(0, std::memory_order_release);
     p->draw_stop = false;
     p->draw_failed = false;
-    if (p->count > 0 && !p->ring_consumer) p->drawer = std::thread(drawer_main, p);
+    p->on_worker = false;
+    p->worker_done = false;
+    if (p->count <= 0 || p->ring_consumer) return;
+    safe_ctx *ctx = p->ctx;
+    static const bool per_call = getenv("SAFE_HIP_DRAW_THREAD") && !strcmp(getenv("SAFE_HIP_DRAW_THREAD"), "percall");   // (A/B: a thread per handle)
+    if (!per_call) {
+        if (!ctx->draw_worker) {
+            ctx->draw_worker = new DrawWorker;
+            ctx->draw_worker->th = std::thread(draw_worker_main, ctx);
+        }
+        DrawWorker *w = ctx->draw_worker;
+        bool taken = false;
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            if (!w->busy) {                                               // (one stream at a time: a second live handle gets its own thread)
+                w->busy = true;
+                taken = true;
+            }
+        }
+        if (taken) {
+            p->on_worker = true;
+            w->job.store(p, std::memory_order_release);
+            w->cv.notify_all();                                            // (a polling worker sees the store; a sleeping one this)
+            return;
+        }
+    }
+    p->drawer = std::thread([p] {
+        draw_thread_apply_cpus();
+        drawer_main(p);
+    });
 }
 
 static void drawer_stop(safe_perms *p) {
+    if (p->on_worker) {
+        {
+            std::lock_guard<std::mutex> lk(p->draw_mu);
+            p->draw_stop = true;
+        }
+        p->draw_cv.notify_all();
+        DrawWorker *w = p->ctx->draw_worker;
+        std::unique_lock<std::mutex> lk(w->mu);
+        w->cv.wait(lk, [&] { return p->worker_done; });
+        p->on_worker = false;
+        return;
+    }
     if (!p->drawer.joinable()) return;
     {
         std::lock_guard<std::mutex> lk(p->draw_mu);

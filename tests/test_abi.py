@@ -73,30 +73,61 @@ def test_product_never_imports_the_oracle():
                 assert 'safe_oracle' not in text and 'import oracle' not in text and 'from oracle' not in text, f
 
 
+def _hidden_regs_checker():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('check_hidden_regs', os.path.join(ROOT, 'safepy_amd', 'csrc', 'check_hidden_regs.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_hidden_register_check_reads_register_ranges_numerically():
+    """The build's guard (safepy_amd/csrc/check_hidden_regs.py, run by make on the fresh enrich.o) must see a reserved register
+    inside ANY range -- v[104:127] names v112..v119 although neither end is one of them."""
+    chk = _hidden_regs_checker()
+    for text in ('v_mov_b32_e32 v115, v3', 'global_load_dwordx4 v[112:115], v20, s[4:5]', 'v_mfma_f32_32x32x2_f32 v[104:127], v1, v2, v[104:127]',
+                 'ds_read_b64 v[118:119], v7', 'v_add_u32_e32 v3, v119, v4', 'scratch_store_dwordx4 off, v[116:119], off'):
+        assert chk.names_reserved(text), text
+    for text in ('v_mov_b32_e32 v111, v120', 'global_load_dwordx4 v[108:111], v20, s[4:5]', 'v_add_u32_e32 v1, 0x112, v2', 'ds_read_b64 v[120:121], v7',
+                 's_mov_b32 s112, s119', 'v_mfma_f32_32x32x2_f32 v[96:111], v1, v2, v[96:111]'):
+        assert not chk.names_reserved(text), text
+    assert chk.OWN.match('global_load_dwordx4 v[116:119], v57, s[8:9]') and chk.OWN.match('v_and_b32_e32 v3, 0xffff, v113')
+    assert not chk.OWN.match('global_load_dwordx4 v[114:117], v57, s[8:9]')
+
+
+def test_the_build_ran_the_hidden_register_check():
+    """The library says how it was built: with llvm-objdump present (this image) the check must have PASSED -- a failed check stops
+    make before the library is linked; without it the library announces that the form without hidden registers runs."""
+    from safepy_amd import backend as be
+    info = be.build_info()
+    assert 'hipcc' in info
+    if os.path.exists('/opt/rocm/lib/llvm/bin/llvm-objdump'):
+        assert 'hidden-register check passed' in info, info
+    else:
+        assert 'NOT run' in info, info
+    assert 'DIAGNOSTIC' not in info, 'the shipped library must be built without the work-skipping diagnostic variants (make DIAG=1)'
+
+
 def test_id_stream_registers_stay_hidden_from_the_compiler(tmp_path):
     """k_permtest_bits_blk keeps its two id quads in v[112:119] behind the compiler's back (enrich.hip, blk_add8s / blk_step: the
-    kernel is compiled with 112 registers, the asm clobber lists make the allocation 120).  If a compiler ever placed a value of
-    its own in one of those registers the prefetches would overwrite it silently -- so the SHIPPED code object is disassembled
-    here and every instruction of those kernels that names v112..v119 must be one of the stream's own: the fetch
-    (global_load_dwordx4 into a whole quad) or an id extraction (v_and_b32 0xffff / v_lshrrev_b32 16 reading one of them)."""
+    kernel is compiled with 112 registers, the asm clobber lists make the allocation 120).  The build checks the fresh object file
+    (previous test); here the SHIPPED library is disassembled once more with the same rules: every instruction of those kernels
+    that names v112..v119 -- singly or inside a range -- must be one of the stream's own."""
     import glob
     import shutil
     import subprocess
     from safepy_amd import _lib
+    chk = _hidden_regs_checker()
     objdump = '/opt/rocm/lib/llvm/bin/llvm-objdump'
     if not os.path.exists(objdump):
-        pytest.skip('no llvm-objdump in this image')
+        pytest.skip('no llvm-objdump in this image (the library then runs the form without hidden registers: previous test)')
     lib = str(tmp_path / 'lib.so')
     shutil.copy(_lib.LIB_PATH, lib)
     subprocess.run([objdump, '--offloading', lib], capture_output=True, cwd=str(tmp_path), check=True)
-    named = re.compile(r'\bv11[2-9]\b|v\[\d+:11[2-9]\]|v\[11[2-9]:\d+\]')
-    own = re.compile(r'^(global_load_dwordx4 v\[11[26]:11[59]\], v\d+, s\[\d+:\d+\]'
-                     r'|v_and_b32_e32 v\d+, 0xffff, v11[2-9]'
-                     r'|v_lshrrev_b32_e32 v\d+, 16, v11[2-9])\s*(//.*)?$')
     kernels, uses, foreign = set(), 0, []
     for co in sorted(glob.glob(str(tmp_path / 'lib.so.*gfx950'))):
         text = subprocess.run([objdump, '-d', '--no-show-raw-insn', co], capture_output=True, text=True, check=True).stdout
-        if 'k_permtest_bits_blkILi8E' not in text:
+        if chk.KERNEL not in text:
             continue
         sym = None
         for line in text.split('\n'):
@@ -104,10 +135,11 @@ def test_id_stream_registers_stay_hidden_from_the_compiler(tmp_path):
             if m:
                 sym = m.group(1)
                 continue
-            if sym and sym.startswith('_Z19k_permtest_bits_blkILi8E') and named.search(line.split('//')[0]):
+            ins = line.split('//')[0].strip()
+            if sym and sym.startswith(chk.KERNEL) and chk.names_reserved(ins):
                 kernels.add(sym)
                 uses += 1
-                if not own.match(line.strip()):
-                    foreign.append((sym[:48], line.strip()))
+                if not chk.OWN.match(ins):
+                    foreign.append((sym[:48], ins))
     assert kernels and uses > 1000, 'the stream kernels were not found in the library'
     assert not foreign, foreign[:5]
