@@ -84,6 +84,10 @@ int safe_dev_free(safe_ctx *ctx, void *dev);
 int safe_dev_memset(safe_ctx *ctx, void *dev, int value, size_t bytes);
 int safe_memcpy_h2d(safe_ctx *ctx, void *dev, const void *host, size_t bytes);   /* synchronous */
 int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes);   /* synchronous */
+/* The same copy for a destination whose pages are RESIDENT (an array that has been written before, e.g. the recycled host
+ * array of a result matrix -- self.nes and its siblings, safepy/safe.py:530-554): one plain copy at the link's rate (56 GB/s
+ * measured), no helper threads.  (safe_memcpy_d2h spreads the page faults of a FRESH destination over copy threads.) */
+int safe_memcpy_d2h_resident(safe_ctx *ctx, void *host, const void *dev, size_t bytes);
 /* Event pair on the context stream, for timing a region that runs on that stream. */
 int safe_timer_start(safe_ctx *ctx);
 int safe_timer_stop_ms(safe_ctx *ctx, double *elapsed_ms);   /* synchronises */

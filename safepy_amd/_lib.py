@@ -82,6 +82,7 @@ PROTOTYPES = {
     'safe_dev_memset': (C.c_int, [_vp, _vp, C.c_int, C.c_size_t]),
     'safe_memcpy_h2d': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'safe_memcpy_d2h': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
+    'safe_memcpy_d2h_resident': (C.c_int, [_vp, _vp, _vp, C.c_size_t]),
     'safe_timer_start': (C.c_int, [_vp]),
     'safe_timer_stop_ms': (C.c_int, [_vp, C.POINTER(C.c_double)]),
     'safe_nbr_euclidean': (C.c_int, [_vp, _vp, _i64, C.c_double, _pp]),

@@ -145,7 +145,13 @@ class DeviceBuffer:
         assert host.nbytes <= self.nbytes
         check(lib.safe_memcpy_h2d(self.ctx.handle, C.c_void_p(self.ptr), _ptr(host), host.nbytes))
 
-    def download(self, shape, dtype=np.float64):
+    def download(self, shape, dtype=np.float64, out=None):
+        """Copy to the host: into a fresh array, or into `out` (an array whose pages are resident -- it has been written
+        before -- takes the plain copy at the link's rate; a fresh one the threaded copy that spreads its page faults)."""
+        if out is not None:
+            assert out.shape == tuple(shape) and out.dtype == dtype and out.flags.c_contiguous and out.nbytes <= self.nbytes
+            check(lib.safe_memcpy_d2h_resident(self.ctx.handle, _ptr(out), C.c_void_p(self.ptr), out.nbytes))
+            return out
         out = np.empty(shape, dtype=dtype)
         assert out.nbytes <= self.nbytes
         check(lib.safe_memcpy_d2h(self.ctx.handle, _ptr(out), C.c_void_p(self.ptr), out.nbytes))

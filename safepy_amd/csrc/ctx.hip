@@ -410,6 +410,15 @@ int safe_memcpy_d2h(safe_ctx *ctx, void *host, const void *dev, size_t bytes) {
     return SAFE_OK;
 }
 
+int safe_memcpy_d2h_resident(safe_ctx *ctx, void *host, const void *dev, size_t bytes) {
+    SAFE_REQUIRE(ctx != nullptr && (bytes == 0 || (dev && host)), "safe_memcpy_d2h_resident: NULL argument");
+    if (bytes == 0) return SAFE_OK;
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    SAFE_HIP_CHECK(hipMemcpyAsync(host, dev, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    SAFE_HIP_CHECK(safe_stream_sync(ctx->stream));
+    return SAFE_OK;
+}
+
 int safe_timer_start(safe_ctx *ctx) {
     SAFE_REQUIRE(ctx != nullptr, "safe_timer_start: ctx is NULL");
     SAFE_HIP_CHECK(hipEventRecord(ctx->t0, ctx->stream));

@@ -1635,6 +1635,10 @@ __device__ __forceinline__ void bits_blk_body(
         constexpr bool OM = WPS > 4;                                      // the wide classes' observed sums come from memory
         // a neighborhood of wdt members cannot sum past wdt: levels by slice width (wave-uniform branch)
         if (np <= 0) {
+        } else if (DBG & 1024) {       // (diagnostic, WRONG results: every class counts with four levels -- what bounding the levels by the attributes' carrier counts could gain at most)
+            blk_task<4, CL, DBG, CLN>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
+        } else if (DBG & 2048) {       // (the same with six levels)
+            blk_task<6, CL, DBG, CLN>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         } else if (wdt <= 8) blk_task<4, CL, DBG, CLN>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         else if (wdt <= 56) blk_task<6, CL, DBG, CLN>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         else if (wdt <= 248) blk_task<8, CL, DBG, CLW, OM>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
@@ -2792,12 +2796,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         case 8: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 8>); break;
         case 16: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 16>); break;
         case 64: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 64>); break;
+        case 1024: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 1024>); break;
+        case 2048: blk_fn = reinterpret_cast<const void *>(k_permtest_bits_blk<8, 2048>); break;
 #endif
         default:
             SAFE_REQUIRE(false, "SAFE_HIP_BITS_DBG=%d is not a variant of this build (correct variants: 0 32 128 256 384 512 640; the "
                                 "work-skipping ones 1 2 4 7 8 16 64 need a library built with make DIAG=1)", dbg);
     }
-    if (dbg & 95) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");
+    if (dbg & (95 | 1024 | 2048)) safe_warn_diagnostic("SAFE_HIP_BITS_DBG");
     uint32_t *d_obs = nullptr;
     if (blk) {
         SAFE_HIP_CHECK(hipFuncSetAttribute(blk_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));

@@ -9,8 +9,11 @@ domains and output writers of the reference are out of scope (SURVEY.md section 
 import configparser
 import logging
 import os
+import sys
 
 import numpy as np
+import pandas as pd        # noqa: F401  at import, like the reference (safepy/safe.py:19): the first compute_pvalues() of a process
+                           # used to pay for it -- 166 of its 178 ms
 
 from . import backend as be
 
@@ -89,8 +92,8 @@ class _DeviceResult:
     def __init__(self, buf, shape):
         self.buf, self.shape = buf, shape
 
-    def get(self):
-        host = self.buf.download(self.shape)
+    def get(self, into=None):
+        host = self.buf.download(self.shape, out=into)
         self.buf.free()
         return host
 
@@ -104,25 +107,45 @@ class _LazyArray:
     (safe.py:530-554, 596-608, 468-472); compute_pvalues() leaves the matrices on the device and the
     copy (139 MB each at 3971 x 4373, 1.6 GB each at 20 000 x 10 000 -- ten to a hundred times the
     compute) happens on the first read of each one, so results that are never looked at are never
-    moved.  `SAFE.lazy_outputs = False` restores the eager copies."""
+    moved.  `SAFE.lazy_outputs = False` restores the eager copies.
+
+    Host arrays are recycled: when a result this descriptor handed out is replaced (the next compute_pvalues(), or the caller
+    setting the attribute to None) the instance keeps the array, and the next read of the same shape copies into it -- IF nobody
+    else holds a reference to it (sys.getrefcount), so an array the caller kept (`old = sf.nes`) is never written again.  A
+    fresh 139 MB array costs 34 000 page faults on its first write (the copy runs at 35 GB/s) and as much again when it is
+    freed; into resident pages the same copy runs at the link's 56 GB/s."""
 
     def __init__(self, name):
         self.slot = '_r_' + name
+        self.made = '_made_' + name          # the host array this descriptor produced last (None: the caller's own value)
+        self.spare = '_spare_' + name        # a produced array that was replaced: may be written again if no one else holds it
 
     def __get__(self, obj, objtype=None):
         if obj is None:
             return self
-        v = obj.__dict__.get(self.slot)
+        d = obj.__dict__
+        v = d.get(self.slot)
         if isinstance(v, _DeviceResult):
-            v = v.get()
-            obj.__dict__[self.slot] = v
+            into = d.pop(self.spare, None)
+            # (local name + getrefcount's argument = 2: no reference outside this function)
+            if not (isinstance(into, np.ndarray) and into.shape == tuple(v.shape) and into.dtype == np.float64
+                    and into.flags.c_contiguous and into.flags.owndata and sys.getrefcount(into) == 2):
+                into = None
+            v = v.get(into)
+            del into
+            d[self.slot] = v
+            d[self.made] = v
         return v
 
     def __set__(self, obj, value):
-        old = obj.__dict__.get(self.slot)
+        d = obj.__dict__
+        old = d.get(self.slot)
         if isinstance(old, _DeviceResult):
             old.drop()
-        obj.__dict__[self.slot] = value
+        elif old is not None and old is d.get(self.made):
+            d[self.spare] = old                                   # ours: kept for the next read of this attribute
+        d[self.made] = None
+        d[self.slot] = value
 
 
 class SAFE:
@@ -601,7 +624,6 @@ class SAFE:
         self.nes_binary, enriched = self._pending_binary
         self._pending_binary = None
         if self.attributes is None:
-            import pandas as pd
             self.attributes = pd.DataFrame({'id': np.arange(len(enriched)), 'name': [str(j) for j in range(len(enriched))]})
         self.attributes['num_neighborhoods_enriched'] = enriched
 
