@@ -533,11 +533,14 @@ def mfma_kernel(ctx, np, be):
     dtz = time.perf_counter() - t0
     perms.close()
     zname, zms, zlaunches = ctx.last_kernel()
-    zops = 2.0 * pieces * 32 * 32 * (32 * ((m + 15) // 16)) * 7 * (nperm + 1)                 # executed pieces, as above
-    zstored = 2.0 * blocks * 256 * 32 * (32 * ((m + 15) // 16)) * 7 * (nperm + 1)
+    zcore, zund = be.last_mfma_filter(ctx)                # filtered: 3 high value | square slices + the not-NaN slice = 4 of 7
+    zpasses = nperm if zcore < 7 else nperm + 1           # (the observed pass of the filtered form runs all seven slices once: counted below)
+    zops = 2.0 * pieces * 32 * 32 * (32 * ((m + 15) // 16)) * (zcore * zpasses + (7 if zcore < 7 else 0))      # executed pieces, as above
+    zstored = 2.0 * blocks * 256 * 32 * (32 * ((m + 15) // 16)) * (zcore * zpasses + (7 if zcore < 7 else 0))
     out[zname + '<z-score>'] = {'bound': 'mfma', 'workload': 'the same share, z-scores', 'kernel_ms': zms * zlaunches, 'call_ms': 1e3 * dtz,
                                 'algorithmic_ops': zops, 'achieved': zops / (zms * zlaunches * 1e-3) / 1e12, 'peak': MFMA_I8_PEAK_TOPS,
                                 'unit': 'TOP/s', 'frac': zops / (zms * zlaunches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS, 'i8_slices': 7,
+                                'i8_slices_multiplied': zcore, 'compares_resolved_from_low_digits': zund, 'config5_rank_share_seconds': dtz,
                                 'stored_block_frac_of_peak': zstored / (zms * zlaunches * 1e-3) / 1e12 / MFMA_I8_PEAK_TOPS,
                                 'mfma_pipe_busy_pmc': mfma_pipe_busy(zname), 'enrichments_per_s': float(n) * m * nperm / dtz}
     for o in outs:

@@ -281,7 +281,8 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
                                                       int64_t col0, int64_t mloc, int64_t n_ct, const int *__restrict__ shift,
                                                       const int *__restrict__ shift2, const unsigned long long *__restrict__ maxbits,
                                                       unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
-                                                      unsigned int *__restrict__ n_small_rounded, unsigned int *__restrict__ n_zero) {
+                                                      unsigned int *__restrict__ n_small_rounded, unsigned int *__restrict__ n_zero,
+                                                      int64_t zf_hi_off, int64_t zf_lo_off) {
     __shared__ double tile[32][17];
     __shared__ unsigned int s_small[16], s_rounded[16], s_zero[16];
     const int64_t ct = blockIdx.x, r0 = static_cast<int64_t>(blockIdx.y) * 32, c0 = ct * 16;
@@ -331,6 +332,21 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
         }
         dst[MF_NS * 32] = present ? 1 : 0;
         dst[MF_NS * 32 + 16] = 0;
+        if (zf_hi_off) {
+            // the filtered form's layouts: high digits (3-5) of values | squares and the not-NaN slice, 128-byte rows; low digits
+            // (0-2), 96-byte rows (read by the resolve kernel only)
+            unsigned char *hi = bs + zf_hi_off + ct * ((n + 1) * 128) + r * 128 + tx;
+            unsigned char *lo = bs + zf_lo_off + ct * ((n + 1) * 96) + r * 96 + tx;
+#pragma unroll
+            for (int t = 0; t < 3; ++t) {
+                lo[t * 32] = static_cast<unsigned char>(((u1 >> (8 * t)) & 0xFFu) ^ 0x80u);
+                lo[t * 32 + 16] = static_cast<unsigned char>(((u2 >> (8 * t)) & 0xFFu) ^ 0x80u);
+                hi[t * 32] = static_cast<unsigned char>(((u1 >> (8 * (t + 3))) & 0xFFu) ^ 0x80u);
+                hi[t * 32 + 16] = static_cast<unsigned char>(((u2 >> (8 * (t + 3))) & 0xFFu) ^ 0x80u);
+            }
+            hi[3 * 32] = present ? 1 : 0;
+            hi[3 * 32 + 16] = 0;
+        }
     }
     if (k_small) atomicAdd(&s_small[tx], k_small);
     if (k_rounded) atomicAdd(&s_rounded[tx], k_rounded);
@@ -434,6 +450,7 @@ struct MfmaFilt {
     int obs_shift = 0;
     int p_base = 0;                           // the launch's first permutation
     unsigned long long *prof = nullptr;       // (diagnostic build 512) cycles per phase, summed over waves: [wave 0-3][8]
+    const double *zobs = nullptr;             // z-scores: the observed scores ns[node][column] (NaN = no test)
 };
 
 template <bool COUNTS, int NS, bool Z = false, bool SKIP = true, int EPI = 0, bool PREF = true, int FM = 0>
@@ -443,8 +460,9 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
     unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap,
     const double *__restrict__ col_scale, double *__restrict__ ns_out, HypLookup hl, MfmaFilt fa) {
-    static_assert(!Z || (NS == MF_NS + 1 && !COUNTS), "z-scores: six value slices + the not-NaN slice");
-    static_assert(FM == 0 || (NS == MF_NS / 2 && !COUNTS && !Z), "filtered form: three slices of 'sum' scores");
+    static_assert(!Z || !COUNTS, "z-scores are a permutation test");
+    static_assert(!Z || (FM == 0 && NS == MF_NS + 1) || (FM == 2 && NS == MF_NS / 2 + 1), "z-scores: six (filtered: three high) value | square slices + the not-NaN slice");
+    static_assert(FM == 0 || Z || (NS == MF_NS / 2 && !COUNTS), "filtered form: three slices of 'sum' scores");
     constexpr int KS = NS * MF_SS, BUF = 4 * KS;                            // LDS bytes per k-step / per super-step buffer
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] + kb list
     __shared__ int slot_box;
@@ -515,8 +533,22 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             for (int r = 0; r < 16; ++r) cnt[r] = 0;
             // filter: this lane's thresholds -- T0 in the LDS slot of the observed score, the window width in a register
             // (0xFFFFFFFF: padding row / column or an empty neighborhood: nothing is counted, nothing recorded)
-            uint32_t win[FM == 2 ? 16 : 1];
-            if constexpr (FM == 2) {
+            uint32_t win[(FM == 2 && !Z) ? 16 : 1];
+            double sc1sq = 1.0;
+            if constexpr (FM == 2 && Z) {
+                // z-scores, filtered: the observed scores of this lane's 16 outputs (formed by the seven-slice kernel in a pass of
+                // its own) go to the LDS slots; NaN (padding, squares' lanes, fewer than three values, no spread) = no test
+                sc1sq = sc1 * sc1;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t u = static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    const int32_t node = rowmap[u];
+                    const bool live = node >= 0 && colz < mloc && !(col_in_tile & 16);
+                    const double o = live ? fa.zobs[static_cast<int64_t>(node) * mloc + colz] : __longlong_as_double(0x7FF8000000000000ll);
+                    obs[r * 512] = __double_as_longlong(o);
+                }
+            }
+            if constexpr (FM == 2 && !Z) {
                 const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -619,7 +651,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 // PF: the B operands of k-step k+1 are read from LDS before the MFMAs of k-step k are issued (two operand sets).
                 // !PF: one operand set, read right before its MFMAs and only for the pieces that hold members -- the SIMD's other
                 // wave covers the LDS latency; the z-score form (seven slices: no room for a second set) always runs this way
-                constexpr bool PF = PREF && !Z;
+                constexpr bool PF = PREF && (!Z || NS <= 4);
                 v4i b_cur[NS], b_nxt[PF ? NS : 1];
                 if constexpr (PF) {
 #pragma unroll
@@ -663,11 +695,38 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     uint32_t undecided = 0;                                 // (filter) outputs the high digits leave open
 #pragma unroll
                     for (int r = 0; r < 16; ++r) {
-                        constexpr int NV = Z ? MF_NS : NS;                  // value slices
+                        constexpr int NV = Z ? (FM == 2 ? MF_NS / 2 : MF_NS) : NS;   // value slices
                         long long v = static_cast<long long>(acc[NV - 1][r]);
 #pragma unroll
                         for (int s = NV - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
-                        if constexpr (Z) {
+                        if constexpr (Z && FM == 2) {
+                            // The filtered z-score test.  Only the HIGH digits were multiplied: S1 = a + S1_low, S2 = b + S2_low with
+                            // |low| <= e = count * MF_LO_MAX.  z >= o is a statement about the sign of S1 and of
+                            //     T = S1^2 sc1^2 (1 + o^2) - o^2 S2 sc2 count          (mu / sigma >= o, squared and cleared of count^2)
+                            // so it is decided here whenever the signs are certain despite the low parts (and the f64 evaluation: a
+                            // 2^-40 margin); whatever is not -- including every score whose variance is not clearly positive --
+                            // goes to k_mfma_resolve_z, which evaluates the reference's formula on the exact sums.
+                            const int lo_sq = __shfl_xor(static_cast<int>(v), 4), hi_sq = __shfl_xor(static_cast<int>(v >> 32), 4);
+                            const long long w = (static_cast<long long>(hi_sq) << 32) | static_cast<long long>(static_cast<uint32_t>(lo_sq));
+                            const double o = __longlong_as_double(obs[r * 512]);
+                            const double members = static_cast<double>(acc[NS - 1][r]);
+                            if (o == o && members >= 3.0) {                  // (observed NaN: no test; fewer than 3 values: the score is NaN -- safe_extras.py:30)
+                                const double a = static_cast<double>(v) * 16777216.0, b = static_cast<double>(w) * 16777216.0;
+                                const double e = members * static_cast<double>(MF_LO_MAX);
+                                const double o2 = o * o, k1 = sc1sq * (1.0 + o2), k2 = o2 * sc2;
+                                const double slack1 = 2.0 * fabs(a) * e + e * e;                         // |S1^2 - a^2| <=
+                                const double p1 = a * a * k1, p2 = b * members * k2;
+                                const double T = p1 - p2;
+                                const double E = k1 * slack1 + k2 * members * e + (p1 + fabs(p2)) * 0x1p-40;
+                                const double V = b * members * sc2 - a * a * sc1sq;                      // count^2 * variance, high parts
+                                const bool var_ok = V - (sc2 * members * e + sc1sq * slack1) > fabs(b) * members * sc2 * 0x1p-20;
+                                const bool t_pos = T > E, t_neg = T < -E, s_pos = a > e, s_neg = a < -e;
+                                const bool greater = var_ok && (o >= 0.0 ? (s_pos && t_pos) : (s_pos || t_neg));
+                                const bool smaller = var_ok && (o >= 0.0 ? (s_neg || t_neg) : (s_neg && t_pos));
+                                cnt[r] += greater ? (1u << 16) : (smaller ? 1u : 0u);
+                                undecided |= (!greater && !smaller) ? (1u << r) : 0u;
+                            }
+                        } else if constexpr (Z) {
                             // columns 0-15 of the tile: sum (and count, slice 6); columns 16-31: sum of squares, one lane-bit away
                             const int lo_sq = __shfl_xor(static_cast<int>(v), 4), hi_sq = __shfl_xor(static_cast<int>(v >> 32), 4);
                             const long long w = (static_cast<long long>(hi_sq) << 32) | static_cast<long long>(static_cast<uint32_t>(lo_sq));
@@ -684,13 +743,13 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                                 const double o = __longlong_as_double(obs[r * 512]);
                                 cnt[r] += (static_cast<uint32_t>(zs >= o) << 16) | static_cast<uint32_t>(zs <= o);
                             }
-                        } else if constexpr (FM == 1) {
+                        } else if constexpr (FM == 1 && !Z) {
                             const int64_t colf = static_cast<int64_t>(ct) * 32 + col_in_tile;
                             if (colf < mloc) {
                                 long long *dst = fa.obs64 + colf * n_padr + static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
                                 *dst = fa.obs_shift ? *dst + (v << fa.obs_shift) : v;
                             }
-                        } else if constexpr (FM == 2) {
+                        } else if constexpr (FM == 2 && !Z) {
                             const long long x = v - obs[r * 512];
                             const bool below = x < 0;
                             const bool above = static_cast<unsigned long long>(x) > static_cast<unsigned long long>(win[FM == 2 ? r : 0]);
@@ -707,7 +766,25 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                             for (int s = 0; s < NS; ++s) acc[s][r] = 0;
                         }
                     }
-                    if constexpr (FM == 2) {
+                    if constexpr (FM == 2 && Z) {
+                        if (__builtin_expect(undecided != 0u, 0)) {
+                            const unsigned long long u0 = static_cast<unsigned long long>(static_cast<int64_t>(g) * MF_R + wrow + 4 * h);
+                            for (uint32_t left = undecided; left;) {
+                                const int r = __builtin_ctz(left);
+                                left &= left - 1u;
+                                const unsigned int at = atomicAdd(fa.amb_count, 1u);
+                                if (at >= fa.amb_cap) continue;
+                                fa.amb[at] = make_ulonglong2((u0 + static_cast<unsigned long long>((r & 3) + 8 * (r >> 2))) |
+                                                                 (static_cast<unsigned long long>(colz) << 32),
+                                                             (3ull << 62) | static_cast<unsigned long long>(fa.p_base + q));
+                            }
+                        }
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[s][r] = 0;
+                    }
+                    if constexpr (FM == 2 && !Z) {
                         // rare (~1e-5 of the compares): the low digits decide (k_mfma_resolve)
                         if (__builtin_expect(undecided != 0u, 0)) {
                             // a per-lane loop over the set bits with a DYNAMIC element index (a select chain over the sixteen
@@ -1983,6 +2060,60 @@ __global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restri
     }
 }
 
+// z-scores: one wave per undecided compare {row u, column, permutation}.  The exact sums of the permuted neighborhood -- values,
+// squares (all six digits of each) and the number of non-NaN members -- then the reference's formula (safe_extras.py:19-31) in
+// its order of operations, exactly as the seven-slice kernel evaluates it, against the observed score.
+__global__ __launch_bounds__(256) void k_mfma_resolve_z(const ulonglong2 *__restrict__ amb, const unsigned int *__restrict__ amb_count,
+                                                        unsigned int amb_cap, const double *__restrict__ zobs, int64_t mloc, int64_t n_padr,
+                                                        const int32_t *__restrict__ rowmap, const int32_t *__restrict__ row_ptr,
+                                                        const int32_t *__restrict__ col_idx, const int32_t *__restrict__ table, int64_t n,
+                                                        const unsigned char *__restrict__ bs_lo, const unsigned char *__restrict__ bs_hi,
+                                                        const double *__restrict__ col_scale, unsigned int *__restrict__ gl_counts) {
+    const unsigned int count = min(*amb_count, amb_cap);
+    const int lane = threadIdx.x & 63;
+    const unsigned int wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
+    for (unsigned int rec = wave0; rec < count; rec += n_waves) {
+        const ulonglong2 w = amb[rec];
+        const int64_t u = static_cast<int64_t>(w.x & 0xFFFFFFFFull), col = static_cast<int64_t>(w.x >> 32);
+        const int64_t perm = static_cast<int64_t>(w.y & 0xFFFFull);
+        const int32_t node = rowmap[u];
+        const int32_t e0 = row_ptr[node], e1 = row_ptr[node + 1];
+        const unsigned char *lo = bs_lo + (col >> 4) * ((n + 1) * 96) + (col & 15);
+        const unsigned char *hi = bs_hi + (col >> 4) * ((n + 1) * 128) + (col & 15);
+        const int32_t *cur = table + perm * (n + 1);
+        long long s1 = 0, s2 = 0;
+        int present = 0;
+        for (int32_t e = e0 + lane; e < e1; e += 64) {
+            const int64_t src = cur[col_idx[e]];
+            const signed char *l = reinterpret_cast<const signed char *>(lo + src * 96), *hh = reinterpret_cast<const signed char *>(hi + src * 128);
+            s1 += static_cast<long long>(static_cast<int>(l[0]) + 256 * static_cast<int>(l[32]) + 65536 * static_cast<int>(l[64])) +
+                  (static_cast<long long>(static_cast<int>(hh[0]) + 256 * static_cast<int>(hh[32]) + 65536 * static_cast<int>(hh[64])) << 24);
+            s2 += static_cast<long long>(static_cast<int>(l[16]) + 256 * static_cast<int>(l[48]) + 65536 * static_cast<int>(l[80])) +
+                  (static_cast<long long>(static_cast<int>(hh[16]) + 256 * static_cast<int>(hh[48]) + 65536 * static_cast<int>(hh[80])) << 24);
+            present += hh[96];
+        }
+#pragma unroll
+        for (int o = 32; o >= 1; o >>= 1) {
+            s1 += __shfl_xor(s1, o);
+            s2 += __shfl_xor(s2, o);
+            present += __shfl_xor(present, o);
+        }
+        if (lane == 0) {
+            const double o = zobs[static_cast<int64_t>(node) * mloc + col];
+            const double sc1 = col_scale[col], sc2 = col_scale[mloc + col];
+            const double members = static_cast<double>(present);
+            const double mean = (static_cast<double>(s1) * sc1) / members;          // safe_extras.py:21-23
+            const double exx = (static_cast<double>(s2) * sc2) / members;           // safe_extras.py:25-26
+            const double sd = sqrt(exx - mean * mean);                              // safe_extras.py:27
+            double zs = mean / sd;                                                  // safe_extras.py:28
+            if (sd == 0.0) zs = __longlong_as_double(0x7FF8000000000000ll);         // safe_extras.py:29
+            if (members < 3.0) zs = __longlong_as_double(0x7FF8000000000000ll);     // safe_extras.py:30
+            const unsigned int add = (static_cast<unsigned int>(zs >= o) << 16) | static_cast<unsigned int>(zs <= o);
+            if (add) atomicAdd(&gl_counts[col * n_padr + u], add);
+        }
+    }
+}
+
 // ns[node][column] = observed score (safe.py:496-499): obs64 is [column][padded row]
 __global__ __launch_bounds__(256) void k_mfma_obs_ns(const long long *__restrict__ obs64, int64_t n_padr, const int32_t *__restrict__ rowmap,
                                                      const double *__restrict__ col_scale, int64_t mloc, double *__restrict__ ns) {
@@ -2050,8 +2181,12 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 
     // ---- the filtered form (six-slice 'sum' columns: three slices on the matrix cores, see k_permtest_mfma)
     const char *filt_env = getenv("SAFE_HIP_MFMA_FILTER");                // =0: all six slices on the matrix cores
-    const bool want_filter = allow_filter && !z && nbr->max_count < (1 << 20) && !(filt_env && !strcmp(filt_env, "0"));
-    const int64_t split_off = want_filter ? n_ct * (n + 1) * (MF_NS / 2) * 32 : 0;   // high digits behind the low digits
+    const bool want_filter = allow_filter && nbr->max_count < (1 << 20) && !(filt_env && !strcmp(filt_env, "0"));
+    const int64_t split_off = (want_filter && !z) ? n_ct * (n + 1) * (MF_NS / 2) * 32 : 0;   // high digits behind the low digits
+    // z-scores, filtered: the seven-slice layout (observed pass) | high digits + not-NaN slice, 128-byte rows | low digits, 96-byte rows
+    const int64_t zf_hi_off = (want_filter && z) ? n_ct * (n + 1) * (MF_NS + 1) * 32 : 0;
+    const int64_t zf_lo_off = zf_hi_off + n_ct * (n + 1) * 128;
+    if (want_filter && z) row_bytes += n_ct * (128 + 96);        // (the scratch below is sized (n + 1) * row_bytes)
 
     // ---- column scales and slices
     int n_slices = MF_NS;                        // i8 slices of this call: 2 / 4 / 6 by the bits its columns need (k_mfma_colfinish)
@@ -2086,10 +2221,10 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                d_scale + mloc, d_inexact, d_bad);
             if (f32)
                 hipLaunchKernelGGL(k_mfma_slice_z<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero);
+                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off);
             else
                 hipLaunchKernelGGL(k_mfma_slice_z<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero);
+                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off);
         } else if (f32)
             hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off);
@@ -2110,14 +2245,15 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         n_slices = z ? MF_NS + 1 : mfma_slices_for(verdict[1]);
         row_bytes = static_cast<int64_t>(n_slices) * 32;          // tile-major: a row of a tile is n_slices x 32 bytes, tiles (n + 1) rows apart
     }
-    const bool filt = want_filter && n_slices == MF_NS;
+    const bool zfilt = want_filter && z;
+    const bool filt = want_filter && !z && n_slices == MF_NS;
     // its own kernel (64 rows per wave, two workgroups per CU) unless a group is too long for its LDS list / a neighborhood too
     // large for its 32-bit thresholds; SAFE_HIP_MFMA_FORM=general: the general kernel's FM = 2 (A/B)
     const char *form_env = getenv("SAFE_HIP_MFMA_FORM");
     const bool filt_own = filt && nbr->bs_max_group_blocks <= MF_F_MAXBLK && nbr->max_count < 2048 && !(form_env && !strcmp(form_env, "general"));
-    const int core_slices = filt ? MF_NS / 2 : n_slices;         // slices the matrix cores multiply
+    const int core_slices = filt ? MF_NS / 2 : zfilt ? MF_NS / 2 + 1 : n_slices;         // slices the matrix cores multiply
     if (filt) row_bytes = static_cast<int64_t>(core_slices) * 32;
-    const unsigned char *d_bs_lo = d_bs, *d_bs_hi = d_bs + split_off;
+    const unsigned char *d_bs_lo = zfilt ? d_bs + zf_lo_off : d_bs, *d_bs_hi = zfilt ? d_bs + zf_hi_off : d_bs + split_off;
 
     // ---- tasks: (row group, column tile), one queue per XCD keyed by column tile so the slice
     //      rows of a tile are pulled into one L2; inside a queue tile-major, heavy groups first
@@ -2156,8 +2292,9 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     int32_t *d_src_id = nullptr;
     unsigned int *d_amb_cnt = nullptr;
     unsigned int amb_cap = 0;
-    if (filt) {
-        SAFE_TRY(ctx_scratch(ctx, 12, static_cast<size_t>(n_padr) * mloc * sizeof(long long), reinterpret_cast<void **>(&d_obs64)));
+    const bool any_filt = filt || zfilt;
+    if (any_filt) {
+        if (filt) SAFE_TRY(ctx_scratch(ctx, 12, static_cast<size_t>(n_padr) * mloc * sizeof(long long), reinterpret_cast<void **>(&d_obs64)));
         const double per_launch = static_cast<double>(n) * static_cast<double>(mloc) * static_cast<double>(span);
         amb_cap = static_cast<unsigned int>(std::min(67108864.0, std::max(1048576.0, per_launch / 512.0)));
         if (const char *e = getenv("SAFE_HIP_MFMA_FILTER_CAP")) amb_cap = static_cast<unsigned int>(std::max(1, atoi(e)));   // (tests: force the fall-back)
@@ -2174,7 +2311,10 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     const char *pref_env = getenv("SAFE_HIP_MFMA_PREF");
     const bool pref = !(pref_env && !strcmp(pref_env, "0"));
     const void *kfn_obs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 1>);
-    const void *kfn = z               ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>)
+    const void *kfn_zobs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>);     // z-scores, all seven slices
+    const size_t lds_zobs = 2 * static_cast<size_t>(4 * (MF_NS + 1) * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    const void *kfn = zfilt           ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2 + 1, true, true, 0, true, 2>)
+                      : z             ? kfn_zobs
                       : filt          ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 2>)
                       : !pref && n_slices == 6 ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS, false, true, 0, false>)
                       : n_slices == 2 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
@@ -2182,6 +2322,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
     SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
     if (filt) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_obs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    if (zfilt) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_zobs, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_zobs)));
 #ifdef SAFE_HIP_DIAG
     static const int mfma_dbg = getenv("SAFE_HIP_MFMA_DBG") ? atoi(getenv("SAFE_HIP_MFMA_DBG")) : 0;
     if (mfma_dbg) safe_warn_diagnostic("SAFE_HIP_MFMA_DBG");
@@ -2207,6 +2348,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     // XCDs round-robin), which costs 3 % of the matrix-core throughput.  Long launches therefore make the table stream wait for
     // their predecessor instead (below): the tables of a span are needed only when that launch has ended.
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(tasks.size()), ctx->num_cu);
+    if (zfilt) row_bytes = 128;                                // the filtered z form's rows: three value | square slices + the not-NaN slice
     const int64_t tile_bytes = (n + 1) * row_bytes;
     const bool long_launches = static_cast<double>(n) * static_cast<double>(mloc) * static_cast<double>(span) >= 2e9;   // >~ 20 ms each
     // z-scores: the counters compare against the observed score itself, which may be NaN (k_counts_finalize<true> reads it)
@@ -2243,6 +2385,25 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                d_scale, mloc, out.ns);
         SAFE_HIP_CHECK(hipGetLastError());
     }
+    if (zfilt) {
+        // the observed z-scores: one pass of the seven-slice kernel over the identity map writes them to out.ns (exact sums, the
+        // reference's formula); the filtered launches compare against them
+        hipLaunchKernelGGL(k_mfma_src, dim3(ceil_div(n_src, 256), 1), dim3(256), 0, ctx->stream, nbr->bs_order, n_src, n,
+                           static_cast<const int32_t *>(nullptr), 0, d_src_id, 0);
+        const unsigned char *bs_p = d_bs;
+        int64_t rb7 = (MF_NS + 1) * 32, tb7 = (n + 1) * rb7;
+        const int32_t *src_c = d_src_id;
+        int n_q = 1;
+        unsigned int *qctr_c = d_qctr + 8 * n_launch + 8;
+        double *ns_c = out.ns;
+        HypLookup no_lookup{};
+        MfmaFilt fa;
+        void *args[] = {(void *)&bs_p, (void *)&rb7, (void *)&tb7, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+                        (void *)&nbr->bs_kb, (void *)&nbr->bs_bits, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c, (void *)&mloc,
+                        (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&ns_c, (void *)&no_lookup, (void *)&fa};
+        SAFE_HIP_CHECK(hipLaunchKernel(kfn_zobs, dim3(blocks), dim3(512), args, lds_zobs, ctx->stream));
+        SAFE_HIP_CHECK(hipGetLastError());
+    }
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->side_stream, ready, 0));
     for (int64_t c = 0; c < n_launch; ++c) {
@@ -2262,15 +2423,16 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         {
             // classic: row 0 of the source maps is the identity (the observed score is formed once per task); filtered form:
             // the observed scores are in d_obs64 and every q is a permutation
-            const int32_t *src_c = filt ? d_src[c & 1] + n_src : d_src[c & 1];
-            int n_q = static_cast<int>(filt ? cnt : cnt + 1);
+            const int32_t *src_c = any_filt ? d_src[c & 1] + n_src : d_src[c & 1];
+            int n_q = static_cast<int>(any_filt ? cnt : cnt + 1);
             unsigned int *qctr_c = d_qctr + 8 * c;
-            double *ns_c = (c == 0 && !filt) ? out.ns : static_cast<double *>(nullptr);
+            double *ns_c = (c == 0 && !any_filt) ? out.ns : static_cast<double *>(nullptr);
             HypLookup no_lookup{};
             no_lookup.dbg = mfma_dbg;        // 1: no transposes / LDS stores of the gathered rows, 4: no barrier per super-step, 8: no score completion
             MfmaFilt fa;
-            if (filt) {
+            if (any_filt) {
                 fa.obs64 = d_obs64;
+                fa.zobs = out.ns;
                 fa.rowcnt = nbr->bs_rowcnt;
                 fa.amb = d_amb[c & 1];
                 fa.amb_count = d_amb_cnt + c;
@@ -2284,7 +2446,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                 }
 #endif
             }
-            const unsigned char *bs_main = filt ? d_bs_hi : d_bs;
+            const unsigned char *bs_main = any_filt ? d_bs_hi : d_bs;
             if (filt_own) {
                 const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
                 int64_t zrow = n;
@@ -2301,9 +2463,13 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         }
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
-        if (filt) {
-            hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
-                               nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_counts);
+        if (any_filt) {
+            if (zfilt)
+                hipLaunchKernelGGL(k_mfma_resolve_z, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, out.ns, mloc, n_padr,
+                                   nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, d_bs_hi, d_scale, d_counts);
+            else
+                hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
+                                   nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_counts);
             SAFE_HIP_CHECK(hipGetLastError());
             if (c == 0 && long_launches && n_launch > 1) {
                 // pilot: data with many equal scores (sparse columns, few distinct values) leaves the high digits little to
@@ -2325,8 +2491,8 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     }
     SAFE_HIP_CHECK(hipEventRecord(side_done, ctx->side_stream));
     SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, side_done, 0));
-    std::vector<unsigned int> amb_seen(filt ? n_launch : 0, 0u);
-    if (filt) SAFE_HIP_CHECK(hipMemcpyAsync(amb_seen.data(), d_amb_cnt, amb_seen.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
+    std::vector<unsigned int> amb_seen(any_filt ? n_launch : 0, 0u);
+    if (any_filt) SAFE_HIP_CHECK(hipMemcpyAsync(amb_seen.data(), d_amb_cnt, amb_seen.size() * sizeof(unsigned int), hipMemcpyDeviceToHost, ctx->stream));
     SAFE_TRY(enrich_finalize_counts(ctx, d_counts, n_padr, nbr->bs_rowmap, mloc, P, out, z ? out.ns : nullptr));
     if (!z) {                                                 // (z-score counters depend on NaN observed scores: not exported)
         ctx->packed_counts = d_counts;
