@@ -57,6 +57,15 @@ def parse():
     return ap.parse_args()
 
 
+def _by_decile(step_ms, values):
+    """Mean of `values` over the steps of each decile of the step-time distribution (None where a value is missing)."""
+    import numpy as np
+    pairs = sorted((s, v) for s, v in zip(step_ms, values) if v is not None)
+    if len(pairs) < 10:
+        return None
+    return [round(float(np.mean([v for _, v in chunk])), 3) for chunk in np.array_split(np.asarray(pairs, dtype=object), 10)]
+
+
 def effective_cores():
     from safepy_amd import backend
     return backend.effective_cores()
@@ -940,6 +949,12 @@ def main():
             'step_ms_slowest3': [float(x) for x in sorted(res['step_ms'])[-3:]],
             'step_ms_deciles': [round(float(x), 3) for x in np.percentile(res['step_ms'], list(range(10, 100, 10)))],
             'step_ms_mean_by_quarter_of_run': [round(float(np.mean(q)), 3) for q in np.array_split(np.asarray(res['step_ms']), 4)],
+            # the host draw chain's busy time of the steps in each decile of the step-time distribution (sorted by step time: a slow
+            # chain thread shows as the last entries growing with the step)
+            'draw_busy_ms_by_step_decile': _by_decile(res['step_ms'], [t.get('draw_busy_ms') for t in res['timings']]),
+            'draw_threads': {'placement': 'persistent per context' if os.environ.get('SAFE_HIP_DRAW_THREAD') != 'percall' else 'one per call',
+                             'reserved_cores': int(os.environ.get('SAFE_BENCH_DRAW_CORES', '2')) if numa_node is not None else 0},
+            'library_build': be.build_info(),
             'step_probe': res['step_probe'],
         }
         if 'exchange_report' in res:

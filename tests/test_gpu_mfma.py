@@ -522,3 +522,53 @@ def test_filtered_form_fall_back_inside_compute_pvalues_counts_enriched_neighbor
     assert be.last_mfma_filter(amd.Context.default(0))[1] < 0
     np.testing.assert_array_equal(sf.nes_binary, want['nes_binary'])
     np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['nes_binary'].sum(axis=0))
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# z-scores, filtered: 4 of the 7 slices on the matrix cores
+# ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('kind', ['normal', 'dyadic'])
+def test_zscore_filtered_form_equals_the_seven_slice_form_and_the_oracle(amd, ctx, monkeypatch, kind):
+    from safepy_amd import backend as be
+    rng = np.random.default_rng(41)
+    n, m, nperm, seed = 800, 29, 90, 2
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.09)
+    b = _zdata(rng, n, m, kind, np.float64, 'C')
+    cn_w, cp_w = orc.run_permutations(a, b, 'z-score', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.09))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name == 'k_permtest_mfma'
+    core, undecided = be.last_mfma_filter(ctx)
+    assert core == 4 and undecided >= 0
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    monkeypatch.setenv('SAFE_HIP_MFMA_FILTER', '0')
+    ns7, cn7, cp7, _ = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert be.last_mfma_filter(ctx)[0] == 7
+    np.testing.assert_array_equal(ns, ns7)
+    np.testing.assert_array_equal(cn, cn7)
+    np.testing.assert_array_equal(cp, cp7)
+    nbr.close()
+
+
+def test_zscore_filtered_form_with_few_distinct_values_and_tiny_neighborhoods(amd, ctx):
+    """Small integers with many zeros and missing values: equal z-scores (ties count on both sides), zero variance and fewer
+    than three values (NaN scores) all over -- what the filter cannot decide goes through the exact resolve kernel, or the
+    call falls back to seven slices; either way the counts are the oracle's."""
+    rng = np.random.default_rng(8)
+    n, m, nperm, seed = 500, 24, 40, 6
+    xy = rng.uniform(size=(n, 2))
+    a = orc.neighborhoods_euclidean(xy, 0.05)                          # ~4 members on average: many neighborhoods below 3 values
+    b = rng.integers(0, 4, size=(n, m)).astype(np.float64)
+    b[rng.uniform(size=(n, m)) < 0.3] = np.nan
+    b[:, 7] = 2.0                                                       # a constant column: zero variance everywhere
+    ns_w = orc.compute_neighborhood_score(a, b, 'z-score')
+    cn_w, cp_w = orc.run_permutations(a, b, 'z-score', nperm, seed)
+    nbr = amd.Neighborhoods.euclidean(ctx, xy, orc.layout_radius(xy[:, 0], 0.05))
+    ns, cn, cp, name = _counts(amd, ctx, nbr, b, nperm, seed, score='z-score')
+    assert name == 'k_permtest_mfma'
+    assert np.array_equal(np.isnan(ns), np.isnan(ns_w))
+    np.testing.assert_array_equal(cn, cn_w)
+    np.testing.assert_array_equal(cp, cp_w)
+    nbr.close()
