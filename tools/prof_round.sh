@@ -17,6 +17,16 @@ CMD="python3 $ROOT/bench.py --steps 3 --warmup 1 --cpu-perms 0"
 timeout 900 rocprofv3 --kernel-trace --stats -d $OUT/trace -o r -- $CMD > $OUT/trace.log 2>&1
 python3 $ROOT/tools/rocpd_summary.py $OUT/trace/r_results.db > $OUT/kernel_stats.txt
 grep '^{' $OUT/trace.log | tail -1 > $OUT/bench_line.json
+# the headline alone, as the driver runs it (5 + 20 steps): k_permtest_bits_blk's average here = the line's roofline.kernel_ms
+CMDH="python3 $ROOT/bench.py --steps 20 --warmup 5 --extras 0 --cpu-perms 0"
+timeout 600 rocprofv3 --kernel-trace --stats -d $OUT/trace_h -o r -- $CMDH > $OUT/trace_h.log 2>&1
+python3 $ROOT/tools/rocpd_summary.py $OUT/trace_h/r_results.db > $OUT/kernel_stats_headline.txt
+grep '^{' $OUT/trace_h.log | tail -1 > $OUT/bench_line_headline.json
+rm -rf $OUT/trace_h
+# GPU timeline of one seeded step
+timeout 300 rocprofv3 --kernel-trace -d $OUT/tr -o r -- python3 $ROOT/tools/trace_step.py > $OUT/trace_step.log 2>&1
+python3 $ROOT/tools/rocpd_timeline.py $(ls $OUT/tr/*.db $OUT/tr/*/*.db 2>/dev/null | head -1) > $OUT/timeline.txt 2>&1
+rm -rf $OUT/tr
 CMD1="python3 $ROOT/bench.py --steps 1 --warmup 1 --cpu-perms 0"
 timeout 900 rocprofv3 --pmc FETCH_SIZE --kernel-trace -d $OUT/fetch -o r -- $CMD1 > $OUT/fetch.log 2>&1
 timeout 900 rocprofv3 --pmc WRITE_SIZE --kernel-trace -d $OUT/write -o r -- $CMD1 > $OUT/write.log 2>&1

@@ -79,7 +79,14 @@ def entry(key, sub, corr=FETCH_CORR, note=None):
     out[key] = e
 
 
-entry('k_permtest_bits_blk', 'k_permtest_bits_blk')
+entry('k_permtest_bits_blk (whole bench: launches of the unseeded and 10 000-permutation extras included)', 'k_permtest_bits_blk')
+# the HEADLINE launches alone (tools/pmc_bits.sh passes 4 / 5: bench.py --extras 0): what roofline.traffic of the bench line quotes
+_hb = os.path.join(src_dir, 'bits', 'pmc_summary.txt')
+if os.path.exists(_hb):
+    _mixed = traffic
+    traffic = counters(_hb)
+    entry('k_permtest_bits_blk', 'k_permtest_bits_blk', FETCH_CORR, 'headline launches only (bench.py --extras 0, warm-up + 1 step)')
+    traffic = _mixed
 entry('k_bits_observed', 'k_bits_observed')
 entry('k_euclid_dense', 'k_euclid_dense')
 entry('k_hyp_emit', 'k_hyp_emit', FETCH_CORR,
@@ -109,6 +116,25 @@ hdr = ('# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 3 --warmu
        'configs[4] share)\n# bench line of the same run: %s ...\n' % (rnd, commit, line[:900]))
 open(os.path.join(ROOT, 'profiles', '%s_bench_kernel_stats.txt' % rnd), 'w').write(hdr + ks)
 
+hk = os.path.join(src_dir, 'kernel_stats_headline.txt')
+if os.path.exists(hk):
+    hline = open(os.path.join(src_dir, 'bench_line_headline.json')).read().strip()
+    open(os.path.join(ROOT, 'profiles', '%s_bench_kernel_stats_headline.txt' % rnd), 'w').write(
+        '# rocprofv3 --kernel-trace --stats -- python3 bench.py --steps 20 --warmup 5 --extras 0 --cpu-perms 0 (tools/prof_round.sh; round %s, commit %s, '
+        'MI355X): the HEADLINE alone -- the average duration of k_permtest_bits_blk here is the kernel_ms of the bench line below '
+        '(roofline.kernel_ms, HIP events); k_replay_targets / k_scan_* / k_permute_cols run beside it on the table streams\n'
+        '# bench line of the same run: %s ...\n' % (rnd, commit, hline[:700]) + open(hk).read())
+tl = os.path.join(src_dir, 'timeline.txt')
+if os.path.exists(tl):
+    open(os.path.join(ROOT, 'profiles', '%s_timeline_step_seeded.txt' % rnd), 'w').write(
+        '# GPU timeline of one seeded headline step (tools/timeline_step.sh: rocprofv3 --kernel-trace -- python3 tools/trace_step.py; round %s, commit %s, '
+        'MI355X).  columns: start, end (us from the first kernel), duration, gap to the previous kernel\'s end (negative = overlapped on '
+        'another stream), kernel.  The first block is the first call of the process (statistics, bit planes, observed sums); the '
+        'second block the steady step: upload + k_replay_targets on the replay stream, k_scan_* on the table stream, k_permute_cols + '
+        'k_permtest_bits_blk alternating on two kernel streams.  A k_replay_targets / k_scan duration that spans a whole '
+        'k_permtest_bits_blk launch is QUEUE WAIT (the persistent kernel holds the CUs; the table kernels get one as its workgroups '
+        'retire), not work: alone, a replay of 128 permutations takes ~60 us\n' % (rnd, commit) + open(tl).read())
+
 # ---- SQ / TCC counters of the headline kernel
 bits_txt = open(os.path.join(src_dir, 'bits', 'pmc_summary.txt')).read()
 hdr = ('# rocprofv3 --pmc <8 SQ counters | 8 SQ counters | TCC_HIT TCC_MISS GRBM_GUI_ACTIVE | FETCH_SIZE | WRITE_SIZE> --kernel-trace -- '
@@ -135,7 +161,13 @@ for key, sub in (('mfma_pipe_busy_sum', 'mfma_sum'), ('mfma_pipe_busy_zscore', '
     if not os.path.exists(path):
         continue
     c = counters(path)
-    busy, gui, n_mfma = get(c, 'k_permtest_mfma', 'SQ_VALU_MFMA_BUSY_CYCLES'), get(c, 'k_permtest_mfma', 'GRBM_GUI_ACTIVE'), get(c, 'k_permtest_mfma', 'SQ_INSTS_MFMA')
+    # the kernel that carries the permutations: the filtered form's own kernel ('sum'), the four-slice z form; before round 5
+    # (or with SAFE_HIP_MFMA_FILTER=0) the six- / seven-slice general kernel
+    want = [s for s in (('k_permtest_mfma_f', 'k_permtest_mfma<false, 6') if sub == 'mfma_sum' else ('k_permtest_mfma<false, 4, true', 'k_permtest_mfma<false, 7'))
+            if get(c, s, 'SQ_VALU_MFMA_BUSY_CYCLES')]
+    kern = want[0] if want else 'k_permtest_mfma'
+    busy, gui, n_mfma = get(c, kern, 'SQ_VALU_MFMA_BUSY_CYCLES'), get(c, kern, 'GRBM_GUI_ACTIVE'), get(c, kern, 'SQ_INSTS_MFMA')
+    mf[key + '_kernel'] = kern
     if busy and gui:
         # GRBM_GUI_ACTIVE sums the 8 XCDs' active clocks; the busy cycles sum over the 1024 SIMDs' matrix pipes
         mf[key] = busy[0] / (gui[0] / 8.0 * 1024.0)
