@@ -953,7 +953,11 @@ def main():
             # chain thread shows as the last entries growing with the step)
             'draw_busy_ms_by_step_decile': _by_decile(res['step_ms'], [t.get('draw_busy_ms') for t in res['timings']]),
             'draw_threads': {'placement': 'persistent per context' if os.environ.get('SAFE_HIP_DRAW_THREAD') != 'percall' else 'one per call',
-                             'reserved_cores': int(os.environ.get('SAFE_BENCH_DRAW_CORES', '2')) if numa_node is not None else 0},
+                             'reserved_cores': int(os.environ.get('SAFE_BENCH_DRAW_CORES', '2')) if numa_node is not None else 0,
+                             # the chain is drawn by two threads at once, the faster one publishes each chunk (rng.cpp, safe_perms::twin)
+                             'twin_chain': bool(res['timings'][-1].get('twin_chain')),
+                             'chunks_per_step': res['timings'][-1].get('chunks'),
+                             'chunks_won_by_twin_per_step_mean': float(np.mean([t.get('chunks_won_by_twin') or 0 for t in res['timings']]))},
             'library_build': be.build_info(),
             'step_probe': res['step_probe'],
         }

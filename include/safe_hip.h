@@ -250,6 +250,11 @@ int safe_perms_create_shared(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
  * node's producer, [4] = role (0 own stream, 1 producer of a shared stream, 2 consumer, 3 generated on the device).  For
  * bench reporting. */
 int safe_perms_timing(safe_perms *perms, double *out5);
+/* The twin chain of a seeded handle (np.random.seed / np.random.permutation, safepy/safe_extras.py:46,58, drawn by two host
+ * threads at once on a shared host: whichever finishes a pipeline chunk first publishes it): *twin_active = it runs for this
+ * handle (opt-in: SAFE_HIP_DRAW_TWIN=1, single-process seeded calls with polling waits -- measured no better than one thread), *chunks = chunks published
+ * so far, *chunks_won_by_twin = how many of them came from the second thread.  For bench reporting. */
+int safe_perms_twin_stats(safe_perms *perms, int *twin_active, int64_t *chunks, int64_t *chunks_won_by_twin);
 /* The ring by itself (host memory only, no device): what safe_perms_create_shared runs on, exported so that the
  * multi-process protocol can be tested on a host without GPUs.  local rank 0 creates, the others attach;
  * safe_ring_begin opens the next call on either side (producer: waits until every consumer has left the previous one;

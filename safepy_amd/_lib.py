@@ -145,6 +145,7 @@ PROTOTYPES = {
     'safe_perms_create_shared': (C.c_int, [_vp, _i64, _vp, _i64, C.c_int, C.c_uint32, _pp]),
     'safe_perms_create_device': (C.c_int, [_vp, _i64, _vp, _i64, C.c_uint64, _pp]),
     'safe_perms_timing': (C.c_int, [_vp, C.POINTER(C.c_double)]),
+    'safe_perms_twin_stats': (C.c_int, [_vp, C.POINTER(C.c_int), _pi64, _pi64]),
     'safe_ring_open': (C.c_int, [C.c_char_p, C.c_int, C.c_int, _i64, _pp]),
     'safe_ring_close': (C.c_int, [_vp]),
     'safe_ring_begin': (C.c_int, [_vp, _i64, _i64, _i64, C.c_uint64, _i64]),

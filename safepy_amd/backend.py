@@ -38,11 +38,11 @@ def _split_off_cores(cpus, n_cores, slot=0):
     cores = sorted(by_core)
     if len(cores) < n_cores * (slot + 1) + 2:
         return None
-    taken = set()
+    taken = []                                            # core after core (the library gives each of its two draw threads one half)
     hi = len(cores) - n_cores * slot                      # (ranks of one node take different cores: slot = local rank)
     for c in cores[hi - n_cores:hi]:
-        taken |= by_core[c]
-    return taken, set(cpus) - taken
+        taken += sorted(by_core[c])
+    return taken, set(cpus) - set(taken)
 
 
 def pin_threads_to_device_numa(device=0, reserve_draw_cores=0):
@@ -74,7 +74,7 @@ def pin_threads_to_device_numa(device=0, reserve_draw_cores=0):
             split = _split_off_cores(cpus, int(reserve_draw_cores), int(device))
             if split is not None:
                 draw_cpus, mine = split
-                arr = (C.c_int * len(draw_cpus))(*sorted(draw_cpus))
+                arr = (C.c_int * len(draw_cpus))(*draw_cpus)
                 check(lib.safe_set_draw_cpus(arr, len(draw_cpus)))
         for tid in os.listdir('/proc/self/task'):
             try:
@@ -479,8 +479,11 @@ class Permutations:
         """Host-side timing of the stream (safe_perms_timing), ms, and this rank's role in it."""
         out = (C.c_double * 5)()
         check(lib.safe_perms_timing(self.handle, out))
+        tw, ch, won = C.c_int(), C.c_int64(), C.c_int64()
+        check(lib.safe_perms_twin_stats(self.handle, C.byref(tw), C.byref(ch), C.byref(won)))
         return {'draw_busy_ms': out[0], 'drawn_all_ms': out[1], 'tables_enqueued_ms': out[2], 'waited_for_producer_ms': out[3],
-                'role': ('own', 'producer', 'consumer', 'device')[int(out[4])]}
+                'role': ('own', 'producer', 'consumer', 'device')[int(out[4])],
+                'twin_chain': bool(tw.value), 'chunks': ch.value, 'chunks_won_by_twin': won.value}
 
     @classmethod
     def from_table(cls, ctx, perm_idx):

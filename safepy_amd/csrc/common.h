@@ -85,7 +85,7 @@ void draw_worker_shutdown(safe_ctx *ctx);
 
 struct safe_ctx {
     int device = 0;
-    DrawWorker *draw_worker = nullptr;
+    DrawWorker *draw_worker = nullptr, *draw_worker2 = nullptr;    // (the second one runs the twin chain: safe_perms::twin)
     hipStream_t own_stream = nullptr;
     hipStream_t stream = nullptr;
     hipStream_t aux_stream = nullptr;           // permutation-table generation (overlaps the enrichment kernels)
@@ -317,6 +317,19 @@ struct safe_perms {
     std::thread drawer;                            // a thread of its own (only when the context's draw worker is busy with another handle)
     bool on_worker = false;                        // this handle's draws run (or ran) on ctx->draw_worker
     bool worker_done = false;                      // (under the worker's mutex) ... and have ended
+    // The TWIN: a second draw thread runs the very same chain (same seed, same words) on another core into buffers of its own,
+    // and whichever thread finishes a chunk first publishes it.  The chain is sequential and cannot be sped up, but on a shared
+    // host one thread runs 1.5-2 x slower for a millisecond or two now and then (a neighbour on its sibling hardware thread, a
+    // pre-emption) -- the idea was that both threads stumbling in the same chunk is rare.  Measured: no better than one thread
+    // (rng.cpp, perms_create_impl), so it is opt-in (SAFE_HIP_DRAW_TWIN=1).
+    bool twin = false;
+    bool on_worker2 = false, worker_done2 = false;
+    DrawStream *stream2 = nullptr;
+    void *h_stage2[3] = {nullptr, nullptr, nullptr};
+    hipEvent_t staged2[3] = {nullptr, nullptr, nullptr};
+    std::vector<uint32_t> h_local2;
+    std::vector<uint8_t> chunk_src;                // (under draw_mu) which thread's staging buffer holds chunk c
+    int64_t twin_wins = 0;                         // chunks the twin published first (diagnostics)
     std::mutex draw_mu;
     std::condition_variable draw_cv;
     int64_t drawn_chunks = 0;                      // chunks whose targets are complete in h_stage[c % kStage]

@@ -501,8 +501,14 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
         if (ci == 0) SAFE_HIP_CHECK(hipStreamWaitEvent(rs, p->movpos_ready, 0));
         if (ci >= 2) SAFE_HIP_CHECK(hipStreamWaitEvent(rs, p->chunk_done[ci - 2], 0));       // this parity's row maps are free again
     }
-    SAFE_HIP_CHECK(hipMemcpyAsync(d_tg, p->h_stage[b], bytes, hipMemcpyHostToDevice, rs));
+    const void *h_src = p->h_stage[b];
+    if (p->twin) {
+        std::lock_guard<std::mutex> lk(p->draw_mu);
+        if (p->chunk_src[ci]) h_src = p->h_stage2[b];                // the twin finished this chunk first
+    }
+    SAFE_HIP_CHECK(hipMemcpyAsync(d_tg, h_src, bytes, hipMemcpyHostToDevice, rs));
     SAFE_HIP_CHECK(hipEventRecord(p->staged[b], rs));
+    if (p->twin) SAFE_HIP_CHECK(hipEventRecord(p->staged2[b], rs));    // (both threads' buffers of this slot are free again after this upload)
     {
         std::lock_guard<std::mutex> lk(p->draw_mu);                  // the draw thread may fill this buffer again once the upload is done
         p->enqueued_chunks = std::max<int64_t>(p->enqueued_chunks, ci + 1);
@@ -561,13 +567,17 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     return SAFE_OK;
 }
 
-static void drawer_main(safe_perms *p) {
-    pthread_setname_np(pthread_self(), "safe-draw");
+static void drawer_main(safe_perms *p, int w = 0) {
+    pthread_setname_np(pthread_self(), w ? "safe-draw2" : "safe-draw");
     (void)hipSetDevice(p->ctx->device);
     const int64_t k = p->k;
     const int64_t n_chunks = stage_count(p);
     const int64_t steps = std::max<int64_t>(k - 1, 0);
-    uint32_t *h = p->h_local.data();
+    // w = 1: the twin (safe_perms::twin) -- its own generator state (same seed), private buffer, staging buffers and events
+    uint32_t *h = w ? p->h_local2.data() : p->h_local.data();
+    DrawStream *gen = w ? p->stream2 : p->stream;
+    void *const *stage = w ? p->h_stage2 : p->h_stage;
+    hipEvent_t *staged = w ? p->staged2 : p->staged;
     for (int64_t c = 0; c < n_chunks; ++c) {
         const int b = static_cast<int>(c % safe_perms::kStage);
         {
@@ -577,7 +587,7 @@ static void drawer_main(safe_perms *p) {
         }
         // the staging buffer's previous chunk (c - kStage) must have left for the device (its upload was queued: see the wait above)
         const int64_t q0 = stage_begin(p, c), cnt = chunk_end(p, c) - q0;
-        if ((c >= safe_perms::kStage && hipEventSynchronize(p->staged[b]) != hipSuccess) || cnt > kChunk) {
+        if ((c >= safe_perms::kStage && hipEventSynchronize(staged[b]) != hipSuccess) || cnt > kChunk) {
             // the launcher waits on draw_cv for this chunk: tell it, or it waits for ever
             {
                 std::lock_guard<std::mutex> lk(p->draw_mu);
@@ -588,11 +598,11 @@ static void drawer_main(safe_perms *p) {
         }
         safe_trace("    drawer: buffer free, drawing");
         const double t_draw = wall_s();
-        char *dst = static_cast<char *>(p->h_stage[b]);
+        char *dst = static_cast<char *>(stage[b]);
         static const bool prof = getenv("SAFE_HIP_DRAW_PROFILE") != nullptr;
         double t_pack = 0.0;
         for (int64_t q = 0; q < cnt; ++q) {
-            draw_stream_targets(p->stream, k, h);                   // into a buffer that stays in L1, then packed onto the wire
+            draw_stream_targets(gen, k, h);                         // into a buffer that stays in L1, then packed onto the wire
             const double tp0 = prof ? wall_s() : 0.0;
             if (p->target_bytes == 2) draws_pack_u16(reinterpret_cast<uint16_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps));
             else memcpy(reinterpret_cast<uint32_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps) * sizeof(uint32_t));
@@ -606,10 +616,14 @@ static void drawer_main(safe_perms *p) {
         if (prof) fprintf(stderr, "draw chunk %lld: %lld perms, draw+pack %.1f us, pack %.1f us\n", (long long)c, (long long)cnt, 1e6 * (wall_s() - t_draw), 1e6 * t_pack);
         {
             std::lock_guard<std::mutex> lk(p->draw_mu);
-            p->drawn_chunks = c + 1;
-            p->drawn_chunks_pub.store(c + 1, std::memory_order_release);
-            p->draw_busy_ms += 1e3 * (wall_s() - t_draw);
-            if (c + 1 == n_chunks) p->drawn_all_ms = 1e3 * (wall_s() - p->t_created_s);
+            if (p->drawn_chunks <= c) {                               // first to finish this chunk (always, without a twin)
+                if (p->twin) p->chunk_src[c] = static_cast<uint8_t>(w);
+                p->twin_wins += w;
+                p->drawn_chunks = c + 1;
+                p->drawn_chunks_pub.store(c + 1, std::memory_order_release);
+                p->draw_busy_ms += 1e3 * (wall_s() - t_draw);
+                if (c + 1 == n_chunks) p->drawn_all_ms = 1e3 * (wall_s() - p->t_created_s);
+            }
         }
         p->draw_cv.notify_all();
     }
@@ -626,20 +640,30 @@ int safe_set_draw_cpus(const int *cpus, int count) {
     return SAFE_OK;
 }
 
-static void draw_thread_apply_cpus() {
+// which = 0: the chain thread, 1: its twin.  With a twin the list is split in two halves (the launcher lists whole physical
+// cores one after the other: safe_set_draw_cpus): the two chains must not share a core -- on sibling hardware threads BOTH run a
+// third slower and the twin is worse than no twin.
+static void draw_thread_apply_cpus(int which = 0, bool split = false) {
     std::lock_guard<std::mutex> lk(g_draw_cpu_mu);
     if (g_draw_cpus.empty()) return;
+    size_t lo = 0, hi = g_draw_cpus.size();
+    if (split && hi >= 2) {
+        const size_t mid = hi / 2;
+        if (which == 0) hi = mid;
+        else lo = mid;
+    }
     cpu_set_t set;
     CPU_ZERO(&set);
-    for (int c : g_draw_cpus)
-        if (c >= 0 && c < CPU_SETSIZE) CPU_SET(c, &set);
+    for (size_t i = lo; i < hi; ++i)
+        if (g_draw_cpus[i] >= 0 && g_draw_cpus[i] < CPU_SETSIZE) CPU_SET(g_draw_cpus[i], &set);
     (void)pthread_setaffinity_np(pthread_self(), sizeof(set), &set);      // (best effort: a refused mask leaves the thread where it was)
 }
 
-static void draw_worker_main(safe_ctx *ctx) {
-    DrawWorker *w = ctx->draw_worker;
-    pthread_setname_np(pthread_self(), "safe-draw");
-    draw_thread_apply_cpus();
+static void draw_worker_main(safe_ctx *ctx, int which) {
+    DrawWorker *w = which ? ctx->draw_worker2 : ctx->draw_worker;
+    pthread_setname_np(pthread_self(), which ? "safe-draw2" : "safe-draw");
+    static const bool twin_on = getenv("SAFE_HIP_DRAW_TWIN") && !strcmp(getenv("SAFE_HIP_DRAW_TWIN"), "1");
+    draw_thread_apply_cpus(which, twin_on && !safe_blocking_sync_selected());
     (void)hipSetDevice(ctx->device);
     static const double spin_s = [] {
         const char *e = getenv("SAFE_HIP_DRAW_IDLE_SPIN_US");              // how long the idle worker polls before it sleeps
@@ -656,10 +680,10 @@ static void draw_worker_main(safe_ctx *ctx) {
             w->cv.wait(lk, [&] { return w->quit || (p = w->job.exchange(nullptr, std::memory_order_acq_rel)) != nullptr; });
             if (!p) return;                                                // quit
         }
-        drawer_main(p);
+        drawer_main(p, which);
         {
             std::lock_guard<std::mutex> lk(w->mu);
-            p->worker_done = true;
+            (which ? p->worker_done2 : p->worker_done) = true;
             w->busy = false;
         }
         w->cv.notify_all();
@@ -667,16 +691,34 @@ static void draw_worker_main(safe_ctx *ctx) {
 }
 
 void draw_worker_shutdown(safe_ctx *ctx) {
-    DrawWorker *w = ctx->draw_worker;
-    if (!w) return;
+    for (DrawWorker **slot : {&ctx->draw_worker, &ctx->draw_worker2}) {
+        DrawWorker *w = *slot;
+        if (!w) continue;
+        {
+            std::lock_guard<std::mutex> lk(w->mu);
+            w->quit = true;
+        }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        delete w;
+        *slot = nullptr;
+    }
+}
+
+static bool worker_post(safe_ctx *ctx, DrawWorker **slot, int which, safe_perms *p) {
+    if (!*slot) {
+        *slot = new DrawWorker;
+        (*slot)->th = std::thread(draw_worker_main, ctx, which);
+    }
+    DrawWorker *w = *slot;
     {
         std::lock_guard<std::mutex> lk(w->mu);
-        w->quit = true;
+        if (w->busy) return false;                                    // (one stream at a time per worker)
+        w->busy = true;
     }
-    w->cv.notify_all();
-    if (w->th.joinable()) w->th.join();
-    delete w;
-    ctx->draw_worker = nullptr;
+    w->job.store(p, std::memory_order_release);
+    w->cv.notify_all();                                               // (a polling worker sees the store; a sleeping one this)
+    return true;
 }
 
 static void drawer_start(safe_perms *p) {
@@ -684,35 +726,23 @@ static void drawer_start(safe_perms *p) {
     p->drawn_chunks_pub.store(0, std::memory_order_release);
     p->draw_stop = false;
     p->draw_failed = false;
-    p->on_worker = false;
-    p->worker_done = false;
+    p->on_worker = p->on_worker2 = false;
+    p->worker_done = p->worker_done2 = false;
+    p->twin_wins = 0;
     if (p->count <= 0 || p->ring_consumer) return;
     safe_ctx *ctx = p->ctx;
     static const bool per_call = getenv("SAFE_HIP_DRAW_THREAD") && !strcmp(getenv("SAFE_HIP_DRAW_THREAD"), "percall");   // (A/B: a thread per handle)
-    if (!per_call) {
-        if (!ctx->draw_worker) {
-            ctx->draw_worker = new DrawWorker;
-            ctx->draw_worker->th = std::thread(draw_worker_main, ctx);
+    if (!per_call && worker_post(ctx, &ctx->draw_worker, 0, p)) {
+        p->on_worker = true;
+        if (p->twin) {
+            if (worker_post(ctx, &ctx->draw_worker2, 1, p)) p->on_worker2 = true;
+            // (a busy second worker -- another live handle -- simply leaves this call without a twin: chunk_src stays 0)
         }
-        DrawWorker *w = ctx->draw_worker;
-        bool taken = false;
-        {
-            std::lock_guard<std::mutex> lk(w->mu);
-            if (!w->busy) {                                               // (one stream at a time: a second live handle gets its own thread)
-                w->busy = true;
-                taken = true;
-            }
-        }
-        if (taken) {
-            p->on_worker = true;
-            w->job.store(p, std::memory_order_release);
-            w->cv.notify_all();                                            // (a polling worker sees the store; a sleeping one this)
-            return;
-        }
+        return;
     }
     p->drawer = std::thread([p] {
         draw_thread_apply_cpus();
-        drawer_main(p);
+        drawer_main(p, 0);
     });
 }
 
@@ -723,10 +753,17 @@ static void drawer_stop(safe_perms *p) {
             p->draw_stop = true;
         }
         p->draw_cv.notify_all();
-        DrawWorker *w = p->ctx->draw_worker;
-        std::unique_lock<std::mutex> lk(w->mu);
-        w->cv.wait(lk, [&] { return p->worker_done; });
-        p->on_worker = false;
+        {
+            DrawWorker *w = p->ctx->draw_worker;
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return p->worker_done; });
+        }
+        if (p->on_worker2) {
+            DrawWorker *w = p->ctx->draw_worker2;
+            std::unique_lock<std::mutex> lk(w->mu);
+            w->cv.wait(lk, [&] { return p->worker_done2; });
+        }
+        p->on_worker = p->on_worker2 = false;
         return;
     }
     if (!p->drawer.joinable()) return;
@@ -805,6 +842,8 @@ static void perms_free(safe_perms *p) {
     for (int b = 0; b < safe_perms::kStage; ++b) {
         if (p->h_stage[b]) (void)hipHostFree(p->h_stage[b]);
         if (p->staged[b]) (void)hipEventDestroy(p->staged[b]);
+        if (p->h_stage2[b]) (void)hipHostFree(p->h_stage2[b]);
+        if (p->staged2[b]) (void)hipEventDestroy(p->staged2[b]);
     }
     for (int b = 0; b < 2; ++b) {
         (void)hipFree(p->d_maps[b]);
@@ -824,6 +863,7 @@ static void perms_free(safe_perms *p) {
     (void)hipFree(p->table16);
     (void)hipFree(p->inverse_t);
     if (p->stream) draw_stream_free(p->stream);
+    if (p->stream2) draw_stream_free(p->stream2);
     delete p;
 }
 
@@ -938,7 +978,17 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     p->ring = ring;
     p->ring_consumer = ring != nullptr && !ring_is_producer(ring);
     p->device_gen = device_gen;
-    p->stream = (p->ring_consumer || device_gen) ? nullptr : draw_stream_new(has_seed ? seed : entropy_seed());
+    const uint32_t stream_seed = has_seed ? seed : entropy_seed();
+    p->stream = (p->ring_consumer || device_gen) ? nullptr : draw_stream_new(stream_seed);
+    // the twin chain (see safe_perms::twin), OPT-IN (SAFE_HIP_DRAW_TWIN=1; single-process seeded calls with polling waits).  Measured on
+    // the bench host, eight driver-style runs each (5 + 20 steps, tools/probe/jitter_ab.sh): without twin mean 3.09-3.22 ms (3.157 on
+    // average), worst step 3.19-4.07; with the twin on a core of its own 3.12-3.39 (3.184), worst 3.23-4.76 -- the slow steps are
+    // not one thread stumbling (both chains slow down together: something host-wide), and two threads on sibling hardware
+    // threads of one core are much worse (median 3.66).  Not the default.
+    static const bool twin_on = getenv("SAFE_HIP_DRAW_TWIN") && !strcmp(getenv("SAFE_HIP_DRAW_TWIN"), "1");
+    p->twin = p->stream != nullptr && ring == nullptr && twin_on && !safe_blocking_sync_selected();
+    if (p->stream2) draw_stream_free(p->stream2);
+    p->stream2 = p->twin ? draw_stream_new(stream_seed) : nullptr;
     p->generated = p->enqueued = 0;
     p->stages = perms_stage_plan(num_permutations);
     if (device_gen) {
@@ -993,6 +1043,17 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
             if (e == hipSuccess && !p->staged[b]) e = hipEventCreateWithFlags(&p->staged[b], safe_event_flags(hipEventDisableTiming));
         }
         if (!p->ring_consumer && !device_gen) p->h_local.resize(std::max<int64_t>(k, 1) + 64);
+        if (p->twin) {
+            p->h_local2.resize(std::max<int64_t>(k, 1) + 64);
+            p->chunk_src.assign(p->stages.size() + 1, 0);
+            for (int b = 0; b < safe_perms::kStage && e == hipSuccess; ++b) {
+                if (!p->h_stage2[b]) {
+                    g_alloc_calls.fetch_add(1, std::memory_order_relaxed);
+                    e = hipHostMalloc(&p->h_stage2[b], p->stage_bytes, hipHostMallocDefault);
+                }
+                if (e == hipSuccess && !p->staged2[b]) e = hipEventCreateWithFlags(&p->staged2[b], safe_event_flags(hipEventDisableTiming));
+            }
+        }
         if (e == hipSuccess) {
             hipLaunchKernelGGL(k_iota, dim3(ceil_div(stride, 256)), dim3(256), 0, ctx->aux_stream, p->d_cur, stride);
             e = hipGetLastError();
@@ -1065,6 +1126,15 @@ int safe_perms_timing(safe_perms *perms, double *out5) {
     out5[2] = perms->enqueued_all_ms;
     out5[3] = perms->ring_wait_ms;
     out5[4] = perms->device_gen ? 3.0 : perms->ring ? (perms->ring_consumer ? 2.0 : 1.0) : 0.0;
+    return SAFE_OK;
+}
+
+int safe_perms_twin_stats(safe_perms *perms, int *twin_active, int64_t *chunks, int64_t *chunks_won_by_twin) {
+    SAFE_REQUIRE(perms && twin_active && chunks && chunks_won_by_twin, "safe_perms_twin_stats: NULL argument");
+    std::lock_guard<std::mutex> lk(perms->draw_mu);
+    *twin_active = perms->twin ? 1 : 0;
+    *chunks = perms->drawn_chunks;
+    *chunks_won_by_twin = perms->twin_wins;
     return SAFE_OK;
 }
 
@@ -1195,6 +1265,8 @@ int safe_perms_destroy(safe_perms *perms) {
     perms_cache_drop(ctx);
     if (perms->stream) draw_stream_free(perms->stream);
     perms->stream = nullptr;
+    if (perms->stream2) draw_stream_free(perms->stream2);
+    perms->stream2 = nullptr;
     (void)hipFree(perms->inverse_t);
     perms->inverse_t = nullptr;
     ctx->perm_cache = perms;

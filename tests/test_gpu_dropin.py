@@ -72,3 +72,23 @@ def test_a_value_the_caller_assigned_is_not_recycled(amd):
     sf.compute_pvalues(how='randomization', num_permutations=20, verbose=False)
     assert sf.nes is not mine
     assert (mine == 7.0).all()
+
+
+@pytest.mark.parametrize('threads', ['0', '1', '4', '16'])
+def test_threaded_read_back_of_a_large_buffer_with_an_odd_tail(amd, monkeypatch, threads):
+    """safe_memcpy_d2h takes its pinned ring + copy threads from 64 MB on: a buffer of 64 MB + an odd tail (a last slot of
+    a few KB, not a multiple of anything) must arrive byte for byte with 1, 4 and 16 copy threads, as with the plain copy
+    (SAFE_HIP_D2H_THREADS=0) and the resident-pages copy."""
+    import ctypes as C
+    from safepy_amd import backend as be
+    ctx = amd.Context.default(0)
+    n_words = (64 << 20) // 8 + 12345
+    src = (np.arange(n_words, dtype=np.uint64) * np.uint64(0x9E3779B97F4A7C15)).view(np.float64)     # every word distinct
+    buf = ctx.alloc_f64(n_words)
+    be.check(be.lib.safe_memcpy_h2d(ctx.handle, C.c_void_p(buf.ptr), src.ctypes.data_as(C.c_void_p), C.c_size_t(src.nbytes)))
+    monkeypatch.setenv('SAFE_HIP_D2H_THREADS', threads)
+    got = buf.download((n_words,))
+    assert np.array_equal(got.view(np.uint64), src.view(np.uint64))
+    again = buf.download((n_words,), out=got)                  # the plain copy into resident pages
+    assert again is got and np.array_equal(got.view(np.uint64), src.view(np.uint64))
+    buf.free()
