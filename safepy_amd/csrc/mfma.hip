@@ -1225,20 +1225,26 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                     uint32_t open = 0;                                // outputs the test leaves undecided
                     const int32_t wcs = static_cast<int32_t>(wc);
 #pragma unroll
-                    for (int j = 0; j < 8; ++j) {                     // the four outputs of counter word j; their thresholds read together
-                        int32_t y0v[4];
+                    for (int jb = 0; jb < 2; ++jb) {                  // sixteen outputs (four counter words) at a time: their thresholds are read together
+                        int32_t y0v[4][4];
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) y0v[f] = y0s[(16 * (f >> 1) + j + 8 * (f & 1)) * 256];
-                        uint32_t inc = 0;
+                        for (int jj = 0; jj < 4; ++jj)
 #pragma unroll
-                        for (int f = 0; f < 4; ++f) {
-                            const int p = f >> 1, r = j + 8 * (f & 1);
-                            const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);   // floor(V_hi / 16)
-                            const int32_t d = y - y0v[f];
-                            inc |= (d < wcs) ? (1u << (8 * f)) : 0u;               // not certainly greater (d < 0: certainly smaller)
-                            open |= (static_cast<uint32_t>(d) < wc) ? (1u << (16 * p + r)) : 0u;
+                            for (int f = 0; f < 4; ++f) y0v[jj][f] = y0s[(16 * (f >> 1) + 4 * jb + jj + 8 * (f & 1)) * 256];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = 4 * jb + jj;
+                            uint32_t inc = 0;
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) {
+                                const int p = f >> 1, r = j + 8 * (f & 1);
+                                const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);   // floor(V_hi / 16)
+                                const int32_t d = y - y0v[jj][f];
+                                inc |= (d < wcs) ? (1u << (8 * f)) : 0u;               // not certainly greater (d < 0: certainly smaller)
+                                open |= (static_cast<uint32_t>(d) < wc) ? (1u << (16 * p + r)) : 0u;
+                            }
+                            if (inc) __hip_atomic_fetch_add(&cnts[j * 256], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                         }
-                        if (inc) __hip_atomic_fetch_add(&cnts[j * 256], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
                     }
                     if (__builtin_expect(open != 0u, 0)) {
                         // rare (~1e-5 of the compares): the resolve kernel forms the exact score from all six digits.  (Nothing here
