@@ -965,7 +965,8 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
 //     accumulator registers), and TWO workgroups share a CU -- the other workgroup's matrix work covers this one's barrier,
 //     gather and score completion;
 //   * the membership words of a super-step are one 16-byte load per piece (blk_bits4: [super-step][row][4 k-steps]);
-//   * threads without a gather role load the zero row (one cache line per instruction) instead of repeating a neighbour's rows;
+//   * threads without a gather role take the source maps' padding block (every index = the zero row: one cache line per load
+//     instruction, no select) instead of repeating a neighbour's rows;
 //   * the thresholds are 32-bit: y = floor(V_hi / 16) against Y0 = floor((O - B') / 2^28), B' = B + 15 * 2^24, with one window
 //     width per task (from the group's largest neighborhood: neighborhoods below 2048 members); what the test leaves open is
 //     appended for k_mfma_resolve, which forms that score from all six digits (the record carries no partial sum);
@@ -981,7 +982,7 @@ constexpr int MF_F_MAXBLK = 2048;         // column blocks per row group this ke
 // as a kernel argument the tests cost the main loop 16 spilled registers and made it three times slower.
 template <int DBG>
 __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
-    const unsigned char *__restrict__ bs, int64_t tile_bytes, int64_t zrow, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
+    const unsigned char *__restrict__ bs, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint4 *__restrict__ blk_bits4,
     const int32_t *__restrict__ grp_maxcnt, const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off,
     unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa) {
@@ -1007,7 +1008,9 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
     const uint32_t w_base = static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
     const uint32_t r_base = static_cast<uint32_t>(h * 512 + lam * 16);
     const int col_in_tile = 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
-    const int32_t row_keep = gth ? -1 : 0, row_else = gth ? 0 : static_cast<int32_t>(zrow);   // non-gather threads: the zero row
+    // threads without a gather role (wave 3) take their source indices from the PADDING block of the source maps (index n_kb:
+    // every entry is the zero row n), so their four row loads hit one cache line and need no select
+    const int kb_pad = static_cast<int>(n_src / 32) - 1;
 
     const int home = blockIdx.x & 7;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -1087,12 +1090,12 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 q = q < n_q ? q : n_q - 1;
                 return *reinterpret_cast<const int4 *>(srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + 4 * rq);
             };
-            auto load_src = [&](int q, int t) -> int4 { return load_src_kb(q, kb_list[4 * t + ks_g]); };
+            auto load_src = [&](int q, int t) -> int4 { return load_src_kb(q, gth ? kb_list[4 * t + ks_g] : kb_pad); };
             auto load_rows = [&](const int4 &src, uint4 (&L)[4]) {
-                L[0] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.x & row_keep) | row_else) * row_bytes);
-                L[1] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.y & row_keep) | row_else) * row_bytes);
-                L[2] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.z & row_keep) | row_else) * row_bytes);
-                L[3] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>((src.w & row_keep) | row_else) * row_bytes);
+                L[0] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.x) * row_bytes);
+                L[1] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.y) * row_bytes);
+                L[2] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.z) * row_bytes);
+                L[3] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(src.w) * row_bytes);
             };
             auto store_quarter = [&](const uint4 (&L)[4], int cw, int buf) {
                 unsigned char *dst = lds + buf * BUF + w_base;
@@ -1148,7 +1151,7 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
             {
                 int q3p = q2, t3p = t2;
                 advance(q3p, t3p);
-                kb_next = kb_list[4 * t3p + ks_g];
+                kb_next = gth ? kb_list[4 * t3p + ks_g] : kb_pad;
             }
             __syncthreads();
 
@@ -1167,13 +1170,12 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 {
                     int q4 = q3, t4 = t3;
                     advance(q4, t4);
-                    kb_next = kb_list[4 * t4 + ks_g];                // (consumed at the top of the next iteration: no wait here)
+                    kb_next = gth ? kb_list[4 * t4 + ks_g] : kb_pad;      // (consumed at the top of the next iteration: no wait here)
                 }
                 // the four row loads of the gather are issued one per k-step below: right after the barrier all four waves of the
                 // workgroup (and often the CU's other workgroup) would queue 24 of them at once -- a wave spent ~450 cycles per
                 // super-step getting its six loads accepted
-                const int32_t row_of[4] = {(src_use.x & row_keep) | row_else, (src_use.y & row_keep) | row_else,
-                                           (src_use.z & row_keep) | row_else, (src_use.w & row_keep) | row_else};
+                const int32_t row_of[4] = {src_use.x, src_use.y, src_use.z, src_use.w};
 
                 const unsigned char *bbuf = lds + ((dbg & 128) ? 0 : buf * BUF) + r_base;
                 if (dbg & 512) c1 = __builtin_amdgcn_s_memtime();
@@ -2584,8 +2586,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
             const unsigned char *bs_main = any_filt ? d_bs_hi : d_bs;
             if (filt_own) {
                 const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
-                int64_t zrow = n;
-                void *args[] = {(void *)&bs_main, (void *)&tile_bytes, (void *)&zrow, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+                void *args[] = {(void *)&bs_main, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                                 (void *)&nbr->bs_kb, (void *)&nbr->bs_bits4, (void *)&nbr->bs_grpmax, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c,
                                 (void *)&mloc, (void *)&d_counts, (void *)&n_padr, (void *)&fa};
                 SAFE_HIP_CHECK(hipLaunchKernel(kfn_own, dim3(blocks_own), dim3(256), args, lds_own, ks));

@@ -305,6 +305,8 @@ class SAFE:
         state = self.__dict__.copy()
         if state.get('_neighborhoods_host') is None and state.get('_nbr') is not None:
             state['_neighborhoods_host'] = self._nbr.to_dense()
+        for key in [k for k in state if k.startswith('_spare_') or k.startswith('_made_')]:
+            del state[key]                   # recycled host arrays and their bookkeeping are not part of the object's value
         state['_nbr'] = None
         state['_attr_dev'] = None
         state['_attr_dev_host'] = None

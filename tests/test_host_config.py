@@ -83,3 +83,60 @@ def test_invalid_option_restores_the_default_and_raises(tmp_path):
     with pytest.raises(ValueError):
         sf.validate_config()
     assert sf.node_distance_metric == 'shortpath_weighted_layout'      # safe.py:205-209
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# the lazy result attributes and their recycled host arrays (safepy_amd/safe.py _LazyArray), with a stand-in for the device buffer
+# ---------------------------------------------------------------------------------------------------------------------
+class _FakeBuffer:
+    def __init__(self, value):
+        self.value, self.freed, self.into = value, False, None
+
+    def download(self, shape, out=None):
+        import numpy as np
+        arr = np.empty(shape) if out is None else out
+        self.into = out
+        arr[...] = self.value
+        return arr
+
+    def free(self):
+        self.freed = True
+
+
+def test_lazy_result_arrays_are_recycled_only_when_nobody_holds_them():
+    import numpy as np
+    import pickle
+    import safepy_amd
+    from safepy_amd import safe as S
+    sf = safepy_amd.SAFE(verbose=False)
+    b1 = _FakeBuffer(1.0)
+    sf.nes = S._DeviceResult(b1, (5, 3))
+    first = sf.nes                                             # first read: copied to the host, the device buffer released
+    assert b1.freed and b1.into is None and (first == 1.0).all()
+    assert sf.nes is first                                     # later reads: the same host array
+    # the caller still holds `first`: the next result must not be written into it
+    b2 = _FakeBuffer(2.0)
+    sf.nes = S._DeviceResult(b2, (5, 3))
+    second = sf.nes
+    assert second is not first and b2.into is None and (first == 1.0).all() and (second == 2.0).all()
+    # nobody holds the second result any more: the third one is written into the same memory
+    addr = second.ctypes.data
+    del second
+    b3 = _FakeBuffer(3.0)
+    sf.nes = S._DeviceResult(b3, (5, 3))
+    third = sf.nes
+    assert third.ctypes.data == addr and b3.into is third and (third == 3.0).all()
+    # another shape: a fresh array; a value the caller assigned is never recycled
+    del third
+    sf.nes = S._DeviceResult(_FakeBuffer(4.0), (2, 2))
+    assert sf.nes.shape == (2, 2) and sf.nes.ctypes.data != addr
+    mine = np.zeros((2, 2))
+    sf.nes = mine
+    b5 = _FakeBuffer(5.0)
+    sf.nes = S._DeviceResult(b5, (2, 2))
+    assert sf.nes is not mine and (mine == 0.0).all()
+    # the bookkeeping is not part of a pickled object
+    state = sf.__getstate__()
+    assert not [k for k in state if k.startswith('_spare_') or k.startswith('_made_')]
+    clone = pickle.loads(pickle.dumps(sf))
+    assert (clone.nes == 5.0).all()
