@@ -189,7 +189,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
                                                     int64_t col0, int64_t mloc, int64_t n_ct, const int *__restrict__ shift,
                                                     const unsigned long long *__restrict__ maxbits, const int *__restrict__ need,
                                                     unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
-                                                    unsigned int *__restrict__ n_small_rounded, int64_t split_off) {
+                                                    unsigned int *__restrict__ n_small_rounded, int64_t split_off, long long *__restrict__ q64) {
     __shared__ double tile[32][33];
     __shared__ unsigned int s_small[32], s_rounded[32];
     const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
@@ -231,6 +231,8 @@ __global__ __launch_bounds__(256) void k_mfma_slice(const void *__restrict__ raw
             k_rounded += q != scaled;
         }
         const unsigned long long u = static_cast<unsigned long long>(static_cast<long long>(q) + bias);
+        // (filtered form) the whole fixed-point value once more as one 64-bit word, [row][column]: what k_mfma_resolve sums
+        if (q64 && split && j < mloc) q64[r * mloc + j] = static_cast<long long>(q);
         unsigned char *dst = bs + ct * tile_bytes + r * row_bytes + tx;
 #pragma unroll
         for (int t = 0; t < MF_NS; ++t)
@@ -2163,7 +2165,7 @@ __global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restri
                                                       const int32_t *__restrict__ rowmap, const int32_t *__restrict__ row_ptr,
                                                       const int32_t *__restrict__ col_idx, const int32_t *__restrict__ table, int64_t n,
                                                       const unsigned char *__restrict__ bs_lo, int64_t tile_bytes, int64_t hi_off,
-                                                      unsigned int *__restrict__ gl_counts) {
+                                                      const long long *__restrict__ q64, int64_t mloc, unsigned int *__restrict__ gl_counts) {
     const unsigned int count = min(*amb_count, amb_cap);
     const int lane = threadIdx.x & 63;
     const unsigned int wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
@@ -2179,6 +2181,9 @@ __global__ __launch_bounds__(256) void k_mfma_resolve(const ulonglong2 *__restri
         const unsigned char *base = bs_lo + (col >> 5) * tile_bytes + (col & 31);
         const int32_t *cur = table + perm * (n + 1);
         long long s = 0;
+        if (full && q64) {                                                       // one 8-byte load per member instead of six bytes from two tiles
+            for (int32_t e = e0 + lane; e < e1; e += 64) s += q64[static_cast<int64_t>(cur[col_idx[e]]) * mloc + col];
+        } else
         for (int32_t e = e0 + lane; e < e1; e += 64) {
             const signed char *d = reinterpret_cast<const signed char *>(base + static_cast<int64_t>(cur[col_idx[e]]) * row_bytes);
             s += static_cast<long long>(static_cast<int>(d[0]) + 256 * static_cast<int>(d[32]) + 65536 * static_cast<int>(d[64]));
@@ -2327,6 +2332,8 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 
     // ---- column scales and slices
     int n_slices = MF_NS;                        // i8 slices of this call: 2 / 4 / 6 by the bits its columns need (k_mfma_colfinish)
+    long long *d_q64 = nullptr;                  // (filtered 'sum' form) the fixed-point values as 64-bit words, [n + 1][mloc]: the resolve kernel's operand
+    if (split_off) SAFE_TRY(ctx_scratch(ctx, 16, static_cast<size_t>(n + 1) * mloc * sizeof(long long), reinterpret_cast<void **>(&d_q64)));
     unsigned char *d_bs = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
     void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale, scale2 f64 | cnt, small, rounded, neg_lowbit u32 | shift, shift2 i32 | bad, need i32
@@ -2364,10 +2371,10 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                    attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off);
         } else if (f32)
             hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off);
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off, d_q64);
         else
             hipLaunchKernelGGL(k_mfma_slice<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off);
+                               attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off, d_q64);
         hipLaunchKernelGGL(k_mfma_colcheck, dim3(ceil_div(mloc, 256)), dim3(256), 0, ctx->stream, d_cnt, d_small, d_rounded,
                            z ? d_zero : static_cast<unsigned int *>(nullptr), d_inexact, mloc, d_bad);
         SAFE_HIP_CHECK(hipGetLastError());
@@ -2605,7 +2612,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                    nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, d_bs_hi, d_scale, d_counts);
             else
                 hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
-                                   nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_counts);
+                                   nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_q64, mloc, d_counts);
             SAFE_HIP_CHECK(hipGetLastError());
             if (c == 0 && long_launches && n_launch > 1) {
                 // pilot: data with many equal scores (sparse columns, few distinct values) leaves the high digits little to
