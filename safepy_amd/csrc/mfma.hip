@@ -284,7 +284,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
                                                       const int *__restrict__ shift2, const unsigned long long *__restrict__ maxbits,
                                                       unsigned char *__restrict__ bs, unsigned int *__restrict__ n_small,
                                                       unsigned int *__restrict__ n_small_rounded, unsigned int *__restrict__ n_zero,
-                                                      int64_t zf_hi_off, int64_t zf_lo_off) {
+                                                      int64_t zf_hi_off, int64_t zf_lo_off, longlong2 *__restrict__ z64) {
     __shared__ double tile[32][17];
     __shared__ unsigned int s_small[16], s_rounded[16], s_zero[16];
     const int64_t ct = blockIdx.x, r0 = static_cast<int64_t>(blockIdx.y) * 32, c0 = ct * 16;
@@ -348,6 +348,10 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
             }
             hi[3 * 32] = present ? 1 : 0;
             hi[3 * 32 + 16] = 0;
+            // ... and both fixed-point values as one 16-byte word, [row][column] (the square is never negative: bit 62 carries the
+            // not-NaN flag): what k_mfma_resolve_z sums
+            if (z64 && j < mloc)
+                z64[r * mloc + j] = make_longlong2(static_cast<long long>(q1), static_cast<long long>(q2) | (present ? (1ll << 62) : 0ll));
         }
     }
     if (k_small) atomicAdd(&s_small[tx], k_small);
@@ -2210,7 +2214,8 @@ __global__ __launch_bounds__(256) void k_mfma_resolve_z(const ulonglong2 *__rest
                                                         const int32_t *__restrict__ rowmap, const int32_t *__restrict__ row_ptr,
                                                         const int32_t *__restrict__ col_idx, const int32_t *__restrict__ table, int64_t n,
                                                         const unsigned char *__restrict__ bs_lo, const unsigned char *__restrict__ bs_hi,
-                                                        const double *__restrict__ col_scale, unsigned int *__restrict__ gl_counts) {
+                                                        const longlong2 *__restrict__ z64, const double *__restrict__ col_scale,
+                                                        unsigned int *__restrict__ gl_counts) {
     const unsigned int count = min(*amb_count, amb_cap);
     const int lane = threadIdx.x & 63;
     const unsigned int wave0 = (blockIdx.x * 256u + threadIdx.x) >> 6, n_waves = (gridDim.x * 256u) >> 6;
@@ -2225,6 +2230,14 @@ __global__ __launch_bounds__(256) void k_mfma_resolve_z(const ulonglong2 *__rest
         const int32_t *cur = table + perm * (n + 1);
         long long s1 = 0, s2 = 0;
         int present = 0;
+        if (z64) {                                                               // one 16-byte load per member
+            for (int32_t e = e0 + lane; e < e1; e += 64) {
+                const longlong2 v = z64[static_cast<int64_t>(cur[col_idx[e]]) * mloc + col];
+                s1 += v.x;
+                s2 += v.y & ((1ll << 62) - 1ll);
+                present += static_cast<int>(v.y >> 62);
+            }
+        } else
         for (int32_t e = e0 + lane; e < e1; e += 64) {
             const int64_t src = cur[col_idx[e]];
             const signed char *l = reinterpret_cast<const signed char *>(lo + src * 96), *hh = reinterpret_cast<const signed char *>(hi + src * 128);
@@ -2334,6 +2347,8 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     int n_slices = MF_NS;                        // i8 slices of this call: 2 / 4 / 6 by the bits its columns need (k_mfma_colfinish)
     long long *d_q64 = nullptr;                  // (filtered 'sum' form) the fixed-point values as 64-bit words, [n + 1][mloc]: the resolve kernel's operand
     if (split_off) SAFE_TRY(ctx_scratch(ctx, 16, static_cast<size_t>(n + 1) * mloc * sizeof(long long), reinterpret_cast<void **>(&d_q64)));
+    longlong2 *d_z64 = nullptr;                  // (filtered z form) value | square + not-NaN flag, [n + 1][mloc]
+    if (zf_hi_off) SAFE_TRY(ctx_scratch(ctx, 17, static_cast<size_t>(n + 1) * mloc * sizeof(longlong2), reinterpret_cast<void **>(&d_z64)));
     unsigned char *d_bs = nullptr;
     SAFE_TRY(ctx_scratch(ctx, 1, static_cast<size_t>(n + 1) * row_bytes, reinterpret_cast<void **>(&d_bs)));
     void *d_colbuf = nullptr;                    // maxbits u64 | sumsq f64 | scale, scale2 f64 | cnt, small, rounded, neg_lowbit u32 | shift, shift2 i32 | bad, need i32
@@ -2365,10 +2380,10 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
                                d_scale + mloc, d_inexact, d_bad);
             if (f32)
                 hipLaunchKernelGGL(k_mfma_slice_z<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off);
+                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off, d_z64);
             else
                 hipLaunchKernelGGL(k_mfma_slice_z<double>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
-                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off);
+                                   attr->col_stride, col0, mloc, n_ct, d_shift, d_shift + mloc, d_max, d_bs, d_small, d_rounded, d_zero, zf_hi_off, zf_lo_off, d_z64);
         } else if (f32)
             hipLaunchKernelGGL(k_mfma_slice<float>, sgrid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_ct, d_shift, d_max, d_need, d_bs, d_small, d_rounded, split_off, d_q64);
@@ -2609,7 +2624,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         if (any_filt) {
             if (zfilt)
                 hipLaunchKernelGGL(k_mfma_resolve_z, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, out.ns, mloc, n_padr,
-                                   nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, d_bs_hi, d_scale, d_counts);
+                                   nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, d_bs_hi, d_z64, d_scale, d_counts);
             else
                 hipLaunchKernelGGL(k_mfma_resolve, dim3(4 * ctx->num_cu), dim3(256), 0, ks, d_amb[c & 1], d_amb_cnt + c, amb_cap, d_obs64, n_padr,
                                    nbr->bs_rowmap, nbr->row_ptr, nbr->col, perms->table, n, d_bs_lo, tile_bytes, split_off, d_q64, mloc, d_counts);
