@@ -985,8 +985,8 @@ static int perms_create_impl(safe_ctx *ctx, int64_t n, const uint8_t *movable_ho
     // average), worst step 3.19-4.07; with the twin on a core of its own 3.12-3.39 (3.184), worst 3.23-4.76 -- the slow steps are
     // not one thread stumbling (both chains slow down together: something host-wide), and two threads on sibling hardware
     // threads of one core are much worse (median 3.66).  Not the default.
-    static const bool twin_on = getenv("SAFE_HIP_DRAW_TWIN") && !strcmp(getenv("SAFE_HIP_DRAW_TWIN"), "1");
-    p->twin = p->stream != nullptr && ring == nullptr && twin_on && !safe_blocking_sync_selected();
+    const char *twin_env = getenv("SAFE_HIP_DRAW_TWIN");                  // (read per handle: tests switch it on and off)
+    p->twin = p->stream != nullptr && ring == nullptr && twin_env && !strcmp(twin_env, "1") && !safe_blocking_sync_selected();
     if (p->stream2) draw_stream_free(p->stream2);
     p->stream2 = p->twin ? draw_stream_new(stream_seed) : nullptr;
     p->generated = p->enqueued = 0;

@@ -95,3 +95,28 @@ def test_partial_reads_follow_the_pipeline(amd, ctx):
     np.testing.assert_array_equal(perms.read(120, 300).astype(np.int64), want[120:300])
     np.testing.assert_array_equal(perms.read().astype(np.int64), want)
     perms.close()
+
+
+@pytest.mark.parametrize('n,k_fixed,nperm,seed', [(3971, 182, 1000, 7), (300, 17, 700, 3), (20000, 1000, 150, 14)])
+def test_twin_chain_gives_the_same_tables(amd, ctx, monkeypatch, n, k_fixed, nperm, seed):
+    """SAFE_HIP_DRAW_TWIN=1 (opt-in): two host threads draw the same chain, whichever finishes a pipeline chunk first publishes
+    it -- the tables must not depend on who won which chunk."""
+    from safepy_amd import backend as be
+    rng = np.random.default_rng(n + 7)
+    flags = np.ones(n, dtype=np.uint8)
+    flags[rng.choice(n, k_fixed, replace=False)] = 0
+    monkeypatch.setenv('SAFE_HIP_DRAW_TWIN', '1')
+    want = numpy_tables(n, flags, nperm, seed)
+    for _ in range(3):                                          # (who wins a chunk changes from run to run)
+        perms = be.Permutations(ctx, n, flags, nperm, seed)
+        got = perms.read().astype(np.int64)
+        t = perms.timing()
+        perms.close()
+        assert t['twin_chain'] and t['chunks'] >= 1
+        np.testing.assert_array_equal(got, want)
+    monkeypatch.setenv('SAFE_HIP_DRAW_TWIN', '0')
+    perms = be.Permutations(ctx, n, flags, nperm, seed)
+    got = perms.read().astype(np.int64)
+    assert not perms.timing()['twin_chain']
+    perms.close()
+    np.testing.assert_array_equal(got, want)
