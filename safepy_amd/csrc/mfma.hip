@@ -2313,7 +2313,9 @@ bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *
     const char *z_env = getenv("SAFE_HIP_MFMA_Z");                       // =0: z-scores stay on the f64 kernels
     if (z && z_env && !strcmp(z_env, "0")) return false;
     if (perms->count < 1 || perms->count > 65535) return false;
-    if (nbr->n > (1ll << 30) / 32 || nbr->max_count >= (1 << 23)) return false;
+    // a score is a sum of `members` fixed-point values below 2^46, combined and compared as 64-bit integers: neighborhoods of
+    // 2^16 members and more could pass 2^62 (the f64 kernels take those)
+    if (nbr->n > (1ll << 30) / 32 || nbr->max_count >= (1 << 16)) return false;
     if (force && !strcmp(force, "mfma")) return true;
     return nbr->n >= 256;                       // below one row group the LDS-resident f64 kernel is the better fit
 }
@@ -2336,7 +2338,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 
     // ---- the filtered form (six-slice 'sum' columns: three slices on the matrix cores, see k_permtest_mfma)
     const char *filt_env = getenv("SAFE_HIP_MFMA_FILTER");                // =0: all six slices on the matrix cores
-    const bool want_filter = allow_filter && nbr->max_count < (1 << 20) && !(filt_env && !strcmp(filt_env, "0"));
+    const bool want_filter = allow_filter && !(filt_env && !strcmp(filt_env, "0"));      // (neighborhoods below 2^16 members: mfma_applicable)
     const int64_t split_off = (want_filter && !z) ? n_ct * (n + 1) * (MF_NS / 2) * 32 : 0;   // high digits behind the low digits
     // z-scores, filtered: the seven-slice layout (observed pass) | high digits + not-NaN slice, 128-byte rows | low digits, 96-byte rows
     const int64_t zf_hi_off = (want_filter && z) ? n_ct * (n + 1) * (MF_NS + 1) * 32 : 0;
