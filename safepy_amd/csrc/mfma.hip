@@ -986,14 +986,19 @@ constexpr int MF_F_MAXBLK = 2048;         // column blocks per row group this ke
 // 1 no transposes / LDS stores, 2 no MFMAs, 4 no barrier per super-step, 8 no score completion, 16 no membership-word loads,
 // 32 no source-index loads, 64 no row gathers, 128 always the same LDS buffer, 256 no LDS operand reads.  A template parameter:
 // as a kernel argument the tests cost the main loop 16 spilled registers and made it three times slower.
-template <int DBG>
+// TR: the gathered rows go to LDS AS THEY ARE ([k][three slices x 32 bytes], one ds_write_b128 per row and thread) and the MFMA
+// operand is read with the transposing LDS read (two ds_read_b64_tr_b8 per slice and k-step: within a 16-lane group lane l
+// receives byte l & 7 of the 8-byte pieces 2 j + (l >> 3), j = 0..7 -- pieces laid over eight consecutive rows, that is column l
+// of an 8 x 16 byte tile, eight consecutive k: tools/ubench/tr8_probe.hip) -- no v_perm transposes, no 4-byte scatter stores.
+// !TR: 4 x 4 byte transposes in registers, k-contiguous LDS image, ds_read_b128 (the general kernel's operand path).
+template <int DBG, bool TR = true>
 __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
     const unsigned char *__restrict__ bs, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
     const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint4 *__restrict__ blk_bits4,
     const int32_t *__restrict__ grp_maxcnt, const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off,
     unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa) {
     constexpr int dbg = DBG;
-    constexpr int NS = MF_NS / 2, KS = NS * MF_SS, BUF = 4 * KS;
+    constexpr int NS = MF_NS / 2, KS = TR ? 32 * NS * 32 : NS * MF_SS, BUF = 4 * KS;
     constexpr int64_t row_bytes = NS * 32;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] | kb list | Y0 [32][256] | counters [8][256]
     __shared__ int slot_box;
@@ -1011,9 +1016,13 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
     const int gt = gth ? tid : 0;
     const int chunk = gt % CH, rq = (gt / CH) % 8, ks_g = gt / (8 * CH);
     const int s_g = chunk >> 1, half_g = chunk & 1;
-    const uint32_t w_base = static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
-    const uint32_t r_base = static_cast<uint32_t>(h * 512 + lam * 16);
-    const int col_in_tile = 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
+    // TR: a thread's row i goes to [k-step][row 4 rq + i][chunk]; a lane reads the 8-byte piece (row (l & 15) >> 1 of its eight,
+    // half l & 1) of column half (lane >> 4) & 1 and k half lane >> 5 -- lane l then owns column l & 31 of the tile
+    const uint32_t w_base = TR ? static_cast<uint32_t>(ks_g * KS + (4 * rq) * 96 + chunk * 16)
+                               : static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
+    const uint32_t r_base = TR ? static_cast<uint32_t>((16 * h + ((lane & 15) >> 1)) * 96 + 16 * ((lane >> 4) & 1) + 8 * (lane & 1))
+                               : static_cast<uint32_t>(h * 512 + lam * 16);
+    const int col_in_tile = TR ? lam : 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
     // threads without a gather role (wave 3) take their source indices from the PADDING block of the source maps (index n_kb:
     // every entry is the zero row n), so their four row loads hit one cache line and need no select
     const int kb_pad = static_cast<int>(n_src / 32) - 1;
@@ -1105,6 +1114,15 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
             };
             auto store_quarter = [&](const uint4 (&L)[4], int cw, int buf) {
                 unsigned char *dst = lds + buf * BUF + w_base;
+                if constexpr (TR) {
+                    uint4 v;                                                     // row cw of the thread's four, as it came
+                    v.x = cw == 0 ? L[0].x : cw == 1 ? L[1].x : cw == 2 ? L[2].x : L[3].x;
+                    v.y = cw == 0 ? L[0].y : cw == 1 ? L[1].y : cw == 2 ? L[2].y : L[3].y;
+                    v.z = cw == 0 ? L[0].z : cw == 1 ? L[1].z : cw == 2 ? L[2].z : L[3].z;
+                    v.w = cw == 0 ? L[0].w : cw == 1 ? L[1].w : cw == 2 ? L[2].w : L[3].w;
+                    *reinterpret_cast<uint4 *>(dst + cw * 96) = v;
+                    return;
+                }
                 const uint32_t w[4] = {cw == 0 ? L[0].x : cw == 1 ? L[0].y : cw == 2 ? L[0].z : L[0].w,
                                        cw == 0 ? L[1].x : cw == 1 ? L[1].y : cw == 2 ? L[1].z : L[1].w,
                                        cw == 0 ? L[2].x : cw == 1 ? L[2].y : cw == 2 ? L[2].z : L[2].w,
@@ -1187,15 +1205,29 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 if (dbg & 512) c1 = __builtin_amdgcn_s_memtime();
                 // two operand sets: the slices of k-step k + 1 are read before the MFMAs of k-step k are issued
                 v4i b_cur[NS], b_nxt[NS];
+                auto read_operand = [&](int k, int s) -> v4i __attribute__((always_inline)) {
+                    if constexpr (TR) {
+                        typedef int v2i __attribute__((ext_vector_type(2)));
+                        typedef __attribute__((address_space(3))) v2i lds_v2i;
+                        const unsigned char *at = bbuf + k * KS + s * 32;
+                        const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at));             // k = 16 h + 0..7
+                        const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at + 8 * 96));    // k = 16 h + 8..15
+                        v4i r;
+                        r[0] = lo[0], r[1] = lo[1], r[2] = hi[0], r[3] = hi[1];
+                        return r;
+                    } else {
+                        return *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+                    }
+                };
 #pragma unroll
                 for (int s = 0; s < NS; ++s)
-                    if (!(dbg & 256)) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
+                    if (!(dbg & 256)) b_cur[s] = read_operand(0, s);
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
                     if (k < 3) {
 #pragma unroll
                         for (int s = 0; s < NS; ++s)
-                            if (!(dbg & 256)) b_nxt[s] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
+                            if (!(dbg & 256)) b_nxt[s] = read_operand(k + 1, s);
                     }
                     if (!(dbg & 64)) L_load[k] = *reinterpret_cast<const uint4 *>(bs_ct + static_cast<int64_t>(row_of[k]) * row_bytes);
                     __builtin_amdgcn_sched_barrier(0);               // the reads and the row load stay ahead of this k-step's MFMAs
@@ -2490,7 +2522,9 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 #else
     constexpr int mfma_dbg = 0;
 #endif
-    const void *kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
+    const char *tr_env = getenv("SAFE_HIP_MFMA_TR");                      // =0: register transposes + ds_read_b128 (A/B)
+    const void *kfn_own = (tr_env && !strcmp(tr_env, "0")) ? reinterpret_cast<const void *>(k_permtest_mfma_f<0, false>)
+                                                          : reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
 #ifdef SAFE_HIP_DIAG
 #define MF_F_DIAG(D) if (mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<D>);
     MF_F_DIAG(1) MF_F_DIAG(2) MF_F_DIAG(4) MF_F_DIAG(8) MF_F_DIAG(15) MF_F_DIAG(31) MF_F_DIAG(47) MF_F_DIAG(79) MF_F_DIAG(271) MF_F_DIAG(127) MF_F_DIAG(383) MF_F_DIAG(511) MF_F_DIAG(512)
