@@ -921,7 +921,11 @@ def main():
 
     # ---------------- the timed mode: inputs (untimed) resident in HBM, then W warm-up and exactly K timed steps ----
     wl = Workload(args, args.workload, args.scaling, args.perms, rank, world, local_rank, ctx, torch, np)
-    res = run_mode(wl, args.steps, args.warmup, ctx, dist, torch, np, be, sharding, world, diag_exchange=True)
+    probe_unseeded = os.environ.get('SAFE_BENCH_SEED') == 'none'       # (probes only: the headline mode as an unseeded call)
+    if probe_unseeded:
+        wl.name += ' [SAFE_BENCH_SEED=none: random_seed=None, tables generated on the device -- NOT the headline configuration]'
+    res = run_mode(wl, args.steps, args.warmup, ctx, dist, torch, np, be, sharding, world, diag_exchange=True,
+                   seed=None if probe_unseeded else 0)
 
     line = None
     if rank == 0:

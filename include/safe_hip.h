@@ -366,6 +366,35 @@ int safe_outputs_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t
                                     int64_t m, int64_t num_permutations, int sign_mode, double enrichment_threshold,
                                     const double *nes_table_host, double *pvalues_neg_dev, double *pvalues_pos_dev,
                                     double *nes_dev, double *nes_binary_dev);
+/* The same exchange in COLUMN CHUNKS (np.concatenate(axis=1) of safepy/safe.py:1355 is the one exchange of the reference's
+ * sharded run, safe.py:1339-1355), optionally overlapped with the last launches of the permutation kernels.
+ * safe_set_exchange_chunks(chunks, cols_per_chunk, cb, user) arms the following safe_randomization calls on this context
+ * (chunks = 0: off): chunk k = this block's columns [k * cols_per_chunk, (k + 1) * cols_per_chunk), cols_per_chunk a
+ * multiple of 64, 1..8 chunks covering the widest rank's block.  safe_export_packed_chunk(k, dst, capacity, stream) copies
+ * chunk k's counters (u32 [columns][n_pad], the layout of safe_export_packed_counts; the rest of `capacity` is zeroed) on
+ * `stream` -- after the call from the finished counters, so that every rank takes part in the same collectives whatever
+ * kernel form its call took (the caller flags slabs that are not bit-sliced counters).
+ * With SAFE_HIP_XCHG_TAIL=<fraction> in the environment and >= 2 chunks, the bit-sliced kernel also runs that last part of
+ * the permutations as one launch per column chunk and calls cb(user) on the calling thread once every launch is enqueued --
+ * before the call waits for them; safe_export_packed_chunk called from there makes `stream` wait until chunk k's counters
+ * are final, so the all-gather of chunk k runs while the later chunks compute.  Off by default: at configs[1] it cost the
+ * step more than the exchange it hides.  safe_packed_chunk_info tells what the last call did
+ * (*chunks = 0: no column-chunked launches).  safe_outputs_from_packed_slabs derives the requested matrices from n_slabs
+ * gathered slabs (slab r: slab_cols[r] columns of counters at slabs_dev + r * slab_stride, written to columns out_col0[r]...
+ * of f64 [n, m_total] matrices), on `stream` (NULL: the context's), without waiting.  safe_randomization_plan: the counter
+ * layout safe_randomization WOULD leave for this block (0 = bit-sliced kernel; -1 otherwise), so that ranks can settle the
+ * form of the exchange in the collective they run before the kernels anyway. */
+typedef void (*safe_enqueued_fn)(void *user);
+int safe_set_exchange_chunks(safe_ctx *ctx, int chunks, int64_t cols_per_chunk, safe_enqueued_fn on_enqueued, void *user);
+int safe_packed_chunk_info(safe_ctx *ctx, int *chunks, int64_t *bounds, int64_t *tail_permutations);
+int safe_export_packed_chunk(safe_ctx *ctx, int chunk, uint32_t *dst_dev, int64_t capacity, void *stream);
+int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *slabs_dev, int layout, int64_t n_pad, int n_slabs,
+                                   int64_t slab_stride, const int64_t *slab_cols, const int64_t *out_col0, int64_t m_total,
+                                   int64_t num_permutations, int sign_mode, double enrichment_threshold,
+                                   const double *nes_table_host, double *pvalues_neg_dev, double *pvalues_pos_dev,
+                                   double *nes_dev, double *nes_binary_dev, void *stream);
+int safe_randomization_plan(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t num_permutations, int score_type,
+                            int *packed_layout);
 
 /* The exchange step of the attribute-sharded path for hosts without their own collective library
  * (replaces np.concatenate(combined_nes, axis=1), safepy/safe.py:1355, and the process pool around it,

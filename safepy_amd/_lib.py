@@ -125,6 +125,12 @@ PROTOTYPES = {
     'safe_export_packed_counts': (C.c_int, [_vp, _vp, _i64, _pi64, _pi64, C.POINTER(C.c_int)]),
     'safe_nes_from_packed_counts': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, _vp, _vp]),
     'safe_outputs_from_packed_counts': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, _i64, _i64, C.c_int, C.c_double, _vp, _vp, _vp, _vp, _vp]),
+    'safe_set_exchange_chunks': (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
+    'safe_packed_chunk_info': (C.c_int, [_vp, C.POINTER(C.c_int), _pi64, _pi64]),
+    'safe_export_packed_chunk': (C.c_int, [_vp, C.c_int, _vp, _i64, _vp]),
+    'safe_outputs_from_packed_slabs': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _i64, _pi64, _pi64, _i64, _i64, C.c_int, C.c_double,
+                                                 _vp, _vp, _vp, _vp, _vp, _vp]),
+    'safe_randomization_plan': (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.POINTER(C.c_int)]),
     'safe_last_kernel_stats': (C.c_int, [_vp, C.c_char_p, C.c_size_t, C.POINTER(C.c_double), _pi64]),
     'safe_last_kernel_busy_ms': (C.c_int, [_vp, C.POINTER(C.c_double)]),
     'safe_last_mfma_slices': (C.c_int, [_vp, C.POINTER(C.c_int)]),

@@ -727,6 +727,72 @@ def export_packed_counts(ctx, dst_ptr, capacity):
     return n_pad.value, m.value, layout.value
 
 
+_ENQUEUED_FN = C.CFUNCTYPE(None, C.c_void_p)
+
+
+def set_exchange_chunks(ctx, chunks, cols_per_chunk=0, on_enqueued=None):
+    """Arms (chunks >= 2) or switches off (0) the column-chunked tail of the following randomization calls on `ctx`
+    (safe_set_exchange_chunks).  `on_enqueued()` is called on the calling thread, inside the randomization call, once all
+    of its launches are enqueued.  An exception it raises is kept and re-raised by take_exchange_error()."""
+    if not chunks:
+        check(lib.safe_set_exchange_chunks(ctx.handle, 0, 0, None, None))
+        ctx._xc_cb = None
+        return
+    ctx._xc_error = None
+
+    def trampoline(_user):
+        try:
+            if on_enqueued is not None:
+                on_enqueued()
+        except BaseException as err:           # (an exception cannot cross the C frames of the call)
+            ctx._xc_error = err
+    cb = _ENQUEUED_FN(trampoline)
+    ctx._xc_cb = cb                             # the library keeps the raw pointer: the object must outlive the calls
+    check(lib.safe_set_exchange_chunks(ctx.handle, int(chunks), int(cols_per_chunk), C.cast(cb, C.c_void_p), None))
+
+
+def take_exchange_error(ctx):
+    err, ctx._xc_error = getattr(ctx, '_xc_error', None), None
+    if err is not None:
+        raise err
+
+
+def packed_chunk_info(ctx):
+    """(chunks, [column bounds], tail permutations) of the last randomization call; chunks = 0: it ran no column-chunked launches."""
+    k, tail = C.c_int(), C.c_int64()
+    bounds = (C.c_int64 * 9)()
+    check(lib.safe_packed_chunk_info(ctx.handle, C.byref(k), bounds, C.byref(tail)))
+    return k.value, [bounds[i] for i in range(k.value + 1)] if k.value else [], tail.value
+
+
+def export_packed_chunk(ctx, chunk, dst_ptr, capacity, stream=None):
+    check(lib.safe_export_packed_chunk(ctx.handle, int(chunk), C.c_void_p(dst_ptr), int(capacity), C.c_void_p(stream) if stream else None))
+
+
+def outputs_from_packed_slabs(ctx, nbr, slabs_ptr, layout, n_pad, slab_stride, slab_cols, out_col0, m_total, num_permutations,
+                              attribute_sign, enrichment_threshold, out_ptrs, table=None, stream=None):
+    """out_ptrs = (pvalues_neg, pvalues_pos, nes, nes_binary) device pointers of f64 [n, m_total] matrices (None = not wanted);
+    slab r = slab_cols[r] columns of u32 counters at slabs_ptr + 4 * r * slab_stride, written to columns out_col0[r] ...
+    (safe_outputs_from_packed_slabs); enqueued on `stream` (a raw hipStream_t; None: the context's), not waited for."""
+    if table is None:
+        table = nes_table(num_permutations)
+    k = len(slab_cols)
+    cols = (C.c_int64 * k)(*[int(v) for v in slab_cols])
+    col0 = (C.c_int64 * k)(*[int(v) for v in out_col0])
+    pn, pp, nes, nb = (C.c_void_p(p) if p else None for p in out_ptrs)
+    check(lib.safe_outputs_from_packed_slabs(ctx.handle, nbr.handle, C.c_void_p(slabs_ptr), int(layout), int(n_pad), k, int(slab_stride),
+                                             cols, col0, int(m_total), int(num_permutations), _SIGN[attribute_sign],
+                                             float(enrichment_threshold), _ptr(table), pn, pp, nes, nb,
+                                             C.c_void_p(stream) if stream else None))
+
+
+def randomization_plan(ctx, nbr, attr, num_permutations, score_type):
+    """The packed-counter layout safe_randomization would leave for this block (0 = bit-sliced kernel), -1 = none predicted."""
+    layout = C.c_int()
+    check(lib.safe_randomization_plan(ctx.handle, nbr.handle, attr.handle, int(num_permutations), _SCORE[score_type], C.byref(layout)))
+    return layout.value
+
+
 def nes_from_packed_counts(ctx, nbr, counts_ptr, layout, n_pad, m, num_permutations, attribute_sign, nes_ptr, table=None):
     if table is None:
         table = nes_table(num_permutations)

@@ -110,6 +110,19 @@ struct safe_ctx {
     const unsigned int *packed_counts = nullptr;
     int64_t packed_n_pad = 0, packed_m = 0, packed_perms = 0;
     int packed_layout = -1;
+    // Exchange overlap of the sharded step (safe_set_exchange_chunks; sharding.py): the bit-sliced launches run the LAST part of
+    // the permutations column chunk by column chunk, so that a chunk's counters are final -- and can travel -- while the later
+    // chunks still compute.  xc_want / xc_cols: what the caller armed; xc_made / xc_bounds / xc_events: what the last call did.
+    static constexpr int XC_MAX = 8;
+    int xc_want = 0;
+    int64_t xc_cols = 0;
+    void (*xc_callback)(void *) = nullptr;      // called once every launch of the call is enqueued (before the call's own sync)
+    void *xc_user = nullptr;
+    int xc_made = 0;
+    int64_t xc_bounds[XC_MAX + 1] = {};         // column boundaries of the chunks (this rank's columns: clipped to packed_m)
+    int64_t xc_tail_perms = 0;                  // permutations the column-chunked launches covered
+    hipEvent_t xc_events[XC_MAX] = {};          // chunk k's counters are final
+    std::vector<double> nes_tab_host;           // safe_outputs_from_packed_slabs: the table it uploaded last (no sync per call)
     void *pinned = nullptr;
     size_t pinned_bytes = 0;
     // large device-to-host copies into pageable memory (safe_memcpy_d2h): a ring of pinned slots the DMA engine fills while host
@@ -275,6 +288,7 @@ struct PermOut {
     double nes_threshold;     // -log10(enrichment_threshold)
     int sign_mode;
     int mode;                 // 0 = score only, 1 = raw counts, 2 = full post-processing
+    int64_t ld;               // row pitch of the output matrices in elements (0 = the column count of the call)
 };
 
 struct safe_attr {
@@ -410,7 +424,7 @@ static inline std::vector<int64_t> perm_launch_starts(const safe_perms *perms, i
 int perms_wait(safe_perms *perms, int64_t upto, hipStream_t s);   // make stream s wait until rows [0, upto) exist (rng.cpp)
 // counters [column][position] (#less << 16 | #greater) -> outputs; rowmap[position] = row or -1 (enrich.hip)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
-                           int64_t n_perm, const PermOut &out, const double *ns_direct);
+                           int64_t n_perm, const PermOut &out, const double *ns_direct, hipStream_t on = nullptr);
 // MFMA (i8, exact fixed point) form of the permutation test for quantitative attributes (mfma.hip)
 bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *attr, const safe_perms *perms, bool z);
 int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1, bool z,

@@ -234,6 +234,8 @@ int safe_ctx_destroy(safe_ctx *ctx) {
     if (ctx->d2h_ring) (void)hipHostFree(ctx->d2h_ring);
     for (hipEvent_t e : ctx->d2h_events)
         if (e) (void)hipEventDestroy(e);
+    for (hipEvent_t e : ctx->xc_events)
+        if (e) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_timing) (void)hipEventDestroy(e);
     for (hipEvent_t e : ctx->ev_plain) (void)hipEventDestroy(e);
     for (int i = 0; i < safe_ctx::N_SCRATCH; ++i)

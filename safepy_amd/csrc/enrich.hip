@@ -1747,13 +1747,13 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
             const int64_t c = c0 + ct * 64 + lane;
             if (c >= mloc) continue;
             const unsigned int v = tile[ct * 64 + lane][ss];
-            const int64_t o = static_cast<int64_t>(row) * mloc + c;
+            const int64_t o = static_cast<int64_t>(row) * (out.ld ? out.ld : mloc) + c;      // (ld: a column block of a wider matrix)
             unsigned int cneg, cpos;
             bool obs_nan = false;
             if (DIRECT) {
                 cneg = v & 0xFFFFu;
                 cpos = v >> 16;
-                const double obs = ns[o];
+                const double obs = ns[static_cast<int64_t>(row) * mloc + c];
                 obs_nan = obs != obs;
             } else {
                 cneg = P - (v & 0xFFFFu);           // #(S_p <= S_obs) = P - #greater
@@ -1800,12 +1800,13 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
 
 // ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
-                           int64_t n_perm, const PermOut &out, const double *ns_direct) {
+                           int64_t n_perm, const PermOut &out, const double *ns_direct, hipStream_t on) {
+    const hipStream_t fin_stream = on ? on : ctx->stream;
     const dim3 grid(n_pad / FIN_TP, ceil_div(mloc, FIN_TC));
     const size_t tab_bytes = static_cast<size_t>(n_perm + 1) * sizeof(double);
     const bool tab_lds = out.mode != 1 && tab_bytes <= 20 * 1024;          // (next to 43 KB of static LDS)
     const size_t dyn = tab_lds ? tab_bytes : 0;
-#define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, ctx->stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out)
+#define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, fin_stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out)
 #define FIN_MODE(D, L)                      \
     do {                                    \
         if (out.mode == 1) FIN(D, 1, false); \
@@ -2538,6 +2539,8 @@ int kernel_stat_from_events(safe_ctx *ctx, hipEvent_t *ev, int64_t n_launch) {
         if (c) SAFE_HIP_CHECK(hipEventElapsedTime(&t0, ev[0], ev[2 * c]));
         ctx->last_kernel.total_ms += ms;
         ctx->last_kernel.launches += 1;
+        static const bool dump = getenv("SAFE_HIP_LAUNCH_TRACE") != nullptr;       // every launch's interval, relative to the first one's start
+        if (dump) fprintf(stderr, "[launch trace] %2lld: %8.3f .. %8.3f ms (%.3f)\n", (long long)c, t0, t0 + ms, ms);
         const double a = std::max<double>(t0, covered_to), b = static_cast<double>(t0) + ms;
         if (b > a) busy += b - a;
         covered_to = std::max(covered_to, b);
@@ -2602,6 +2605,47 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int merge = 1;
     if (const char *e = getenv("SAFE_HIP_BITS_MERGE")) merge = std::max(1, atoi(e));
     const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
+    // Exchange overlap of the sharded step (safe_set_exchange_chunks): the LAST permutations -- the tail -- run as one launch per
+    // COLUMN chunk over all of the tail instead of one launch per stage over all columns.  A chunk's counters are then final when
+    // its launch ends, and its all-gather overlaps the launches of the later chunks (xc_events; sharding.ChunkedExchange).
+    // Tasks keep their size (a chunk has 1/K of the word groups and more permutations), so the kernels' work is the same; the
+    // permuted member lists of the tail are built stage by stage beside the earlier launches and shared by the chunks' launches.
+    // MEASURED (configs[1] on one MI355X with a one-rank RCCL group, tools/probe/xchg_ab.sh; plain step 3.6 ms, kernels 2.55 ms):
+    //   * seeded stream, tail = 0.4 of the permutations: step +0.63 ms.  The stage launches run in step with the host's draws (a
+    //     stage every 0.3 ms, kernels 0.5 ms behind), and a tail's launches cannot start before the LAST draw: every stage
+    //     moved into the tail waits for the end of the stream.
+    //   * seeded, tail = the last stage (waits for nothing new): step +0.7 ms.  A chunk of one stage has 1/K of the tasks: with
+    //     the stages' task size 288 tasks for 960 slots (each chunk launch as long as a whole stage), with tasks cut to fill
+    //     the slots 4.5 x as many task set-ups (table reload, counter flush): the four chunk launches took 0.72 ms for the
+    //     0.31 ms of one launch.
+    //   * unseeded (tables generated on the device, nothing to wait for), tail 0.2 / 0.4 / 1.0: kernels +0.2 .. +0.7 ms, step
+    //     +1.2 ms: the chunks' copy-out and all-gather kernels crawl on the 16 CUs the persistent workgroups leave free.
+    // It hides at most the exchange of K - 1 chunks (~0.9 ms of 1.2 ms at 8 ranks) and never paid for itself at this size, so the
+    // tail is OFF by default (SAFE_HIP_XCHG_TAIL=<fraction of the permutations> switches it on; 1e-9 = the last stage); the
+    // chunked exchange itself (sharding.ChunkedExchange) then runs its collectives right after the kernels, chunk by chunk
+    // beside the derivation of the previous chunk's matrices.
+    const bool blk_expected = [&] {
+        const char *pe = getenv("SAFE_HIP_BITS_PRE"), *ke = getenv("SAFE_HIP_BITS_KERNEL");
+        return (n + 1) * 8 < 65536 && !(pe && !strcmp(pe, "0")) && nbr->sell_col2b != nullptr && !(ke && !strcmp(ke, "pre"));
+    }();
+    int64_t n_major = static_cast<int64_t>(starts.size()) - 1, p_split = P, xc_wpc = 0;
+    int xc_k = 0;
+    ctx->xc_made = 0;
+    const char *ns_env = getenv("SAFE_HIP_BITS_STREAMS");                 // (the fourth launch stream is the tail's list stream)
+    if (ctx->xc_want >= 2 && ctx->xc_cols >= 64 && ctx->xc_cols % 64 == 0 && blk_expected && n_major >= 3 && !(ns_env && atoi(ns_env) >= 4) &&
+        static_cast<int64_t>(std::min<int>(ctx->xc_want, safe_ctx::XC_MAX)) * ctx->xc_cols >= mloc) {
+        double frac = 0.0;                              // (off unless asked for: see the measurements above)
+        if (const char *e = getenv("SAFE_HIP_XCHG_TAIL")) frac = std::min(1.0, std::max(0.0, atof(e)));
+        int64_t c_split = 1;
+        while (c_split < n_major - 1 && static_cast<double>(starts[c_split]) < (1.0 - frac) * static_cast<double>(P)) ++c_split;
+        if (frac > 0.0) {
+            n_major = c_split;
+            p_split = starts[c_split];
+            xc_k = std::min<int>(ctx->xc_want, safe_ctx::XC_MAX);
+            xc_wpc = ctx->xc_cols / 64;
+        }
+    }
+    const int64_t n_tail = xc_k, tail_span = P - p_split;
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
@@ -2631,8 +2675,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int64_t max_ppt = 0;                                 // SAFE_HIP_BITS_MAXPPT: cap on a task's permutations (A/B: long launches with short tasks)
     if (const char *e = getenv("SAFE_HIP_BITS_MAXPPT")) max_ppt = std::max(0, atoi(e));
     struct TaskCost { int4 t; int64_t cost; };
-    auto build_tasks = [&](int64_t span_c) {
-        const int64_t target = std::max<int64_t>(target_min, blocks_per_perm * span_c / tasks_per_wg);    // block-permutations per task
+    auto build_tasks = [&](int64_t span_c, int64_t w_lo = 0, int64_t w_hi = -1) {
+        if (w_hi < 0) w_hi = n_wg;
+        // (a column chunk of the tail has fewer word groups: its tasks are cut so that ITS launch fills the slots once too -- with
+        // the stage launches' task size a chunk of the last stage had 288 tasks for 960 slots and lasted as long as a whole stage)
+        const int64_t tpw = w_hi - w_lo == n_wg ? tasks_per_wg : std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, std::max<int64_t>(1, w_hi - w_lo)));
+        const int64_t target = std::max<int64_t>(target_min, blocks_per_perm * span_c / tpw);    // block-permutations per task
         std::vector<TaskCost> tc;
         for (int64_t g = 0; g < n_sg; ++g) {
             const int64_t bl = std::max<int64_t>(sg_blocks[g], 1);
@@ -2643,7 +2691,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             ppt = ceil_div(span_c, chunks);
             for (int64_t c = 0; c < chunks; ++c) {
                 const int64_t p0 = c * ppt, p1 = std::min<int64_t>(span_c, p0 + ppt);
-                for (int64_t w = 0; w < n_wg; ++w)
+                for (int64_t w = w_lo; w < w_hi; ++w)
                     tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
                                   bl * (p1 - p0)});
             }
@@ -2679,15 +2727,27 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         }
         return out;
     };
-    const int64_t n_launch = static_cast<int64_t>(starts.size()) - 1;
+    const int64_t n_launch = n_major + n_tail;           // stage launches over all columns, then the tail's column chunks
     // the lists only depend on the handle and on these numbers: the handle keeps the last plan
-    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch, max_ppt};
+    std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch, max_ppt,
+                                     n_major, n_tail, xc_wpc};
     plan_key.insert(plan_key.end(), starts.begin(), starts.end());
     BitsTaskPlan &plan = nbr->bits_plan;
     if (plan.key != plan_key) {
         plan = BitsTaskPlan{};
         plan.launch_list.assign(std::max<int64_t>(n_launch, 1), 0);
-        for (int64_t c = 0; c < n_launch; ++c) {
+        for (int64_t k = 0; k < n_tail; ++k) {             // one list per column chunk (possibly empty on a rank with fewer columns)
+            const int64_t w_lo = std::min<int64_t>(k * xc_wpc, n_wg), w_hi = k + 1 == n_tail ? n_wg : std::min<int64_t>((k + 1) * xc_wpc, n_wg);
+            BitsQueues bq{};
+            const std::vector<int4> one = w_hi > w_lo ? split_queues(build_tasks(tail_span, w_lo, w_hi), bq.off) : std::vector<int4>();
+            plan.launch_list[n_major + k] = static_cast<int64_t>(plan.list_span.size());
+            plan.list_queues.push_back(bq);
+            plan.list_span.push_back(-1 - k);                // (never matches a stage's span)
+            plan.list_first.push_back(static_cast<int64_t>(plan.tasks.size()));
+            plan.list_count.push_back(static_cast<int64_t>(one.size()));
+            plan.tasks.insert(plan.tasks.end(), one.begin(), one.end());
+        }
+        for (int64_t c = 0; c < n_major; ++c) {
             const int64_t span_c = starts[c + 1] - starts[c];
             size_t k = 0;
             while (k < plan.list_span.size() && plan.list_span[k] != span_c) ++k;
@@ -2761,6 +2821,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         for (int b = 0; b < NS; ++b)
             SAFE_TRY(ctx_scratch(ctx, b < 2 ? 4 + b : 10 + b, static_cast<size_t>(span) * entries_pad * sizeof(uint16_t),
                                  reinterpret_cast<void **>(&d_ids[b])));
+    uint16_t *d_ids_tail = nullptr;                   // the tail's permuted member lists: built once, read by every column chunk's launch
+    if (n_tail)
+        SAFE_TRY(ctx_scratch(ctx, 18, static_cast<size_t>(tail_span) * entries_pad * sizeof(uint16_t), reinterpret_cast<void **>(&d_ids_tail)));
     hipStream_t kstreams[4] = {ctx->stream, ctx->side_stream, ctx->more_streams[0], ctx->more_streams[1]};
     const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
@@ -2833,25 +2896,58 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     ctx->last_kernel.launches = 0;
     hipEvent_t *ev = nullptr, *plain = nullptr;                   // pooled on the context
     SAFE_TRY(ctx_events(ctx, true, 2 * n_launch, &ev));
-    SAFE_TRY(ctx_events(ctx, false, 4, &plain));
+    SAFE_TRY(ctx_events(ctx, false, 12, &plain));                 // 0: inputs ready, 1..3: end join, 4..7: join before the tail, 8: tail lists
+    SAFE_REQUIRE(!n_tail || blk, "launch_bits: column-chunked tail without the blocked kernel");
+    for (int64_t k = 0; k < n_tail; ++k)
+        if (!ctx->xc_events[k]) SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->xc_events[k], hipEventDisableTiming));
     // consecutive spans alternate between two streams so the tail of one launch (a few long
     // tasks) overlaps the head of the next; both wait for the inputs prepared on ctx->stream
     hipEvent_t ready = plain[0];
     SAFE_HIP_CHECK(hipEventRecord(ready, ctx->stream));
     for (int b = 1; b < NS; ++b) SAFE_HIP_CHECK(hipStreamWaitEvent(kstreams[b], ready, 0));
+    hipStream_t tail_ps = ctx->more_streams[1];
+    int xc_rc = SAFE_OK;
+    auto chunk_final = [&](int64_t c, hipStream_t ks) {          // behind chunk launch c on ks: the event that says its counters are final
+        for (int b = 0; b < NS; ++b)
+            if (kstreams[b] != ks && hipStreamWaitEvent(ks, plain[4 + b], 0) != hipSuccess) xc_rc = SAFE_E_HIP;
+        if (hipEventRecord(ctx->xc_events[c - n_major], ks) != hipSuccess) xc_rc = SAFE_E_HIP;
+    };
     for (int64_t c = 0; c < n_launch; ++c) {
-        const int64_t p_base = starts[c], p_limit = starts[c + 1];
+        const bool tail = c >= n_major;                                     // a column chunk over the tail's permutations
+        const int64_t p_base = tail ? p_split : starts[c], p_limit = tail ? P : starts[c + 1];
         const int64_t n_tasks = list_count[launch_list[c]];                 // this launch size's task list
         const int4 *d_tasks = d_task_lists + list_first[launch_list[c]];
         const int64_t blocks = std::min<int64_t>(n_tasks, slots);
         hipStream_t ks = kstreams[c % NS];
-        SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
+        if (tail && c == n_major) {
+            // the tail's permuted member lists: one k_permute_cols per pipeline stage as its tables arrive, on a stream of their
+            // own beside the stage launches (in one piece after the last draw they were 0.1 ms of idle GPU)
+            const int64_t n_stage = static_cast<int64_t>(starts.size()) - 1;
+            SAFE_HIP_CHECK(hipStreamWaitEvent(tail_ps, ready, 0));
+            for (int64_t t = n_major; t < n_stage; ++t) {
+                SAFE_TRY(perms_wait(perms, starts[t + 1], tail_ps));
+                hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), starts[t + 1] - starts[t]), dim3(256),
+                                   static_cast<size_t>(perms->stride16) * sizeof(uint16_t), tail_ps, perms->table16, perms->stride16,
+                                   nbr->sell_col2b, nbr->sell_entries, entries_pad, starts[t], starts[t + 1] - starts[t],
+                                   static_cast<uint32_t>(8 * n), d_ids_tail + (starts[t] - p_split) * entries_pad, diag_banks);
+                SAFE_HIP_CHECK(hipGetLastError());
+            }
+            SAFE_HIP_CHECK(hipEventRecord(plain[8], tail_ps));
+            // a chunk's counters are final once ITS launch and every stage launch have ended: the chunk launches themselves do not
+            // wait for the stage launches of the other stream (their tails overlap as everywhere else) -- the chunk's event does
+            for (int b = 0; b < NS; ++b) {
+                SAFE_HIP_CHECK(hipEventRecord(plain[4 + b], kstreams[b]));
+                SAFE_HIP_CHECK(hipStreamWaitEvent(kstreams[b], plain[8], 0));
+            }
+        }
+        if (!tail) SAFE_TRY(perms_wait(perms, p_limit, ks));            // host draws + table kernels for this span
         safe_trace("launch_bits: span tables enqueued");
         if (pre) {
-            hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
-                               static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
-                               perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
-                               p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c % NS], diag_banks);
+            if (!tail)
+                hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
+                                   static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
+                                   perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
+                                   p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c % NS], diag_banks);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
@@ -2861,8 +2957,13 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
+            if (blk && tail && n_tasks == 0) {                           // (a rank with fewer columns: nothing in this chunk)
+                SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
+                chunk_final(c, ks);
+                continue;
+            }
             if (blk) {
-                const uint16_t *ids_c = d_ids[c % NS];
+                const uint16_t *ids_c = tail ? d_ids_tail : d_ids[c % NS];
                 unsigned int *queue_c = d_queue + 8 * c;
                 BitsQueues bq = list_queues[launch_list[c]];
                 void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
@@ -2872,6 +2973,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                 const int64_t blocks_blk = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                                           std::max<size_t>(1, std::min<size_t>(occ5 ? 5 : 4, (160 * 1024) / lds_pre)));   // 4 (5): the register file holds 16 (20) waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
+                if (tail) chunk_final(c, ks);
             } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
@@ -2902,16 +3004,25 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
         SAFE_HIP_CHECK(hipGetLastError());
         SAFE_HIP_CHECK(hipEventRecord(ev[2 * c + 1], ks));
     }
-    for (int b = 1; b < NS; ++b) {
-        SAFE_HIP_CHECK(hipEventRecord(plain[b], kstreams[b]));
-        SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, plain[b], 0));
-    }
-    SAFE_TRY(enrich_finalize_counts(ctx, d_gl, n_pad, nbr->sell_row, mloc, P, out, nullptr));
     ctx->packed_counts = d_gl;
     ctx->packed_n_pad = n_pad;
     ctx->packed_m = mloc;
     ctx->packed_perms = P;
     ctx->packed_layout = 0;
+    SAFE_REQUIRE(xc_rc == SAFE_OK, "launch_bits: recording a column chunk's event failed");
+    if (n_tail) {
+        ctx->xc_made = static_cast<int>(n_tail);
+        ctx->xc_tail_perms = tail_span;
+        for (int64_t k = 0; k <= n_tail; ++k) ctx->xc_bounds[k] = std::min<int64_t>(k * ctx->xc_cols, mloc);
+        ctx->xc_bounds[n_tail] = mloc;
+        safe_trace("launch_bits: column chunks enqueued");
+        if (ctx->xc_callback) ctx->xc_callback(ctx->xc_user);          // the caller's exchange of the chunks goes out behind these launches
+    }
+    for (int b = 1; b < NS; ++b) {
+        SAFE_HIP_CHECK(hipEventRecord(plain[b], kstreams[b]));
+        SAFE_HIP_CHECK(hipStreamWaitEvent(ctx->stream, plain[b], 0));
+    }
+    SAFE_TRY(enrich_finalize_counts(ctx, d_gl, n_pad, nbr->sell_row, mloc, P, out, nullptr));
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
@@ -3615,6 +3726,118 @@ int safe_outputs_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t
     int rc = enrich_finalize_counts(ctx, counts_dev, n_pad, rowmap, m, P, out, nullptr);
     if (rc == SAFE_OK && safe_stream_sync(ctx->stream) != hipSuccess) rc = SAFE_E_HIP;   // tab is a host vector
     return rc;
+}
+
+int safe_set_exchange_chunks(safe_ctx *ctx, int chunks, int64_t cols_per_chunk, void (*on_enqueued)(void *), void *user) {
+    SAFE_REQUIRE(ctx, "safe_set_exchange_chunks: NULL context");
+    SAFE_REQUIRE(chunks == 0 || (chunks >= 1 && chunks <= safe_ctx::XC_MAX && cols_per_chunk >= 64 && cols_per_chunk % 64 == 0),
+                 "safe_set_exchange_chunks: %d chunks of %lld columns (1..%d chunks of a multiple of 64 columns, or 0 to switch off)", chunks,
+                 (long long)cols_per_chunk, safe_ctx::XC_MAX);
+    ctx->xc_want = chunks;
+    ctx->xc_cols = chunks ? cols_per_chunk : 0;
+    ctx->xc_callback = chunks ? on_enqueued : nullptr;
+    ctx->xc_user = chunks ? user : nullptr;
+    if (chunks) ctx->xc_made = 0;                     // (switching off keeps what the last call did: safe_packed_chunk_info)
+    return SAFE_OK;
+}
+
+int safe_packed_chunk_info(safe_ctx *ctx, int *chunks, int64_t *bounds, int64_t *tail_permutations) {
+    SAFE_REQUIRE(ctx && chunks, "safe_packed_chunk_info: NULL argument");
+    const int made = ctx->packed_layout == 0 ? ctx->xc_made : 0;
+    *chunks = made;
+    if (bounds)
+        for (int k = 0; k <= made; ++k) bounds[k] = ctx->xc_bounds[k];
+    if (tail_permutations) *tail_permutations = made ? ctx->xc_tail_perms : 0;
+    return SAFE_OK;
+}
+
+int safe_export_packed_chunk(safe_ctx *ctx, int chunk, uint32_t *dst_dev, int64_t capacity, void *stream) {
+    SAFE_REQUIRE(ctx && dst_dev, "safe_export_packed_chunk: NULL argument");
+    SAFE_REQUIRE(ctx->packed_layout >= 0 && ctx->xc_want >= 1 && chunk >= 0 && chunk < ctx->xc_want,
+                 "safe_export_packed_chunk: chunk %d of %d armed, counters %s", chunk, ctx->xc_want, ctx->packed_layout >= 0 ? "present" : "absent");
+    // the armed grid, whether or not the call ran its tail chunk by chunk (it did not: a kernel form without the tail, too few
+    // stages -- then the call has ended, the counters are final and no event is waited for)
+    const int64_t c0 = std::min<int64_t>(chunk * ctx->xc_cols, ctx->packed_m);
+    const int64_t c1 = chunk + 1 == ctx->xc_want ? ctx->packed_m : std::min<int64_t>((chunk + 1) * ctx->xc_cols, ctx->packed_m);
+    const int64_t cells = (c1 - c0) * ctx->packed_n_pad;
+    SAFE_REQUIRE(capacity >= cells, "safe_export_packed_chunk: buffer holds %lld counters, %lld needed", (long long)capacity, (long long)cells);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    if (ctx->xc_made > 0) {
+        SAFE_REQUIRE(ctx->xc_made == ctx->xc_want && ctx->xc_bounds[chunk] == c0 && ctx->xc_bounds[chunk + 1] == c1,
+                     "safe_export_packed_chunk: the call's chunks are not the armed ones");
+        SAFE_HIP_CHECK(hipStreamWaitEvent(s, ctx->xc_events[chunk], 0));
+    }
+    if (cells)
+        SAFE_HIP_CHECK(hipMemcpyAsync(dst_dev, ctx->packed_counts + c0 * ctx->packed_n_pad, static_cast<size_t>(cells) * sizeof(uint32_t),
+                                      hipMemcpyDeviceToDevice, s));
+    if (capacity > cells)                              // (a rank with fewer columns: zero counters in the padding columns)
+        SAFE_HIP_CHECK(hipMemsetAsync(dst_dev + cells, 0, static_cast<size_t>(capacity - cells) * sizeof(uint32_t), s));
+    return SAFE_OK;
+}
+
+int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *slabs_dev, int layout, int64_t n_pad, int n_slabs,
+                                   int64_t slab_stride, const int64_t *slab_cols, const int64_t *out_col0, int64_t m_total,
+                                   int64_t num_permutations, int sign_mode, double enrichment_threshold, const double *nes_table_host,
+                                   double *pvalues_neg_dev, double *pvalues_pos_dev, double *nes_dev, double *nes_binary_dev,
+                                   void *stream) {
+    SAFE_REQUIRE(ctx && nbr && slabs_dev && slab_cols && out_col0 && n_slabs >= 1, "safe_outputs_from_packed_slabs: NULL argument");
+    SAFE_REQUIRE(pvalues_neg_dev || pvalues_pos_dev || nes_dev || nes_binary_dev, "safe_outputs_from_packed_slabs: no output requested");
+    SAFE_REQUIRE(layout == 0 || layout == 1, "safe_outputs_from_packed_slabs: bad layout %d", layout);
+    SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_outputs_from_packed_slabs: bad sign_mode %d", sign_mode);
+    SAFE_REQUIRE(num_permutations >= 1 && num_permutations <= 65535 && m_total >= 1, "safe_outputs_from_packed_slabs: bad sizes");
+    SAFE_REQUIRE(enrichment_threshold > 0.0 || !nes_binary_dev, "safe_outputs_from_packed_slabs: enrichment_threshold must be positive");
+    const int32_t *rowmap = layout == 0 ? nbr->sell_row : nbr->bs_rowmap;
+    const int64_t want_pad = layout == 0 ? nbr->n_slices * 64 : nbr->bs_groups * 256;
+    SAFE_REQUIRE(rowmap && n_pad == want_pad, "safe_outputs_from_packed_slabs: counters are for %lld positions, the membership has %lld",
+                 (long long)n_pad, (long long)want_pad);
+    for (int r = 0; r < n_slabs; ++r)
+        SAFE_REQUIRE(slab_cols[r] >= 0 && slab_cols[r] * n_pad <= slab_stride && out_col0[r] >= 0 && out_col0[r] + slab_cols[r] <= m_total,
+                     "safe_outputs_from_packed_slabs: slab %d (%lld columns at column %lld) does not fit", r, (long long)slab_cols[r],
+                     (long long)out_col0[r]);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    const int64_t P = num_permutations;
+    std::vector<double> tab(P + 1);
+    if (nes_table_host) {
+        std::copy(nes_table_host, nes_table_host + P + 1, tab.begin());
+    } else {
+        tab[0] = -std::log10(1.0 / static_cast<double>(P));
+        for (int64_t k = 1; k <= P; ++k) tab[k] = -std::log10(static_cast<double>(k) / static_cast<double>(P));
+    }
+    // the table stays on the device between calls (one call per column chunk of a step: no upload, no sync after the first)
+    double *d_tab = nullptr;
+    const bool grow = ctx->scratch_bytes[19] < (P + 1) * sizeof(double);
+    SAFE_TRY(ctx_scratch(ctx, 19, (P + 1) * sizeof(double), reinterpret_cast<void **>(&d_tab)));
+    if (grow || ctx->nes_tab_host != tab) {
+        SAFE_HIP_CHECK(hipMemcpyAsync(d_tab, tab.data(), (P + 1) * sizeof(double), hipMemcpyHostToDevice, s));
+        SAFE_HIP_CHECK(safe_stream_sync(s));                                                  // (tab is a host vector)
+        ctx->nes_tab_host = tab;
+    }
+    for (int r = 0; r < n_slabs; ++r) {
+        if (slab_cols[r] == 0) continue;
+        PermOut out{};
+        out.pvalues_neg = pvalues_neg_dev ? pvalues_neg_dev + out_col0[r] : nullptr;
+        out.pvalues_pos = pvalues_pos_dev ? pvalues_pos_dev + out_col0[r] : nullptr;
+        out.nes = nes_dev ? nes_dev + out_col0[r] : nullptr;
+        out.nes_binary = nes_binary_dev ? nes_binary_dev + out_col0[r] : nullptr;
+        out.nes_table = d_tab;
+        out.nes_threshold = enrichment_threshold > 0.0 ? -std::log10(enrichment_threshold) : 0.0;
+        out.sign_mode = sign_mode;
+        out.mode = 4;
+        out.ld = m_total;
+        SAFE_TRY(enrich_finalize_counts(ctx, slabs_dev + static_cast<int64_t>(r) * slab_stride, n_pad, rowmap, slab_cols[r], P, out, nullptr, s));
+    }
+    return SAFE_OK;
+}
+
+int safe_randomization_plan(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t num_permutations, int score_type, int *packed_layout) {
+    SAFE_REQUIRE(ctx && nbr && attr && packed_layout, "safe_randomization_plan: NULL argument");
+    SAFE_REQUIRE(score_type == SAFE_SCORE_SUM || score_type == SAFE_SCORE_ZSCORE, "safe_randomization_plan: bad score_type %d", score_type);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    // what safe_randomization would run for this block: only the bit-sliced form is predicted (layout 0); everything else -1
+    *packed_layout = choose_path(ctx, nbr, attr, num_permutations, score_type == SAFE_SCORE_ZSCORE) == PATH_BITS ? 0 : -1;
+    return SAFE_OK;
 }
 
 int safe_nes_from_packed_counts(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *counts_dev, int layout, int64_t n_pad, int64_t m,

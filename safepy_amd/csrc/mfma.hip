@@ -1205,7 +1205,7 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                 if (dbg & 512) c1 = __builtin_amdgcn_s_memtime();
                 // two operand sets: the slices of k-step k + 1 are read before the MFMAs of k-step k are issued
                 v4i b_cur[NS], b_nxt[NS];
-                auto read_operand = [&](int k, int s) -> v4i __attribute__((always_inline)) {
+                auto read_operand = [&](int k, int s) -> v4i {
                     if constexpr (TR) {
                         typedef int v2i __attribute__((ext_vector_type(2)));
                         typedef __attribute__((address_space(3))) v2i lds_v2i;

@@ -66,14 +66,16 @@ def reduce_stats(local_stats, group=None):
     return {'n_other': int(sums[0]), 'n_non_integer': int(sums[1]), 'max_nan_col': int(mx[0])}
 
 
-def reduce_flags_and_stats(local_flags, local_stats, group=None, random_seed=0):
+def reduce_flags_and_stats(local_flags, local_stats, group=None, random_seed=0, agree=1):
     """reduce_row_flags + reduce_stats in ONE collective: every rank contributes
-    [flags (n), n_other, n_non_integer, max_nan_col, seed] as int64, the all-gathered [world, n+4]
-    table is reduced locally (MAX over flags and the worst NaN column, SUM over the counts).
+    [flags (n), n_other, n_non_integer, max_nan_col, seed, agree] as int64, the all-gathered [world, n+5]
+    table is reduced locally (MAX over flags and the worst NaN column, SUM over the counts, MIN over `agree`).
     Returns (flags uint8 [n], stats dict), identical on every rank.  stats['random_seed'] is the
     seed all ranks must use: `random_seed` itself when it is given, else ONE value drawn from OS
     entropy by rank 0 -- the reference permutes whole rows, one stream shared by all attributes
-    (safe_extras.py:46, 58), so ranks that each seeded themselves would not be a split of one run."""
+    (safe_extras.py:46, 58), so ranks that each seeded themselves would not be a split of one run.
+    stats['agree'] = the smallest `agree` of any rank: what the ranks settle BEFORE the kernels run without a collective of
+    its own (randomization_step: 1 = this rank's block will leave bit-sliced counters and can exchange them chunk by chunk)."""
     import torch
     dist = _dist()
     dev = _device_for(group)
@@ -82,17 +84,17 @@ def reduce_flags_and_stats(local_flags, local_stats, group=None, random_seed=0):
     # NumPy on the host side on purpose: torch CPU kernels may open an OpenMP region whose
     # workers then spin (hundreds of CPU-milliseconds per call) -- under a container CPU quota
     # that gets the whole process throttled for the rest of the scheduler period
-    mine = np.empty(n + 4, dtype=np.int64)
+    mine = np.empty(n + 5, dtype=np.int64)
     mine[:n] = np.asarray(local_flags, dtype=np.int64)
     seed = _entropy63() if random_seed is None else int(random_seed)
-    mine[n:] = (int(local_stats['n_other']), int(local_stats['n_non_integer']), int(local_stats['max_nan_col']), seed)
+    mine[n:] = (int(local_stats['n_other']), int(local_stats['n_non_integer']), int(local_stats['max_nan_col']), seed, int(agree))
     mine = torch.from_numpy(mine).to(dev)
-    table = torch.empty(world * (n + 4), dtype=torch.int64, device=dev)     # flat: gloo wants 1-D buffers
+    table = torch.empty(world * (n + 5), dtype=torch.int64, device=dev)     # flat: gloo wants 1-D buffers
     dist.all_gather_into_tensor(table, mine, group=group)
-    table = table.cpu().numpy().reshape(world, n + 4)
+    table = table.cpu().numpy().reshape(world, n + 5)
     flags = table[:, :n].max(axis=0).astype(np.uint8)
     stats = {'n_other': int(table[:, n].sum()), 'n_non_integer': int(table[:, n + 1].sum()),
-             'max_nan_col': int(table[:, n + 2].max()), 'random_seed': int(table[0, n + 3])}
+             'max_nan_col': int(table[:, n + 2].max()), 'random_seed': int(table[0, n + 3]), 'agree': int(table[:, n + 4].min())}
     return flags, stats
 
 
@@ -225,6 +227,131 @@ def gather_outputs(ctx, nbr, bufs, names, m_total, num_permutations, attribute_s
     return full
 
 
+def exchange_chunk_grid(m_total, world):
+    """(chunks, columns per chunk) of the chunked exchange for a run of m_total attributes over `world` ranks.
+    SAFE_HIP_XCHG_CHUNKS: 1..8 chunks (default 1: the whole block in one slab), fewer when the widest block has fewer than two
+    64-column word groups per chunk."""
+    import os
+    want = max(1, min(8, int(os.environ.get('SAFE_HIP_XCHG_CHUNKS', '1'))))
+    widest = max(c1 - c0 for c0, c1 in column_shards(m_total, world))
+    groups = max(1, -(-widest // 64))
+    chunks = max(1, min(want, groups // 2))
+    return chunks, 64 * (-(-groups // chunks))
+
+
+class ChunkedExchange:
+    """The final exchange of randomization_step when every rank's block runs the bit-sliced kernel -- settled BEFORE the kernels in
+    the head collective (reduce_flags_and_stats: `agree`), so no collective and no host synchronisation is spent on agreeing
+    afterwards (gather_outputs: one MIN all-reduce and two stream syncs per step).
+
+    The counters travel in `chunks` column slabs (default 1).  Each slab is copied out on a side stream and all-gathered
+    (RCCL: asynchronous, its own stream; gloo: staged through the host); the f64 matrices of chunk k are derived while chunk
+    k + 1 travels (safe_outputs_from_packed_slabs writes column blocks of the full matrices).  One word travels with every slab:
+    1 = bit-sliced counters; a rank whose call took another form after all still takes part in the same collectives and flags
+    its slabs 0, and every rank then falls back to the f64 exchange (gather_columns) together.  One host wait, at the end.
+
+    With SAFE_HIP_XCHG_TAIL set and >= 2 chunks the library also runs the last permutations one column chunk at a time and calls
+    `launched()` from inside the randomization call; the chunks then travel while the later ones compute.  Measured at
+    configs[1]: costs the step more than it hides -- off by default."""
+    HEADER = 64                     # u32 words behind a slab (one used; keeps slabs 256-byte aligned)
+
+    def __init__(self, ctx, nbr, bufs, names, m_total, num_permutations, attribute_sign, enrichment_threshold, group, table,
+                 chunks, cols):
+        import torch
+        self.ctx, self.nbr, self.bufs, self.names, self.m_total = ctx, nbr, bufs, tuple(names), int(m_total)
+        self.P, self.sign, self.thr, self.group, self.table = int(num_permutations), attribute_sign, enrichment_threshold, group, table
+        self.chunks, self.cols = int(chunks), int(cols)
+        dist = _dist()
+        self.world, self.rank = dist.get_world_size(group), dist.get_rank(group)
+        self.shards = column_shards(self.m_total, self.world)
+        self.dev = bufs[self.names[0]].device
+        self.xdev = _device_for(group)
+        self.n = bufs[self.names[0]].shape[0]
+        self.n_pad = 64 * (-(-self.n // 64))                 # SELL-64 positions: the bit-sliced kernel's counter rows
+        self.cap = self.cols * self.n_pad + self.HEADER
+        # ONE side stream per context: torch hands out pooled streams round-robin, and its caching allocator keeps a pool per stream
+        # -- a fresh stream per step meant fresh hipMallocs of every slab per step (the step doubled)
+        side = getattr(ctx, '_xc_side', None)
+        if side is None or side.device != self.dev:
+            side = ctx._xc_side = torch.cuda.Stream(device=self.dev)
+        self.side = side
+        self.mine = [None] * self.chunks
+        self.every = [None] * self.chunks
+        self.work = [None] * self.chunks
+        self.issued = False
+        self.t_launched = None
+
+    def arm(self):
+        from . import backend as be
+        be.set_exchange_chunks(self.ctx, self.chunks, self.cols, self.launched)
+
+    def disarm(self):
+        from . import backend as be
+        be.set_exchange_chunks(self.ctx, 0)
+
+    def _issue(self, valid):
+        """Copy-out + all-gather of every chunk, in order; `valid`: this rank's counters are bit-sliced ones."""
+        import time
+        import torch
+        from . import backend as be
+        dist = _dist()
+        self.t_launched = time.perf_counter()
+        with torch.cuda.stream(self.side):
+            for k in range(self.chunks):
+                mine = torch.empty(self.cap, dtype=torch.int32, device=self.dev)
+                if valid:
+                    be.export_packed_chunk(self.ctx, k, mine.data_ptr(), self.cap - self.HEADER, self.side.cuda_stream)
+                mine[self.cap - self.HEADER:].fill_(1 if valid else 0)
+                if self.xdev.type == 'cuda':
+                    every = torch.empty(self.world * self.cap, dtype=torch.int32, device=self.dev)
+                    self.work[k] = dist.all_gather_into_tensor(every, mine, group=self.group, async_op=True)
+                else:
+                    every = torch.empty(self.world * self.cap, dtype=torch.int32)
+                    mine = mine.cpu()                      # (waits for this chunk's launch: tests and one-GPU rehearsals only)
+                    self.work[k] = dist.all_gather_into_tensor(every, mine, group=self.group, async_op=True)
+                self.mine[k], self.every[k] = mine, every
+        self.issued = True
+
+    def launched(self):
+        """Called inside the randomization call, all launches enqueued."""
+        from . import backend as be
+        made, _bounds, _tail = be.packed_chunk_info(self.ctx)
+        if made == self.chunks:
+            self._issue(True)
+
+    def finish(self, report=None):
+        """After the randomization call: {name: full [N, m_total] device tensor} on every rank."""
+        import torch
+        from . import backend as be
+        be.take_exchange_error(self.ctx)
+        if not self.issued:                    # the call ran no chunked tail here: the same collectives, from the finished counters
+            self._issue(be.packed_counts_info(self.ctx)[2] == 0)
+        full = {k: torch.empty((self.n, self.m_total), dtype=torch.float64, device=self.dev) for k in self.names}
+        ptrs = [full[k].data_ptr() if k in full else None for k in COUNTER_OUTPUTS]
+        headers = []
+        with torch.cuda.stream(self.side):
+            for k in range(self.chunks):
+                self.work[k].wait()            # RCCL: the side stream waits; gloo: the host does
+                every = self.every[k] if self.every[k].is_cuda else self.every[k].to(self.dev, non_blocking=True)
+                self.every[k] = every
+                slabs = every.view(self.world, self.cap)
+                headers.append(slabs[:, self.cap - self.HEADER])
+                cols = [max(0, min(self.cols if k + 1 < self.chunks else c1 - c0, c1 - c0 - k * self.cols)) for c0, c1 in self.shards]
+                col0 = [c0 + k * self.cols for c0, _c1 in self.shards]
+                be.outputs_from_packed_slabs(self.ctx, self.nbr, every.data_ptr(), 0, self.n_pad, self.cap, cols, col0, self.m_total,
+                                             self.P, self.sign, self.thr, ptrs, table=self.table, stream=self.side.cuda_stream)
+            ok = bool((torch.stack(headers) == 1).all().item())          # (the one host wait: everything above has finished)
+        if report is not None:
+            report.update(form='packed u32 counters in %d column chunk%s (agreed before the kernels), %s rebuilt on every rank'
+                               % (self.chunks, '' if self.chunks == 1 else 's', ' / '.join(self.names)),
+                          bytes_received=int(4 * self.cap * self.chunks * (self.world - 1)), chunks=self.chunks)
+        if not ok:
+            if report is not None:
+                report.update(form='f64 blocks (a rank left no bit-sliced counters)')
+            return {k: gather_columns(self.bufs[k], self.m_total, self.group) for k in self.names}
+        return full
+
+
 def gather_nes(ctx, nbr, local_nes, m_total, num_permutations, attribute_sign, group=None, table=None):
     """The NES matrix alone (gather_outputs with names=('nes',))."""
     return gather_outputs(ctx, nbr, {'nes': local_nes}, ('nes',), m_total, num_permutations, attribute_sign, 0.05, group, table)['nes']
@@ -321,7 +448,7 @@ HYPERGEOM_OUTPUTS = ('pvalues_pos', 'nes', 'nes_binary')
 
 def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
                        neighborhood_score_type='sum', attribute_sign='both', enrichment_threshold=0.05, group=None,
-                       table=None, flags=None, exchange=True, timing=None, unseeded=None):
+                       table=None, flags=None, exchange=True, timing=None, unseeded=None, overlap=None):
     """One rank's share of compute_pvalues_by_randomization (safe.py:474-554) on DEVICE-resident inputs and
     outputs, plus the path's exchange steps -- the function bench.py times and the host-level drivers below
     call, so what is measured is what runs.
@@ -335,46 +462,73 @@ def randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, b
     keeps its block).  Without a process group it is the plain single-GPU step.  `timing`: a dict that
     receives this rank's host-stream / kernel / exchange times of the step (bench.py).
     random_seed=None (or unseeded=True with `random_seed` = the value the ranks agreed on): an UNSEEDED run -- the tables are
-    generated on every rank's device from the agreed value (backend.Permutations, device stream): no host stream, no sharing."""
+    generated on every rank's device from the agreed value (backend.Permutations, device stream): no host stream, no sharing.
+    overlap: True = the ranks agreed (stats['agree'] of the caller's own reduce_flags_and_stats) that every block leaves bit-sliced
+    counters: the exchange then travels in column chunks behind the last launches (ChunkedExchange); None = settled here when the
+    step runs the head collective itself, off when the caller passed `flags` (SAFE_HIP_XCHG_OVERLAP=0 switches it off)."""
+    import os
+    import time
     from . import backend as be
     alone = not _dist().is_initialized()               # a single process: the same step without the two exchanges
     if unseeded is None:
         unseeded = random_seed is None
+    names = () if not exchange else ('nes',) if exchange is True else tuple(exchange)
+    # the overlapped exchange (ChunkedExchange) is settled in the head collective: every rank says whether ITS block will run the
+    # bit-sliced kernel (safe_randomization_plan); it needs that collective, so a caller that exchanged the flags itself says
+    # what was agreed there with overlap=True
+    chunks, cols = (0, 0)
+    if not alone and names and os.environ.get('SAFE_HIP_XCHG_OVERLAP', '1') != '0' and bufs[names[0]].is_cuda:
+        chunks, cols = exchange_chunk_grid(m_total, _dist().get_world_size(group))
     if flags is None:
         stats = attr.stats()                           # (the dispatch rule's inputs: part of every compute_pvalues pass)
         flags = attr.row_flags()
         if not alone:
-            flags, stats = reduce_flags_and_stats(flags, stats, group, random_seed)
+            mine_ok = chunks >= 1 and be.randomization_plan(ctx, nbr, attr, int(num_permutations), neighborhood_score_type) == 0
+            flags, stats = reduce_flags_and_stats(flags, stats, group, random_seed, agree=1 if mine_ok else 0)   # (cf. _block_agrees)
             random_seed = stats['random_seed']
+            if overlap is None:
+                overlap = stats['agree'] == 1
     if not alone:
         attr.set_row_flags(flags)                      # indx_vals of the FULL matrix (safe_extras.py:51)
     perms = _call_permutations(ctx, attr.n, flags, int(num_permutations), random_seed, unseeded, alone, group)
     if timing is not None:
         timing['stream_role'] = perms.timing()['role']
+    xc = None
+    if overlap and chunks >= 1:
+        xc = ChunkedExchange(ctx, nbr, bufs, names, m_total, num_permutations, attribute_sign, enrichment_threshold, group, table,
+                             chunks, cols)
     try:
+        if xc is not None:
+            xc.arm()
         be.randomization(ctx, nbr, attr, perms, neighborhood_score_type, attribute_sign, enrichment_threshold,
                          [bufs[k].data_ptr() for k in RANDOMIZATION_OUTPUTS] + [enriched.data_ptr()], table=table)
+        t_x = time.perf_counter()
         if timing is not None:
-            import time
             timing.update(perms.timing())
             name, k_ms, launches = ctx.last_kernel()
             timing.update(kernel=name, gpu_kernel_ms=k_ms * max(int(launches), 1), gpu_kernel_busy_ms=ctx.last_kernel_busy_ms())
-            t_x = time.perf_counter()
         if not exchange:
             return None
         if alone and exchange is True:
             return bufs['nes']
-        names = ('nes',) if exchange is True else tuple(exchange)
         if alone:
             return {k: bufs[k] for k in names}
         report = {} if timing is not None else None
-        full = gather_outputs(ctx, nbr, bufs, names, m_total, int(num_permutations), attribute_sign, enrichment_threshold, group,
-                              table=table, report=report)
+        if xc is not None:
+            full = xc.finish(report)
+            if timing is not None:
+                # what the step still waited for after its kernels, and the whole window from the first chunk's copy-out on
+                timing['exchange_window_ms'] = 1e3 * (time.perf_counter() - xc.t_launched)
+        else:
+            full = gather_outputs(ctx, nbr, bufs, names, m_total, int(num_permutations), attribute_sign, enrichment_threshold, group,
+                                  table=table, report=report)
         if timing is not None:
             timing['exchange_ms'] = 1e3 * (time.perf_counter() - t_x)
             timing['exchange'] = report
         return full['nes'] if exchange is True else full
     finally:
+        if xc is not None:
+            xc.disarm()
         perms.close()
 
 
@@ -385,8 +539,18 @@ def _alloc_outputs(ctx, n, mloc, names):
             torch.empty((mloc,), dtype=torch.float64, device=dev))
 
 
+def _block_agrees(ctx, nbr, attr, m_total, num_permutations, neighborhood_score_type, group):
+    """This rank's word for the head collective: 1 = its block will leave bit-sliced counters and the run is wide enough for the
+    chunked exchange (randomization_step's `overlap`)."""
+    import os
+    from . import backend as be
+    if os.environ.get('SAFE_HIP_XCHG_OVERLAP', '1') == '0':
+        return 0
+    return 1 if be.randomization_plan(ctx, nbr, attr, int(num_permutations), neighborhood_score_type) == 0 else 0
+
+
 def _randomization_host(ctx, nbr, attr, m_total, num_permutations, random_seed, flags, neighborhood_score_type,
-                        attribute_sign, enrichment_threshold, group, gather, multiple_testing, unseeded=False):
+                        attribute_sign, enrichment_threshold, group, gather, multiple_testing, unseeded=False, overlap=False):
     import torch
     bufs, enriched = _alloc_outputs(ctx, attr.n, attr.m, RANDOMIZATION_OUTPUTS)
     torch.cuda.current_stream().synchronize()
@@ -395,7 +559,7 @@ def _randomization_host(ctx, nbr, attr, m_total, num_permutations, random_seed, 
     wanted = tuple(k for k in COUNTER_OUTPUTS if k in gather) if not multiple_testing else ('pvalues_neg', 'pvalues_pos')
     ready = randomization_step(ctx, nbr, attr, m_total, num_permutations, random_seed, bufs, enriched,
                                neighborhood_score_type, attribute_sign, enrichment_threshold, group, flags=flags,
-                               exchange=wanted if wanted else False, unseeded=unseeded)
+                               exchange=wanted if wanted else False, unseeded=unseeded, overlap=overlap)
     ctx.sync()
     full = _fdr_whole_matrix(ctx, bufs, m_total, num_permutations, attribute_sign, enrichment_threshold,
                              group, ready=ready) if multiple_testing else None
@@ -415,10 +579,12 @@ def sharded_randomization(ctx, nbr, local_attr_host, m_total, num_permutations, 
     from . import backend as be
     attr = be.Attributes.from_host(ctx, local_attr_host)
     try:
-        flags, stats = reduce_flags_and_stats(attr.row_flags(), attr.stats(), group, random_seed)
+        stats0 = attr.stats()
+        flags, stats = reduce_flags_and_stats(attr.row_flags(), stats0, group, random_seed,
+                                              agree=_block_agrees(ctx, nbr, attr, m_total, num_permutations, neighborhood_score_type, group))
         return _randomization_host(ctx, nbr, attr, m_total, num_permutations, stats['random_seed'], flags,
                                    neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
-                                   multiple_testing, unseeded=random_seed is None)
+                                   multiple_testing, unseeded=random_seed is None, overlap=stats['agree'] == 1)
     finally:
         attr.close()
 
@@ -532,7 +698,9 @@ def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type=
     from . import backend as be
     attr = be.Attributes.from_host(ctx, local_attr_host)
     try:
-        flags, stats = reduce_flags_and_stats(attr.row_flags(), attr.stats(), group, random_seed)
+        stats0 = attr.stats()
+        flags, stats = reduce_flags_and_stats(attr.row_flags(), stats0, group, random_seed,
+                                              agree=_block_agrees(ctx, nbr, attr, m_total, num_permutations, neighborhood_score_type, group))
         if (enrichment_type == 'hypergeometric') or (enrichment_type == 'auto' and stats['n_other'] == 0):
             out = _hypergeom_host(ctx, nbr, attr, m_total, flags, enrichment_threshold, group, gather,
                                   multiple_testing, attribute_sign)
@@ -540,7 +708,7 @@ def sharded_compute_pvalues(ctx, nbr, local_attr_host, m_total, enrichment_type=
         else:
             out = _randomization_host(ctx, nbr, attr, m_total, num_permutations, stats['random_seed'], flags,
                                       neighborhood_score_type, attribute_sign, enrichment_threshold, group, gather,
-                                      multiple_testing, unseeded=random_seed is None)
+                                      multiple_testing, unseeded=random_seed is None, overlap=stats['agree'] == 1)
             out['how'] = 'randomization'
     finally:
         attr.close()

@@ -107,8 +107,88 @@ def main():
                 np.testing.assert_allclose(out['full_pvalues_pos'], want['pvalues_pos'], rtol=1e-6, atol=1e-300)
                 np.testing.assert_allclose(out['full_nes'], want['nes'], rtol=1e-6, atol=1e-9)
 
-        # who drew: with a shared stream only local rank 0 runs a draw thread, the others fetched every chunk from its ring
+        # ---- the chunked exchange (sharding.ChunkedExchange): settled in the head collective, one slab by default; a block wide
+        # enough to be cut into column chunks; the column-chunked tail of the launches (SAFE_HIP_XCHG_TAIL) behind which they travel
         from safepy_amd import backend as be
+        wide = (rng.uniform(size=(n, 256 * world + 77)) < 0.03).astype(np.float32)
+        wide[rng.choice(n, 9, replace=False)] = np.nan
+        mw = wide.shape[1]
+        c0, c1 = sharding.column_shards(mw, world)[rank]
+        want_wide = {}
+        for P in (300, 60):
+            sf.random_seed = 9
+            sf.load_attributes(attribute_file=wide.copy())
+            sf.compute_pvalues(how='randomization', num_permutations=P, neighborhood_score_type='sum', multiple_testing=False)
+            want_wide[P] = {k: getattr(sf, k).copy() for k in ('nes', 'nes_binary', 'pvalues_pos', 'pvalues_neg')}
+            want_wide[P]['enriched'] = sf.attributes['num_neighborhoods_enriched'].values.copy()
+
+        def xc_env(chunks, tail):
+            for key, val in (('SAFE_HIP_XCHG_CHUNKS', chunks), ('SAFE_HIP_XCHG_TAIL', tail)):
+                if val is None:
+                    os.environ.pop(key, None)
+                else:
+                    os.environ[key] = val
+
+        for P, chunks, tail, want_made, what in (
+                (300, None, None, 0, 'one slab (the default)'),
+                (300, '4', None, 0, 'column chunks after the kernels'),
+                (300, '4', '0.4', 2, 'column-chunked tail of the launches'),
+                (300, '2', '1e-9', 2, 'the last stage as the tail'),
+                (60, '4', '0.4', 0, 'too few stages for a tail: the armed grid served from the finished counters')):
+            xc_env(chunks, tail)
+            attr = be.Attributes.from_host(ctx, np.ascontiguousarray(wide[:, c0:c1]))
+            bufs, enriched = sharding._alloc_outputs(ctx, n, c1 - c0, sharding.RANDOMIZATION_OUTPUTS)
+            torch.cuda.current_stream().synchronize()
+            t = {}
+            full = sharding.randomization_step(ctx, nbr, attr, mw, P, 9, bufs, enriched, 'sum', 'both', 0.05,
+                                               exchange=('nes', 'nes_binary', 'pvalues_pos', 'pvalues_neg'), timing=t)
+            want_chunks = 1 if chunks is None else 2          # (the widest block has five word groups: two chunks at most)
+            assert t['exchange'].get('chunks') == want_chunks and 'agreed before the kernels' in t['exchange']['form'], (what, t['exchange'])
+            made = be.packed_chunk_info(ctx)[0]
+            assert made == want_made, (what, made)
+            for k, v in full.items():
+                assert np.array_equal(v.cpu().numpy(), want_wide[P][k], equal_nan=True), (what, k, rank)
+            assert np.array_equal(bufs['nes'].cpu().numpy(), want_wide[P]['nes'][:, c0:c1], equal_nan=True), what
+            assert np.array_equal(enriched.cpu().numpy(), want_wide[P]['enriched'][c0:c1]), what
+            attr.close()
+        # the product's driver takes the same path, and a repeated call reuses the armed state cleanly
+        xc_env('4', '0.4')
+        out = sharding.sharded_compute_pvalues(ctx, nbr, np.ascontiguousarray(wide[:, c0:c1]), mw, enrichment_type='randomization',
+                                               num_permutations=300, random_seed=9, gather=('nes', 'pvalues_neg'))
+        assert np.array_equal(out['full_nes'], want_wide[300]['nes'], equal_nan=True)
+        assert np.array_equal(out['full_pvalues_neg'], want_wide[300]['pvalues_neg'], equal_nan=True)
+        # a rank whose call leaves no bit-sliced counters although it said it would (here: forced onto the f64 kernels after the
+        # agreement): it still takes part in every chunk's collective, flags its slabs, and ALL ranks fall back to f64 blocks
+        if world > 1:
+            for chunks, tail in (('4', '0.4'), (None, None)):
+                xc_env(chunks, tail)
+                attr = be.Attributes.from_host(ctx, np.ascontiguousarray(wide[:, c0:c1]))
+                bufs, enriched = sharding._alloc_outputs(ctx, n, c1 - c0, sharding.RANDOMIZATION_OUTPUTS)
+                torch.cuda.current_stream().synchronize()
+                real_plan = be.randomization_plan
+                if rank == world - 1:
+                    os.environ['SAFE_HIP_FORCE_PATH'] = 'gather'
+                    be.randomization_plan = lambda *a, **k: 0
+                t = {}
+                try:
+                    full = sharding.randomization_step(ctx, nbr, attr, mw, 300, 9, bufs, enriched, 'sum', 'both', 0.05,
+                                                       exchange=('nes', 'pvalues_pos'), timing=t)
+                finally:
+                    be.randomization_plan = real_plan
+                    os.environ.pop('SAFE_HIP_FORCE_PATH', None)
+                assert t['exchange']['form'].startswith('f64 blocks'), t['exchange']
+                for k, v in full.items():
+                    assert np.array_equal(v.cpu().numpy(), want_wide[300][k], equal_nan=True), ('fallback', k, rank)
+                attr.close()
+        xc_env(None, None)
+        # SAFE_HIP_XCHG_OVERLAP=0: the exchange that agrees after the kernels (gather_outputs) -- the same matrices
+        os.environ['SAFE_HIP_XCHG_OVERLAP'] = '0'
+        out = sharding.sharded_compute_pvalues(ctx, nbr, np.ascontiguousarray(wide[:, c0:c1]), mw, enrichment_type='randomization',
+                                               num_permutations=300, random_seed=9, gather=('nes',))
+        assert np.array_equal(out['full_nes'], want_wide[300]['nes'], equal_nan=True)
+        del os.environ['SAFE_HIP_XCHG_OVERLAP']
+
+        # who drew: with a shared stream only local rank 0 runs a draw thread, the others fetched every chunk from its ring
         assert (ctx.shared_stream is not None) == (stream == 'shared' and world > 1), ctx.shared_stream
         flags = np.ones(n, dtype=np.uint8)
         flags[::7] = 0

@@ -61,7 +61,19 @@ def _worker(rank, world, port, tmpdir):
             'n_non_integer': int((~np.isnan(local) & (local != np.floor(local))).sum()),
             'max_nan_col': int(np.isnan(local).sum(axis=0).max())})
         assert np.array_equal(flags1, flags) and flags1.dtype == np.uint8
-        assert {k: v for k, v in st1.items() if k != 'random_seed'} == st and st1['random_seed'] == 0
+        assert {k: v for k, v in st1.items() if k not in ('random_seed', 'agree')} == st and st1['random_seed'] == 0
+        assert st1['agree'] == 1
+        # the word the ranks settle before the kernels (the overlapped exchange): the smallest one wins
+        _, st1b = sharding.reduce_flags_and_stats(local_flags, st, agree=1 if rank == 0 else 0)
+        assert st1b['agree'] == 0
+        assert sharding.exchange_chunk_grid(8 * 3971, 8) == (1, 4032) and sharding.exchange_chunk_grid(131, 2) == (1, 128)
+        os.environ['SAFE_HIP_XCHG_CHUNKS'] = '4'
+        try:
+            assert sharding.exchange_chunk_grid(8 * 3971, 8) == (4, 1024) and sharding.exchange_chunk_grid(131, 2) == (1, 128)
+            chunks, cols = sharding.exchange_chunk_grid(2 * 256 + 77, 2)
+            assert chunks == 2 and cols % 64 == 0 and chunks * cols >= 295
+        finally:
+            del os.environ['SAFE_HIP_XCHG_CHUNKS']
         # one permutation stream for the whole matrix (safe_extras.py:46, 58): a given seed is kept, an unset one
         # (random_seed=None) becomes rank 0's draw on EVERY rank
         _, st2 = sharding.reduce_flags_and_stats(local_flags, st, random_seed=1234 + rank)
