@@ -36,6 +36,19 @@ constexpr int MF_NS = 6;              // i8 slices per value
 constexpr int MF_CN = 6;              // counts form: 32-column tiles per task (one i8 plane each)
 constexpr int MF_SS = 1024 + 16;      // LDS bytes per (k-step, slice): [2 halves][32 lanes][16 B] + 16 B skew
 constexpr int MF_KS = MF_NS * MF_SS;  // LDS bytes per k-step (32 attribute rows)
+// The general kernel's LDS form of a gathered k-step.  mf_trg(slices): rows as they come ([32 rows][RS bytes]; RS = 32 bytes per
+// slice, padded to an ODD multiple of 32 so that the eight rows a transposing read touches fall into eight different groups of
+// eight banks) and the B operand read with ds_read_b64_tr_b8; else transposed in registers by the gather threads (v_perm) into
+// [slice][2 halves][32 lanes][16 B] and read with ds_read_b128.  Same box, configs[4] rank share (tools/probe/trg_ab.sh): six
+// slices 1.384 -> 1.347 s with the transposing reads, but three slices 0.929 -> 0.970 s and the filtered z-scores (four slices)
+// 2.513 -> 2.657 s -- eight waves read every tile, and two 8-byte reads per slice instead of one 16-byte read cost them more LDS
+// issue slots than the gather threads save on few slices -- so: six slices and more (-DSAFE_MFMA_TRG=0: never; =2: always).
+#ifndef SAFE_MFMA_TRG
+#define SAFE_MFMA_TRG 1
+#endif
+constexpr bool mf_trg(int ns) { return SAFE_MFMA_TRG == 2 || (SAFE_MFMA_TRG == 1 && ns >= 6); }
+constexpr int mf_rs(int ns) { return 32 * (ns | 1); }                                  // row bytes in LDS (transposing-read form)
+constexpr int mf_ks(int ns) { return mf_trg(ns) ? 32 * mf_rs(ns) : ns * MF_SS; }       // LDS bytes per k-step
 constexpr int MF_BUF = 4 * MF_KS;     // one buffer = one super-step = 4 k-steps
 constexpr int MF_MAXBLK = 4096;       // column blocks per row group the kernel can index from LDS
 constexpr int MF_SHIFT_BITS = 45;     // |q| < 2^46 after scaling: six balanced base-256 digits hold +-(2^47 - ...)
@@ -347,7 +360,7 @@ __global__ __launch_bounds__(256) void k_mfma_slice_z(const void *__restrict__ r
                 hi[t * 32 + 16] = static_cast<unsigned char>(((u2 >> (8 * (t + 3))) & 0xFFu) ^ 0x80u);
             }
             hi[3 * 32] = present ? 1 : 0;
-            hi[3 * 32 + 16] = 0;
+            hi[3 * 32 + 16] = present ? 1 : 0;      // (also under the squares' columns: their lanes count the members of the rows THEY test)
             // ... and both fixed-point values as one 16-byte word, [row][column] (the square is never negative: bit 62 carries the
             // not-NaN flag): what k_mfma_resolve_z sums
             if (z64 && j < mloc)
@@ -469,7 +482,9 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     static_assert(!Z || !COUNTS, "z-scores are a permutation test");
     static_assert(!Z || (FM == 0 && NS == MF_NS + 1) || (FM == 2 && NS == MF_NS / 2 + 1), "z-scores: six (filtered: three high) value | square slices + the not-NaN slice");
     static_assert(FM == 0 || Z || (NS == MF_NS / 2 && !COUNTS), "filtered form: three slices of 'sum' scores");
-    constexpr int KS = NS * MF_SS, BUF = 4 * KS;                            // LDS bytes per k-step / per super-step buffer
+    constexpr bool MF_TRG = mf_trg(NS);
+    constexpr int KS = mf_ks(NS), BUF = 4 * KS, RS = mf_rs(NS);             // LDS bytes per k-step / per super-step buffer / per row (MF_TRG)
+    constexpr int MF_SQ_LANE = MF_TRG ? 16 : 4;   // z-scores: the lane holding column c + 16 (the squares) of the lane that holds column c
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];       // [2][BUF] + kb list
     __shared__ int slot_box;
     __shared__ unsigned int wg_xmax;
@@ -496,9 +511,14 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
     const int s_g = chunk >> 1, half_g = chunk & 1;
     // this thread's LDS write base inside a buffer; column i of its 16 goes to lane slot
     // (i & 3) + 4 * half + 8 * (i >> 2)
-    const uint32_t w_base = static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
-    const uint32_t r_base = static_cast<uint32_t>(h * 512 + lam * 16);        // MFMA B operand of this lane
-    const int col_in_tile = 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
+    const uint32_t w_base = MF_TRG ? static_cast<uint32_t>(ks_g * KS + (4 * rq) * RS + chunk * 16)
+                                   : static_cast<uint32_t>(ks_g * KS + s_g * MF_SS + (rq >> 2) * 512 + (4 * half_g) * 16 + (rq & 3) * 4);
+    // MFMA B operand of this lane.  MF_TRG: within 16 lanes, lane l reads the 8-byte piece (row l >> 1, half l & 1) of the 16-byte
+    // column group (lane >> 4) & 1 and receives column l of the 8 x 16 tile (tools/ubench/tr8_probe.hip)
+    const uint32_t r_base = MF_TRG ? static_cast<uint32_t>((16 * h + ((lane & 15) >> 1)) * RS + 16 * ((lane >> 4) & 1) + 8 * (lane & 1))
+                                   : static_cast<uint32_t>(h * 512 + lam * 16);
+    const int col_in_tile = MF_TRG ? lam : 16 * ((lam >> 2) & 1) + 4 * (lam >> 3) + (lam & 3);
+    (void)s_g, (void)half_g;
 
     const int home = blockIdx.x & 7;
     for (int attempt = 0; attempt < 8; ++attempt) {
@@ -544,14 +564,18 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             if constexpr (FM == 2 && Z) {
                 // z-scores, filtered: the observed scores of this lane's 16 outputs (formed by the seven-slice kernel in a pass of
                 // its own) go to the LDS slots; NaN (padding, squares' lanes, fewer than three values, no spread) = no test
+                // the lanes of the VALUE columns test rows r = 0..7 of their 16 accumulator rows, the lanes of the SQUARES' columns
+                // (idle in the seven-slice form: one lane-bit away, same attribute) rows 8..15 -- slot rr of either holds its row
                 sc1sq = sc1 * sc1;
+                const int r_off = (col_in_tile & 16) ? 8 : 0;
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = rr + r_off;
                     const int64_t u = static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
                     const int32_t node = rowmap[u];
-                    const bool live = node >= 0 && colz < mloc && !(col_in_tile & 16);
+                    const bool live = node >= 0 && colz < mloc;
                     const double o = live ? fa.zobs[static_cast<int64_t>(node) * mloc + colz] : __longlong_as_double(0x7FF8000000000000ll);
-                    obs[r * 512] = __double_as_longlong(o);
+                    obs[rr * 512] = __double_as_longlong(o);
                 }
             }
             if constexpr (FM == 2 && !Z) {
@@ -583,6 +607,15 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             // transpose to k-contiguous bytes and write the four lane slots b + 8cw (+ 4 half)
             auto store_quarter = [&](const uint4 (&L)[4], int cw, int buf) {
                 unsigned char *dst = lds + buf * BUF + w_base;
+                if constexpr (MF_TRG) {
+                    uint4 v;                                                     // row cw of the thread's four, as it came
+                    v.x = cw == 0 ? L[0].x : cw == 1 ? L[1].x : cw == 2 ? L[2].x : L[3].x;   // (component-wise: a select between
+                    v.y = cw == 0 ? L[0].y : cw == 1 ? L[1].y : cw == 2 ? L[2].y : L[3].y;   // whole uint4 lvalues keeps L in
+                    v.z = cw == 0 ? L[0].z : cw == 1 ? L[1].z : cw == 2 ? L[2].z : L[3].z;   // scratch memory)
+                    v.w = cw == 0 ? L[0].w : cw == 1 ? L[1].w : cw == 2 ? L[2].w : L[3].w;
+                    *reinterpret_cast<uint4 *>(dst + cw * RS) = v;
+                    return;
+                }
                 const uint32_t w[4] = {cw == 0 ? L[0].x : cw == 1 ? L[0].y : cw == 2 ? L[0].z : L[0].w,
                                        cw == 0 ? L[1].x : cw == 1 ? L[1].y : cw == 2 ? L[1].z : L[1].w,
                                        cw == 0 ? L[2].x : cw == 1 ? L[2].y : cw == 2 ? L[2].z : L[2].w,
@@ -659,9 +692,23 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                 // wave covers the LDS latency; the z-score form (seven slices: no room for a second set) always runs this way
                 constexpr bool PF = PREF && (!Z || NS <= 4);
                 v4i b_cur[NS], b_nxt[PF ? NS : 1];
+                auto read_operand = [&](int k, int s) -> v4i {
+                    if constexpr (MF_TRG) {
+                        typedef int v2i __attribute__((ext_vector_type(2)));
+                        typedef __attribute__((address_space(3))) v2i lds_v2i;
+                        const unsigned char *at = bbuf + k * KS + s * 32;
+                        const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at));            // k = 16 h + 0..7
+                        const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at + 8 * RS));   // k = 16 h + 8..15
+                        v4i r;
+                        r[0] = lo[0], r[1] = lo[1], r[2] = hi[0], r[3] = hi[1];
+                        return r;
+                    } else {
+                        return *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+                    }
+                };
                 if constexpr (PF) {
 #pragma unroll
-                    for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + s * MF_SS);
+                    for (int s = 0; s < NS; ++s) b_cur[s] = read_operand(0, s);
                 }
 #pragma unroll
                 for (int k = 0; k < 4; ++k) {
@@ -669,14 +716,14 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                         if (k < 3) {
 #pragma unroll
                             for (int s = 0; s < NS; ++s)
-                                b_nxt[PF ? s : 0] = *reinterpret_cast<const v4i *>(bbuf + (k + 1) * KS + s * MF_SS);
+                                b_nxt[PF ? s : 0] = read_operand(k + 1, s);
                         }
                         __builtin_amdgcn_sched_barrier(0);           // keep the LDS reads ahead of this k-step's MFMAs
                     }
                     if (nz[k]) {
                         if constexpr (!PF) {
 #pragma unroll
-                            for (int s = 0; s < NS; ++s) b_cur[s] = *reinterpret_cast<const v4i *>(bbuf + k * KS + s * MF_SS);
+                            for (int s = 0; s < NS; ++s) b_cur[s] = read_operand(k, s);
                         }
                         v4i a;
                         a[0] = static_cast<int>(expand4(aw[k], 16 * h));
@@ -699,23 +746,31 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                     // (the counts are written once, after the loop)
                 } else if (t == S - 1 && !MF_DIAG(hl.dbg & 8)) {     // a score is complete
                     uint32_t undecided = 0;                                 // (filter) outputs the high digits leave open
+                    if constexpr (Z && FM == 2) {
+                        // The filtered z-score test.  Only the HIGH digits were multiplied: S1 = a + S1_low, S2 = b + S2_low with
+                        // |low| <= e = count * MF_LO_MAX.  z >= o is a statement about the sign of S1 and of
+                        //     T = S1^2 sc1^2 (1 + o^2) - o^2 S2 sc2 count          (mu / sigma >= o, squared and cleared of count^2)
+                        // so it is decided here whenever the signs are certain despite the low parts (and the f64 evaluation: a
+                        // 2^-40 margin); whatever is not -- including every score whose variance is not clearly positive --
+                        // goes to k_mfma_resolve_z, which evaluates the reference's formula on the exact sums.
+                        // The work is split between the value lane and the squares' lane of an attribute: the value lane hands over
+                        // its sums of rows 8..15 and receives the squares of rows 0..7 (one exchange per row pair), then BOTH evaluate
+                        // eight outputs (all 64 lanes busy; with the value lanes doing all sixteen this was 27 % of the kernel)
+                        const bool sq = (col_in_tile & 16) != 0;
 #pragma unroll
-                    for (int r = 0; r < 16; ++r) {
-                        constexpr int NV = Z ? (FM == 2 ? MF_NS / 2 : MF_NS) : NS;   // value slices
-                        long long v = static_cast<long long>(acc[NV - 1][r]);
+                        for (int rr = 0; rr < 8; ++rr) {
+                            long long x = static_cast<long long>(acc[2][rr]), y = static_cast<long long>(acc[2][rr + 8]);
 #pragma unroll
-                        for (int s = NV - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
-                        if constexpr (Z && FM == 2) {
-                            // The filtered z-score test.  Only the HIGH digits were multiplied: S1 = a + S1_low, S2 = b + S2_low with
-                            // |low| <= e = count * MF_LO_MAX.  z >= o is a statement about the sign of S1 and of
-                            //     T = S1^2 sc1^2 (1 + o^2) - o^2 S2 sc2 count          (mu / sigma >= o, squared and cleared of count^2)
-                            // so it is decided here whenever the signs are certain despite the low parts (and the f64 evaluation: a
-                            // 2^-40 margin); whatever is not -- including every score whose variance is not clearly positive --
-                            // goes to k_mfma_resolve_z, which evaluates the reference's formula on the exact sums.
-                            const int lo_sq = __shfl_xor(static_cast<int>(v), 4), hi_sq = __shfl_xor(static_cast<int>(v >> 32), 4);
-                            const long long w = (static_cast<long long>(hi_sq) << 32) | static_cast<long long>(static_cast<uint32_t>(lo_sq));
-                            const double o = __longlong_as_double(obs[r * 512]);
-                            const double members = static_cast<double>(acc[NS - 1][r]);
+                            for (int s = 1; s >= 0; --s) {
+                                x = (x << 8) + static_cast<long long>(acc[s][rr]);
+                                y = (y << 8) + static_cast<long long>(acc[s][rr + 8]);
+                            }
+                            const long long give = sq ? x : y;
+                            const int g_lo = __shfl_xor(static_cast<int>(give), MF_SQ_LANE), g_hi = __shfl_xor(static_cast<int>(give >> 32), MF_SQ_LANE);
+                            const long long got = (static_cast<long long>(g_hi) << 32) | static_cast<long long>(static_cast<uint32_t>(g_lo));
+                            const long long v = sq ? got : x, w = sq ? y : got;        // sums / sums of squares (high digits) of MY row
+                            const double o = __longlong_as_double(obs[rr * 512]);
+                            const double members = static_cast<double>(sq ? acc[3][rr + 8] : acc[3][rr]);   // (the not-NaN slice is in both halves)
                             if (o == o && members >= 3.0) {                  // (observed NaN: no test; fewer than 3 values: the score is NaN -- safe_extras.py:30)
                                 const double a = static_cast<double>(v) * 16777216.0, b = static_cast<double>(w) * 16777216.0;
                                 const double e = members * static_cast<double>(MF_LO_MAX);
@@ -729,12 +784,22 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                                 const bool t_pos = T > E, t_neg = T < -E, s_pos = a > e, s_neg = a < -e;
                                 const bool greater = var_ok && (o >= 0.0 ? (s_pos && t_pos) : (s_pos || t_neg));
                                 const bool smaller = var_ok && (o >= 0.0 ? (s_neg || t_neg) : (s_neg && t_pos));
-                                cnt[r] += greater ? (1u << 16) : (smaller ? 1u : 0u);
-                                undecided |= (!greater && !smaller) ? (1u << r) : 0u;
+                                cnt[rr] += greater ? (1u << 16) : (smaller ? 1u : 0u);
+                                undecided |= (!greater && !smaller) ? (1u << rr) : 0u;
                             }
+                        }
+                    }
+#pragma unroll
+                    for (int r = 0; r < ((Z && FM == 2) ? 0 : 16); ++r) {
+                        constexpr int NV = Z ? (FM == 2 ? MF_NS / 2 : MF_NS) : NS;   // value slices
+                        long long v = static_cast<long long>(acc[NV - 1][r]);
+#pragma unroll
+                        for (int s = NV - 2; s >= 0; --s) v = (v << 8) + static_cast<long long>(acc[s][r]);
+                        if constexpr (Z && FM == 2) {
+                            // (handled above: eight outputs per lane)
                         } else if constexpr (Z) {
-                            // columns 0-15 of the tile: sum (and count, slice 6); columns 16-31: sum of squares, one lane-bit away
-                            const int lo_sq = __shfl_xor(static_cast<int>(v), 4), hi_sq = __shfl_xor(static_cast<int>(v >> 32), 4);
+                            // columns 0-15 of the tile: sum (and count, slice 6); columns 16-31: sum of squares, one lane-bit away (MF_SQ_LANE)
+                            const int lo_sq = __shfl_xor(static_cast<int>(v), MF_SQ_LANE), hi_sq = __shfl_xor(static_cast<int>(v >> 32), MF_SQ_LANE);
                             const long long w = (static_cast<long long>(hi_sq) << 32) | static_cast<long long>(static_cast<uint32_t>(lo_sq));
                             const double members = static_cast<double>(acc[NS - 1][r]);
                             const double mean = (static_cast<double>(v) * sc1) / members;          // safe_extras.py:21-23
@@ -776,7 +841,7 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
                         if (__builtin_expect(undecided != 0u, 0)) {
                             const unsigned long long u0 = static_cast<unsigned long long>(static_cast<int64_t>(g) * MF_R + wrow + 4 * h);
                             for (uint32_t left = undecided; left;) {
-                                const int r = __builtin_ctz(left);
+                                const int r = __builtin_ctz(left) + ((col_in_tile & 16) ? 8 : 0);       // (slot -> accumulator row of this lane)
                                 left &= left - 1u;
                                 const unsigned int at = atomicAdd(fa.amb_count, 1u);
                                 if (at >= fa.amb_cap) continue;
@@ -934,7 +999,16 @@ __global__ __launch_bounds__(512) void k_permtest_mfma(
             }
             // ---- task epilogue: observed scores (first span only) and the counters
             const int64_t col = Z ? colz : static_cast<int64_t>(ct) * 32 + col_in_tile;
-            if (!COUNTS && FM != 1 && col < mloc && !(Z && (col_in_tile & 16))) {
+            if constexpr (Z && FM == 2) {                                 // eight outputs per lane: value lanes rows 0..7, squares' lanes 8..15
+                if (col < mloc) {
+#pragma unroll
+                    for (int rr = 0; rr < 8; ++rr) {
+                        const int r = rr + ((col_in_tile & 16) ? 8 : 0);
+                        const int64_t u = static_cast<int64_t>(g) * MF_R + wrow + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (cnt[rr]) atomicAdd(&gl_counts[col * n_padr + u], cnt[rr]);
+                    }
+                }
+            } else if (!COUNTS && FM != 1 && col < mloc && !(Z && (col_in_tile & 16))) {
                 const double sc = (ns_out && !Z) ? col_scale[col] : 0.0;
 #pragma unroll
                 for (int r = 0; r < 16; ++r) {
@@ -2026,7 +2100,7 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
             hipLaunchKernelGGL(k_mfma_planes01<double>, grid, dim3(256), 0, ctx->stream, attr->raw, n, attr->row_stride,
                                attr->col_stride, col0, mloc, n_grp, cs->d_bs);
     }
-    const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
+    const size_t lds_bytes = 2 * (4 * mf_ks(MF_CN)) + MF_MAXBLK * sizeof(int32_t);
     for (const void *fn : {reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 0>),
                            reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 1>),
                            reinterpret_cast<const void *>(k_permtest_mfma<true, MF_CN, false, true, 2>)})
@@ -2035,7 +2109,7 @@ int counts_setup(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, int64_t col0, in
 }
 
 void counts_launch(safe_ctx *ctx, safe_nbr *nbr, const CountsSetup &cs, const HypLookup &hl, int spare_cus = 0) {
-    const size_t lds_bytes = 2 * (4 * MF_CN * MF_SS) + MF_MAXBLK * sizeof(int32_t);
+    const size_t lds_bytes = 2 * (4 * mf_ks(MF_CN)) + MF_MAXBLK * sizeof(int32_t);
     const int64_t blocks = std::min<int64_t>(static_cast<int64_t>(cs.tasks->size()), std::max(1, ctx->num_cu - spare_cus));
 #define COUNTS_LAUNCH(EPI)                                                                                                              \
     hipLaunchKernelGGL((k_permtest_mfma<true, MF_CN, false, true, EPI>), dim3(blocks), dim3(512), lds_bytes, ctx->stream, cs.d_bs,      \
@@ -2500,12 +2574,12 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
         SAFE_HIP_CHECK(hipMemsetAsync(d_amb_cnt, 0, static_cast<size_t>(n_launch) * sizeof(unsigned int), ctx->stream));
     }
 
-    const size_t lds_bytes = 2 * static_cast<size_t>(4 * core_slices * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    const size_t lds_bytes = 2 * static_cast<size_t>(4 * mf_ks(core_slices)) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
     const char *pref_env = getenv("SAFE_HIP_MFMA_PREF");
     const bool pref = !(pref_env && !strcmp(pref_env, "0"));
     const void *kfn_obs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 1>);
     const void *kfn_zobs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>);     // z-scores, all seven slices
-    const size_t lds_zobs = 2 * static_cast<size_t>(4 * (MF_NS + 1) * MF_SS) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
+    const size_t lds_zobs = 2 * static_cast<size_t>(4 * mf_ks(MF_NS + 1)) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
     const void *kfn = zfilt           ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2 + 1, true, true, 0, true, 2>)
                       : z             ? kfn_zobs
                       : filt          ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 2>)
