@@ -1703,11 +1703,14 @@ __global__ __launch_bounds__(256, WPS) void k_permtest_bits_blk_plain(
 // Tile shape: FIN_TP SELL positions x FIN_TC columns.  A 64 x 64 tile wrote 512-byte runs (3.6 TB/s); with 16 x 512 a wave
 // writes 4 KiB of one output row back to back (the counter reads become 64-byte pieces, but they are an eighth of the bytes).
 constexpr int FIN_TP = 16, FIN_TC = 512;
+// pv_lds: behind the NES table in LDS sits a second one, k / P for k = 0..P (each entry one correctly rounded division, as the
+// reference's counts / num_permutations, safe.py:532-533): two look-ups per output instead of two f64 divisions (~60 VALU
+// instructions per output against four stores)
 template <bool DIRECT, int MODE, bool TAB_LDS>
 __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ counts, int64_t n_pad,
                                                          const int32_t *__restrict__ sell_row,
                                                          const double *__restrict__ ns, int64_t mloc, int64_t n_perm,
-                                                         PermOut out) {
+                                                         PermOut out, int pv_lds) {
     __shared__ unsigned int tile[FIN_TC][FIN_TP + 1];
     __shared__ unsigned int part[4][FIN_TC];
     __shared__ int32_t rows[FIN_TP];
@@ -1731,9 +1734,13 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
     }
     if (threadIdx.x < FIN_TP) rows[threadIdx.x] = sell_row[spos0 + threadIdx.x];
     if (TAB_LDS && MODE != 1)
-        for (int64_t i = threadIdx.x; i <= n_perm; i += 256) tab_lds[i] = out.nes_table[i];
+        for (int64_t i = threadIdx.x; i <= n_perm; i += 256) {
+            tab_lds[i] = out.nes_table[i];
+            if (pv_lds) tab_lds[n_perm + 1 + i] = static_cast<double>(i) / static_cast<double>(n_perm);
+        }
     __syncthreads();
     const double *tab = TAB_LDS ? tab_lds : out.nes_table;
+    const double *pv = (TAB_LDS && pv_lds) ? tab_lds + n_perm + 1 : nullptr;
     const unsigned int P = static_cast<unsigned int>(n_perm);
     const double p_f = static_cast<double>(P);
     unsigned int hits[FIN_TC / 64];
@@ -1768,8 +1775,8 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
             } else if (MODE == 4) {                                  // any subset of the matrices from all-gathered 'sum' counters
                 const double en = tab[cneg], ep = tab[cpos];
                 const double nes = out.sign_mode == SAFE_SIGN_HIGHEST ? ep : out.sign_mode == SAFE_SIGN_LOWEST ? en : ep - en;
-                if (out.pvalues_neg) out.pvalues_neg[o] = static_cast<double>(cneg) / p_f;
-                if (out.pvalues_pos) out.pvalues_pos[o] = static_cast<double>(cpos) / p_f;
+                if (out.pvalues_neg) out.pvalues_neg[o] = pv ? pv[cneg] : static_cast<double>(cneg) / p_f;
+                if (out.pvalues_pos) out.pvalues_pos[o] = pv ? pv[cpos] : static_cast<double>(cpos) / p_f;
                 if (out.nes) out.nes[o] = nes;
                 if (out.nes_binary) out.nes_binary[o] = fabs(nes) > out.nes_threshold ? 1.0 : 0.0;
             } else if (MODE == 2) {
@@ -1779,8 +1786,8 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
                 if (out.sign_mode == SAFE_SIGN_HIGHEST) nes = ep;
                 if (out.sign_mode == SAFE_SIGN_LOWEST) nes = en;
                 const bool hit = (nes == nes) && (fabs(nes) > out.nes_threshold);
-                out.pvalues_neg[o] = obs_nan ? qnan : static_cast<double>(cneg) / p_f;
-                out.pvalues_pos[o] = obs_nan ? qnan : static_cast<double>(cpos) / p_f;
+                out.pvalues_neg[o] = obs_nan ? qnan : pv ? pv[cneg] : static_cast<double>(cneg) / p_f;
+                out.pvalues_pos[o] = obs_nan ? qnan : pv ? pv[cpos] : static_cast<double>(cpos) / p_f;
                 out.nes[o] = nes;
                 out.nes_binary[o] = hit ? 1.0 : 0.0;
                 hits[ct] += hit;
@@ -1805,8 +1812,10 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
     const dim3 grid(n_pad / FIN_TP, ceil_div(mloc, FIN_TC));
     const size_t tab_bytes = static_cast<size_t>(n_perm + 1) * sizeof(double);
     const bool tab_lds = out.mode != 1 && tab_bytes <= 20 * 1024;          // (next to 43 KB of static LDS)
-    const size_t dyn = tab_lds ? tab_bytes : 0;
-#define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, fin_stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out)
+    static const bool pv_off = getenv("SAFE_HIP_FIN_PV") && !strcmp(getenv("SAFE_HIP_FIN_PV"), "0");     // (A/B: divide per output)
+    const int pv_lds = tab_lds && 2 * tab_bytes <= 20 * 1024 && !pv_off ? 1 : 0;                       // k / P table behind the NES table
+    const size_t dyn = tab_lds ? (pv_lds ? 2 : 1) * tab_bytes : 0;
+#define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, fin_stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out, pv_lds)
 #define FIN_MODE(D, L)                      \
     do {                                    \
         if (out.mode == 1) FIN(D, 1, false); \

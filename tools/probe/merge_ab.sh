@@ -1,0 +1,10 @@
+for i in 1 2; do
+for m in 1 2 3; do
+SAFE_HIP_BITS_MERGE=$m python3 bench.py --steps 100 --warmup 30 --extras 0 --cpu-perms 0 2>/dev/null | python3 -c "
+import sys, json
+for ln in sys.stdin:
+    if ln.startswith('{'):
+        d = json.loads(ln); r = d['per_rank'][0]
+        print('merge=$m: step mean %.3f median %.3f  kernels busy %.3f  draw busy %.3f' % (d['ms_per_step'], d['step_ms_min_median_max'][1], r['gpu_kernel_busy_ms'], r['draw_busy_ms']))
+"
+done; done
