@@ -637,6 +637,7 @@ class StepProbe:
                 self._cg = path
                 break
         self.rows = []
+        self._thread_faults0 = thread_minor_faults()
         self._last = self._read()
 
     def _read(self):
@@ -676,7 +677,25 @@ class StepProbe:
                 t = timings[row['step']]
                 row.update({'tables_enqueued_ms': t.get('tables_enqueued_ms'), 'draw_busy_ms': t.get('draw_busy_ms'),
                             'gpu_kernel_busy_ms': t.get('gpu_kernel_busy_ms'), 'gpu_kernel_sum_ms': t.get('gpu_kernel_ms')})
-        return {'totals_over_timed_steps': total, 'slowest_steps': slow, 'gc': 'frozen + disabled inside the timed region'}
+        # which threads took the minor faults of the timed region (two reads of /proc/self/task/*/stat, outside the steps)
+        now = thread_minor_faults()
+        by_thread = sorted(((v - self._thread_faults0.get(k, 0), k[1]) for k, v in now.items() if v - self._thread_faults0.get(k, 0) > 0), reverse=True)[:4]
+        return {'totals_over_timed_steps': total, 'slowest_steps': slow, 'gc': 'frozen + disabled inside the timed region',
+                'minor_faults_by_thread': [{'thread': name, 'minor_faults': int(cnt)} for cnt, name in by_thread]}
+
+
+def thread_minor_faults():
+    """Minor page faults of every thread of this process so far, by (tid, name): /proc/self/task/*/stat field 10."""
+    out = {}
+    for tid in os.listdir('/proc/self/task'):
+        try:
+            with open('/proc/self/task/%s/stat' % tid) as f:
+                text = f.read()
+            name = text[text.index('(') + 1:text.rindex(')')]
+            out[(int(tid), name)] = int(text[text.rindex(')') + 2:].split()[7])
+        except (OSError, ValueError, IndexError):
+            pass
+    return out
 
 
 def thread_cpu_ms():
