@@ -637,6 +637,7 @@ class StepProbe:
                 self._cg = path
                 break
         self.rows = []
+        self._smaps0 = smaps_rss() if os.environ.get('SAFE_BENCH_SMAPS') == '1' else None      # (diagnostics: which mapping grew)
         self._thread_faults0 = thread_minor_faults()
         self._last = self._read()
 
@@ -660,7 +661,13 @@ class StepProbe:
             allocs = be.device_alloc_count()
         except Exception:
             pass
-        return (ru.ru_minflt, ru.ru_majflt, ru.ru_nivcsw, ru.ru_nvcsw, thr, thr_us, allocs)
+        rss = 0
+        try:
+            with open('/proc/self/statm') as f:
+                rss = int(f.read().split()[1])                      # resident pages (a few microseconds)
+        except (OSError, ValueError, IndexError):
+            pass
+        return (ru.ru_minflt, ru.ru_majflt, ru.ru_nivcsw, ru.ru_nvcsw, thr, thr_us, allocs, rss)
 
     def sample(self):
         now = self._read()
@@ -668,7 +675,8 @@ class StepProbe:
         self._last = now
 
     def report(self, step_ms, timings=None):
-        keys = ('minor_faults', 'major_faults', 'involuntary_switches', 'voluntary_switches', 'cfs_throttled_periods', 'cfs_throttled_us', 'device_allocations')
+        keys = ('minor_faults', 'major_faults', 'involuntary_switches', 'voluntary_switches', 'cfs_throttled_periods', 'cfs_throttled_us', 'device_allocations',
+                'resident_pages_change')
         total = {k: int(sum(r[i] for r in self.rows)) for i, k in enumerate(keys)}
         order = sorted(range(len(step_ms)), key=lambda i: -step_ms[i])[:3]
         slow = [dict({'step': int(i), 'ms': float(step_ms[i])}, **{k: int(self.rows[i][j]) for j, k in enumerate(keys)}) for i in order if i < len(self.rows)]
@@ -680,8 +688,32 @@ class StepProbe:
         # which threads took the minor faults of the timed region (two reads of /proc/self/task/*/stat, outside the steps)
         now = thread_minor_faults()
         by_thread = sorted(((v - self._thread_faults0.get(k, 0), k[1]) for k, v in now.items() if v - self._thread_faults0.get(k, 0) > 0), reverse=True)[:4]
-        return {'totals_over_timed_steps': total, 'slowest_steps': slow, 'gc': 'frozen + disabled inside the timed region',
-                'minor_faults_by_thread': [{'thread': name, 'minor_faults': int(cnt)} for cnt, name in by_thread]}
+        rep = {'totals_over_timed_steps': total, 'slowest_steps': slow, 'gc': 'frozen + disabled inside the timed region',
+               'minor_faults_by_thread': [{'thread': name, 'minor_faults': int(cnt)} for cnt, name in by_thread]}
+        if os.environ.get('SAFE_BENCH_SMAPS') == '2':              # nothing read before the timed region: the largest mappings after it
+            after = smaps_rss()
+            rep['mappings_largest_kb'] = [{'mapping': key, 'rss_kb': int(kb)} for kb, key in sorted(((kb, key) for key, kb in after.items()), reverse=True)[:14]]
+        if self._smaps0 is not None:
+            after = smaps_rss()
+            grown = sorted(((kb - self._smaps0.get(key, 0), key) for key, kb in after.items() if kb - self._smaps0.get(key, 0) >= 1024), reverse=True)[:6]
+            rep['mappings_grown_kb'] = [{'mapping': key, 'rss_kb_grown': int(kb)} for kb, key in grown]
+        return rep
+
+
+def smaps_rss():
+    """Resident kB of every mapping of this process: {'start-end name': kB} (/proc/self/smaps; tens of milliseconds -- diagnostics only)."""
+    out, key = {}, None
+    try:
+        with open('/proc/self/smaps') as f:
+            for line in f:
+                head = line.split()
+                if head and '-' in head[0] and not head[0].endswith(':'):
+                    key = head[0] + ' ' + (head[5] if len(head) > 5 else '[anon]') + ' ' + head[1]
+                elif line.startswith('Rss:') and key is not None:
+                    out[key] = int(head[1])
+    except OSError:
+        pass
+    return out
 
 
 def thread_minor_faults():
