@@ -176,6 +176,49 @@ int safe_device_pci_bus_id(int device, char *buf, size_t buf_len) {
     return SAFE_OK;
 }
 
+// The runtime opens a queue of its own for host <-> device copies the first time it needs one -- as far as can be told from
+// outside, the first time a copy finds no free DMA engine -- and opening a queue on this platform means populating a 173 MiB
+// context-save area plus 16 MiB in host memory on the spot: 7-12 ms, taken by one of the runtime's threads in the middle of
+// whatever call is running.  Left alone that happened in one run of `bench.py --steps 20 --warmup 5` out of three (busy boxes) to
+// ten, inside the first timed steps: one step of 10-15 ms among 3 ms ones, 4105-4108 minor faults, resident set +189 MiB
+// (bench.py's step probe).  It never happens with HSA_ENABLE_SDMA=0 (every copy a shader copy from the start -- but the step is
+// 0.8 ms slower), and it stops happening when the context starts with a burst of copies in both directions on a few streams at
+// once: 0 of 90 driver-style runs with the burst against 7 of 60 without, interleaved on the same boxes, medians unchanged
+// (tools/probe/env_ab.sh SAFE_HIP_PREWARM_COPIES "0 4 16").  Cost: ~35 ms of context creation (199 against 165 ms), 64 MiB of
+// pinned and device memory for its duration.  SAFE_HIP_PREWARM_COPIES=<streams> (default 4, 0 = off).  Best effort: errors are
+// ignored.
+static void ctx_open_copy_queue(safe_ctx *ctx) {
+    const char *e = getenv("SAFE_HIP_PREWARM_COPIES");
+    const int n_streams = e ? std::max(0, std::min(32, atoi(e))) : 4;
+    if (n_streams == 0) return;
+    const size_t bytes = size_t(8) << 20;
+    void *host = nullptr, *dev = nullptr;
+    if (hipHostMalloc(&host, 2 * n_streams * bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&dev, 2 * n_streams * bytes) != hipSuccess) {
+        (void)hipGetLastError();
+        if (host) (void)hipHostFree(host);
+        return;
+    }
+    memset(host, 0, 2 * n_streams * bytes);
+    std::vector<hipStream_t> streams(n_streams, nullptr);
+    for (hipStream_t &s : streams)
+        if (hipStreamCreateWithFlags(&s, hipStreamNonBlocking) != hipSuccess) s = nullptr;
+    for (int round = 0; round < 3; ++round)
+        for (int i = 0; i < n_streams; ++i) {
+            if (!streams[i]) continue;
+            char *h = static_cast<char *>(host) + 2 * i * bytes, *d = static_cast<char *>(dev) + 2 * i * bytes;
+            (void)hipMemcpyAsync(d, h, bytes, hipMemcpyHostToDevice, streams[i]);
+            (void)hipMemcpyAsync(h + bytes, d + bytes, bytes, hipMemcpyDeviceToHost, streams[i]);
+        }
+    for (hipStream_t s : streams)
+        if (s) (void)hipStreamSynchronize(s);
+    for (hipStream_t s : streams)
+        if (s) (void)hipStreamDestroy(s);
+    (void)hipFree(dev);
+    (void)hipHostFree(host);
+    (void)hipGetLastError();
+    (void)ctx;
+}
+
 int safe_ctx_create(int device, safe_ctx **out) {
     SAFE_REQUIRE(out != nullptr, "safe_ctx_create: out is NULL");
     *out = nullptr;
@@ -214,6 +257,7 @@ int safe_ctx_create(int device, safe_ctx **out) {
     SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->t1, safe_event_flags(hipEventDefault)));
     SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->k0, safe_event_flags(hipEventDefault)));
     SAFE_HIP_CHECK(hipEventCreateWithFlags(&ctx->k1, safe_event_flags(hipEventDefault)));
+    ctx_open_copy_queue(ctx);
     *out = ctx;
     return SAFE_OK;
 }
