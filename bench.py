@@ -669,6 +669,12 @@ class StepProbe:
             pass
         return (ru.ru_minflt, ru.ru_majflt, ru.ru_nivcsw, ru.ru_nvcsw, thr, thr_us, allocs, rss)
 
+    def rebase(self):
+        """Start counting from now (called right before the timed region)."""
+        self.rows = []
+        self._thread_faults0 = thread_minor_faults()
+        self._last = self._read()
+
     def sample(self):
         now = self._read()
         self.rows.append(tuple(a - b for a, b in zip(now, self._last)))
@@ -805,10 +811,11 @@ def run_mode(wl, n_steps, n_warmup, ctx, dist, torch, np, be, sharding, world, d
     gc.freeze()
     gc_was_enabled = gc.isenabled()
     gc.disable()
+    probe = StepProbe()                 # (its imports and file look-ups happen before the last warm-up steps, not between them and the timed region)
     for _ in range(n_tail):
         step()
     timings.clear()
-    probe = StepProbe()
+    probe.rebase()
     cpu0 = time.process_time()
     try:
         elapsed, step_ms = timed(n_steps, step, probe)
