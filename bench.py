@@ -1014,6 +1014,10 @@ def main():
             # the host draw chain's busy time of the steps in each decile of the step-time distribution (sorted by step time: a slow
             # chain thread shows as the last entries growing with the step)
             'draw_busy_ms_by_step_decile': _by_decile(res['step_ms'], [t.get('draw_busy_ms') for t in res['timings']]),
+            # the first steps of a fresh process are slower: which clock moves (kernels' busy time / host stream / draw chain), in run order
+            'first_8_steps_ms': [[round(float(res['step_ms'][i]), 3), round(float(res['timings'][i].get('gpu_kernel_busy_ms') or 0.0), 3),
+                                  round(float(res['timings'][i].get('tables_enqueued_ms') or 0.0), 3), round(float(res['timings'][i].get('draw_busy_ms') or 0.0), 3)]
+                                 for i in range(min(8, len(res['step_ms']), len(res['timings'])))],
             'draw_threads': {'placement': 'persistent per context' if os.environ.get('SAFE_HIP_DRAW_THREAD') != 'percall' else 'one per call',
                              'reserved_cores': int(os.environ.get('SAFE_BENCH_DRAW_CORES', '2')) if numa_node is not None else 0,
                              # the chain is drawn by two threads at once, the faster one publishes each chunk (rng.cpp, safe_perms::twin)
