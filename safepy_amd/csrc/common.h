@@ -230,6 +230,8 @@ struct safe_nbr {
     int32_t *bs_rowcnt = nullptr;   // [bs_groups*256] members of that node's neighborhood (-1 = padding row)
     int32_t *bs_grpmax = nullptr;   // [bs_groups] largest neighborhood of the group's rows
     uint4 *bs_bits4 = nullptr;      // the membership bits again, [super-step of 4 blocks][256 rows][4]: one 16-byte load per row and super-step
+    uint4 *bs_bits4p = nullptr;     // bs_bits4 with the bits of every word in operand order: bit 8 b + 4 h + j = member 16 h + 4 j + b of the block
+                                    // (k_permtest_mfma_g: register j of lane half h is (word >> (4 h + j)) & 0x01010101)
     int64_t bs_max_group_blocks = 0;   // blocks of the longest group
     int32_t *bs_ptr = nullptr;      // [bs_groups+1] first block of a group
     int32_t *bs_kb = nullptr;       // [bs_blocks] ordered column block of a stored block

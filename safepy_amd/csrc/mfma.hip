@@ -1315,10 +1315,14 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
                         }
                         if (__builtin_amdgcn_ballot_w64(word != 0u) != 0ull && !(dbg & 2)) {   // (a piece without members is skipped)
                             v4i a;
-                            a[0] = static_cast<int>(expand4(word, 16 * h));
-                            a[1] = static_cast<int>(expand4(word, 16 * h + 4));
-                            a[2] = static_cast<int>(expand4(word, 16 * h + 8));
-                            a[3] = static_cast<int>(expand4(word, 16 * h + 12));
+                            if (dbg & 1024) {                        // (diagnostic: what a FREE bit -> i8 expansion would give)
+                                a[0] = a[1] = a[2] = a[3] = static_cast<int>(word);
+                            } else {
+                                a[0] = static_cast<int>(expand4(word, 16 * h));
+                                a[1] = static_cast<int>(expand4(word, 16 * h + 4));
+                                a[2] = static_cast<int>(expand4(word, 16 * h + 8));
+                                a[3] = static_cast<int>(expand4(word, 16 * h + 12));
+                            }
 #pragma unroll
                             for (int s = 0; s < NS; ++s) acc[p][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[p][s], 0, 0, 0);
                         }
@@ -1409,6 +1413,358 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
             for (int it = 0; it < total; it += 2) {
                 body(it, L_a, L_b, src_a, src_b);
                 if (it + 1 < total) body(it + 1, L_b, L_a, src_b, src_a);
+            }
+            if ((dbg & 512) && lane == 0 && fa.prof) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    atomicAdd(&fa.prof[wave * 8 + i], prof_acc[i]);
+                    prof_acc[i] = 0;
+                }
+            }
+            if (since_flush) flush();
+            if (dbg & 8) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mf_keep(static_cast<uint32_t>(acc[p][s][r]));
+            }
+            __syncthreads();                                         // kb_list / buffers / thresholds are reused by the next task
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// k_permtest_mfma_g (round 6): k_permtest_mfma_f's shape -- four waves of 64 rows, two workgroups per CU, thresholds and 8-bit
+// counters in LDS -- with three changes that take instructions and waits out of the super-step:
+//  * the gather is LDS-DMA (global_load_lds_dwordx4).  A super-step's 128 gathered rows x 96 bytes lie in LDS as six PLANES of
+//    [128 rows][16 bytes] (plane c = bytes 16 c .. 16 c + 15 of a row = slice c >> 1, column half c & 1); a wave-instruction
+//    writes 64 consecutive rows of one plane (the DMA's destination is wave-uniform base + lane x 16).  Thread (wave w, lane l)
+//    stages row 64 (w & 1) + l of the super-step, planes 3 (w >> 1) .. + 2: ONE source index, ONE address and three DMA
+//    instructions per thread and super-step -- no staging registers (k_permtest_mfma_f: 32), no ds_write, no wait for
+//    gathered rows inside the k-loop, all four waves take part.  The DMAs of super-step it + 1 are issued at the top of
+//    super-step it (their buffer was last read in it - 1: the barrier in between orders that) and have the whole super-step to
+//    land; the one vmcnt(0) is in front of the barrier.  The transposing read takes its 8-byte pieces from a plane:
+//    piece i of a 16-lane group = row i >> 1, bytes 8 (i & 1) ..: 128 contiguous bytes per group.
+//  * the membership words come bit-permuted (bs_bits4p): operand register j of lane half h = (word >> (4 h + j)) & 0x01010101 --
+//    8 VALU per 32 x 32 piece instead of 12 (bit-field extract, multiply, mask per four bits).
+//  * score completion: thresholds are stored as Y0 + W, so "not certainly greater" is the SIGN of d' = y - (Y0 + W); the four
+//    signs of a counter word are collected with one v_alignbit each (top bytes side by side, one AND + shift per word), and
+//    "undecided" (-W <= d' < 0) is detected for the lane's 32 outputs at once from the unsigned maximum of d' (v_max3_u32);
+//    the per-output mask is only formed in the rare wave that has one (2.5 % of the wave-permutations at configs[4]).
+// DBG (diagnostic builds only): 2 no MFMAs (nor expansions), 4 no barrier, 8 no score completion, 64 no DMA, 512 per-phase cycle
+// counters, 1024 the operand registers without their expansion (the word itself: what a FREE bit -> i8 expansion would give).
+template <int DBG>
+__global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
+    const unsigned char *__restrict__ bs, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
+    const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint4 *__restrict__ blk_bits4p,
+    const int32_t *__restrict__ grp_maxcnt, const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off,
+    unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa) {
+    constexpr int dbg = DBG;
+    constexpr int NS = MF_NS / 2, PL = 128 * 16, BUF = 2 * NS * PL;           // plane = 2 KB, buffer = one super-step = 12 KB
+    constexpr int64_t row_bytes = NS * 32;
+    typedef __attribute__((address_space(3))) void lds_void;
+    typedef __attribute__((address_space(1))) const void gl_void;
+    // ONE shared array (a second __shared__ object makes the compiler drain the DMA queue before every LDS read):
+    // [2][BUF] | kb list | Y0 + W [32][256] | counters [8][256] | task slot
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lam = lane & 31, h = lane >> 5;
+    int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * BUF);
+    int32_t *y0s = reinterpret_cast<int32_t *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t)) + tid;
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t)) + tid;
+    int *slot_box = reinterpret_cast<int *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t));
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte *)lds));      // LDS byte address of the array
+    // staging role: row 64 (wave & 1) + lane of the super-step (k-step ks_g, row r_g of its block), planes 3 (wave >> 1) + 0..2
+    const int ks_g = 2 * (wave & 1) + h, r_g = lam;
+    const int dma_base = __builtin_amdgcn_readfirstlane(3 * (wave >> 1) * PL + (wave & 1) * 1024);
+    // operand read: lane l of a 16-lane group supplies piece l = row (l >> 1) of eight, bytes 8 (l & 1) .. of the plane's 16; the group
+    // (lane >> 4) & 1 reads the column half's plane, the lane half h the k rows 16 h ..; lane l then owns column l & 31 of the tile
+    const uint32_t r_base = static_cast<uint32_t>(((lane >> 4) & 1) * PL + (16 * h + ((lane & 15) >> 1)) * 16 + 8 * (lane & 1));
+    const uint32_t sh0 = 4u * h, sh1 = sh0 + 1u, sh2 = sh0 + 2u, sh3 = sh0 + 3u;
+
+    const int home = blockIdx.x & 7;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int qx = (home + attempt) & 7;
+        const int q_begin = q_off[qx], q_len = q_off[qx + 1] - q_begin;
+        for (;;) {
+            if (tid == 0) *slot_box = static_cast<int>(atomicAdd(&q_ctr[qx], 1u));
+            __syncthreads();
+            const int slot = *slot_box;
+            __syncthreads();
+            if (slot >= q_len) break;
+            const int2 task = tasks[q_begin + slot];
+            const int g = task.x, ct = task.y;
+            const int b0 = blk_ptr[g], nb = blk_ptr[g + 1] - b0, S = nb >> 2;
+            if (S == 0) continue;
+            for (int i = tid; i < nb; i += 256) kb_list[i] = blk_kb[b0 + i];
+
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + 48 * (wave >> 1);
+            const uint4 *bits_w = blk_bits4p + static_cast<int64_t>(b0 >> 2) * MF_R + wave * 64 + lane;   // lane l: row l of the wave's 64
+            const int total = n_q * S;
+            const int64_t colf = static_cast<int64_t>(ct) * 32 + lam;
+            const int64_t u_lane = static_cast<int64_t>(g) * MF_R + wave * 64 + 4 * h;     // + 32 p + (r & 3) + 8 (r >> 2)
+
+            // thresholds of this lane's 32 outputs, stored as Y0 + W (32-bit, in LDS); the window width is one number per task
+            const long long b_max = static_cast<long long>(grp_maxcnt[g]) * MF_LO_MAX;
+            const uint32_t wc = static_cast<uint32_t>((2 * b_max + (15ll << 24)) >> 28) + 2u;
+            const int32_t wcs = static_cast<int32_t>(wc);
+#pragma unroll
+            for (int p = 0; p < 2; ++p) {
+                long long o64[16];
+                int32_t members[16];
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int64_t u = u_lane + 32 * p + (r & 3) + 8 * (r >> 2);
+                    members[r] = fa.rowcnt[u];
+                    o64[r] = colf < mloc ? fa.obs64[colf * n_padr + u] : 0ll;
+                }
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const long long bp = static_cast<long long>(members[r]) * MF_LO_MAX + (15ll << 24);
+                    // padding rows (-1 members) and padding columns only ever form y = 0: Y0 = 1 counts them "smaller" without any
+                    // further test (their counters are never read); an EMPTY neighborhood of a real row takes the general rule
+                    y0s[(16 * p + r) * 256] = ((colf < mloc && members[r] >= 0) ? static_cast<int32_t>((o64[r] - bp) >> 28) : 1) + wcs;
+                }
+            }
+            __syncthreads();                                         // kb_list
+
+            v16i acc[2][NS];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnts[j * 256] = 0;
+            int since_flush = 0;
+            unsigned long long prof_acc[5] = {0, 0, 0, 0, 0};
+
+            auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t w = cnts[j * 256];
+                    cnts[j * 256] = 0;
+                    if (colf < mloc) {
+#pragma unroll
+                        for (int f = 0; f < 4; ++f) {                    // byte f: piece f >> 1, accumulator element j + 8 (f & 1)
+                            const uint32_t smaller = (w >> (8 * f)) & 0xFFu;
+                            const int r = j + 8 * (f & 1);
+                            atomicAdd(&gl_counts[colf * n_padr + u_lane + 32 * (f >> 1) + (r & 3) + 8 * (r >> 2)],
+                                      (smaller << 16) | (static_cast<uint32_t>(since_flush) - smaller));
+                        }
+                    }
+                }
+            };
+            auto src_of = [&](int q, int kb) -> int32_t {
+                q = q < n_q ? q : n_q - 1;
+                return srcp[static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + r_g];
+            };
+            auto stage = [&](int32_t src, int buf) __attribute__((always_inline)) {
+                if (dbg & 64) return;
+                // Written as asm: through the builtin the compiler drains the DMA queue (vmcnt(0)) before the next LDS read it cannot
+                // prove disjoint from the destination -- right after the issue.  The DMAs are therefore not in the compiler's
+                // vmcnt bookkeeping: they are older than every counted load whose wait follows them (so those waits cover them),
+                // and the explicit vmcnt(0) in front of the super-step's barrier is what publishes the rows.
+                const unsigned char *from = bs_ct + static_cast<int64_t>(src) * row_bytes;
+                const unsigned char *from1 = from + 16, *from2 = from + 32;
+                const uint32_t to = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_base + buf * BUF + dma_base)));
+                uint32_t keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %4\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, off\n\t"
+                    "s_add_u32 m0, %4, 0x800\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %2, off\n\t"
+                    "s_add_u32 m0, %4, 0x1000\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %3, off\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(from), "v"(from1), "v"(from2), "s"(to)
+                    : "memory", "scc");
+            };
+            auto advance = [&](int &qq, int &tt) {
+                if (++tt == S) {
+                    tt = 0;
+                    ++qq;
+                }
+            };
+            // membership words of a super-step: lane l loads the four words of row l; v_permlane32_swap then gives every lane the
+            // words of row (l & 31) of piece 0 and of piece 1 (one 16-byte load per lane instead of two)
+            auto split_rows = [&](const uint4 &raw, uint4 (&w)[2]) __attribute__((always_inline)) {
+                typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+                const v2u x = __builtin_amdgcn_permlane32_swap(raw.x, raw.x, false, false);
+                const v2u y = __builtin_amdgcn_permlane32_swap(raw.y, raw.y, false, false);
+                const v2u z = __builtin_amdgcn_permlane32_swap(raw.z, raw.z, false, false);
+                const v2u ww = __builtin_amdgcn_permlane32_swap(raw.w, raw.w, false, false);
+                w[0] = make_uint4(x[0], y[0], z[0], ww[0]);
+                w[1] = make_uint4(x[1], y[1], z[1], ww[1]);
+            };
+
+            // pipeline: super-step it computes from buffer it & 1; at its top the rows of it + 1 are handed to the DMA (source
+            // index loaded during it - 1), the source index of it + 2 and the membership words of it + 1 are requested
+            int q1 = 0, t1 = 0, q2, t2;
+            advance(q1, t1);
+            q2 = q1, t2 = t1;
+            advance(q2, t2);
+            stage(src_of(0, kb_list[ks_g]), 0);
+            int32_t src_nx = src_of(q1, kb_list[4 * t1 + ks_g]);
+            int kb_next = kb_list[4 * t2 + ks_g];
+            uint4 aw[2];
+            split_rows(bits_w[0], aw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            int q = 0, t = 0;
+            for (int it = 0; it < total; ++it) {
+                const int buf = it & 1;
+                int q3 = q2, t3 = t2;
+                advance(q3, t3);
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                if (dbg & 512) c0 = __builtin_amdgcn_s_memtime();
+                stage(src_nx, buf ^ 1);                                  // (unconditional: behind the task's last super-step the clamped
+                                                                         //  index stages rows nobody reads -- a branch here would put a
+                                                                         //  vmcnt(0) behind the DMA issue, where the paths meet again)
+                src_nx = src_of(q2, kb_next);
+                kb_next = kb_list[4 * t3 + ks_g];                        // (consumed at the top of the next iteration)
+                const uint4 aw_raw = bits_w[static_cast<int64_t>(t1) * MF_R];
+
+                const unsigned char *bbuf = lds + buf * BUF + r_base;
+                if (dbg & 512) c1 = __builtin_amdgcn_s_memtime();
+                // two operand sets: the slices of k-step k + 1 are read before the MFMAs of k-step k are issued
+                v4i b_cur[NS], b_nxt[NS];
+                auto read_operand = [&](int k, int s) -> v4i {
+                    typedef int v2i __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(3))) v2i lds_v2i;
+                    const unsigned char *at = bbuf + k * 512 + s * 2 * PL;
+                    const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at));            // k rows 16 h + 0..7
+                    const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at + 128));      // k rows 16 h + 8..15
+                    v4i r;
+                    r[0] = lo[0], r[1] = lo[1], r[2] = hi[0], r[3] = hi[1];
+                    return r;
+                };
+#pragma unroll
+                for (int s = 0; s < NS; ++s) b_cur[s] = read_operand(0, s);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < 3) {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) b_nxt[s] = read_operand(k + 1, s);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);               // the reads stay ahead of this k-step's MFMAs
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t word = k == 0 ? aw[p].x : k == 1 ? aw[p].y : k == 2 ? aw[p].z : aw[p].w;
+                        if (dbg & 2) {
+                            mf_keep(word);
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) mf_keep(b_cur[s]);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(word != 0u) != 0ull && !(dbg & 2)) {   // (a piece without members is skipped)
+                            v4i a;
+                            if (dbg & 1024) {
+                                a[0] = a[1] = a[2] = a[3] = static_cast<int>(word);
+                            } else {
+                                a[0] = static_cast<int>((word >> sh0) & 0x01010101u);
+                                a[1] = static_cast<int>((word >> sh1) & 0x01010101u);
+                                a[2] = static_cast<int>((word >> sh2) & 0x01010101u);
+                                a[3] = static_cast<int>((word >> sh3) & 0x01010101u);
+                            }
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) acc[p][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[p][s], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
+                }
+
+                if (dbg & 512) c2 = __builtin_amdgcn_s_memtime();
+                if (t == S - 1 && !(dbg & 8)) {                      // the scores of permutation q are complete
+                    uint32_t mx = 0u;                                 // unsigned maximum of d' = y - (Y0 + W) over the lane's outputs
+#pragma unroll
+                    for (int jb = 0; jb < 2; ++jb) {                  // sixteen outputs (four counter words) at a time: their thresholds are read together
+                        int32_t y0v[4][4];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj)
+#pragma unroll
+                            for (int f = 0; f < 4; ++f) y0v[jj][f] = y0s[(16 * (f >> 1) + 4 * jb + jj + 8 * (f & 1)) * 256];
+#pragma unroll
+                        for (int jj = 0; jj < 4; ++jj) {
+                            const int j = 4 * jb + jj;
+                            uint32_t tops = 0u;                       // the top bytes of the four d' side by side: their sign bits are the increments
+#pragma unroll
+                            for (int f = 3; f >= 0; --f) {
+                                const int p = f >> 1, r = j + 8 * (f & 1);
+                                const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);   // floor(V_hi / 16)
+                                const uint32_t d = static_cast<uint32_t>(y - y0v[jj][f]);
+                                tops = __builtin_amdgcn_alignbit(tops, d, 24);
+                                mx = d > mx ? d : mx;
+                            }
+                            // d' < 0: not certainly greater (counted "smaller"; an undecided one is taken back below)
+                            __hip_atomic_fetch_add(&cnts[j * 256], (tops >> 7) & 0x01010101u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    if (__builtin_expect(~mx < wc, 0)) {
+                        // rare (~1e-5 of the compares): -W <= d' < 0 for one of this lane's outputs -- find them (the thresholds again)
+                        // and hand them to the resolve kernel, which forms the exact score from all six digits
+                        uint32_t open = 0;
+#pragma unroll
+                        for (int o = 0; o < 32; ++o) {
+                            const int p = o >> 4, r = o & 15;
+                            const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);
+                            const uint32_t d = static_cast<uint32_t>(y - y0s[o * 256]);
+                            open |= (~d < wc) ? (1u << o) : 0u;
+                        }
+                        for (uint32_t left = open; left;) {
+                            const int o = __builtin_ctz(left);
+                            left &= left - 1u;
+                            const int64_t u = u_lane + 32 * (o >> 4) + (o & 3) + 8 * ((o & 15) >> 2);
+                            atomicAdd(&gl_counts[colf * n_padr + u], 0xFFFF0000u);       // it was counted "smaller" above: taken back
+                            const unsigned int at = atomicAdd(fa.amb_count, 1u);
+                            if (at < fa.amb_cap)
+                                fa.amb[at] = make_ulonglong2(static_cast<unsigned long long>(u) | (static_cast<unsigned long long>(colf) << 32),
+                                                             (1ull << 63) | static_cast<unsigned long long>(fa.p_base + q));
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
+                    if (++since_flush == 255) {
+                        flush();
+                        since_flush = 0;
+                    }
+                }
+                split_rows(aw_raw, aw);
+                if (dbg & 512) {
+                    mf_keep(aw[0]);                                  // (the wait for the membership words belongs to this phase)
+                    mf_keep(aw[1]);
+                    c3 = __builtin_amdgcn_s_memtime();
+                }
+                if (!(dbg & 4)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next super-step's rows has landed
+                    __syncthreads();
+                }
+                if (dbg & 512) {
+                    const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+                    prof_acc[0] += c1 - c0;                          // DMA issue, look-ahead loads
+                    prof_acc[1] += c2 - c1;                          // operand reads, expansions, MFMAs
+                    prof_acc[2] += c3 - c2;                          // score completion (+ the wait for the next membership words)
+                    prof_acc[3] += c4 - c3;                          // DMA landed + barrier
+                    prof_acc[4] += 1;
+                }
+                q = q1, t = t1;
+                q1 = q2, t1 = t2;
+                q2 = q3, t2 = t3;
             }
             if ((dbg & 512) && lane == 0 && fa.prof) {
 #pragma unroll
@@ -1647,6 +2003,17 @@ int build_blocks(safe_nbr *nbr) {
     std::vector<uint32_t> bits4(bits.size());
     for (size_t b = 0; b < kbs.size(); ++b)
         for (int r = 0; r < MF_R; ++r) bits4[((b >> 2) * MF_R + r) * 4 + (b & 3)] = bits[b * MF_R + r];
+    // ... and in the operand order of k_permtest_mfma_g: the MFMA's A operand of lane half h holds member 16 h + 4 j + b of the
+    // block in byte b of register j -- stored at bit 8 b + 4 h + j, register j is one shift and one AND of the word
+    std::vector<uint32_t> bits4p(bits4.size());
+    for (size_t i = 0; i < bits4.size(); ++i) {
+        const uint32_t w = bits4[i];
+        uint32_t o = 0;
+        for (int h = 0; h < 2; ++h)
+            for (int j = 0; j < 4; ++j)
+                for (int b = 0; b < 4; ++b) o |= ((w >> (16 * h + 4 * j + b)) & 1u) << (8 * b + 4 * h + j);
+        bits4p[i] = o;
+    }
     std::vector<int32_t> h_grpmax(n_groups, 0);
     nbr->bs_max_group_blocks = 0;
     for (int64_t g = 0; g < n_groups; ++g) {
@@ -1672,6 +2039,8 @@ int build_blocks(safe_nbr *nbr) {
     SAFE_TRY(dev_alloc(&nbr->bs_bits4, bits4.size() / 4));
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_grpmax, h_grpmax.data(), h_grpmax.size() * sizeof(int32_t), hipMemcpyHostToDevice));
     if (!bits4.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits4, bits4.data(), bits4.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
+    SAFE_TRY(dev_alloc(&nbr->bs_bits4p, bits4p.size() / 4));
+    if (!bits4p.empty()) SAFE_HIP_CHECK(hipMemcpy(nbr->bs_bits4p, bits4p.data(), bits4p.size() * sizeof(uint32_t), hipMemcpyHostToDevice));
     SAFE_TRY(dev_alloc(&nbr->bs_kb, kbs.size()));
     SAFE_TRY(dev_alloc(&nbr->bs_bits, bits.size()));
     SAFE_HIP_CHECK(hipMemcpy(nbr->bs_order, h_order.data(), n_src * sizeof(int32_t), hipMemcpyHostToDevice));
@@ -1686,6 +2055,7 @@ int build_blocks(safe_nbr *nbr) {
     {
         SAFE_HIP_CHECK(hipMemset(nbr->bs_bits, 0, bits.size() * sizeof(uint32_t)));
         SAFE_HIP_CHECK(hipMemset(nbr->bs_bits4, 0, bits.size() * sizeof(uint32_t)));
+        SAFE_HIP_CHECK(hipMemset(nbr->bs_bits4p, 0, bits.size() * sizeof(uint32_t)));
     }
 #endif
     nbr->blocks_ready = true;
@@ -2400,8 +2770,9 @@ void nbr_free_blocks(safe_nbr *nbr) {
     (void)hipFree(nbr->bs_rowcnt);
     (void)hipFree(nbr->bs_grpmax);
     (void)hipFree(nbr->bs_bits4);
+    (void)hipFree(nbr->bs_bits4p);
     nbr->bs_rowcnt = nbr->bs_grpmax = nullptr;
-    nbr->bs_bits4 = nullptr;
+    nbr->bs_bits4 = nbr->bs_bits4p = nullptr;
     (void)hipFree(nbr->bs_ptr);
     (void)hipFree(nbr->bs_kb);
     (void)hipFree(nbr->bs_bits);
@@ -2597,14 +2968,22 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     constexpr int mfma_dbg = 0;
 #endif
     const char *tr_env = getenv("SAFE_HIP_MFMA_TR");                      // =0: register transposes + ds_read_b128 (A/B)
-    const void *kfn_own = (tr_env && !strcmp(tr_env, "0")) ? reinterpret_cast<const void *>(k_permtest_mfma_f<0, false>)
-                                                          : reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
+    // SAFE_HIP_MFMA_FORM=f: round 5's kernel (register-staged gather); default: k_permtest_mfma_g (LDS-DMA gather)
+    const bool form_f = form_env && !strcmp(form_env, "f");
+    const void *kfn_own = !form_f                            ? reinterpret_cast<const void *>(k_permtest_mfma_g<0>)
+                          : (tr_env && !strcmp(tr_env, "0")) ? reinterpret_cast<const void *>(k_permtest_mfma_f<0, false>)
+                                                             : reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
 #ifdef SAFE_HIP_DIAG
-#define MF_F_DIAG(D) if (mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<D>);
-    MF_F_DIAG(1) MF_F_DIAG(2) MF_F_DIAG(4) MF_F_DIAG(8) MF_F_DIAG(15) MF_F_DIAG(31) MF_F_DIAG(47) MF_F_DIAG(79) MF_F_DIAG(271) MF_F_DIAG(127) MF_F_DIAG(383) MF_F_DIAG(511) MF_F_DIAG(512)
+#define MF_F_DIAG(D) if (form_f && mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<D>);
+    MF_F_DIAG(1) MF_F_DIAG(2) MF_F_DIAG(4) MF_F_DIAG(8) MF_F_DIAG(15) MF_F_DIAG(31) MF_F_DIAG(47) MF_F_DIAG(79) MF_F_DIAG(271) MF_F_DIAG(127) MF_F_DIAG(383) MF_F_DIAG(511) MF_F_DIAG(512) MF_F_DIAG(1024)
 #undef MF_F_DIAG
+#define MF_G_DIAG(D) if (!form_f && mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_g<D>);
+    MF_G_DIAG(2) MF_G_DIAG(4) MF_G_DIAG(8) MF_G_DIAG(64) MF_G_DIAG(66) MF_G_DIAG(512) MF_G_DIAG(1024)
+#undef MF_G_DIAG
 #endif
-    const size_t lds_own = 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t);
+    const size_t lds_own = form_f ? 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t)
+                                  : 2 * static_cast<size_t>(MF_NS * 128 * 16) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t) + 16;
+    const uint4 *bits_own = form_f ? nbr->bs_bits4 : nbr->bs_bits4p;
     if (filt_own)
         SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_own, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_own)));
     ctx->last_slices = n_slices;
@@ -2719,7 +3098,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
             if (filt_own) {
                 const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
                 void *args[] = {(void *)&bs_main, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
-                                (void *)&nbr->bs_kb, (void *)&nbr->bs_bits4, (void *)&nbr->bs_grpmax, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c,
+                                (void *)&nbr->bs_kb, (void *)&bits_own, (void *)&nbr->bs_grpmax, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c,
                                 (void *)&mloc, (void *)&d_counts, (void *)&n_padr, (void *)&fa};
                 SAFE_HIP_CHECK(hipLaunchKernel(kfn_own, dim3(blocks_own), dim3(256), args, lds_own, ks));
             } else {

@@ -715,8 +715,10 @@ static bool worker_post(safe_ctx *ctx, DrawWorker **slot, int which, safe_perms 
         std::lock_guard<std::mutex> lk(w->mu);
         if (w->busy) return false;                                    // (one stream at a time per worker)
         w->busy = true;
+        // Published under the mutex: the worker evaluates its wait predicate under the same mutex, so a store + notify can
+        // never fall between its last look and its block (a lost wake-up would leave the seeded call waiting forever).
+        w->job.store(p, std::memory_order_release);
     }
-    w->job.store(p, std::memory_order_release);
     w->cv.notify_all();                                               // (a polling worker sees the store; a sleeping one this)
     return true;
 }
