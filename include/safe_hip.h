@@ -388,6 +388,14 @@ typedef void (*safe_enqueued_fn)(void *user);
 int safe_set_exchange_chunks(safe_ctx *ctx, int chunks, int64_t cols_per_chunk, safe_enqueued_fn on_enqueued, void *user);
 int safe_packed_chunk_info(safe_ctx *ctx, int *chunks, int64_t *bounds, int64_t *tail_permutations);
 int safe_export_packed_chunk(safe_ctx *ctx, int chunk, uint32_t *dst_dev, int64_t capacity, void *stream);
+/* The same slab with the counter pair packed to what the permutation count needs (the concatenated blocks of
+ * safepy/safe.py:1355 carry counts of at most num_permutations, safe_extras.py:63-66): for num_permutations <= 1023 a pair is
+ * 10 + 10 bits and two outputs travel in five bytes -- a column is n_pad / 2 words (low 32 bits of every 40) followed by
+ * n_pad / 2 bytes (the high 8), 5 * n_pad / 8 words per column, 0.625 of the u32 slab.  capacity_words: u32 words at dst_dev
+ * (the rest is zeroed).  safe_outputs_from_packed_slabs takes such slabs with SAFE_PACKED_NARROW added to `layout`
+ * (slab_stride stays in u32 words).  More than 1023 permutations: use the u32 form. */
+#define SAFE_PACKED_NARROW 16
+int safe_export_packed_chunk_narrow(safe_ctx *ctx, int chunk, uint32_t *dst_dev, int64_t capacity_words, void *stream);
 int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *slabs_dev, int layout, int64_t n_pad, int n_slabs,
                                    int64_t slab_stride, const int64_t *slab_cols, const int64_t *out_col0, int64_t m_total,
                                    int64_t num_permutations, int sign_mode, double enrichment_threshold,

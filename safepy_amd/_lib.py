@@ -128,6 +128,7 @@ PROTOTYPES = {
     'safe_set_exchange_chunks': (C.c_int, [_vp, C.c_int, _i64, _vp, _vp]),
     'safe_packed_chunk_info': (C.c_int, [_vp, C.POINTER(C.c_int), _pi64, _pi64]),
     'safe_export_packed_chunk': (C.c_int, [_vp, C.c_int, _vp, _i64, _vp]),
+    'safe_export_packed_chunk_narrow': (C.c_int, [_vp, C.c_int, _vp, _i64, _vp]),
     'safe_outputs_from_packed_slabs': (C.c_int, [_vp, _vp, _vp, C.c_int, _i64, C.c_int, _i64, _pi64, _pi64, _i64, _i64, C.c_int, C.c_double,
                                                  _vp, _vp, _vp, _vp, _vp, _vp]),
     'safe_randomization_plan': (C.c_int, [_vp, _vp, _vp, _i64, C.c_int, C.POINTER(C.c_int)]),

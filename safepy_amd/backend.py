@@ -765,8 +765,19 @@ def packed_chunk_info(ctx):
     return k.value, [bounds[i] for i in range(k.value + 1)] if k.value else [], tail.value
 
 
-def export_packed_chunk(ctx, chunk, dst_ptr, capacity, stream=None):
-    check(lib.safe_export_packed_chunk(ctx.handle, int(chunk), C.c_void_p(dst_ptr), int(capacity), C.c_void_p(stream) if stream else None))
+PACKED_NARROW = 16          # safe_hip.h SAFE_PACKED_NARROW: slabs of 20-bit counter pairs (num_permutations <= 1023)
+
+
+def packed_slab_words(cols, n_pad, narrow):
+    """u32 words of a slab of `cols` columns of packed counters: n_pad per column, or 5 n_pad / 8 in the narrow form."""
+    return int(cols) * (int(n_pad) // 8 * 5 if narrow else int(n_pad))
+
+
+def export_packed_chunk(ctx, chunk, dst_ptr, capacity, stream=None, narrow=False):
+    """Chunk `chunk` of the last randomization call's counters to dst_ptr (`capacity` u32 words, the rest zeroed) on `stream`;
+    narrow: two outputs in five bytes (safe_export_packed_chunk_narrow, num_permutations <= 1023)."""
+    fn = lib.safe_export_packed_chunk_narrow if narrow else lib.safe_export_packed_chunk
+    check(fn(ctx.handle, int(chunk), C.c_void_p(dst_ptr), int(capacity), C.c_void_p(stream) if stream else None))
 
 
 def outputs_from_packed_slabs(ctx, nbr, slabs_ptr, layout, n_pad, slab_stride, slab_cols, out_col0, m_total, num_permutations,

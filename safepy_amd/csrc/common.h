@@ -426,7 +426,7 @@ static inline std::vector<int64_t> perm_launch_starts(const safe_perms *perms, i
 int perms_wait(safe_perms *perms, int64_t upto, hipStream_t s);   // make stream s wait until rows [0, upto) exist (rng.cpp)
 // counters [column][position] (#less << 16 | #greater) -> outputs; rowmap[position] = row or -1 (enrich.hip)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
-                           int64_t n_perm, const PermOut &out, const double *ns_direct, hipStream_t on = nullptr);
+                           int64_t n_perm, const PermOut &out, const double *ns_direct, hipStream_t on = nullptr, bool pk20 = false);
 // MFMA (i8, exact fixed point) form of the permutation test for quantitative attributes (mfma.hip)
 bool mfma_applicable(const safe_ctx *ctx, const safe_nbr *nbr, const safe_attr *attr, const safe_perms *perms, bool z);
 int launch_mfma(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1, bool z,

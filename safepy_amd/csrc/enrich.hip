@@ -1706,7 +1706,9 @@ constexpr int FIN_TP = 16, FIN_TC = 512;
 // pv_lds: behind the NES table in LDS sits a second one, k / P for k = 0..P (each entry one correctly rounded division, as the
 // reference's counts / num_permutations, safe.py:532-533): two look-ups per output instead of two f64 divisions (~60 VALU
 // instructions per output against four stores)
-template <bool DIRECT, int MODE, bool TAB_LDS>
+// PK20 (exchanged counters of other ranks, P <= 1023): a column is n_pad / 2 words + n_pad / 2 bytes -- two 20-bit pairs
+// (#less << 10 | #greater) in 40 bits, low 32 bits in the word, high 8 in the byte (safe_export_packed_chunk_narrow)
+template <bool DIRECT, int MODE, bool TAB_LDS, bool PK20 = false>
 __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__restrict__ counts, int64_t n_pad,
                                                          const int32_t *__restrict__ sell_row,
                                                          const double *__restrict__ ns, int64_t mloc, int64_t n_perm,
@@ -1726,7 +1728,16 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
 #pragma unroll
             for (int k = 0; k < 16; ++k) {
                 const int64_t c = c0 + cq + 16 * (half * 16 + k);
-                v[k] = counts[(c < mloc ? c : mloc - 1) * n_pad + spos0 + p];
+                if (PK20) {
+                    const unsigned int *col = counts + (c < mloc ? c : mloc - 1) * (n_pad / 8 * 5);
+                    const int64_t pos = spos0 + p, i = pos >> 1;
+                    const unsigned long long x = static_cast<unsigned long long>(col[i]) |
+                                                 (static_cast<unsigned long long>(reinterpret_cast<const unsigned char *>(col + n_pad / 2)[i]) << 32);
+                    const unsigned int pair = static_cast<unsigned int>(x >> (20 * (pos & 1))) & 0xFFFFFu;
+                    v[k] = ((pair >> 10) << 16) | (pair & 0x3FFu);
+                } else {
+                    v[k] = counts[(c < mloc ? c : mloc - 1) * n_pad + spos0 + p];
+                }
             }
 #pragma unroll
             for (int k = 0; k < 16; ++k) tile[cq + 16 * (half * 16 + k)][p] = v[k];
@@ -1807,7 +1818,7 @@ __global__ __launch_bounds__(256) void k_counts_finalize(const unsigned int *__r
 
 // ns_direct != NULL: the counters hold (#>= << 16 | #<=) against the observed scores in ns_direct (NaN there = no test)
 int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_pad, const int32_t *rowmap, int64_t mloc,
-                           int64_t n_perm, const PermOut &out, const double *ns_direct, hipStream_t on) {
+                           int64_t n_perm, const PermOut &out, const double *ns_direct, hipStream_t on, bool pk20) {
     const hipStream_t fin_stream = on ? on : ctx->stream;
     const dim3 grid(n_pad / FIN_TP, ceil_div(mloc, FIN_TC));
     const size_t tab_bytes = static_cast<size_t>(n_perm + 1) * sizeof(double);
@@ -1823,7 +1834,14 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
         else if (out.mode == 3) FIN(D, 3, L); \
         else if (out.mode == 4) FIN(D, 4, L); \
     } while (0)
-    if (ns_direct) {
+    if (pk20) {                                        // (exchanged slabs only: mode 4, no observed scores)
+        if (ns_direct || out.mode != 4 || n_perm > 1023) {
+            safe_set_error("enrich_finalize_counts: 20-bit counter pairs serve the exchanged 'sum' counters of at most 1023 permutations");
+            return SAFE_E_INVALID;
+        }
+        if (tab_lds) hipLaunchKernelGGL((k_counts_finalize<false, 4, true, true>), grid, dim3(256), dyn, fin_stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out, pv_lds);
+        else hipLaunchKernelGGL((k_counts_finalize<false, 4, false, true>), grid, dim3(256), dyn, fin_stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out, pv_lds);
+    } else if (ns_direct) {
         if (tab_lds) FIN_MODE(true, true);
         else FIN_MODE(true, false);
     } else {
@@ -3785,6 +3803,48 @@ int safe_export_packed_chunk(safe_ctx *ctx, int chunk, uint32_t *dst_dev, int64_
     return SAFE_OK;
 }
 
+// counters (#less << 16 | #greater), both <= 1023  ->  20-bit pairs, two outputs in five bytes, column by column
+__global__ __launch_bounds__(256) void k_pack_counts20(const unsigned int *__restrict__ counts, int64_t n_pad, int64_t cols,
+                                                       unsigned int *__restrict__ dst) {
+    const int64_t half = n_pad / 2, idx = static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x;
+    if (idx >= cols * half) return;
+    const int64_t c = idx / half, i = idx % half;
+    const uint2 v = *reinterpret_cast<const uint2 *>(counts + c * n_pad + 2 * i);
+    const unsigned long long x0 = ((v.x >> 16) << 10) | (v.x & 0x3FFu), x1 = ((v.y >> 16) << 10) | (v.y & 0x3FFu);
+    const unsigned long long x = x0 | (x1 << 20);
+    unsigned int *col = dst + c * (n_pad / 8 * 5);
+    col[i] = static_cast<unsigned int>(x);
+    reinterpret_cast<unsigned char *>(col + half)[i] = static_cast<unsigned char>(x >> 32);
+}
+
+int safe_export_packed_chunk_narrow(safe_ctx *ctx, int chunk, uint32_t *dst_dev, int64_t capacity_words, void *stream) {
+    SAFE_REQUIRE(ctx && dst_dev, "safe_export_packed_chunk_narrow: NULL argument");
+    SAFE_REQUIRE(ctx->packed_layout >= 0 && ctx->xc_want >= 1 && chunk >= 0 && chunk < ctx->xc_want,
+                 "safe_export_packed_chunk_narrow: chunk %d of %d armed, counters %s", chunk, ctx->xc_want, ctx->packed_layout >= 0 ? "present" : "absent");
+    SAFE_REQUIRE(ctx->packed_perms >= 1 && ctx->packed_perms <= 1023, "safe_export_packed_chunk_narrow: %lld permutations do not fit 10-bit counters",
+                 (long long)ctx->packed_perms);
+    const int64_t c0 = std::min<int64_t>(chunk * ctx->xc_cols, ctx->packed_m);
+    const int64_t c1 = chunk + 1 == ctx->xc_want ? ctx->packed_m : std::min<int64_t>((chunk + 1) * ctx->xc_cols, ctx->packed_m);
+    const int64_t words = (c1 - c0) * (ctx->packed_n_pad / 8 * 5);
+    SAFE_REQUIRE(capacity_words >= words, "safe_export_packed_chunk_narrow: buffer holds %lld words, %lld needed", (long long)capacity_words, (long long)words);
+    SAFE_HIP_CHECK(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? static_cast<hipStream_t>(stream) : ctx->stream;
+    if (ctx->xc_made > 0) {
+        SAFE_REQUIRE(ctx->xc_made == ctx->xc_want && ctx->xc_bounds[chunk] == c0 && ctx->xc_bounds[chunk + 1] == c1,
+                     "safe_export_packed_chunk_narrow: the call's chunks are not the armed ones");
+        SAFE_HIP_CHECK(hipStreamWaitEvent(s, ctx->xc_events[chunk], 0));
+    }
+    if (words) {
+        const int64_t pairs = (c1 - c0) * (ctx->packed_n_pad / 2);
+        hipLaunchKernelGGL(k_pack_counts20, dim3(static_cast<unsigned int>(ceil_div(pairs, 256))), dim3(256), 0, s,
+                           ctx->packed_counts + c0 * ctx->packed_n_pad, ctx->packed_n_pad, c1 - c0, dst_dev);
+        SAFE_HIP_CHECK(hipGetLastError());
+    }
+    if (capacity_words > words)                        // (a rank with fewer columns: zero counters in the padding columns)
+        SAFE_HIP_CHECK(hipMemsetAsync(dst_dev + words, 0, static_cast<size_t>(capacity_words - words) * sizeof(uint32_t), s));
+    return SAFE_OK;
+}
+
 int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t *slabs_dev, int layout, int64_t n_pad, int n_slabs,
                                    int64_t slab_stride, const int64_t *slab_cols, const int64_t *out_col0, int64_t m_total,
                                    int64_t num_permutations, int sign_mode, double enrichment_threshold, const double *nes_table_host,
@@ -3792,7 +3852,10 @@ int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t 
                                    void *stream) {
     SAFE_REQUIRE(ctx && nbr && slabs_dev && slab_cols && out_col0 && n_slabs >= 1, "safe_outputs_from_packed_slabs: NULL argument");
     SAFE_REQUIRE(pvalues_neg_dev || pvalues_pos_dev || nes_dev || nes_binary_dev, "safe_outputs_from_packed_slabs: no output requested");
+    const bool pk20 = (layout & SAFE_PACKED_NARROW) != 0;   // slabs of 20-bit pairs (safe_export_packed_chunk_narrow)
+    layout &= ~SAFE_PACKED_NARROW;
     SAFE_REQUIRE(layout == 0 || layout == 1, "safe_outputs_from_packed_slabs: bad layout %d", layout);
+    SAFE_REQUIRE(!pk20 || num_permutations <= 1023, "safe_outputs_from_packed_slabs: 20-bit pairs hold at most 1023 permutations");
     SAFE_REQUIRE(sign_mode >= SAFE_SIGN_HIGHEST && sign_mode <= SAFE_SIGN_BOTH, "safe_outputs_from_packed_slabs: bad sign_mode %d", sign_mode);
     SAFE_REQUIRE(num_permutations >= 1 && num_permutations <= 65535 && m_total >= 1, "safe_outputs_from_packed_slabs: bad sizes");
     SAFE_REQUIRE(enrichment_threshold > 0.0 || !nes_binary_dev, "safe_outputs_from_packed_slabs: enrichment_threshold must be positive");
@@ -3801,7 +3864,7 @@ int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t 
     SAFE_REQUIRE(rowmap && n_pad == want_pad, "safe_outputs_from_packed_slabs: counters are for %lld positions, the membership has %lld",
                  (long long)n_pad, (long long)want_pad);
     for (int r = 0; r < n_slabs; ++r)
-        SAFE_REQUIRE(slab_cols[r] >= 0 && slab_cols[r] * n_pad <= slab_stride && out_col0[r] >= 0 && out_col0[r] + slab_cols[r] <= m_total,
+        SAFE_REQUIRE(slab_cols[r] >= 0 && slab_cols[r] * (pk20 ? n_pad / 8 * 5 : n_pad) <= slab_stride && out_col0[r] >= 0 && out_col0[r] + slab_cols[r] <= m_total,
                      "safe_outputs_from_packed_slabs: slab %d (%lld columns at column %lld) does not fit", r, (long long)slab_cols[r],
                      (long long)out_col0[r]);
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
@@ -3835,7 +3898,7 @@ int safe_outputs_from_packed_slabs(safe_ctx *ctx, safe_nbr *nbr, const uint32_t 
         out.sign_mode = sign_mode;
         out.mode = 4;
         out.ld = m_total;
-        SAFE_TRY(enrich_finalize_counts(ctx, slabs_dev + static_cast<int64_t>(r) * slab_stride, n_pad, rowmap, slab_cols[r], P, out, nullptr, s));
+        SAFE_TRY(enrich_finalize_counts(ctx, slabs_dev + static_cast<int64_t>(r) * slab_stride, n_pad, rowmap, slab_cols[r], P, out, nullptr, s, pk20));
     }
     return SAFE_OK;
 }

@@ -1439,15 +1439,14 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_f(
 // ---------------------------------------------------------------------------------------
 // k_permtest_mfma_g (round 6): k_permtest_mfma_f's shape -- four waves of 64 rows, two workgroups per CU, thresholds and 8-bit
 // counters in LDS -- with three changes that take instructions and waits out of the super-step:
-//  * the gather is LDS-DMA (global_load_lds_dwordx4).  A super-step's 128 gathered rows x 96 bytes lie in LDS as six PLANES of
-//    [128 rows][16 bytes] (plane c = bytes 16 c .. 16 c + 15 of a row = slice c >> 1, column half c & 1); a wave-instruction
-//    writes 64 consecutive rows of one plane (the DMA's destination is wave-uniform base + lane x 16).  Thread (wave w, lane l)
-//    stages row 64 (w & 1) + l of the super-step, planes 3 (w >> 1) .. + 2: ONE source index, ONE address and three DMA
-//    instructions per thread and super-step -- no staging registers (k_permtest_mfma_f: 32), no ds_write, no wait for
-//    gathered rows inside the k-loop, all four waves take part.  The DMAs of super-step it + 1 are issued at the top of
-//    super-step it (their buffer was last read in it - 1: the barrier in between orders that) and have the whole super-step to
-//    land; the one vmcnt(0) is in front of the barrier.  The transposing read takes its 8-byte pieces from a plane:
-//    piece i of a 16-lane group = row i >> 1, bytes 8 (i & 1) ..: 128 contiguous bytes per group.
+//  * the gather is LDS-DMA (global_load_lds_dwordx4).  A super-step's gathered rows lie in LDS as they are in memory,
+//    [k-step][32 rows][96 bytes]; the DMA's destination is wave-uniform base + lane x 16, so the 192 16-byte chunks of a
+//    k-step are three wave-instructions: wave w stages k-step w, lane l of instruction j the chunk 64 j + l = row (64 j + l) / 6,
+//    bytes 16 ((64 j + l) % 6) .. -- six adjacent lanes read one 96-byte row (1-2 cache lines; a first form with one row per
+//    lane and [plane][row][16 B] in LDS touched 64 lines per instruction and spent 530 cycles per super-step issuing them).
+//    No staging registers (k_permtest_mfma_f: 32), no ds_write, no wait for gathered rows inside the k-loop, all four waves
+//    take part.  The DMAs of super-step it + 1 are issued at the top of super-step it (their buffer was last read in it - 1:
+//    the barrier in between orders that) and have the whole super-step to land; the one vmcnt(0) is in front of the barrier.
 //  * the membership words come bit-permuted (bs_bits4p): operand register j of lane half h = (word >> (4 h + j)) & 0x01010101 --
 //    8 VALU per 32 x 32 piece instead of 12 (bit-field extract, multiply, mask per four bits).
 //  * score completion: thresholds are stored as Y0 + W, so "not certainly greater" is the SIGN of d' = y - (Y0 + W); the four
@@ -1463,7 +1462,7 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
     const int32_t *__restrict__ grp_maxcnt, const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off,
     unsigned int *__restrict__ q_ctr, int64_t mloc, unsigned int *__restrict__ gl_counts, int64_t n_padr, MfmaFilt fa) {
     constexpr int dbg = DBG;
-    constexpr int NS = MF_NS / 2, PL = 128 * 16, BUF = 2 * NS * PL;           // plane = 2 KB, buffer = one super-step = 12 KB
+    constexpr int NS = MF_NS / 2, KS = 32 * NS * 32, BUF = 4 * KS;            // k-step = 32 rows x 96 B, buffer = one super-step = 12 KB
     constexpr int64_t row_bytes = NS * 32;
     typedef __attribute__((address_space(3))) void lds_void;
     typedef __attribute__((address_space(1))) const void gl_void;
@@ -1478,12 +1477,14 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
     int *slot_box = reinterpret_cast<int *>(lds + 2 * BUF + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t));
     typedef __attribute__((address_space(3))) unsigned char lds_byte;
     const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte *)lds));      // LDS byte address of the array
-    // staging role: row 64 (wave & 1) + lane of the super-step (k-step ks_g, row r_g of its block), planes 3 (wave >> 1) + 0..2
-    const int ks_g = 2 * (wave & 1) + h, r_g = lam;
-    const int dma_base = __builtin_amdgcn_readfirstlane(3 * (wave >> 1) * PL + (wave & 1) * 1024);
-    // operand read: lane l of a 16-lane group supplies piece l = row (l >> 1) of eight, bytes 8 (l & 1) .. of the plane's 16; the group
-    // (lane >> 4) & 1 reads the column half's plane, the lane half h the k rows 16 h ..; lane l then owns column l & 31 of the tile
-    const uint32_t r_base = static_cast<uint32_t>(((lane >> 4) & 1) * PL + (16 * h + ((lane & 15) >> 1)) * 16 + 8 * (lane & 1));
+    // staging role: k-step `wave` of the super-step; instruction j: chunk 64 j + lane = row r_g[j] of the block, bytes 16 c_g[j] ..
+    const int r_g[3] = {lane / 6, (64 + lane) / 6, (128 + lane) / 6};
+    const int c16_g[3] = {16 * (lane % 6), 16 * ((64 + lane) % 6), 16 * ((128 + lane) % 6)};
+    const int dma_base = __builtin_amdgcn_readfirstlane(wave * KS);
+    // operand read (ds_read_b64_tr_b8): lane l of a 16-lane group supplies piece l = row (l >> 1) of eight, bytes 8 (l & 1) .. of a
+    // 16-byte column half; the group (lane >> 4) & 1 is the column half, the lane half h the k rows 16 h ..; lane l then owns
+    // column l & 31 of the tile
+    const uint32_t r_base = static_cast<uint32_t>((16 * h + ((lane & 15) >> 1)) * 96 + 16 * ((lane >> 4) & 1) + 8 * (lane & 1));
     const uint32_t sh0 = 4u * h, sh1 = sh0 + 1u, sh2 = sh0 + 2u, sh3 = sh0 + 3u;
 
     const int home = blockIdx.x & 7;
@@ -1502,7 +1503,7 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
             if (S == 0) continue;
             for (int i = tid; i < nb; i += 256) kb_list[i] = blk_kb[b0 + i];
 
-            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + 48 * (wave >> 1);
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes;
             const uint4 *bits_w = blk_bits4p + static_cast<int64_t>(b0 >> 2) * MF_R + wave * 64 + lane;   // lane l: row l of the wave's 64
             const int total = n_q * S;
             const int64_t colf = static_cast<int64_t>(ct) * 32 + lam;
@@ -1560,35 +1561,38 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                     }
                 }
             };
-            auto src_of = [&](int q, int kb) -> int32_t {
-                q = q < n_q ? q : n_q - 1;
-                return srcp[static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + r_g];
+            struct Src3 {
+                int32_t a, b, c;
             };
-            auto stage = [&](int32_t src, int buf) __attribute__((always_inline)) {
+            auto src_of = [&](int q, int kb) -> Src3 {
+                q = q < n_q ? q : n_q - 1;
+                const int32_t *at = srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32;
+                return Src3{at[r_g[0]], at[r_g[1]], at[r_g[2]]};
+            };
+            // One DMA instruction: chunk 64 j + lane of k-step `wave` of the super-step in buffer `buf`.  Written as asm: through the
+            // builtin the compiler drains the DMA queue (vmcnt(0)) before the next LDS read it cannot prove disjoint from the
+            // destination -- right after the issue.  The DMAs are therefore not in the compiler's vmcnt bookkeeping: every counted
+            // load whose wait follows them is younger (so that wait covers them), and the explicit vmcnt(0) in front of the
+            // super-step's barrier is what publishes the rows.
+            auto stage1 = [&](int32_t src, int buf, int j) __attribute__((always_inline)) {
                 if (dbg & 64) return;
-                // Written as asm: through the builtin the compiler drains the DMA queue (vmcnt(0)) before the next LDS read it cannot
-                // prove disjoint from the destination -- right after the issue.  The DMAs are therefore not in the compiler's
-                // vmcnt bookkeeping: they are older than every counted load whose wait follows them (so those waits cover them),
-                // and the explicit vmcnt(0) in front of the super-step's barrier is what publishes the rows.
-                const unsigned char *from = bs_ct + static_cast<int64_t>(src) * row_bytes;
-                const unsigned char *from1 = from + 16, *from2 = from + 32;
-                const uint32_t to = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_base + buf * BUF + dma_base)));
+                const unsigned char *from = bs_ct + static_cast<int64_t>(src) * row_bytes + c16_g[j];
+                const uint32_t to = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_base + buf * BUF + dma_base + j * 1024)));
                 uint32_t keep;
                 asm volatile(
                     "s_mov_b32 %0, m0\n\t"
-                    "s_mov_b32 m0, %4\n\t"
+                    "s_mov_b32 m0, %2\n\t"
                     "s_nop 0\n\t"
                     "global_load_lds_dwordx4 %1, off\n\t"
-                    "s_add_u32 m0, %4, 0x800\n\t"
-                    "s_nop 0\n\t"
-                    "global_load_lds_dwordx4 %2, off\n\t"
-                    "s_add_u32 m0, %4, 0x1000\n\t"
-                    "s_nop 0\n\t"
-                    "global_load_lds_dwordx4 %3, off\n\t"
                     "s_mov_b32 m0, %0"
                     : "=&s"(keep)
-                    : "v"(from), "v"(from1), "v"(from2), "s"(to)
-                    : "memory", "scc");
+                    : "v"(from), "s"(to)
+                    : "memory");
+            };
+            auto stage = [&](const Src3 &src, int buf) __attribute__((always_inline)) {
+                stage1(src.a, buf, 0);
+                stage1(src.b, buf, 1);
+                stage1(src.c, buf, 2);
             };
             auto advance = [&](int &qq, int &tt) {
                 if (++tt == S) {
@@ -1614,9 +1618,12 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
             advance(q1, t1);
             q2 = q1, t2 = t1;
             advance(q2, t2);
-            stage(src_of(0, kb_list[ks_g]), 0);
-            int32_t src_nx = src_of(q1, kb_list[4 * t1 + ks_g]);
-            int kb_next = kb_list[4 * t2 + ks_g];
+            stage(src_of(0, kb_list[wave]), 0);
+            Src3 src_nx = src_of(q1, kb_list[4 * t1 + wave]);
+            int kb_next = kb_list[4 * t2 + wave];
+            int32_t y0r[32];                                         // the thresholds, read at the top of a permutation's last super-step
+#pragma unroll
+            for (int o = 0; o < 32; ++o) y0r[o] = 0;
             uint4 aw[2];
             split_rows(bits_w[0], aw);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -1629,11 +1636,18 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                 advance(q3, t3);
                 unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
                 if (dbg & 512) c0 = __builtin_amdgcn_s_memtime();
-                stage(src_nx, buf ^ 1);                                  // (unconditional: behind the task's last super-step the clamped
-                                                                         //  index stages rows nobody reads -- a branch here would put a
-                                                                         //  vmcnt(0) behind the DMA issue, where the paths meet again)
+                // The three DMAs of super-step it + 1.  A wave spends ~570 cycles of the super-step's ~2100 getting them accepted (the
+                // address unit takes a 64-lane gather at about a lane per cycle, and the CU's eight waves issue 24 of them per
+                // super-step); issued one per k-step instead they cost the k-loop what they save here (measured: 9.75 against
+                // 9.60 ms per launch).  Unconditional: behind the task's last super-step the clamped index stages rows nobody
+                // reads -- a branch would put a vmcnt(0) where the paths meet again.
+                stage(src_nx, buf ^ 1);
                 src_nx = src_of(q2, kb_next);
-                kb_next = kb_list[4 * t3 + ks_g];                        // (consumed at the top of the next iteration)
+                kb_next = kb_list[4 * t3 + wave];                        // (consumed at the top of the next iteration)
+                if (t == S - 1 && !(dbg & 8)) {                          // (their LDS latency passes under the k-loop)
+#pragma unroll
+                    for (int o = 0; o < 32; ++o) y0r[o] = y0s[o * 256];
+                }
                 const uint4 aw_raw = bits_w[static_cast<int64_t>(t1) * MF_R];
 
                 const unsigned char *bbuf = lds + buf * BUF + r_base;
@@ -1643,9 +1657,9 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                 auto read_operand = [&](int k, int s) -> v4i {
                     typedef int v2i __attribute__((ext_vector_type(2)));
                     typedef __attribute__((address_space(3))) v2i lds_v2i;
-                    const unsigned char *at = bbuf + k * 512 + s * 2 * PL;
+                    const unsigned char *at = bbuf + k * KS + s * 32;
                     const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at));            // k rows 16 h + 0..7
-                    const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at + 128));      // k rows 16 h + 8..15
+                    const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at + 8 * 96));   // k rows 16 h + 8..15
                     v4i r;
                     r[0] = lo[0], r[1] = lo[1], r[2] = hi[0], r[3] = hi[1];
                     return r;
@@ -1688,22 +1702,15 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                 if (dbg & 512) c2 = __builtin_amdgcn_s_memtime();
                 if (t == S - 1 && !(dbg & 8)) {                      // the scores of permutation q are complete
                     uint32_t mx = 0u;                                 // unsigned maximum of d' = y - (Y0 + W) over the lane's outputs
+                    {
 #pragma unroll
-                    for (int jb = 0; jb < 2; ++jb) {                  // sixteen outputs (four counter words) at a time: their thresholds are read together
-                        int32_t y0v[4][4];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj)
-#pragma unroll
-                            for (int f = 0; f < 4; ++f) y0v[jj][f] = y0s[(16 * (f >> 1) + 4 * jb + jj + 8 * (f & 1)) * 256];
-#pragma unroll
-                        for (int jj = 0; jj < 4; ++jj) {
-                            const int j = 4 * jb + jj;
+                        for (int j = 0; j < 8; ++j) {
                             uint32_t tops = 0u;                       // the top bytes of the four d' side by side: their sign bits are the increments
 #pragma unroll
                             for (int f = 3; f >= 0; --f) {
                                 const int p = f >> 1, r = j + 8 * (f & 1);
                                 const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);   // floor(V_hi / 16)
-                                const uint32_t d = static_cast<uint32_t>(y - y0v[jj][f]);
+                                const uint32_t d = static_cast<uint32_t>(y - y0r[16 * p + r]);
                                 tops = __builtin_amdgcn_alignbit(tops, d, 24);
                                 mx = d > mx ? d : mx;
                             }
@@ -1719,7 +1726,7 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                         for (int o = 0; o < 32; ++o) {
                             const int p = o >> 4, r = o & 15;
                             const int32_t y = acc[p][2][r] * 4096 + acc[p][1][r] * 16 + (acc[p][0][r] >> 4);
-                            const uint32_t d = static_cast<uint32_t>(y - y0s[o * 256]);
+                            const uint32_t d = static_cast<uint32_t>(y - y0r[o]);
                             open |= (~d < wc) ? (1u << o) : 0u;
                         }
                         for (uint32_t left = open; left;) {
@@ -2982,7 +2989,7 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 #undef MF_G_DIAG
 #endif
     const size_t lds_own = form_f ? 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t)
-                                  : 2 * static_cast<size_t>(MF_NS * 128 * 16) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t) + 16;
+                                  : 2 * static_cast<size_t>(4 * 32 * (MF_NS / 2) * 32) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t) + 16;
     const uint4 *bits_own = form_f ? nbr->bs_bits4 : nbr->bs_bits4p;
     if (filt_own)
         SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_own, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_own)));

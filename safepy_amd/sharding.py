@@ -268,7 +268,11 @@ class ChunkedExchange:
         self.xdev = _device_for(group)
         self.n = bufs[self.names[0]].shape[0]
         self.n_pad = 64 * (-(-self.n // 64))                 # SELL-64 positions: the bit-sliced kernel's counter rows
-        self.cap = self.cols * self.n_pad + self.HEADER
+        # P <= 1023: the counter pair is 10 + 10 bits, two outputs travel in five bytes (safe_export_packed_chunk_narrow) --
+        # 0.625 of the u32 slab; more permutations keep u32 pairs
+        from . import backend as be
+        self.narrow = self.P <= 1023
+        self.cap = be.packed_slab_words(self.cols, self.n_pad, self.narrow) + self.HEADER
         # ONE side stream per context: torch hands out pooled streams round-robin, and its caching allocator keeps a pool per stream
         # -- a fresh stream per step meant fresh hipMallocs of every slab per step (the step doubled)
         side = getattr(ctx, '_xc_side', None)
@@ -298,10 +302,12 @@ class ChunkedExchange:
         self.t_launched = time.perf_counter()
         with torch.cuda.stream(self.side):
             for k in range(self.chunks):
-                mine = torch.empty(self.cap, dtype=torch.int32, device=self.dev)
                 if valid:
-                    be.export_packed_chunk(self.ctx, k, mine.data_ptr(), self.cap - self.HEADER, self.side.cuda_stream)
-                mine[self.cap - self.HEADER:].fill_(1 if valid else 0)
+                    mine = torch.empty(self.cap, dtype=torch.int32, device=self.dev)
+                    be.export_packed_chunk(self.ctx, k, mine.data_ptr(), self.cap - self.HEADER, self.side.cuda_stream, narrow=self.narrow)
+                    mine[self.cap - self.HEADER:].fill_(1)
+                else:                                      # zero counters decode to in-range table entries on every rank
+                    mine = torch.zeros(self.cap, dtype=torch.int32, device=self.dev)
                 if self.xdev.type == 'cuda':
                     every = torch.empty(self.world * self.cap, dtype=torch.int32, device=self.dev)
                     self.work[k] = dist.all_gather_into_tensor(every, mine, group=self.group, async_op=True)
@@ -337,13 +343,15 @@ class ChunkedExchange:
                 slabs = every.view(self.world, self.cap)
                 headers.append(slabs[:, self.cap - self.HEADER])
                 cols = [max(0, min(self.cols if k + 1 < self.chunks else c1 - c0, c1 - c0 - k * self.cols)) for c0, c1 in self.shards]
-                col0 = [c0 + k * self.cols for c0, _c1 in self.shards]
-                be.outputs_from_packed_slabs(self.ctx, self.nbr, every.data_ptr(), 0, self.n_pad, self.cap, cols, col0, self.m_total,
+                col0 = [min(c0 + k * self.cols, c1) for c0, c1 in self.shards]      # (an empty trailing chunk starts at the block's end)
+                be.outputs_from_packed_slabs(self.ctx, self.nbr, every.data_ptr(), be.PACKED_NARROW if self.narrow else 0, self.n_pad,
+                                             self.cap, cols, col0, self.m_total,
                                              self.P, self.sign, self.thr, ptrs, table=self.table, stream=self.side.cuda_stream)
             ok = bool((torch.stack(headers) == 1).all().item())          # (the one host wait: everything above has finished)
         if report is not None:
-            report.update(form='packed u32 counters in %d column chunk%s (agreed before the kernels), %s rebuilt on every rank'
-                               % (self.chunks, '' if self.chunks == 1 else 's', ' / '.join(self.names)),
+            report.update(form='packed %s counters in %d column chunk%s (agreed before the kernels), %s rebuilt on every rank'
+                               % ('10 + 10 bit (2.5 B per node x attribute)' if self.narrow else 'u32', self.chunks,
+                                  '' if self.chunks == 1 else 's', ' / '.join(self.names)),
                           bytes_received=int(4 * self.cap * self.chunks * (self.world - 1)), chunks=self.chunks)
         if not ok:
             if report is not None:

@@ -115,7 +115,7 @@ def main():
         mw = wide.shape[1]
         c0, c1 = sharding.column_shards(mw, world)[rank]
         want_wide = {}
-        for P in (300, 60):
+        for P in (300, 60, 1100):
             sf.random_seed = 9
             sf.load_attributes(attribute_file=wide.copy())
             sf.compute_pvalues(how='randomization', num_permutations=P, neighborhood_score_type='sum', multiple_testing=False)
@@ -134,7 +134,9 @@ def main():
                 (300, '4', None, 0, 'column chunks after the kernels'),
                 (300, '4', '0.4', 2, 'column-chunked tail of the launches'),
                 (300, '2', '1e-9', 2, 'the last stage as the tail'),
-                (60, '4', '0.4', 0, 'too few stages for a tail: the armed grid served from the finished counters')):
+                (60, '4', '0.4', 0, 'too few stages for a tail: the armed grid served from the finished counters'),
+                (1100, None, None, 0, 'more than 1023 permutations: u32 counter pairs'),
+                (1100, '4', None, 0, 'u32 counter pairs in column chunks')):
             xc_env(chunks, tail)
             attr = be.Attributes.from_host(ctx, np.ascontiguousarray(wide[:, c0:c1]))
             bufs, enriched = sharding._alloc_outputs(ctx, n, c1 - c0, sharding.RANDOMIZATION_OUTPUTS)
@@ -144,6 +146,13 @@ def main():
                                                exchange=('nes', 'nes_binary', 'pvalues_pos', 'pvalues_neg'), timing=t)
             want_chunks = 1 if chunks is None else 2          # (the widest block has five word groups: two chunks at most)
             assert t['exchange'].get('chunks') == want_chunks and 'agreed before the kernels' in t['exchange']['form'], (what, t['exchange'])
+            # P <= 1023: the counter pair travels as 10 + 10 bits, two outputs in five bytes -- 0.625 of the u32 slab
+            n_pad_x, cols_x = 64 * (-(-n // 64)), sharding.exchange_chunk_grid(mw, world)[1]
+            slab_u32 = cols_x * n_pad_x + sharding.ChunkedExchange.HEADER
+            want_words = (cols_x * (n_pad_x // 8 * 5) + sharding.ChunkedExchange.HEADER) if P <= 1023 else slab_u32
+            assert t['exchange']['form'].startswith('packed 10 + 10 bit' if P <= 1023 else 'packed u32'), (what, t['exchange'])
+            assert t['exchange']['bytes_received'] == 4 * want_words * want_chunks * (world - 1), (what, t['exchange'])
+            assert P > 1023 or want_words <= 0.65 * slab_u32
             made = be.packed_chunk_info(ctx)[0]
             assert made == want_made, (what, made)
             for k, v in full.items():

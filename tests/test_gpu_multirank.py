@@ -145,4 +145,4 @@ def test_bench_single_rank_rccl_group_reports_the_exchange():
     line = _bench_line(['--gpus', '1', '--steps', '3', '--warmup', '1', '--nodes', '1200', '--attrs', '640', '--perms', '200',
                         '--cpu-perms', '0', '--extras', '0'],
                        env={'SAFE_BENCH_FORCE_DIST': '1', 'MASTER_PORT': str(_free_port())})
-    assert line['n_gpus'] == 1 and 'exchange' in line and line['exchange']['form'].startswith('packed u32')
+    assert line['n_gpus'] == 1 and 'exchange' in line and line['exchange']['form'].startswith('packed 10 + 10 bit')
