@@ -66,6 +66,16 @@ def _by_decile(step_ms, values):
     return [round(float(np.mean([v for _, v in chunk])), 3) for chunk in np.array_split(np.asarray(pairs, dtype=object), 10)]
 
 
+def _cpu_model():
+    try:
+        for ln in open('/proc/cpuinfo'):
+            if ln.startswith('model name'):
+                return ln.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
 def effective_cores():
     from safepy_amd import backend
     return backend.effective_cores()
@@ -1018,13 +1028,20 @@ def main():
             'first_8_steps_ms': [[round(float(res['step_ms'][i]), 3), round(float(res['timings'][i].get('gpu_kernel_busy_ms') or 0.0), 3),
                                   round(float(res['timings'][i].get('tables_enqueued_ms') or 0.0), 3), round(float(res['timings'][i].get('draw_busy_ms') or 0.0), 3)]
                                  for i in range(min(8, len(res['step_ms']), len(res['timings'])))],
-            'draw_threads': {'placement': 'persistent per context' if os.environ.get('SAFE_HIP_DRAW_THREAD') != 'percall' else 'one per call',
+            'draw_threads': {'placement': 'persistent per context',
                              'reserved_cores': int(os.environ.get('SAFE_BENCH_DRAW_CORES', '2')) if numa_node is not None else 0,
                              # the chain is drawn by two threads at once, the faster one publishes each chunk (rng.cpp, safe_perms::twin)
                              'twin_chain': bool(res['timings'][-1].get('twin_chain')),
                              'chunks_per_step': res['timings'][-1].get('chunks'),
                              'chunks_won_by_twin_per_step_mean': float(np.mean([t.get('chunks_won_by_twin') or 0 for t in res['timings']]))},
             'library_build': be.build_info(),
+            # what paces the seeded step on THIS box: the host's masked-rejection chain (one thread; safe_extras.py:46,58) against the
+            # kernels' busy time -- the step is the larger of the two plus the pipeline's fill and drain
+            'draw_chain': {'cpu_model': _cpu_model(), 'path': be.build_info().rsplit('seeded draw chain: ', 1)[-1],
+                           'us_per_permutation': 1e3 * float(np.mean([t.get('draw_busy_ms') or 0.0 for t in res['timings']])) / max(1, wl.P),
+                           'busy_ms_per_step': float(np.mean([t.get('draw_busy_ms') or 0.0 for t in res['timings']])),
+                           'step_minus_chain_ms': ms_per_step - float(np.mean([t.get('draw_busy_ms') or 0.0 for t in res['timings']])),
+                           'step_minus_kernels_busy_ms': ms_per_step - float(np.mean([t.get('gpu_kernel_busy_ms') or 0.0 for t in res['timings']]))},
             'step_probe': res['step_probe'],
         }
         if 'exchange_report' in res:

@@ -40,6 +40,7 @@ extern "C" {
 
 #define SAFE_DTYPE_F32 0
 #define SAFE_DTYPE_F64 1
+#define SAFE_DTYPE_U8 2       /* safe_attr_create_host only: 0/1 (or small integer) values as bytes, no missing values */
 
 #define SAFE_SCORE_SUM 0      /* neighborhood_score_type == 'sum'     */
 #define SAFE_SCORE_ZSCORE 1   /* neighborhood_score_type == 'z-score' */
@@ -154,7 +155,9 @@ int safe_edge_lengths(safe_ctx *ctx, const double *xy_host, int64_t n, int64_t n
 /* self.node2attribute (safepy/safe_io.py:410): [n,m], f32 or f64, NaN = missing, with
  * element strides (row_stride, col_stride): (m,1) for C order, (1,n) for Fortran order.
  * The _host form uploads a copy; the _dev form borrows the caller's device buffer, which
- * must outlive the handle. */
+ * must outlive the handle.  Additive (the reference's loader hands over f32, safe_io.py:361, and the
+ * upload of a 0/1 matrix is most of a hypergeometric call, safe.py:556-608): the _host form also
+ * takes SAFE_DTYPE_U8 -- one byte per value over the link, widened to f32 on the device. */
 int safe_attr_create_host(safe_ctx *ctx, const void *b_host, int dtype, int64_t n, int64_t m,
                           int64_t row_stride, int64_t col_stride, safe_attr **out);
 int safe_attr_create_dev(safe_ctx *ctx, const void *b_dev, int dtype, int64_t n, int64_t m,

@@ -11,7 +11,7 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, 'libsafe_hip.so')
 
 ABI_VERSION = 3
-DTYPE_F32, DTYPE_F64 = 0, 1
+DTYPE_F32, DTYPE_F64, DTYPE_U8 = 0, 1, 2
 SCORE_SUM, SCORE_ZSCORE = 0, 1
 SIGN_HIGHEST, SIGN_LOWEST, SIGN_BOTH = 0, 1, 2
 E_INVALID, E_HIP, E_NOMEM, E_UNSUPPORTED, E_VALUE = -1, -2, -3, -4, -5

@@ -347,13 +347,17 @@ class Attributes:
         self._keepalive = keepalive
 
     @staticmethod
-    def _layout(b):
+    def _layout(b, allow_u8=False):
         if b.ndim != 2:
             raise ValueError('node2attribute must be 2-D, got shape %s' % (b.shape,))
         if b.dtype == np.float32:
             dt = _lib.DTYPE_F32
         elif b.dtype == np.float64:
             dt = _lib.DTYPE_F64
+        elif allow_u8 and b.dtype in (np.uint8, np.bool_):
+            # additive: a 0/1 matrix as bytes travels as bytes (a quarter of the f32 upload) and is f32 on the device
+            b = b.view(np.uint8)
+            dt = _lib.DTYPE_U8
         else:
             b = b.astype(np.float64)
             dt = _lib.DTYPE_F64
@@ -368,7 +372,7 @@ class Attributes:
 
     @classmethod
     def from_host(cls, ctx, b):
-        b, dt, n, m, rs, cs = cls._layout(np.asarray(b))
+        b, dt, n, m, rs, cs = cls._layout(np.asarray(b), allow_u8=True)
         h = C.c_void_p()
         check(lib.safe_attr_create_host(ctx.handle, _ptr(b), dt, n, m, rs, cs, C.byref(h)))
         return cls(ctx, h, n, m)

@@ -406,7 +406,7 @@ int safe_attr_prepare(safe_attr *attr) {
 
 static int attr_new(safe_ctx *ctx, int dtype, int64_t n, int64_t m, int64_t rs, int64_t cs, safe_attr **out) {
     SAFE_REQUIRE(ctx && out, "safe_attr_create: NULL argument");
-    SAFE_REQUIRE(dtype == SAFE_DTYPE_F32 || dtype == SAFE_DTYPE_F64, "safe_attr_create: dtype must be f32 or f64");
+    SAFE_REQUIRE(dtype == SAFE_DTYPE_F32 || dtype == SAFE_DTYPE_F64, "safe_attr_create: dtype must be f32 or f64 (u8: host form only)");
     SAFE_REQUIRE(n >= 1 && m >= 1, "safe_attr_create: empty matrix (%lld x %lld)", (long long)n, (long long)m);
     SAFE_REQUIRE((rs == m && cs == 1) || (rs == 1 && cs == n) || (m == 1 && cs >= 1 && rs == 1) || (n == 1 && cs == 1),
                  "safe_attr_create: matrix must be C- or Fortran-contiguous (strides %lld,%lld for %lld x %lld)",
@@ -424,20 +424,54 @@ static int attr_new(safe_ctx *ctx, int dtype, int64_t n, int64_t m, int64_t rs, 
 
 extern "C" {
 
+// SAFE_DTYPE_U8: one byte per value on the host and over the link, f32 on the device (same strides)
+__global__ __launch_bounds__(256) void k_u8_to_f32(const uint8_t *__restrict__ src, int64_t count, float *__restrict__ dst) {
+    const int64_t i = (static_cast<int64_t>(blockIdx.x) * 256 + threadIdx.x) * 16;
+    if (i + 16 <= count) {
+        const uint4 v = *reinterpret_cast<const uint4 *>(src + i);
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+            *reinterpret_cast<float4 *>(dst + i + 4 * q) = make_float4(static_cast<float>(w[q] & 0xFFu), static_cast<float>((w[q] >> 8) & 0xFFu),
+                                                                       static_cast<float>((w[q] >> 16) & 0xFFu), static_cast<float>(w[q] >> 24));
+    } else {
+        for (int64_t j = i; j < count; ++j) dst[j] = static_cast<float>(src[j]);
+    }
+}
+
 int safe_attr_create_host(safe_ctx *ctx, const void *b_host, int dtype, int64_t n, int64_t m, int64_t row_stride,
                           int64_t col_stride, safe_attr **out) {
     SAFE_REQUIRE(b_host != nullptr, "safe_attr_create_host: b_host is NULL");
+    const bool u8 = dtype == SAFE_DTYPE_U8;                 // (a 0/1 matrix as bytes: a quarter of the f32 upload; f32 from here on)
     safe_attr *a = nullptr;
-    SAFE_TRY(attr_new(ctx, dtype, n, m, row_stride, col_stride, &a));
+    SAFE_TRY(attr_new(ctx, u8 ? SAFE_DTYPE_F32 : dtype, n, m, row_stride, col_stride, &a));
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    const size_t bytes = static_cast<size_t>(n) * m * (dtype == SAFE_DTYPE_F32 ? 4 : 8);
+    const size_t count = static_cast<size_t>(n) * m;
+    const size_t bytes = count * (dtype == SAFE_DTYPE_F64 ? 8 : 4);
     uint8_t *d = nullptr;
     int rc = dev_alloc(&d, bytes);
     if (rc != SAFE_OK) {
         delete a;
         return rc;
     }
-    hipError_t e = hipMemcpyAsync(d, b_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    hipError_t e = hipSuccess;
+    if (u8) {
+        void *staged = nullptr;                               // the bytes as they came (16-byte loads: padded)
+        rc = ctx_scratch(ctx, 20, (count + 15) / 16 * 16, &staged);
+        if (rc != SAFE_OK) {
+            (void)hipFree(d);
+            delete a;
+            return rc;
+        }
+        e = hipMemcpyAsync(staged, b_host, count, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(k_u8_to_f32, dim3(static_cast<unsigned int>(ceil_div(static_cast<int64_t>(count), 256 * 16))), dim3(256), 0, ctx->stream,
+                               static_cast<const uint8_t *>(staged), static_cast<int64_t>(count), reinterpret_cast<float *>(d));
+            e = hipGetLastError();
+        }
+    } else {
+        e = hipMemcpyAsync(d, b_host, bytes, hipMemcpyHostToDevice, ctx->stream);
+    }
     if (e == hipSuccess) e = safe_stream_sync(ctx->stream);
     if (e != hipSuccess) {
         safe_set_error("safe_attr_create_host: %s", hipGetErrorString(e));

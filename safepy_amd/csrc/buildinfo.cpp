@@ -4,6 +4,7 @@
 #include <cstring>
 
 #include "common.h"
+#include "draws.h"
 #include "obj/buildinfo.h"
 
 bool safe_hidden_regs_checked() { return SAFE_HIDDEN_REGS_CHECKED != 0; }
@@ -15,6 +16,6 @@ int safe_build_info(char *out, size_t out_len) {
 #else
     const char *diag = "";
 #endif
-    snprintf(out, out_len, "%s; %s%s", SAFE_BUILD_COMPILER, SAFE_BUILD_NOTE, diag);
+    snprintf(out, out_len, "%s; %s%s; seeded draw chain: %s", SAFE_BUILD_COMPILER, SAFE_BUILD_NOTE, diag, draws_path_name());
     return SAFE_OK;
 }

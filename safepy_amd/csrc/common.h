@@ -134,7 +134,7 @@ struct safe_ctx {
     hipEvent_t d2h_events[D2H_SLOTS] = {};
     std::vector<hipEvent_t> ev_timing, ev_plain;   // reused per-launch events (creating 20 per call costs ~0.1 ms)
     std::vector<std::pair<size_t, void *>> block_cache;   // small device blocks of destroyed handles (ctx_block_alloc)
-    static constexpr int N_SCRATCH = 20;
+    static constexpr int N_SCRATCH = 21;
     void *scratch[N_SCRATCH] = {};
     size_t scratch_bytes[N_SCRATCH] = {};
 };

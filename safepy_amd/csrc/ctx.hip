@@ -184,13 +184,11 @@ int safe_device_pci_bus_id(int device, char *buf, size_t buf_len) {
 // (bench.py's step probe).  It never happens with HSA_ENABLE_SDMA=0 (every copy a shader copy from the start -- but the step is
 // 0.8 ms slower), and it stops happening when the context starts with a burst of copies in both directions on a few streams at
 // once: 0 of 90 driver-style runs with the burst against 7 of 60 without, interleaved on the same boxes, medians unchanged
-// (tools/probe/env_ab.sh SAFE_HIP_PREWARM_COPIES "0 4 16").  Cost: ~35 ms of context creation (199 against 165 ms), 64 MiB of
-// pinned and device memory for its duration.  SAFE_HIP_PREWARM_COPIES=<streams> (default 4, 0 = off).  Best effort: errors are
+// (round 5, a switch then).  Cost: ~35 ms of context creation (199 against 165 ms), 64 MiB of
+// pinned and device memory for its duration.  Four streams (16 measured the same).  Best effort: errors are
 // ignored.
 static void ctx_open_copy_queue(safe_ctx *ctx) {
-    const char *e = getenv("SAFE_HIP_PREWARM_COPIES");
-    const int n_streams = e ? std::max(0, std::min(32, atoi(e))) : 4;
-    if (n_streams == 0) return;
+    const int n_streams = 4;
     const size_t bytes = size_t(8) << 20;
     void *host = nullptr, *dev = nullptr;
     if (hipHostMalloc(&host, 2 * n_streams * bytes, hipHostMallocDefault) != hipSuccess || hipMalloc(&dev, 2 * n_streams * bytes) != hipSuccess) {

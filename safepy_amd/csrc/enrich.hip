@@ -1544,6 +1544,9 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
         const int n_valid = static_cast<int>(mloc - c_first < 32 ? (mloc - c_first > 0 ? mloc - c_first : 0) : 32);
         // (the OFFSET walks in a vector register pair, the base stays the kernel argument: laundering the pointer itself made it a
         // generic one, and the 64 updates became flat atomics -- both wait counters, the slower path)
+        // (TWO positions per 8-byte atomic -- the even lane of a lane pair adding attribute `bit` of both positions, the odd lane
+        // attribute `bit + 1` -- was built in round 6 because the flush is 30 kclk of a wave-task waiting for its 64 updates to be
+        // accepted: global_atomic_add_x2 made it 170-280 kclk and the seeded step 4.4 ms instead of 3.2; four-byte updates stay)
         int64_t off = c_first * n_pad + spos;
 #pragma unroll
         for (int bit = 0; bit < 32; ++bit) {
@@ -1560,7 +1563,7 @@ __device__ __forceinline__ void flush_counters(const uint32_t (&g0)[CL], const u
 // each task it ran in this buffer -- s_memtime: shader clocks on gfx9 -- and launch_bits prints how long the tasks took, in clocks
 // per block-iteration and by slice width (clocks of different XCDs are not synchronised: only durations are used).
 constexpr int BLK_TRACE_MAX = 1 << 17;
-__device__ unsigned long long g_blk_trace[BLK_TRACE_MAX * 4];
+__device__ unsigned long long g_blk_trace[BLK_TRACE_MAX * 8];
 __device__ unsigned int g_blk_trace_n;
 
 // WPS = waves per SIMD the kernel is built for: 4 (128 registers; every class keeps its observed sums in registers and counts
@@ -1626,6 +1629,8 @@ __device__ __forceinline__ void bits_blk_body(
         const u32x4 *perm_ids = reinterpret_cast<const u32x4 *>(ids_p + (p_begin - p_base) * entries_pad) + my_blk;
         const int64_t perm_stride = entries_pad / 8;
         __syncthreads();                                                  // T is complete; waves are independent from here
+        unsigned long long t_ready = 0, t_counted = 0;
+        if (DBG & 128) t_ready = __builtin_readcyclecounter();
 
         uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
 #pragma unroll
@@ -1645,6 +1650,10 @@ __device__ __forceinline__ void bits_blk_body(
         else if (wdt <= 504) blk_task<9, CL, DBG, CLW, OM>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
         else blk_task<BT_LV, CL, DBG, CLW, OM>(my_obs, perm_ids, perm_stride, lane, nblk, np, g0, g1, l0, l1);
 
+        if (DBG & 128) {
+            asm volatile("" : "+v"(g0[0]), "+v"(l0[0]));                  // (the counters exist: the counting is over)
+            t_counted = __builtin_readcyclecounter();
+        }
         const int64_t spos = s * 64 + lane;
         if (!(DBG & 2)) {
             if (np > 0) flush_counters<CL, (DBG & 64) != 0>(g0, g1, l0, l1, gl_counts, static_cast<int64_t>(wg) * 64, mloc, n_pad, spos, active);
@@ -1654,10 +1663,12 @@ __device__ __forceinline__ void bits_blk_body(
         if ((DBG & 128) && lane == 0) {
             const unsigned int at = atomicAdd(&g_blk_trace_n, 1u);
             if (at < BLK_TRACE_MAX) {
-                g_blk_trace[4 * at] = (static_cast<unsigned long long>(blockIdx.x) << 32) | (static_cast<unsigned long long>(slot) << 2) | wave;
-                g_blk_trace[4 * at + 1] = t_begin;
-                g_blk_trace[4 * at + 2] = __builtin_readcyclecounter();
-                g_blk_trace[4 * at + 3] = (static_cast<unsigned long long>(nblk) << 32) | static_cast<unsigned int>(np);
+                g_blk_trace[8 * at] = (static_cast<unsigned long long>(blockIdx.x) << 32) | (static_cast<unsigned long long>(slot) << 2) | wave;
+                g_blk_trace[8 * at + 1] = t_begin;
+                g_blk_trace[8 * at + 2] = __builtin_readcyclecounter();
+                g_blk_trace[8 * at + 3] = (static_cast<unsigned long long>(nblk) << 32) | static_cast<unsigned int>(np);
+                g_blk_trace[8 * at + 4] = t_ready;
+                g_blk_trace[8 * at + 5] = t_counted;
             }
         }
         __syncthreads();                                                  // before T is overwritten by the next task
@@ -1823,8 +1834,7 @@ int enrich_finalize_counts(safe_ctx *ctx, const unsigned int *counts, int64_t n_
     const dim3 grid(n_pad / FIN_TP, ceil_div(mloc, FIN_TC));
     const size_t tab_bytes = static_cast<size_t>(n_perm + 1) * sizeof(double);
     const bool tab_lds = out.mode != 1 && tab_bytes <= 20 * 1024;          // (next to 43 KB of static LDS)
-    static const bool pv_off = getenv("SAFE_HIP_FIN_PV") && !strcmp(getenv("SAFE_HIP_FIN_PV"), "0");     // (A/B: divide per output)
-    const int pv_lds = tab_lds && 2 * tab_bytes <= 20 * 1024 && !pv_off ? 1 : 0;                       // k / P table behind the NES table
+    const int pv_lds = tab_lds && 2 * tab_bytes <= 20 * 1024 ? 1 : 0;                                  // k / P table behind the NES table
     const size_t dyn = tab_lds ? (pv_lds ? 2 : 1) * tab_bytes : 0;
 #define FIN(D, M, L) hipLaunchKernelGGL((k_counts_finalize<D, M, L>), grid, dim3(256), dyn, fin_stream, counts, n_pad, rowmap, ns_direct, mloc, n_perm, out, pv_lds)
 #define FIN_MODE(D, L)                      \
@@ -2507,8 +2517,7 @@ static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     const size_t lds_bytes = scatter_lds_bytes(n);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t blocks = std::min<int64_t>(mloc, static_cast<int64_t>(ctx->num_cu) * per_cu);
-    int waves = 4;
-    if (const char *w = getenv("SAFE_HIP_SCATTER_WAVES")) waves = atoi(w);
+    constexpr int waves = 4;
 #define LAUNCH_SCATTER(W)                                                                                          \
     do {                                                                                                           \
         SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_scatter<W>),                  \
@@ -2518,9 +2527,8 @@ static int launch_scatter(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
                            perms->inverse_t, perms->inv_stride, nbr->at_ptr, nbr->at_col, attr->sup_ptr, attr->sup_row, \
                            col0, d_order, mloc, d_queue, out);                                                                          \
     } while (0)
-    if (waves == 1) LAUNCH_SCATTER(1);
-    else if (waves == 4) LAUNCH_SCATTER(4);
-    else LAUNCH_SCATTER(2);
+    static_assert(waves == 4, "k_permtest_scatter is launched with four waves");
+    LAUNCH_SCATTER(4);
 #undef LAUNCH_SCATTER
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
@@ -2566,8 +2574,6 @@ int kernel_stat_from_events(safe_ctx *ctx, hipEvent_t *ev, int64_t n_launch) {
         if (c) SAFE_HIP_CHECK(hipEventElapsedTime(&t0, ev[0], ev[2 * c]));
         ctx->last_kernel.total_ms += ms;
         ctx->last_kernel.launches += 1;
-        static const bool dump = getenv("SAFE_HIP_LAUNCH_TRACE") != nullptr;       // every launch's interval, relative to the first one's start
-        if (dump) fprintf(stderr, "[launch trace] %2lld: %8.3f .. %8.3f ms (%.3f)\n", (long long)c, t0, t0 + ms, ms);
         const double a = std::max<double>(t0, covered_to), b = static_cast<double>(t0) + ms;
         if (b > a) busy += b - a;
         covered_to = std::max(covered_to, b);
@@ -2581,7 +2587,7 @@ static void blk_trace_dump(int n_launch) {
     unsigned int cnt = 0;
     if (hipMemcpyFromSymbol(&cnt, HIP_SYMBOL(g_blk_trace_n), sizeof(cnt)) != hipSuccess) return;
     cnt = std::min<unsigned int>(cnt, BLK_TRACE_MAX);
-    std::vector<unsigned long long> rec(static_cast<size_t>(cnt) * 4);
+    std::vector<unsigned long long> rec(static_cast<size_t>(cnt) * 8);
     if (cnt && hipMemcpyFromSymbol(rec.data(), HIP_SYMBOL(g_blk_trace), rec.size() * sizeof(unsigned long long)) != hipSuccess) return;
     const unsigned int zero = 0;
     (void)hipMemcpyToSymbol(HIP_SYMBOL(g_blk_trace_n), &zero, sizeof(zero));
@@ -2589,10 +2595,10 @@ static void blk_trace_dump(int n_launch) {
     double busy = 0.0, work = 0.0;
     std::vector<double> dur;
     for (unsigned int i = 0; i < cnt; ++i) {
-        const double d = static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]);
+        const double d = static_cast<double>(rec[8 * i + 2] - rec[8 * i + 1]);
         busy += d;
         dur.push_back(d);
-        work += std::max<double>(1.0, static_cast<double>(rec[4 * i + 3] >> 32)) * static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
+        work += std::max<double>(1.0, static_cast<double>(rec[8 * i + 3] >> 32)) * static_cast<double>(rec[8 * i + 3] & 0xFFFFFFFFu);
     }
     std::sort(dur.begin(), dur.end());
     fprintf(stderr, "[blk trace] %u wave-tasks over %d launches; wave-task duration min %.0f median %.0f p90 %.0f max %.0f kclk; "
@@ -2600,15 +2606,25 @@ static void blk_trace_dump(int n_launch) {
             cnt, n_launch, dur.front() / 1e3, dur[dur.size() / 2] / 1e3, dur[dur.size() * 9 / 10] / 1e3, dur.back() / 1e3, work, busy / std::max(work, 1.0));
     double cls_busy[5] = {0, 0, 0, 0, 0}, cls_work[5] = {0, 0, 0, 0, 0};
     for (unsigned int i = 0; i < cnt; ++i) {
-        const double nb = static_cast<double>(rec[4 * i + 3] >> 32), np = static_cast<double>(rec[4 * i + 3] & 0xFFFFFFFFu);
+        const double nb = static_cast<double>(rec[8 * i + 3] >> 32), np = static_cast<double>(rec[8 * i + 3] & 0xFFFFFFFFu);
         const int c = nb <= 1 ? 0 : nb <= 7 ? 1 : nb <= 31 ? 2 : nb <= 63 ? 3 : 4;
-        cls_busy[c] += static_cast<double>(rec[4 * i + 2] - rec[4 * i + 1]);
+        cls_busy[c] += static_cast<double>(rec[8 * i + 2] - rec[8 * i + 1]);
         cls_work[c] += std::max(nb, 1.0) * np;
     }
     const char *names[5] = {"1 block", "2-7 blocks", "8-31 blocks", "32-63 blocks", ">= 64 blocks"};
+    double ph[5][3] = {}, cls_n[5] = {0, 0, 0, 0, 0};                 // per class: table load + barrier | counting | flush, kclk per wave-task
+    for (unsigned int i = 0; i < cnt; ++i) {
+        const double nb = static_cast<double>(rec[8 * i + 3] >> 32);
+        const int c = nb <= 1 ? 0 : nb <= 7 ? 1 : nb <= 31 ? 2 : nb <= 63 ? 3 : 4;
+        ph[c][0] += static_cast<double>(rec[8 * i + 4] - rec[8 * i + 1]);
+        ph[c][1] += static_cast<double>(rec[8 * i + 5] - rec[8 * i + 4]);
+        ph[c][2] += static_cast<double>(rec[8 * i + 2] - rec[8 * i + 5]);
+        cls_n[c] += 1.0;
+    }
     for (int c = 0; c < 5; ++c)
         if (cls_work[c] > 0)
-            fprintf(stderr, "[blk trace]   slices of %-12s: %.3g block-iterations, %.0f clocks each\n", names[c], cls_work[c], cls_busy[c] / cls_work[c]);
+            fprintf(stderr, "[blk trace]   slices of %-12s: %.3g block-iterations, %.0f clocks each; %.0f wave-tasks: table %.1f | counting %.1f | flush %.1f kclk each\n",
+                    names[c], cls_work[c], cls_busy[c] / cls_work[c], cls_n[c], ph[c][0] / cls_n[c] / 1e3, ph[c][1] / cls_n[c] / 1e3, ph[c][2] / cls_n[c] / 1e3);
 }
 
 static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms *perms, int64_t col0, int64_t col1,
@@ -2624,13 +2640,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // group, group of 4 adjacent slices, permutation sub-range), sized to about equal cost
     // with several per workgroup slot, heaviest first for the dynamic queue.
     int64_t span = 1;
-    // launches follow the stream's stages (32, 96, then 128 permutations each).  SAFE_HIP_BITS_MERGE=m lets a
-    // launch cover m stages after the start-up: fewer tails and less per-task fixed cost (kernel time per 1000
-    // permutations 4.06 -> 3.94 / 3.89 ms at m = 2 / 3), but the step gets LONGER (5.2 -> 5.5 / 5.8 ms): the
-    // host draw thread delivers 128 permutations per 0.36-0.41 ms, barely ahead of the kernels, and a merged
-    // launch waits for its last stage.
-    int merge = 1;
-    if (const char *e = getenv("SAFE_HIP_BITS_MERGE")) merge = std::max(1, atoi(e));
+    // launches follow the stream's stages, one launch per stage (a launch over m stages after the start-up has fewer tails and
+    // less per-task fixed cost -- kernel time per 1000 permutations 4.06 -> 3.94 / 3.89 ms at m = 2 / 3 in round 3 -- but the
+    // step gets LONGER, 5.2 -> 5.5 / 5.8 ms: a merged launch waits for its last stage's draws)
+    const int merge = 1;
     const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
     // Exchange overlap of the sharded step (safe_set_exchange_chunks): the LAST permutations -- the tail -- run as one launch per
     // COLUMN chunk over all of the tail instead of one launch per stage over all columns.  A chunk's counters are then final when
@@ -2658,8 +2671,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     int64_t n_major = static_cast<int64_t>(starts.size()) - 1, p_split = P, xc_wpc = 0;
     int xc_k = 0;
     ctx->xc_made = 0;
-    const char *ns_env = getenv("SAFE_HIP_BITS_STREAMS");                 // (the fourth launch stream is the tail's list stream)
-    if (ctx->xc_want >= 2 && ctx->xc_cols >= 64 && ctx->xc_cols % 64 == 0 && blk_expected && n_major >= 3 && !(ns_env && atoi(ns_env) >= 4) &&
+    if (ctx->xc_want >= 2 && ctx->xc_cols >= 64 && ctx->xc_cols % 64 == 0 && blk_expected && n_major >= 3 &&
         static_cast<int64_t>(std::min<int>(ctx->xc_want, safe_ctx::XC_MAX)) * ctx->xc_cols >= mloc) {
         double frac = 0.0;                              // (off unless asked for: see the measurements above)
         if (const char *e = getenv("SAFE_HIP_XCHG_TAIL")) frac = std::min(1.0, std::max(0.0, atof(e)));
@@ -2684,23 +2696,24 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // five waves per SIMD (k_permtest_bits_blk<.., 5>) when T fits five times into a CU's LDS; its wide classes count with five
     // levels, so their tasks hold at most 31 permutations
     const size_t lds_T = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
-    bool occ5 = 5 * lds_T <= 160 * 1024;
-    if (const char *e = getenv("SAFE_HIP_BITS_OCC")) occ5 = occ5 && atoi(e) >= 5;
-    else occ5 = false;                                   // (experimental: opt-in)
+    (void)lds_T;
+    const bool occ5 = false;                             // (five waves per SIMD: built and measured in round 3, slower; the kernel form stays for reference)
     int tasks_per_slot = 1;                              // queue depth per workgroup slot: every task reloads T and flushes its counters (64 wave-atomics
                                                          // + two 32 x 32 bit transposes per wave: 11 % of the kernel at depth 2, tools/bits_ablate.py dbg=2), so
                                                          // as few tasks as fill the chip once -- depth 1 vs 2: seeded step 3.52 -> 3.41 ms, 10 000 unseeded
                                                          // permutations 25.8 -> 24.4 ms (tools/exp_ab.sh; round 3 had chosen 2 while the host stream bound the step)
-    if (const char *e = getenv("SAFE_HIP_BITS_TASKS")) tasks_per_slot = std::max(1, atoi(e));
     const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
     // One task list per DISTINCT launch size: the stream's stages are 32, 96, 128 ... and short last ones, and a list cut for 128
     // permutations leaves a 32-permutation launch with half-empty and empty tasks (each still reloads T): a 32-permutation launch
     // took 207 us, 6.5 us per permutation against 3.2 in the long launches.
-    int64_t min_ppt = 16, target_min = 256;              // floors of a task's size: permutations, block-permutations
-    if (const char *e = getenv("SAFE_HIP_BITS_MINPPT")) min_ppt = std::max(1, atoi(e));
-    if (const char *e = getenv("SAFE_HIP_BITS_TARGETMIN")) target_min = std::max(1, atoi(e));
-    int64_t max_ppt = 0;                                 // SAFE_HIP_BITS_MAXPPT: cap on a task's permutations (A/B: long launches with short tasks)
-    if (const char *e = getenv("SAFE_HIP_BITS_MAXPPT")) max_ppt = std::max(0, atoi(e));
+    const int64_t min_ppt = 16, target_min = 256;        // floors of a task's size: permutations, block-permutations
+    const int64_t max_ppt = 0;                           // (a cap on a task's permutations -- long launches with short tasks -- measured no gain)
+    // SHORT launches (the ramp at the head of the stream, the stage behind the last draw: nothing else runs beside them) cost
+    // ~150 us + 2 us per permutation alone on the chip (10 / 16 / 32 / 64 / 128 permutations: 160 / 200 / 186 / 266 / 413 us,
+    // tools/r6/short_launch.sh): their heaviest slice group's tasks are the critical path (16 permutations x 40-49 blocks x
+    // 420-700 clocks) and every wave-task carries 13 + 30 + 30-60 kclk of table load, start-up and counter flush.  Cutting
+    // their tasks finer (4 or 8 permutations per task at least) shortened a lone 16-permutation launch to 170 / 145 us but the
+    // seeded step got LONGER (3.16-3.34 -> 3.30-3.38 ms: twice the wave-tasks, each with its fixed part) -- not kept.
     struct TaskCost { int4 t; int64_t cost; };
     auto build_tasks = [&](int64_t span_c, int64_t w_lo = 0, int64_t w_hi = -1) {
         if (w_hi < 0) w_hi = n_wg;
@@ -2730,8 +2743,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     };
     // the blocked kernel's per-XCD queues: the tasks of one (slice group, permutation range) -- one per word group, adjacent
     // after the stable sort -- go to one queue, (group, range) pairs dealt round-robin in heaviest-first order
-    const char *xq_env = getenv("SAFE_HIP_BITS_XCDQ");
-    const bool xcd_queues = !(xq_env && !strcmp(xq_env, "0"));
+    const bool xcd_queues = true;
     auto split_queues = [&](const std::vector<int4> &list, int (&off)[9]) {
         std::vector<std::vector<int4>> q(8);
         int64_t pair = -1;
@@ -2832,17 +2844,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
     const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
     const int64_t entries_pad = (nbr->sell_entries + 1024 + 255) / 256 * 256;    // tail: the kernels fetch ids two blocks (2 x 512) ahead
-    // consecutive launches run on NS streams (SAFE_HIP_BITS_STREAMS, 2..4; default 2): a launch is as long as its longest task, the
-    // next one fills the slots its short tasks leave.  Three or four launches in flight measure WORSE (unseeded 1000-permutation
-    // step 3.01 -> 3.19 -> 3.43 ms, tools/exp_ab.sh): the later launches' workgroups take slots from the long tasks of the first
-    int NS = 2;
-    if (const char *e = getenv("SAFE_HIP_BITS_STREAMS")) NS = std::min(4, std::max(2, atoi(e)));
-#ifdef SAFE_HIP_DIAG
-    const int diag_banks = getenv("SAFE_HIP_BITS_DIAG_BANKS") ? 1 : 0;      // (wrong results: conflict-free gather addresses, see k_permute_cols)
-    if (diag_banks) safe_warn_diagnostic("SAFE_HIP_BITS_DIAG_BANKS");
-#else
-    const int diag_banks = 0;
-#endif
+    // consecutive launches run on NS = 2 streams: a launch is as long as its longest task, the next one fills the slots its short
+    // tasks leave.  Three or four launches in flight measured WORSE (unseeded 1000-permutation step 3.01 -> 3.19 -> 3.43 ms,
+    // round 4): the later launches' workgroups take slots from the long tasks of the first
+    constexpr int NS = 2;
+    const int diag_banks = 0;                          // (k_permute_cols' diagnostic address form: conflict-free gathers measured no gain, round 5)
     uint16_t *d_ids[4] = {nullptr, nullptr, nullptr, nullptr};
     if (pre)
         for (int b = 0; b < NS; ++b)
@@ -2978,10 +2984,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
-            // workgroup to finish.  A few CUs are therefore left out of the grid (SAFE_HIP_BITS_SPARE, default 8 of 256):
+            // workgroup to finish.  A few CUs are therefore left out of the grid (16 of 256):
             // the median step shrinks by ~3 % at 1000 permutations, ~6 % at 10 000 (round-3 sweep, CHANGELOG.md)
-            int spare = std::min(16, ctx->num_cu / 8);        // (8 until the kernels got faster than k_permute_cols on 8 CUs: 10 000-permutation step 27.1 -> 26.3 ms with 16)
-            if (const char *e = getenv("SAFE_HIP_BITS_SPARE")) spare = std::max(0, atoi(e));
+            const int spare = std::min(16, ctx->num_cu / 8);  // (8 until the kernels got faster than k_permute_cols on 8 CUs: 10 000-permutation step 27.1 -> 26.3 ms with 16)
             const int64_t blocks_pre = std::min<int64_t>(n_tasks, static_cast<int64_t>(std::max(1, ctx->num_cu - spare)) *
                                                          std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_pre)));
             if (blk && tail && n_tasks == 0) {                           // (a rank with fewer columns: nothing in this chunk)
@@ -3128,17 +3133,14 @@ static int launch_lds_f64(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_pe
     int64_t span = 1;
     // a narrow block (the reference's Example 3: ONE attribute, 10 000 permutations) gives a launch almost nothing to do: its 128
     // permutations take 0.25 ms of launch and tail latency whatever the width, so after the start-up stages a launch covers
-    // eight pipeline stages (SAFE_HIP_LDS_MERGE; at the Example-3 shape 7.5 -> 2.0 ms unseeded, 11.6 -> 10.5 ms seeded, where the
+    // eight pipeline stages (at the Example-3 shape 7.5 -> 2.0 ms unseeded, 11.6 -> 10.5 ms seeded, where the
     // host draws of 10 000 short shuffles are then the bound)
-    int merge = n * mloc <= 204800 ? 8 : 1;
-    if (const char *e = getenv("SAFE_HIP_LDS_MERGE")) merge = std::max(1, atoi(e));
+    const int merge = n * mloc <= 204800 ? 8 : 1;
     const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
     const size_t lds_bytes = ldsf64_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
-    int NW = 16;                                   // waves (= adjacent slices) per workgroup: LDS allows one workgroup per CU
-    if (const char *e = getenv("SAFE_HIP_LDS_WAVES")) NW = atoi(e);
-    NW = NW >= 16 ? 16 : (NW >= 8 ? 8 : 4);
+    const int NW = 16;                             // waves (= adjacent slices) per workgroup: LDS allows one workgroup per CU
     const int64_t n_sg = ceil_div(nbr->n_slices, NW);
     std::vector<int64_t> sg_blocks(n_sg, 0);
     int64_t blocks_per_perm = 0;

@@ -1893,8 +1893,7 @@ int build_blocks(safe_nbr *nbr) {
     std::vector<std::vector<uint32_t>> g_bits(n_groups);
     const int n_thr = static_cast<int>(std::max<int64_t>(1, std::min<int64_t>({8, n_groups, static_cast<int64_t>(std::thread::hardware_concurrency())})));
     std::atomic<int64_t> next_group{0};
-    const char *deal_env = getenv("SAFE_HIP_MFMA_DEAL");
-    const bool deal_blocks = !(deal_env && !strcmp(deal_env, "0"));
+    const bool deal_blocks = true;
     auto worker = [&]() {
         std::vector<int32_t> slot(n_kb, -1), touched;
         for (;;) {
@@ -2232,125 +2231,7 @@ __device__ __forceinline__ void hyp_emit_rows(const unsigned int *__restrict__ s
         if (hits[j]) atomicAdd(&hl.enriched[col[j]], hits[j]);
 }
 
-// The same rows with 16-byte stores (even column counts): a lane owns the column PAIR (2 cp, 2 cp + 1) of three tiles for one of
-// TWO rows per trip -- lane = (row of the pair, cp, hh) -- so a store instruction of a wave still covers 512 contiguous bytes
-// of each row, with half as many store instructions (k_euclid_dense's pure-store ceiling is reached with 16-byte stores).
-// A lane reads the two 12-byte count records of its columns as three 8-byte loads.
-template <int UN, bool STAGED>
-__device__ __forceinline__ void hyp_emit_rows_pair(const unsigned int *__restrict__ cnt16, int64_t grp, int64_t n_padr, const int4 *__restrict__ rows,
-                                                   int2 task, const double2 *__restrict__ lut, uint32_t n_kid, const uint32_t (&kofs)[3][2],
-                                                   const bool (&ok)[3], const int64_t (&col)[3], int hh, int rsel, int cp, int lane, int64_t mloc,
-                                                   const HypLookup &hl) {
-    double *const dummy = hl.dummy + (lane & ~1);                         // (16-byte aligned per-lane scratch slot for the padding)
-    unsigned int hits[3][2] = {{0u, 0u}, {0u, 0u}, {0u, 0u}};
-    const uint2 *src = reinterpret_cast<const uint2 *>(cnt16 + (grp * n_padr * 32 + 2 * cp) * 3);     // + row position * 96 dwords
-    int4 r[UN];
-    uint2 w[UN][3];
-    auto load_batch = [&](int i0, int4 (&rr)[UN], uint2 (&ww)[UN][3]) __attribute__((always_inline)) {
-#pragma unroll
-        for (int i = 0; i < UN; ++i) {
-            const int at = i0 + 2 * i + rsel;
-            rr[i] = rows[min(at, task.y - 1)];
-            rr[i].w = at < task.y;
-        }
-#pragma unroll
-        for (int i = 0; i < UN; ++i)
-#pragma unroll
-            for (int q = 0; q < 3; ++q) ww[i][q] = src[static_cast<int64_t>(rr[i].x) * 48 + q];
-    };
-    auto batch = [&](int i0, const int4 (&rc)[UN], const uint2 (&wc)[UN][3], int4 (&rn)[UN], uint2 (&wn)[UN][3]) __attribute__((always_inline)) {
-        load_batch(i0 + 2 * UN, rn, wn);
-        __builtin_amdgcn_sched_barrier(0);
-        double2 val[UN][3][2];
-#pragma unroll
-        for (int i = 0; i < UN; ++i) {
-            // the six dwords = record of column 2 cp (dwords 0-2) and of column 2 cp + 1 (dwords 3-5); dword j of a record packs tiles 2 j | 2 j + 1
-            const uint32_t d[6] = {wc[i][0].x, wc[i][0].y, wc[i][1].x, wc[i][1].y, wc[i][2].x, wc[i][2].y};
-#pragma unroll
-            for (int j = 0; j < 3; ++j)
-#pragma unroll
-                for (int c = 0; c < 2; ++c) {
-                    const uint32_t x = hh ? d[3 * c + j] >> 16 : d[3 * c + j] & 0xffffu;
-                    val[i][j][c] = lut[kofs[j][c] + (ok[j] ? x * n_kid : 0u)];
-                }
-        }
-#pragma unroll
-        for (int i = 0; i < UN; ++i) {
-            const int64_t o = static_cast<int64_t>(rc[i].y) * mloc;
-#pragma unroll
-            for (int j = 0; j < 3; ++j) {
-                const bool live = ok[j];
-                const bool h0 = live && val[i][j][0].x < hl.p_cut, h1 = live && val[i][j][1].x < hl.p_cut;   // safe.py:468-470 (nes_p_cut)
-                double2 *pp = reinterpret_cast<double2 *>(live ? hl.pvalues_pos + o + col[j] : dummy);
-                double2 *pn = reinterpret_cast<double2 *>(live ? hl.nes + o + col[j] : dummy);
-                double2 *pb = reinterpret_cast<double2 *>(live ? hl.nes_binary + o + col[j] : dummy);
-                __builtin_nontemporal_store(val[i][j][0].x, &pp->x);
-                __builtin_nontemporal_store(val[i][j][1].x, &pp->y);
-                __builtin_nontemporal_store(val[i][j][0].y, &pn->x);                                        // -log10 p from the table (safe.py:608)
-                __builtin_nontemporal_store(val[i][j][1].y, &pn->y);
-                __builtin_nontemporal_store(h0 ? 1.0 : 0.0, &pb->x);
-                __builtin_nontemporal_store(h1 ? 1.0 : 0.0, &pb->y);
-                hits[j][0] += h0 && rc[i].w != 0;
-                hits[j][1] += h1 && rc[i].w != 0;
-            }
-        }
-        __builtin_amdgcn_sched_barrier(0);
-    };
-    int4 r2[UN];
-    uint2 w2[UN][3];
-    load_batch(task.x, r, w);
-    for (int i0 = task.x; i0 < task.y; i0 += 4 * UN) {
-        batch(i0, r, w, r2, w2);
-        batch(i0 + 2 * UN, r2, w2, r, w);
-    }
-#pragma unroll
-    for (int j = 0; j < 3; ++j)
-#pragma unroll
-        for (int c = 0; c < 2; ++c)
-            if (hits[j][c]) atomicAdd(&hl.enriched[col[j] + c], hits[j][c]);
-}
 
-template <int UN>
-__global__ __launch_bounds__(512) void k_hyp_emit_pair(const unsigned int *__restrict__ cnt16, int64_t n_padr, int64_t n_grp,
-                                                       const int4 *__restrict__ rows, const int2 *__restrict__ tasks, int64_t mloc,
-                                                       HypLookup hl, int lds_entries) {
-    extern __shared__ __attribute__((aligned(16))) unsigned char emit_lds[];
-    double2 *slab = reinterpret_cast<double2 *>(emit_lds);
-    const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
-    const int rsel = lane >> 5, cp = (lane >> 1) & 15, hh = lane & 1;
-    const int2 task = tasks[blockIdx.y];
-    const int nid = rows[task.x].z;
-    const uint32_t xc = min(static_cast<uint32_t>(*hl.xmax) + 1u, static_cast<uint32_t>(hl.xs));
-    const uint32_t n_kid = static_cast<uint32_t>(hl.n_kid), xs = static_cast<uint32_t>(hl.xs);
-    const bool staged = n_kid * xc <= static_cast<uint32_t>(lds_entries);      // uniform over the whole launch
-    const double2 *tab_n = hl.tab + static_cast<int64_t>(nid) * n_kid * xs;
-    if (staged) {
-        const uint32_t total = n_kid * xc;
-        for (uint32_t e0 = threadIdx.x; e0 < total; e0 += 4 * 512) {
-            double2 v[4];
-#pragma unroll
-            for (int q = 0; q < 4; ++q) v[q] = tab_n[min(e0 + q * 512u, total - 1u)];
-#pragma unroll
-            for (int q = 0; q < 4; ++q)
-                if (e0 + q * 512u < total) slab[e0 + q * 512u] = v[q];
-        }
-        __syncthreads();
-    }
-    const int64_t grp = static_cast<int64_t>(blockIdx.x) * 8 + wave;
-    if (grp >= n_grp) return;
-    int64_t col[3];
-    uint32_t kofs[3][2];
-    bool ok[3];
-#pragma unroll
-    for (int j = 0; j < 3; ++j) {
-        col[j] = (grp * 6 + hh + 2 * j) * 32 + 2 * cp;
-        ok[j] = col[j] + 1 < mloc;                                          // (mloc is even: a pair is inside or outside as a whole)
-        kofs[j][0] = ok[j] ? static_cast<uint32_t>(hl.kid[col[j]]) : 0u;
-        kofs[j][1] = ok[j] ? static_cast<uint32_t>(hl.kid[col[j] + 1]) : 0u;
-    }
-    if (staged) hyp_emit_rows_pair<UN, true>(cnt16, grp, n_padr, rows, task, slab, n_kid, kofs, ok, col, hh, rsel, cp, lane, mloc, hl);
-    else hyp_emit_rows_pair<UN, false>(cnt16, grp, n_padr, rows, task, tab_n, n_kid, kofs, ok, col, hh, rsel, cp, lane, mloc, hl);
-}
 
 template <int UN, bool TAIL>
 __global__ __launch_bounds__(512) void k_hyp_emit(const unsigned int *__restrict__ cnt16, int64_t n_padr, int64_t n_grp,
@@ -2606,11 +2487,8 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
     const int64_t lds_cap = lds_env ? std::max(0, atoi(lds_env)) * 1024ll : (64ll << 10);
     const int lds_bytes = static_cast<int>(std::min<int64_t>(want, std::min<int64_t>(lds_cap, 64 << 10)));
     SAFE_HIP_CHECK(hipEventRecord(ctx->k0, ctx->stream));                 // the timed kernel of this form is the HBM-bound one
-    const char *un_env = getenv("SAFE_HIP_EMIT_UN");
-    const int un = un_env ? atoi(un_env) : EMIT_UN;
-    const char *order_env = getenv("SAFE_HIP_EMIT_ORDER");
-    const int order = order_env ? atoi(order_env) : 0;
-    const dim3 egrid = order == 0 ? dim3(ceil_div(n_grp, 8), st->tasks.size()) : dim3(st->tasks.size(), ceil_div(n_grp, 8));
+    constexpr int order = 0;                                // (blockIdx.x walks the column groups: the other order measured slower)
+    const dim3 egrid(ceil_div(n_grp, 8), st->tasks.size());
     const int lds_entries = lds_bytes / static_cast<int>(sizeof(double2));
 #define EMIT_LAUNCH(U, T)                                                                                                              \
     do {                                                                                                                            \
@@ -2619,20 +2497,10 @@ int mfma_counts_split_emit(safe_ctx *ctx, safe_nbr *nbr, MfmaCountsSplit *st, co
         hipLaunchKernelGGL((k_hyp_emit<U, T>), egrid, dim3(512), lds_bytes, ctx->stream, st->cnt16, n_padr, n_grp, d_rows, d_tasks,    \
                            st->cs.mloc, hl, lds_entries, order);                                                                      \
     } while (0)
-    const char *tail_env = getenv("SAFE_HIP_EMIT_TAIL");
-    const bool tail = !(tail_env && !strcmp(tail_env, "0"));
-    // SAFE_HIP_EMIT_PAIR=1: 16-byte pair stores (k_hyp_emit_pair).  Measured flat against the 8-byte form at configs[3]
-    // (1.205 vs 1.190 ms on one box, same results): the emit kernel is not bound by the width of its stores -- opt-in, A/B only
-    const char *pair_env = getenv("SAFE_HIP_EMIT_PAIR");
-    const bool pair = st->cs.mloc % 2 == 0 && order == 0 && pair_env && !strcmp(pair_env, "1") &&
-                      reinterpret_cast<uintptr_t>(hl.pvalues_pos) % 16 == 0 && reinterpret_cast<uintptr_t>(hl.nes) % 16 == 0 &&
-                      reinterpret_cast<uintptr_t>(hl.nes_binary) % 16 == 0;
-    if (pair) {
-        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_hyp_emit_pair<1>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes));
-        hipLaunchKernelGGL((k_hyp_emit_pair<1>), egrid, dim3(512), lds_bytes, ctx->stream, st->cnt16, n_padr, n_grp, d_rows, d_tasks, st->cs.mloc, hl, lds_entries);
-    } else if (un == 4) EMIT_LAUNCH(4, false);
-    else if (tail) EMIT_LAUNCH(2, true);
-    else EMIT_LAUNCH(2, false);
+    // (16-byte pair stores -- a lane owning two adjacent columns of two rows -- measured flat against this form at configs[3] in
+    // round 5, 1.205 vs 1.190 ms: the emit kernel is not bound by the width of its stores; that kernel is gone)
+    static_assert(EMIT_UN == 2, "k_hyp_emit<2, true> is the measured best");
+    EMIT_LAUNCH(2, true);
 #undef EMIT_LAUNCH
     SAFE_HIP_CHECK(hipGetLastError());
     SAFE_HIP_CHECK(hipEventRecord(ctx->k1, ctx->stream));
@@ -2953,15 +2821,12 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     }
 
     const size_t lds_bytes = 2 * static_cast<size_t>(4 * mf_ks(core_slices)) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
-    const char *pref_env = getenv("SAFE_HIP_MFMA_PREF");
-    const bool pref = !(pref_env && !strcmp(pref_env, "0"));
     const void *kfn_obs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 1>);
     const void *kfn_zobs = reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS + 1, true>);     // z-scores, all seven slices
     const size_t lds_zobs = 2 * static_cast<size_t>(4 * mf_ks(MF_NS + 1)) + MF_MAXBLK * sizeof(int32_t) + 16 * 512 * sizeof(long long);
     const void *kfn = zfilt           ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2 + 1, true, true, 0, true, 2>)
                       : z             ? kfn_zobs
                       : filt          ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS / 2, false, true, 0, true, 2>)
-                      : !pref && n_slices == 6 ? reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS, false, true, 0, false>)
                       : n_slices == 2 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 2>)
                       : n_slices == 4 ? reinterpret_cast<const void *>(k_permtest_mfma<false, 4>)
                                       : reinterpret_cast<const void *>(k_permtest_mfma<false, MF_NS>);
@@ -2974,11 +2839,9 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 #else
     constexpr int mfma_dbg = 0;
 #endif
-    const char *tr_env = getenv("SAFE_HIP_MFMA_TR");                      // =0: register transposes + ds_read_b128 (A/B)
     // SAFE_HIP_MFMA_FORM=f: round 5's kernel (register-staged gather); default: k_permtest_mfma_g (LDS-DMA gather)
     const bool form_f = form_env && !strcmp(form_env, "f");
     const void *kfn_own = !form_f                            ? reinterpret_cast<const void *>(k_permtest_mfma_g<0>)
-                          : (tr_env && !strcmp(tr_env, "0")) ? reinterpret_cast<const void *>(k_permtest_mfma_f<0, false>)
                                                              : reinterpret_cast<const void *>(k_permtest_mfma_f<0>);
 #ifdef SAFE_HIP_DIAG
 #define MF_F_DIAG(D) if (form_f && mfma_dbg == D) kfn_own = reinterpret_cast<const void *>(k_permtest_mfma_f<D>);

@@ -557,8 +557,7 @@ int safe_euclidean_dense_dev(safe_ctx *ctx, const double *xy_dev, int64_t n, dou
     SAFE_REQUIRE(ctx && xy_dev && n >= 1, "safe_euclidean_dense_dev: bad argument");
     SAFE_REQUIRE(mask_out_dev || dist_out_dev, "safe_euclidean_dense_dev: no output requested");
     SAFE_HIP_CHECK(hipSetDevice(ctx->device));
-    int64_t wgs = 4 * static_cast<int64_t>(ctx->num_cu);   // resident workgroups (16 waves per CU hide the scalar-load and f64 latency); they sweep whole rows together
-    if (const char *e = getenv("SAFE_HIP_EUCLID_GRID")) wgs = std::max<int64_t>(1, atoll(e));
+    const int64_t wgs = 4 * static_cast<int64_t>(ctx->num_cu);   // resident workgroups (16 waves per CU hide the scalar-load and f64 latency); they sweep whole rows together
     const int64_t chunks_per_row = ceil_div(n, 512);
     const int64_t rows_per_sweep = std::max<int64_t>(1, std::min<int64_t>(n, wgs / chunks_per_row));
     const int mode = (mask_out_dev ? 1 : 0) | (dist_out_dev ? 2 : 0);

@@ -251,12 +251,8 @@ __global__ __launch_bounds__(64) void k_perms_device(int64_t n, int64_t k, int64
 // --------------------------------------------------------------------------------------
 // chunked generation
 // --------------------------------------------------------------------------------------
-// permutations per host/GPU pipeline stage (SAFE_HIP_CHUNK for A/B)
-static const int64_t kChunk = [] {
-    const char *e = getenv("SAFE_HIP_CHUNK");
-    const long long v = e ? atoll(e) : 128;
-    return static_cast<int64_t>(v >= 32 && v <= 255 ? v : 128);
-}();
+// permutations per host/GPU pipeline stage (every per-stage buffer holds this many)
+static constexpr int64_t kChunk = 128;
 // Stage boundaries of the host / GPU pipeline for `count` permutations: a ramp [0, 16), [16, 64), [64, 192), then 128-permutation
 // stages, and a SHORT last stage (the final stages are cut to <= 96 and 32 permutations: what the last stage holds runs after the
 // draws have ended).  The ramp: the first kernel launch waits for the first stage's draws, replay and scan, so it is short; the
@@ -285,12 +281,14 @@ std::vector<int64_t> perms_stage_plan(int64_t count) {
         if (q < count) b.push_back(q);
     for (int64_t q = head.back() + kChunk; q < count; q += kChunk) b.push_back(q);
     const int64_t last = b.back();
-    static const int tail_rule = getenv("SAFE_HIP_TAIL_STAGE") ? atoi(getenv("SAFE_HIP_TAIL_STAGE")) : 1;
-    if (tail_rule == 1 && count - last > 48 && count > kChunk) b.push_back(count - 32);       // ... | <= 96 | 32
-    if (tail_rule == 2 && b.size() >= 3 && count - last < 64) b.pop_back();                   // a short tail joins its predecessor
+    // the tail: ... | <= 96 | 32.  (Round 6, on a box whose chain was slowed to 5 us per permutation so that the stages behind the last
+    // draw are what is measured: ... | <= 112 | 32 | 16 made the step LONGER, 5.73-5.86 -> 5.91-5.94 ms -- a launch costs ~150 us
+    // plus 2 us per permutation whatever its size (its heaviest slice group's tasks are its critical path), so more and
+    // shorter stages behind the last draw add more than they take away; a short tail joined to its predecessor was no better.)
+    if (count - last > 48 && count > kChunk) b.push_back(count - 32);
     b.push_back(count);
-    // every per-stage buffer (pinned staging, ring slot, row maps, targets) holds kChunk permutations: whatever SAFE_HIP_CHUNK,
-    // SAFE_HIP_STAGES and the tail rules asked for, no stage may be longer
+    // every per-stage buffer (pinned staging, ring slot, row maps, targets) holds kChunk permutations: whatever SAFE_HIP_STAGES
+    // and the tail rule asked for, no stage may be longer
     std::vector<int64_t> cut;
     cut.push_back(0);
     for (size_t i = 1; i < b.size(); ++i) {
@@ -493,7 +491,7 @@ static int enqueue_chunk(safe_perms *p, int64_t ci) {
     // of each other (only the scan composes with the previous chunk's last row), so chunk c's upload and replay run beside chunk
     // c - 1's scan: in the ramp of the pipeline (stages of 16 / 48 / 128 permutations, each waiting for its draws) the tables of the
     // second and third stage are ready 65-85 us earlier.  Buffers alternate by the chunk's parity.
-    static const bool one_stream = getenv("SAFE_HIP_REPLAY_STREAM") && atoi(getenv("SAFE_HIP_REPLAY_STREAM")) == 0;      // (A/B)
+    constexpr bool one_stream = false;                 // (replay on the table stream: measured 3.18-3.20 against 3.13-3.14 ms, round 5)
     const int par = one_stream ? 0 : static_cast<int>(ci & 1);
     hipStream_t rs = one_stream ? gs : ctx->more_streams[0];
     void *d_tg = par ? p->d_targets_odd : p->d_targets;
@@ -599,21 +597,16 @@ static void drawer_main(safe_perms *p, int w = 0) {
         safe_trace("    drawer: buffer free, drawing");
         const double t_draw = wall_s();
         char *dst = static_cast<char *>(stage[b]);
-        static const bool prof = getenv("SAFE_HIP_DRAW_PROFILE") != nullptr;
-        double t_pack = 0.0;
         for (int64_t q = 0; q < cnt; ++q) {
             draw_stream_targets(gen, k, h);                         // into a buffer that stays in L1, then packed onto the wire
-            const double tp0 = prof ? wall_s() : 0.0;
             if (p->target_bytes == 2) draws_pack_u16(reinterpret_cast<uint16_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps));
             else memcpy(reinterpret_cast<uint32_t *>(dst) + q * p->target_width, h, static_cast<size_t>(steps) * sizeof(uint32_t));
-            if (prof) t_pack += wall_s() - tp0;
             if ((q & 15) == 15) {
                 std::lock_guard<std::mutex> lk(p->draw_mu);
                 if (p->draw_stop) return;
             }
         }
         safe_trace("    drawer: chunk drawn");
-        if (prof) fprintf(stderr, "draw chunk %lld: %lld perms, draw+pack %.1f us, pack %.1f us\n", (long long)c, (long long)cnt, 1e6 * (wall_s() - t_draw), 1e6 * t_pack);
         {
             std::lock_guard<std::mutex> lk(p->draw_mu);
             if (p->drawn_chunks <= c) {                               // first to finish this chunk (always, without a twin)
@@ -665,10 +658,7 @@ static void draw_worker_main(safe_ctx *ctx, int which) {
     static const bool twin_on = getenv("SAFE_HIP_DRAW_TWIN") && !strcmp(getenv("SAFE_HIP_DRAW_TWIN"), "1");
     draw_thread_apply_cpus(which, twin_on && !safe_blocking_sync_selected());
     (void)hipSetDevice(ctx->device);
-    static const double spin_s = [] {
-        const char *e = getenv("SAFE_HIP_DRAW_IDLE_SPIN_US");              // how long the idle worker polls before it sleeps
-        return 1e-6 * (e ? std::max(0, atoi(e)) : 1500);
-    }();
+    constexpr double spin_s = 1.5e-3;                                      // how long the idle worker polls before it sleeps (20 ms measured the same)
     for (;;) {
         safe_perms *p = nullptr;
         if (!safe_blocking_sync_selected()) {
@@ -733,8 +723,9 @@ static void drawer_start(safe_perms *p) {
     p->twin_wins = 0;
     if (p->count <= 0 || p->ring_consumer) return;
     safe_ctx *ctx = p->ctx;
-    static const bool per_call = getenv("SAFE_HIP_DRAW_THREAD") && !strcmp(getenv("SAFE_HIP_DRAW_THREAD"), "percall");   // (A/B: a thread per handle)
-    if (!per_call && worker_post(ctx, &ctx->draw_worker, 0, p)) {
+    // the context's persistent worker; a thread of the handle's own only when that worker is busy with another live handle
+    // (a thread per call measured 2.5 % slower and with 5-10 ms outliers, round 5)
+    if (worker_post(ctx, &ctx->draw_worker, 0, p)) {
         p->on_worker = true;
         if (p->twin) {
             if (worker_post(ctx, &ctx->draw_worker2, 1, p)) p->on_worker2 = true;

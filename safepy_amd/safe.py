@@ -601,7 +601,8 @@ class SAFE:
             if resident is not None:                                       # both copies, the host one stays read-only
                 resident.nan_to_zero()
                 self.node2attribute.flags.writeable = True
-            self.node2attribute[np.isnan(self.node2attribute)] = 0         # in place, like safe.py:451
+            if np.issubdtype(self.node2attribute.dtype, np.floating):      # (a uint8 / bool matrix has no missing values)
+                self.node2attribute[np.isnan(self.node2attribute)] = 0     # in place, like safe.py:451
             if resident is not None:
                 self.node2attribute.flags.writeable = False
 

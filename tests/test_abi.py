@@ -143,3 +143,21 @@ def test_id_stream_registers_stay_hidden_from_the_compiler(tmp_path):
                     foreign.append((sym[:48], ins))
     assert kernels and uses > 1000, 'the stream kernels were not found in the library'
     assert not foreign, foreign[:5]
+
+
+def test_design_lists_every_environment_switch():
+    """DESIGN.md section 8 names exactly the SAFE_HIP_* switches the sources read (getenv in the library, os.environ in the
+    package) -- and there are at most 30 of them in the library."""
+    import glob
+    csrc = os.path.join(ROOT, 'safepy_amd', 'csrc')
+    in_c = set()
+    for path in glob.glob(os.path.join(csrc, '*.hip')) + glob.glob(os.path.join(csrc, '*.cpp')) + glob.glob(os.path.join(csrc, '*.h')):
+        in_c |= set(re.findall(r'getenv\("(SAFE_HIP_[A-Z0-9_]+)"\)', open(path).read()))
+    in_py = set()
+    for path in glob.glob(os.path.join(ROOT, 'safepy_amd', '*.py')):
+        in_py |= set(re.findall(r"""environ[^\n]*?['"](SAFE_HIP_[A-Z0-9_]+)['"]""", open(path).read()))
+    design = open(os.path.join(ROOT, 'DESIGN.md')).read()
+    section = design[design.index('## 8. Environment switches'):]
+    listed = set(re.findall(r'`(SAFE_HIP_[A-Z0-9_]+)`', section))
+    assert len(in_c) <= 30, sorted(in_c)
+    assert listed == in_c | in_py, (sorted(listed - in_c - in_py), sorted((in_c | in_py) - listed))

@@ -491,15 +491,13 @@ def test_midsize_hypergeometric_vs_oracle(amd, ctx, monkeypatch, counts):
     np.testing.assert_array_equal(sf.attributes['num_neighborhoods_enriched'].values, want['num_neighborhoods_enriched'])
 
 
-@pytest.mark.parametrize('n,m,pair', [(257, 5, False), (300, 193, False), (1000, 1, False), (300, 194, True), (257, 6, True), (1100, 400, True)])
-def test_split_hypergeometric_edge_shapes(amd, ctx, monkeypatch, n, m, pair):
+@pytest.mark.parametrize('n,m', [(257, 5), (300, 193), (1000, 1), (300, 194), (257, 6), (1100, 400)])
+def test_split_hypergeometric_edge_shapes(amd, ctx, monkeypatch, n, m):
     """Split matrix-core form on awkward shapes: one row past a row group, fewer columns than one lane group,
     one column past a column group; columns without any annotation (every count 0: the table is cut at x = 0),
-    a column annotating every node (K = N, p = 1 everywhere), an all-NaN row, isolated nodes.  pair: the opt-in emit kernel
-    with 16-byte stores (SAFE_HIP_EMIT_PAIR=1, even column counts; odd task lengths and ragged tiles included)."""
+    a column annotating every node (K = N, p = 1 everywhere), an all-NaN row, isolated nodes; even and odd column counts,
+    odd task lengths and ragged tiles."""
     monkeypatch.setenv('SAFE_HIP_COUNTS', 'mfma')
-    if pair:
-        monkeypatch.setenv('SAFE_HIP_EMIT_PAIR', '1')
     rng = np.random.default_rng(n + m)
     xy = rng.uniform(size=(n, 2))
     xy[:3] += 10.0                                           # three nodes far away: neighborhoods of one

@@ -1,7 +1,7 @@
 """Kernel-only time of the bit-sliced permutation test at configs[1] (tables generated before the call), per kernel
-variant, launch plan and diagnostic build:  SAFE_HIP_BITS_KERNEL = blk | pre;  SAFE_HIP_BITS_TASKS = queue depth per
-workgroup slot;  SAFE_HIP_BITS_MERGE = pipeline stages per launch;  SAFE_HIP_BITS_DBG bit 0 = no LDS gathers, bit 1 = no
-counter flush, bit 2 = no compare / count (wrong results; shows what the time goes to).
+variant and diagnostic build:  SAFE_HIP_BITS_KERNEL = blk | pre;  SAFE_HIP_BITS_DBG bit 0 = no LDS gathers, bit 1 = no
+counter flush, bit 2 = no compare / count (make DIAG=1: wrong results; shows what the time goes to), 128 = the per-task
+clock trace (results stay correct).
 usage: bits_ablate.py [P]   -- each configuration runs in its own child process."""
 import os, subprocess, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -39,8 +39,8 @@ def one(P):
         if it and (best is None or dt < best[0]):
             best = (dt, name, ms, launches)
     dt, name, ms, launches = best
-    print('%-22s tasks=%s dbg=%s merge=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
-        name, os.environ.get('SAFE_HIP_BITS_TASKS', '2'), os.environ.get('SAFE_HIP_BITS_DBG', '0'), os.environ.get('SAFE_HIP_BITS_MERGE', '1'), 1e3 * dt, launches, ms, ms * launches), flush=True)
+    print('%-22s dbg=%s: call %.2f ms, %d launches x %.3f ms = %.2f ms' % (
+        name, os.environ.get('SAFE_HIP_BITS_DBG', '0'), 1e3 * dt, launches, ms, ms * launches), flush=True)
 
 
 if __name__ == '__main__':
@@ -48,9 +48,8 @@ if __name__ == '__main__':
         one(int(sys.argv[2]))
         sys.exit(0)
     P = int(sys.argv[1]) if len(sys.argv) > 1 else 1000
-    K, TK = 'SAFE_HIP_BITS_KERNEL', 'SAFE_HIP_BITS_TASKS'
+    K = 'SAFE_HIP_BITS_KERNEL'
     D = 'SAFE_HIP_BITS_DBG'
-    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', TK: '1'}, {K: 'blk', TK: '3'}, {K: 'blk', D: '1'}, {K: 'blk', D: '2'}, {K: 'blk', D: '4'},
-               {K: 'blk', D: '7'}, {K: 'blk', 'SAFE_HIP_BITS_MERGE': '2'}]
+    configs = [{K: 'pre'}, {K: 'blk'}, {K: 'blk', D: '1'}, {K: 'blk', D: '2'}, {K: 'blk', D: '4'}, {K: 'blk', D: '7'}]
     for cfg in configs:
         subprocess.run([sys.executable, os.path.abspath(__file__), '--one', str(P)], env=dict(os.environ, **cfg))
