@@ -1464,8 +1464,6 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
     constexpr int dbg = DBG;
     constexpr int NS = MF_NS / 2, KS = 32 * NS * 32, BUF = 4 * KS;            // k-step = 32 rows x 96 B, buffer = one super-step = 12 KB
     constexpr int64_t row_bytes = NS * 32;
-    typedef __attribute__((address_space(3))) void lds_void;
-    typedef __attribute__((address_space(1))) const void gl_void;
     // ONE shared array (a second __shared__ object makes the compiler drain the DMA queue before every LDS read):
     // [2][BUF] | kb list | Y0 + W [32][256] | counters [8][256] | task slot
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -1569,30 +1567,34 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                 const int32_t *at = srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32;
                 return Src3{at[r_g[0]], at[r_g[1]], at[r_g[2]]};
             };
-            // One DMA instruction: chunk 64 j + lane of k-step `wave` of the super-step in buffer `buf`.  Written as asm: through the
-            // builtin the compiler drains the DMA queue (vmcnt(0)) before the next LDS read it cannot prove disjoint from the
-            // destination -- right after the issue.  The DMAs are therefore not in the compiler's vmcnt bookkeeping: every counted
-            // load whose wait follows them is younger (so that wait covers them), and the explicit vmcnt(0) in front of the
-            // super-step's barrier is what publishes the rows.
-            auto stage1 = [&](int32_t src, int buf, int j) __attribute__((always_inline)) {
+            // The three DMA instructions of this thread: chunks 64 j + lane (j = 0..2) of k-step `wave` of the super-step in buffer `buf`.
+            // Written as asm: through the builtin the compiler drains the DMA queue (vmcnt(0)) before the next LDS read it cannot
+            // prove disjoint from the destination -- right after the issue.  The DMAs are therefore not in the compiler's vmcnt
+            // bookkeeping: every counted load whose wait follows them is younger (so that wait covers them), and the explicit
+            // vmcnt(0) in front of the super-step's barrier is what publishes the rows.  ONE statement: three statements (each
+            // saving and restoring m0, each a scheduling fence) measured 10.5 against 9.6 ms per launch.
+            auto stage = [&](const Src3 &src, int buf) __attribute__((always_inline)) {
                 if (dbg & 64) return;
-                const unsigned char *from = bs_ct + static_cast<int64_t>(src) * row_bytes + c16_g[j];
-                const uint32_t to = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_base + buf * BUF + dma_base + j * 1024)));
+                const unsigned char *from = bs_ct + static_cast<int64_t>(src.a) * row_bytes + c16_g[0];
+                const unsigned char *from1 = bs_ct + static_cast<int64_t>(src.b) * row_bytes + c16_g[1];
+                const unsigned char *from2 = bs_ct + static_cast<int64_t>(src.c) * row_bytes + c16_g[2];
+                const uint32_t to = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_base + buf * BUF + dma_base)));
                 uint32_t keep;
                 asm volatile(
                     "s_mov_b32 %0, m0\n\t"
-                    "s_mov_b32 m0, %2\n\t"
+                    "s_mov_b32 m0, %4\n\t"
                     "s_nop 0\n\t"
                     "global_load_lds_dwordx4 %1, off\n\t"
+                    "s_add_u32 m0, %4, 0x400\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %2, off\n\t"
+                    "s_add_u32 m0, %4, 0x800\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %3, off\n\t"
                     "s_mov_b32 m0, %0"
                     : "=&s"(keep)
-                    : "v"(from), "s"(to)
-                    : "memory");
-            };
-            auto stage = [&](const Src3 &src, int buf) __attribute__((always_inline)) {
-                stage1(src.a, buf, 0);
-                stage1(src.b, buf, 1);
-                stage1(src.c, buf, 2);
+                    : "v"(from), "v"(from1), "v"(from2), "s"(to)
+                    : "memory", "scc");
             };
             auto advance = [&](int &qq, int &tt) {
                 if (++tt == S) {
@@ -1790,6 +1792,398 @@ __global__ __launch_bounds__(256, 2) void k_permtest_mfma_g(
                         for (int r = 0; r < 16; ++r) mf_keep(static_cast<uint32_t>(acc[p][s][r]));
             }
             __syncthreads();                                         // kb_list / buffers / thresholds are reused by the next task
+        }
+    }
+}
+
+
+// ---------------------------------------------------------------------------------------
+// k_permtest_mfma_gz (round 6): the FILTERED Z-SCORE test (k_permtest_mfma's FM = 2, Z) in k_permtest_mfma_g's shape -- four waves
+// of 64 rows (two 32 x 32 pieces each: an operand read feeds two MFMAs), two workgroups per CU, LDS-DMA gather, bit-permuted
+// membership words.  A task is a tile of SIXTEEN attributes: bytes 0-15 of a slice row are value digits, bytes 16-31 the digits of
+// the squares; slices 0-2 = the three HIGH digits, slice 3 = the not-NaN flags (under both halves): 128-byte rows, eight adjacent
+// lanes of a DMA instruction read one row, four instructions per wave and super-step (wave w stages k-step w).
+// The test is the general kernel's, operation for operation (the decision rules and their margins are the ones the parity tests
+// pin): S1 = a + low, S2 = b + low with |low| <= count * MF_LO_MAX; z >= o is a statement about the signs of S1 and of
+// T = S1^2 sc1^2 (1 + o^2) - o^2 S2 sc2 count; what the high parts leave open goes to k_mfma_resolve_z.  The value lane of an
+// attribute (tile column c) and its squares' lane (column c + 16 = lane ^ 16) split the work: the value lane tests accumulator rows
+// 0..7 of a piece, the squares' lane rows 8..15, after one exchange per row pair.  Observed scores (f64) sit in LDS, [16 outputs]
+// [thread]; counters are 8-bit LDS fields (#certainly greater | #certainly smaller, two outputs per word), flushed every 255
+// permutations as (#>= << 16 | #<=) atomics -- the f64 kernels' counter form, which k_counts_finalize<true> reads with the
+// observed scores.
+// DBG (diagnostic builds only): 2 no MFMAs, 4 no barrier, 8 no score completion, 64 no DMA, 512 per-phase cycle counters.
+constexpr int MF_GZ_MAXBLK = 1024;        // column blocks per row group this kernel can index from LDS (else the general kernel)
+// F32 (default): the same decision in single precision.  In units of 2^24 x the value grid, u = the high value sum, w = the high
+// sum of squares, c = count, d = c x MF_LO_MAX / 2^24 >= |low parts|:
+//     T' = u^2 - rho gamma w c,   gamma = sc2 / (sc1^2 2^24) (a power of two),   rho = o^2 / (1 + o^2)   (T = T' x a positive factor)
+//     |T' - its true value| <= d (2 |u| + d) + rho gamma c d     (the low parts)   +   2^-21 (u^2 + rho gamma |w| c)   (f32 roundings)
+// decided when |T'| exceeds (1 + 2^-10) x the first bound + 2^-19 x the second -- margins a superset of the f64 form's (which
+// already include the reference's own roundings), so every compare this form decides the f64 form decides the same way, and the
+// counters stay equal to the seven-slice kernel's; per output the workgroup keeps copysign(rho, o) as f32 in LDS (NaN = no test).
+// 16 outputs cost ~800 VALU instructions instead of ~2850 (f64 products, 64-bit sums and two exchanges per output).
+template <int DBG, bool F32 = true>
+__global__ __launch_bounds__(256, 2) void k_permtest_mfma_gz(
+    const unsigned char *__restrict__ bs, int64_t tile_bytes, const int32_t *__restrict__ srcp, int64_t n_src, int n_q,
+    const int32_t *__restrict__ blk_ptr, const int32_t *__restrict__ blk_kb, const uint4 *__restrict__ blk_bits4p,
+    const int2 *__restrict__ tasks, const int32_t *__restrict__ q_off, unsigned int *__restrict__ q_ctr, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_padr, const int32_t *__restrict__ rowmap, const double *__restrict__ col_scale,
+    MfmaFilt fa) {
+    constexpr int dbg = DBG;
+    constexpr int NS = MF_NS / 2 + 1, KS = 32 * NS * 32, BUF = 4 * KS;        // k-step = 32 rows x 128 B, buffer = one super-step = 16 KB
+    constexpr int64_t row_bytes = NS * 32;
+    // ONE shared array: [2][BUF] | kb list | observed scores f64 [16][256] | counters [8][256] | task slot
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int tid = threadIdx.x, wave = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63;
+    const int lam = lane & 31, h = lane >> 5;
+    int32_t *kb_list = reinterpret_cast<int32_t *>(lds + 2 * BUF);
+    long long *obs = reinterpret_cast<long long *>(lds + 2 * BUF + MF_GZ_MAXBLK * sizeof(int32_t)) + tid;
+    float *rhos = reinterpret_cast<float *>(lds + 2 * BUF + MF_GZ_MAXBLK * sizeof(int32_t)) + tid;      // (F32: the same space, [16][256] floats)
+    uint32_t *cnts = reinterpret_cast<uint32_t *>(lds + 2 * BUF + MF_GZ_MAXBLK * sizeof(int32_t) + 16 * 256 * sizeof(long long)) + tid;
+    int *slot_box = reinterpret_cast<int *>(lds + 2 * BUF + MF_GZ_MAXBLK * sizeof(int32_t) + 16 * 256 * sizeof(long long) + 8 * 256 * sizeof(uint32_t));
+    typedef __attribute__((address_space(3))) unsigned char lds_byte;
+    const uint32_t lds_base = static_cast<uint32_t>(reinterpret_cast<uintptr_t>((lds_byte *)lds));      // LDS byte address of the array
+    // staging role: k-step `wave` of the super-step; instruction j: chunk 64 j + lane = row 8 j + (lane >> 3), bytes 16 (lane & 7) ..
+    const int r_g0 = lane >> 3, c16_g = 16 * (lane & 7);
+    const int dma_base = __builtin_amdgcn_readfirstlane(wave * KS);
+    const uint32_t r_base = static_cast<uint32_t>((16 * h + ((lane & 15) >> 1)) * 128 + 16 * ((lane >> 4) & 1) + 8 * (lane & 1));
+    const uint32_t sh0 = 4u * h, sh1 = sh0 + 1u, sh2 = sh0 + 2u, sh3 = sh0 + 3u;
+    const bool sq = (lam & 16) != 0;                                          // this lane owns a column of squares
+    const int r_off = sq ? 8 : 0;
+    const uint32_t sq_mask = sq ? 0xFFFFFFFFu : 0u;
+
+    const int home = blockIdx.x & 7;
+    for (int attempt = 0; attempt < 8; ++attempt) {
+        const int qx = (home + attempt) & 7;
+        const int q_begin = q_off[qx], q_len = q_off[qx + 1] - q_begin;
+        for (;;) {
+            if (tid == 0) *slot_box = static_cast<int>(atomicAdd(&q_ctr[qx], 1u));
+            __syncthreads();
+            const int slot = *slot_box;
+            __syncthreads();
+            if (slot >= q_len) break;
+            const int2 task = tasks[q_begin + slot];
+            const int g = task.x, ct = task.y;
+            const int b0 = blk_ptr[g], nb = blk_ptr[g + 1] - b0, S = nb >> 2;
+            if (S == 0) continue;
+            for (int i = tid; i < nb; i += 256) kb_list[i] = blk_kb[b0 + i];
+
+            const unsigned char *bs_ct = bs + static_cast<int64_t>(ct) * tile_bytes + c16_g;
+            const uint4 *bits_w = blk_bits4p + static_cast<int64_t>(b0 >> 2) * MF_R + wave * 64 + lane;   // lane l: row l of the wave's 64
+            const int total = n_q * S;
+            const int64_t colz = static_cast<int64_t>(ct) * 16 + (lam & 15);
+            const int64_t u_lane = static_cast<int64_t>(g) * MF_R + wave * 64 + 4 * h;     // + 32 p + (r & 3) + 8 (r >> 2)
+            double sc1 = 1.0, sc2 = 1.0;
+            if (colz < mloc) {
+                sc1 = col_scale[colz];
+                sc2 = col_scale[mloc + colz];
+            }
+            const double sc1sq = sc1 * sc1;
+            // the observed scores of this lane's 16 outputs (8 per piece: value lanes accumulator rows 0..7, squares' lanes 8..15);
+            // NaN (padding, fewer than three values, no spread) = no test
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int rr = 0; rr < 8; ++rr) {
+                    const int r = rr + r_off;
+                    const int32_t node = rowmap[u_lane + 32 * p + (r & 3) + 8 * (r >> 2)];
+                    const bool live = node >= 0 && colz < mloc;
+                    const double o = live ? fa.zobs[static_cast<int64_t>(node) * mloc + colz] : __longlong_as_double(0x7FF8000000000000ll);
+                    if constexpr (F32) {
+                        const double o2 = o * o;
+                        const double rho = o2 > 0x1p1000 ? 1.0 : o2 / (1.0 + o2);            // (o = +-inf: the limit)
+                        rhos[(8 * p + rr) * 256] = o == o ? copysignf(static_cast<float>(rho), o < 0.0 ? -1.0f : 1.0f) : __int_as_float(0x7FC00000);
+                    } else {
+                        obs[(8 * p + rr) * 256] = __double_as_longlong(o);
+                    }
+                }
+            const float gamma = static_cast<float>(sc2 / (sc1sq * 16777216.0));            // (powers of two: exact)
+            __syncthreads();                                         // kb_list
+
+            v16i acc[2][NS];
+#pragma unroll
+            for (int p = 0; p < 2; ++p)
+#pragma unroll
+                for (int s = 0; s < NS; ++s)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
+#pragma unroll
+            for (int j = 0; j < 8; ++j) cnts[j * 256] = 0;
+            int since_flush = 0;
+            unsigned long long prof_acc[5] = {0, 0, 0, 0, 0};
+
+            // counter word j: outputs 2 j and 2 j + 1 (output o = 8 p + rr), bytes {#greater, #smaller} of each
+            auto flush = [&]() __attribute__((always_inline)) {
+#pragma unroll
+                for (int j = 0; j < 8; ++j) {
+                    const uint32_t w = cnts[j * 256];
+                    cnts[j * 256] = 0;
+                    if (colz < mloc && w) {
+#pragma unroll
+                        for (int e = 0; e < 2; ++e) {
+                            const int o = 2 * j + e, r = (o & 7) + r_off;
+                            const uint32_t add = (((w >> (16 * e)) & 0xFFu) << 16) | ((w >> (16 * e + 8)) & 0xFFu);
+                            if (add) atomicAdd(&gl_counts[colz * n_padr + u_lane + 32 * (o >> 3) + (r & 3) + 8 * (r >> 2)], add);
+                        }
+                    }
+                }
+            };
+            struct Src4 {
+                int32_t a, b, c, d;
+            };
+            auto src_of = [&](int q, int kb) -> Src4 {
+                q = q < n_q ? q : n_q - 1;
+                const int32_t *at = srcp + static_cast<int64_t>(q) * n_src + static_cast<int64_t>(kb) * 32 + r_g0;
+                return Src4{at[0], at[8], at[16], at[24]};
+            };
+            // (one asm statement: see k_permtest_mfma_g)
+            auto stage = [&](const Src4 &src, int buf) __attribute__((always_inline)) {
+                if (dbg & 64) return;
+                const unsigned char *from = bs_ct + static_cast<int64_t>(src.a) * row_bytes;
+                const unsigned char *from1 = bs_ct + static_cast<int64_t>(src.b) * row_bytes;
+                const unsigned char *from2 = bs_ct + static_cast<int64_t>(src.c) * row_bytes;
+                const unsigned char *from3 = bs_ct + static_cast<int64_t>(src.d) * row_bytes;
+                const uint32_t to = static_cast<uint32_t>(__builtin_amdgcn_readfirstlane(static_cast<int>(lds_base + buf * BUF + dma_base)));
+                uint32_t keep;
+                asm volatile(
+                    "s_mov_b32 %0, m0\n\t"
+                    "s_mov_b32 m0, %5\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %1, off\n\t"
+                    "s_add_u32 m0, %5, 0x400\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %2, off\n\t"
+                    "s_add_u32 m0, %5, 0x800\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %3, off\n\t"
+                    "s_add_u32 m0, %5, 0xc00\n\t"
+                    "s_nop 0\n\t"
+                    "global_load_lds_dwordx4 %4, off\n\t"
+                    "s_mov_b32 m0, %0"
+                    : "=&s"(keep)
+                    : "v"(from), "v"(from1), "v"(from2), "v"(from3), "s"(to)
+                    : "memory", "scc");
+            };
+            auto advance = [&](int &qq, int &tt) {
+                if (++tt == S) {
+                    tt = 0;
+                    ++qq;
+                }
+            };
+            auto split_rows = [&](const uint4 &raw, uint4 (&w)[2]) __attribute__((always_inline)) {
+                typedef unsigned int v2u __attribute__((ext_vector_type(2)));
+                const v2u x = __builtin_amdgcn_permlane32_swap(raw.x, raw.x, false, false);
+                const v2u y = __builtin_amdgcn_permlane32_swap(raw.y, raw.y, false, false);
+                const v2u z = __builtin_amdgcn_permlane32_swap(raw.z, raw.z, false, false);
+                const v2u ww = __builtin_amdgcn_permlane32_swap(raw.w, raw.w, false, false);
+                w[0] = make_uint4(x[0], y[0], z[0], ww[0]);
+                w[1] = make_uint4(x[1], y[1], z[1], ww[1]);
+            };
+
+            int q1 = 0, t1 = 0, q2, t2;
+            advance(q1, t1);
+            q2 = q1, t2 = t1;
+            advance(q2, t2);
+            stage(src_of(0, kb_list[wave]), 0);
+            Src4 src_nx = src_of(q1, kb_list[4 * t1 + wave]);
+            int kb_next = kb_list[4 * t2 + wave];
+            uint4 aw[2];
+            split_rows(bits_w[0], aw);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+
+            int q = 0, t = 0;
+            for (int it = 0; it < total; ++it) {
+                const int buf = it & 1;
+                int q3 = q2, t3 = t2;
+                advance(q3, t3);
+                unsigned long long c0 = 0, c1 = 0, c2 = 0, c3 = 0;
+                if (dbg & 512) c0 = __builtin_amdgcn_s_memtime();
+                stage(src_nx, buf ^ 1);                                  // (unconditional: see k_permtest_mfma_g)
+                src_nx = src_of(q2, kb_next);
+                kb_next = kb_list[4 * t3 + wave];
+                const uint4 aw_raw = bits_w[static_cast<int64_t>(t1) * MF_R];
+
+                const unsigned char *bbuf = lds + buf * BUF + r_base;
+                if (dbg & 512) c1 = __builtin_amdgcn_s_memtime();
+                v4i b_cur[NS], b_nxt[NS];
+                auto read_operand = [&](int k, int s) -> v4i {
+                    typedef int v2i __attribute__((ext_vector_type(2)));
+                    typedef __attribute__((address_space(3))) v2i lds_v2i;
+                    const unsigned char *at = bbuf + k * KS + s * 32;
+                    const v2i lo = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at));             // k rows 16 h + 0..7
+                    const v2i hi = __builtin_amdgcn_ds_read_tr8_b64_v2i32((lds_v2i *)(at + 8 * 128));   // k rows 16 h + 8..15
+                    v4i r;
+                    r[0] = lo[0], r[1] = lo[1], r[2] = hi[0], r[3] = hi[1];
+                    return r;
+                };
+#pragma unroll
+                for (int s = 0; s < NS; ++s) b_cur[s] = read_operand(0, s);
+#pragma unroll
+                for (int k = 0; k < 4; ++k) {
+                    if (k < 3) {
+#pragma unroll
+                        for (int s = 0; s < NS; ++s) b_nxt[s] = read_operand(k + 1, s);
+                    }
+                    __builtin_amdgcn_sched_barrier(0);               // the reads stay ahead of this k-step's MFMAs
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+                        const uint32_t word = k == 0 ? aw[p].x : k == 1 ? aw[p].y : k == 2 ? aw[p].z : aw[p].w;
+                        if (dbg & 2) {
+                            mf_keep(word);
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) mf_keep(b_cur[s]);
+                        }
+                        if (__builtin_amdgcn_ballot_w64(word != 0u) != 0ull && !(dbg & 2)) {   // (a piece without members is skipped)
+                            v4i a;
+                            a[0] = static_cast<int>((word >> sh0) & 0x01010101u);
+                            a[1] = static_cast<int>((word >> sh1) & 0x01010101u);
+                            a[2] = static_cast<int>((word >> sh2) & 0x01010101u);
+                            a[3] = static_cast<int>((word >> sh3) & 0x01010101u);
+#pragma unroll
+                            for (int s = 0; s < NS; ++s) acc[p][s] = __builtin_amdgcn_mfma_i32_32x32x32_i8(a, b_cur[s], acc[p][s], 0, 0, 0);
+                        }
+                    }
+#pragma unroll
+                    for (int s = 0; s < NS; ++s) b_cur[s] = b_nxt[s];
+                }
+
+                if (dbg & 512) c2 = __builtin_amdgcn_s_memtime();
+                if (t == S - 1 && !(dbg & 8)) {                      // the scores of permutation q are complete
+                    // The filtered z-score test of k_permtest_mfma (FM = 2, Z), operation for operation.
+                    uint32_t undecided = 0;
+#pragma unroll
+                    for (int p = 0; p < 2; ++p) {
+#pragma unroll
+                        for (int rp = 0; rp < 4; ++rp) {
+                            uint32_t inc = 0;
+#pragma unroll
+                            for (int e = 0; e < 2; ++e) {
+                                const int rr = 2 * rp + e;
+                                if constexpr (F32) {
+                                    auto hi_sum = [&](int r) -> float {           // acc2 x 65536 + acc1 x 256 + acc0 (each below 2^24: exact conversions)
+                                        return fmaf(static_cast<float>(acc[p][2][r]), 65536.0f,
+                                                    fmaf(static_cast<float>(acc[p][1][r]), 256.0f, static_cast<float>(acc[p][0][r])));
+                                    };
+                                    // (selects between the value lane's and the squares' lane's roles are bit selects with a per-lane mask,
+                                    // the decision is mask logic without short-circuit branches: as written with ?: and && the compiler
+                                    // re-derived the lane predicate for every select and branched around every clause -- 2700 instructions)
+                                    const uint32_t m_lo = __float_as_uint(hi_sum(rr)), m_hi = __float_as_uint(hi_sum(rr + 8));
+                                    const uint32_t got = static_cast<uint32_t>(__shfl_xor(static_cast<int>((m_lo & sq_mask) | (m_hi & ~sq_mask)), 16));
+                                    const float u = __uint_as_float((got & sq_mask) | (m_lo & ~sq_mask));      // high sum of values of MY row
+                                    const float w = __uint_as_float((m_hi & sq_mask) | (got & ~sq_mask));      // high sum of squares
+                                    const float cf = static_cast<float>(static_cast<int>((static_cast<uint32_t>(acc[p][3][rr + 8]) & sq_mask) |
+                                                                                         (static_cast<uint32_t>(acc[p][3][rr]) & ~sq_mask)));
+                                    const float rs = rhos[(8 * p + rr) * 256], rho = fabsf(rs);
+                                    const float d = cf * (static_cast<float>(MF_LO_MAX) / 16777216.0f * 1.000244140625f);   // >= the low parts, in units of 2^24
+                                    const float au = fabsf(u), uu = u * u, gwc = (gamma * w) * cf, kwc = rho * gwc;
+                                    const float slack_u = d * fmaf(2.0f, au, d), gcd = gamma * (cf * d);
+                                    const float T = uu - kwc, V = gwc - uu;
+                                    const float e_t = fmaf(0x1p-19f, uu + fabsf(kwc), fmaf(rho, gcd, slack_u) * 1.0009765625f);
+                                    const float e_v = fmaf(0x1p-18f, uu + fabsf(gwc), (slack_u + gcd) * 1.0009765625f);
+                                    const float m_s = fmaf(au, 0x1p-20f, d);
+                                    // (observed NaN: no test; fewer than 3 values: the permuted score is NaN -- safe_extras.py:30)
+                                    const bool live = (rs == rs) & (cf >= 3.0f), ok = live & (V > e_v);
+                                    const bool t_pos = T > e_t, t_neg = -T > e_t, s_pos = u > m_s, s_neg = -u > m_s;
+                                    const bool nn = __float_as_int(rs) >= 0;                                   // o >= 0
+                                    const bool greater = ok & ((nn & s_pos & t_pos) | (!nn & (s_pos | t_neg)));
+                                    const bool smaller = ok & ((nn & (s_neg | t_neg)) | (!nn & s_neg & t_pos));
+                                    inc |= (greater ? (1u << (16 * e)) : 0u) | (smaller ? (1u << (16 * e + 8)) : 0u);
+                                    undecided |= (live & !greater & !smaller) ? (1u << (8 * p + rr)) : 0u;
+                                } else {
+                                long long x = static_cast<long long>(acc[p][2][rr]), y = static_cast<long long>(acc[p][2][rr + 8]);
+#pragma unroll
+                                for (int s = 1; s >= 0; --s) {
+                                    x = (x << 8) + static_cast<long long>(acc[p][s][rr]);
+                                    y = (y << 8) + static_cast<long long>(acc[p][s][rr + 8]);
+                                }
+                                const long long give = sq ? x : y;
+                                const int g_lo = __shfl_xor(static_cast<int>(give), 16), g_hi = __shfl_xor(static_cast<int>(give >> 32), 16);
+                                const long long got = (static_cast<long long>(g_hi) << 32) | static_cast<long long>(static_cast<uint32_t>(g_lo));
+                                const long long v = sq ? got : x, w = sq ? y : got;        // sums / sums of squares (high digits) of MY row
+                                const double o = __longlong_as_double(obs[(8 * p + rr) * 256]);
+                                const double members = static_cast<double>(sq ? acc[p][3][rr + 8] : acc[p][3][rr]);   // (the not-NaN slice is in both halves)
+                                if (o == o && members >= 3.0) {                  // (observed NaN: no test; fewer than 3 values: the score is NaN -- safe_extras.py:30)
+                                    const double a = static_cast<double>(v) * 16777216.0, b = static_cast<double>(w) * 16777216.0;
+                                    const double eb = members * static_cast<double>(MF_LO_MAX);
+                                    const double o2 = o * o, k1 = sc1sq * (1.0 + o2), k2 = o2 * sc2;
+                                    const double slack1 = 2.0 * fabs(a) * eb + eb * eb;                      // |S1^2 - a^2| <=
+                                    const double p1 = a * a * k1, p2 = b * members * k2;
+                                    const double T = p1 - p2;
+                                    const double E = k1 * slack1 + k2 * members * eb + (p1 + fabs(p2)) * 0x1p-40;
+                                    const double V = b * members * sc2 - a * a * sc1sq;                      // count^2 * variance, high parts
+                                    const bool var_ok = V - (sc2 * members * eb + sc1sq * slack1) > fabs(b) * members * sc2 * 0x1p-20;
+                                    const bool t_pos = T > E, t_neg = T < -E, s_pos = a > eb, s_neg = a < -eb;
+                                    const bool greater = var_ok && (o >= 0.0 ? (s_pos && t_pos) : (s_pos || t_neg));
+                                    const bool smaller = var_ok && (o >= 0.0 ? (s_neg || t_neg) : (s_neg && t_pos));
+                                    inc |= greater ? (1u << (16 * e)) : (smaller ? (1u << (16 * e + 8)) : 0u);
+                                    undecided |= (!greater && !smaller) ? (1u << (8 * p + rr)) : 0u;
+                                }
+                            }
+                            }
+                            if (inc) __hip_atomic_fetch_add(&cnts[(4 * p + rp) * 256], inc, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                        }
+                    }
+                    if (__builtin_expect(undecided != 0u, 0)) {
+                        for (uint32_t left = undecided; left;) {
+                            const int o = __builtin_ctz(left), r = (o & 7) + r_off;
+                            left &= left - 1u;
+                            const unsigned int at = atomicAdd(fa.amb_count, 1u);
+                            if (at >= fa.amb_cap) continue;
+                            fa.amb[at] = make_ulonglong2(static_cast<unsigned long long>(u_lane + 32 * (o >> 3) + (r & 3) + 8 * (r >> 2)) |
+                                                             (static_cast<unsigned long long>(colz) << 32),
+                                                         (3ull << 62) | static_cast<unsigned long long>(fa.p_base + q));
+                        }
+                    }
+#pragma unroll
+                    for (int p = 0; p < 2; ++p)
+#pragma unroll
+                        for (int s = 0; s < NS; ++s)
+#pragma unroll
+                            for (int r = 0; r < 16; ++r) acc[p][s][r] = 0;
+                    if (++since_flush == 255) {
+                        flush();
+                        since_flush = 0;
+                    }
+                }
+                split_rows(aw_raw, aw);
+                if (dbg & 512) {
+                    mf_keep(aw[0]);
+                    mf_keep(aw[1]);
+                    c3 = __builtin_amdgcn_s_memtime();
+                }
+                if (!(dbg & 4)) {
+                    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's share of the next super-step's rows has landed
+                    __syncthreads();
+                }
+                if (dbg & 512) {
+                    const unsigned long long c4 = __builtin_amdgcn_s_memtime();
+                    prof_acc[0] += c1 - c0;
+                    prof_acc[1] += c2 - c1;
+                    prof_acc[2] += c3 - c2;
+                    prof_acc[3] += c4 - c3;
+                    prof_acc[4] += 1;
+                }
+                q = q1, t = t1;
+                q1 = q2, t1 = t2;
+                q2 = q3, t2 = t3;
+            }
+            if ((dbg & 512) && lane == 0 && fa.prof) {
+#pragma unroll
+                for (int i = 0; i < 5; ++i) {
+                    atomicAdd(&fa.prof[wave * 8 + i], prof_acc[i]);
+                    prof_acc[i] = 0;
+                }
+            }
+            if (since_flush) flush();
+            if (dbg & 8) {
+#pragma unroll
+                for (int p = 0; p < 2; ++p)
+#pragma unroll
+                    for (int s = 0; s < NS; ++s)
+#pragma unroll
+                        for (int r = 0; r < 16; ++r) mf_keep(static_cast<uint32_t>(acc[p][s][r]));
+            }
+            __syncthreads();                                         // kb_list / buffers / observed scores are reused by the next task
         }
     }
 }
@@ -2851,6 +3245,17 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
     MF_G_DIAG(2) MF_G_DIAG(4) MF_G_DIAG(8) MF_G_DIAG(64) MF_G_DIAG(66) MF_G_DIAG(512) MF_G_DIAG(1024)
 #undef MF_G_DIAG
 #endif
+    // filtered z-scores: their own kernel in the same shape (SAFE_HIP_MFMA_FORM=general keeps the general kernel's FM = 2)
+    const bool zfilt_own = zfilt && nbr->bs_max_group_blocks <= MF_GZ_MAXBLK && !(form_env && (!strcmp(form_env, "general") || !strcmp(form_env, "f")));
+    const void *kfn_gz = (form_env && !strcmp(form_env, "gz64")) ? reinterpret_cast<const void *>(k_permtest_mfma_gz<0, false>)   // (A/B: the f64 test)
+                                                                 : reinterpret_cast<const void *>(k_permtest_mfma_gz<0>);
+#ifdef SAFE_HIP_DIAG
+#define MF_GZ_DIAG(D) if (mfma_dbg == D) kfn_gz = reinterpret_cast<const void *>(k_permtest_mfma_gz<D>);
+    MF_GZ_DIAG(2) MF_GZ_DIAG(4) MF_GZ_DIAG(8) MF_GZ_DIAG(64) MF_GZ_DIAG(512)
+#undef MF_GZ_DIAG
+#endif
+    const size_t lds_gz = 2 * static_cast<size_t>(4 * 32 * (MF_NS / 2 + 1) * 32) + MF_GZ_MAXBLK * sizeof(int32_t) + 16 * 256 * sizeof(long long) + 8 * 256 * sizeof(uint32_t) + 16;
+    if (zfilt_own) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn_gz, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_gz)));
     const size_t lds_own = form_f ? 2 * static_cast<size_t>(4 * (MF_NS / 2) * MF_SS) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t)
                                   : 2 * static_cast<size_t>(4 * 32 * (MF_NS / 2) * 32) + MF_F_MAXBLK * sizeof(int32_t) + 32 * 256 * sizeof(int32_t) + 8 * 256 * sizeof(uint32_t) + 16;
     const uint4 *bits_own = form_f ? nbr->bs_bits4 : nbr->bs_bits4p;
@@ -2965,7 +3370,13 @@ static int launch_mfma_run(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_p
 #endif
             }
             const unsigned char *bs_main = any_filt ? d_bs_hi : d_bs;
-            if (filt_own) {
+            if (zfilt_own) {
+                const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
+                void *args[] = {(void *)&bs_main, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
+                                (void *)&nbr->bs_kb, (void *)&nbr->bs_bits4p, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c,
+                                (void *)&mloc, (void *)&d_counts, (void *)&n_padr, (void *)&nbr->bs_rowmap, (void *)&d_scale, (void *)&fa};
+                SAFE_HIP_CHECK(hipLaunchKernel(kfn_gz, dim3(blocks_own), dim3(256), args, lds_gz, ks));
+            } else if (filt_own) {
                 const int64_t blocks_own = std::min<int64_t>(static_cast<int64_t>(tasks.size()), 2 * static_cast<int64_t>(ctx->num_cu));
                 void *args[] = {(void *)&bs_main, (void *)&tile_bytes, (void *)&src_c, (void *)&n_src, (void *)&n_q, (void *)&nbr->bs_ptr,
                                 (void *)&nbr->bs_kb, (void *)&bits_own, (void *)&nbr->bs_grpmax, (void *)&d_tasks, (void *)&d_qoff, (void *)&qctr_c,

@@ -527,9 +527,14 @@ def test_filtered_form_fall_back_inside_compute_pvalues_counts_enriched_neighbor
 # ---------------------------------------------------------------------------------------------------------------------
 # z-scores, filtered: 4 of the 7 slices on the matrix cores
 # ---------------------------------------------------------------------------------------------------------------------
+@pytest.mark.parametrize('form', ['', 'gz64', 'general'])
 @pytest.mark.parametrize('kind', ['normal', 'dyadic'])
-def test_zscore_filtered_form_equals_the_seven_slice_form_and_the_oracle(amd, ctx, monkeypatch, kind):
+def test_zscore_filtered_form_equals_the_seven_slice_form_and_the_oracle(amd, ctx, monkeypatch, kind, form):
+    """form: '' = k_permtest_mfma_gz with the single-precision decision (the default), 'gz64' = the same kernel with the f64
+    decision, 'general' = the general kernel's filtered form -- all three leave the seven-slice kernel's counters."""
     from safepy_amd import backend as be
+    if form:
+        monkeypatch.setenv('SAFE_HIP_MFMA_FORM', form)
     rng = np.random.default_rng(41)
     n, m, nperm, seed = 800, 29, 90, 2
     xy = rng.uniform(size=(n, 2))

@@ -50,5 +50,6 @@ else:
         dt = time.perf_counter() - t
         perms.close()
         name, kms, kl = ctx.last_kernel()
-        print('%s %s: call %.1f ms, kernel %.2f ms x %d -> %.3g enrichments/s (n=%d m=%d P=%d); config-5 rank share (6250 x 1000) ~ %.1f s'
-              % (score, name, 1e3 * dt, kms, kl, n * m * P / dt, n, m, P, dt * (6250 / m) * (1000 / P)))
+        core, undecided = be.last_mfma_filter(ctx)
+        print('%s %s: call %.1f ms, kernel %.2f ms x %d -> %.3g enrichments/s (n=%d m=%d P=%d); config-5 rank share (6250 x 1000) ~ %.2f s; %d slices on the matrix cores, %d compares (%.2e) settled exactly'
+              % (score, name, 1e3 * dt, kms, kl, n * m * P / dt, n, m, P, dt * (6250 / m) * (1000 / P), core, undecided, undecided / (float(n) * m * P)))

@@ -18,7 +18,7 @@ if [ -f safepy_amd/libsafe_hip_diag.so ]; then
   for spec in ${2:-g:0 g:1024 g:2 g:8 g:64 g:4 g:512}; do
     form=${spec%%:*}; dbg=${spec##*:}
     echo "== DIAG form=$form dbg=$dbg" >> $S
-    SAFE_HIP_MFMA_FORM=$form SAFE_HIP_MFMA_DBG=$dbg timeout 300 python tools/bench_big.py quant 2048 200 2>&1 | grep -v "^define\|DIAGNOSTIC\|diagnostic\|amdgpu.ids" | tail -5 | grep -v "call 1[0-9][0-9]\.\|call [6-9][0-9]\." >> $S
+    SAFE_HIP_MFMA_FORM=$form SAFE_HIP_MFMA_DBG=$dbg timeout 300 python tools/bench_big.py quant 2048 200 ${5:-sum} 2>&1 | grep -v "^define\|DIAGNOSTIC\|diagnostic\|amdgpu.ids" | tail -5 | grep -v "call 1[0-9][0-9]\.\|call [6-9][0-9]\." >> $S
   done
   cp /tmp/keep.so safepy_amd/libsafe_hip.so
 fi
