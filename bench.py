@@ -427,6 +427,9 @@ def dropin_extras(np, torch):
     b = (np.random.default_rng(5).uniform(size=(n, m)) < 0.01).astype(np.float32)
     notebook_flow('configs3', safepy_amd.LayoutGraph(workloads.uniform_layout(4, n)), 'euclidean', b, {})
     measure('configs3_hypergeometric', safepy_amd.LayoutGraph(workloads.uniform_layout(4, n)), 'euclidean', b, {}, 3)
+    # the same 0/1 matrix handed over as uint8 (additive: SAFE_DTYPE_U8): a quarter of the bytes over the link, identical results
+    # (tests/test_gpu_u8.py); the f32 figure above stays the reference-layout one (safe_io.py:361 loads float32)
+    measure('configs3_hypergeometric_uint8_matrix', safepy_amd.LayoutGraph(workloads.uniform_layout(4, n)), 'euclidean', b.astype(np.uint8), {}, 3)
     return out
 
 
@@ -566,6 +569,60 @@ def mfma_kernel(ctx, np, be):
         o.free()
     attr.close()
     nbr.close()
+    return out
+
+
+def off_fast_path(ctx, np, be, headline):
+    """Binary randomization on the shapes that fall off the blocked bit-sliced kernel (its word column must fit LDS: 8 (N + 1) <
+    65536, N <= 8190; neighborhoods below 1024 members) -- the reference has no such cliff (safe_extras.py:56-66 is one dgemm at
+    any N).  Outside the timed region; unseeded tables (generated on the device), so the figures are the kernels':
+      * N = 8300, the configs[1] surrogate's recipe at that size (k_permtest_bits, word column read from L2)
+      * configs[3]'s network: N = 20 000 uniform layout, euclidean r = 0.1, 577 members on average (matrix cores, 0/1 planes)
+    each x 1000 permutations; cost per member-word = time / (membership entries x 64-attribute words x permutations), beside the
+    headline kernel's (`headline`: kernel busy ms, nnz, words)."""
+    import safepy_amd
+    from safepy_amd import workloads
+    out = {}
+    cases = []
+    d = workloads.costanzo_surrogate(seed=1, n=8300, m=2048, target_edges=int(28202 * 8300 / 3971), n_nan_rows=int(182 * 8300 / 3971))
+    sf = safepy_amd.SAFE(verbose=False)
+    sf.graph = safepy_amd.LayoutGraph(d['xy'], d['edge_u'], d['edge_v'], length=d['length'])
+    sf.define_neighborhoods()
+    cases.append(('N=8300 x M=2048 binary, shortpath_weighted_layout r=0.1 (the surrogate recipe)', sf._nbr, d['attributes'], sf))
+    xy = workloads.uniform_layout(4, 20000)
+    nbr20 = be.Neighborhoods.euclidean(ctx, xy, 0.1 * (xy[:, 0].max() - xy[:, 0].min()))
+    rng = np.random.default_rng(5)
+    cases.append(('configs[3] network: N=20000 euclidean r=0.1 x M=2048 binary (density 1 %)', nbr20,
+                  np.asfortranarray((rng.uniform(size=(20000, 2048)) < 0.01).astype(np.float32)), None))
+    nperm = 1000
+    for what, nbr, b, keep in cases:
+        n, m = b.shape
+        attr = be.Attributes.from_host(ctx, b)
+        outs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
+        best = None
+        for _ in range(3):
+            perms = be.Permutations(ctx, n, attr.row_flags(), nperm, None)
+            ctx.sync()
+            t0 = time.perf_counter()
+            be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [o.ptr for o in outs])
+            ctx.sync()
+            dt = time.perf_counter() - t0
+            perms.close()
+            name, ms, launches = ctx.last_kernel()
+            if best is None or dt < best[0]:
+                best = (dt, name, ms * launches)
+        dt, name, kms = best
+        words = (m + 63) // 64
+        out[what] = {'kernel': name, 'call_ms': 1e3 * dt, 'kernel_ms_sum': kms, 'enrichments_per_s': float(n) * m * nperm / dt,
+                     'membership_nnz': int(nbr.nnz), 'members_mean': nbr.nnz / float(n),
+                     'ps_per_member_word_permutation': 1e12 * dt / (float(nbr.nnz) * words * nperm)}
+        for o in outs:
+            o.free()
+        attr.close()
+        if keep is None:
+            nbr.close()
+    out['headline_for_comparison'] = {'kernel': 'k_permtest_bits_blk', 'kernel_busy_ms': headline['busy_ms'],
+                                      'ps_per_member_word_permutation': 1e12 * 1e-3 * headline['busy_ms'] / (float(headline['nnz']) * headline['words'] * headline['perms'])}
     return out
 
 
@@ -1109,6 +1166,8 @@ def main():
             line['mfma_bound_kernels'] = mfma_kernel(ctx, np, be)
             line['dropin_compute_pvalues'] = dropin_extras(np, torch)
             line['example3_published_shape'] = example3_extra(np, args.cpu_perms > 0)
+            line['off_fast_path_shapes'] = off_fast_path(ctx, np, be, {'busy_ms': roof.get('kernel_busy_ms_per_step') or 0.0, 'nnz': line['config']['membership_nnz'],
+                                                                         'words': (line['config']['attributes_per_gpu'] + 63) // 64, 'perms': line['config']['permutations']})
     # RCCL prints a version banner through C stdio (flushed at exit when stdout is a pipe): tear the group down and flush every
     # rank's C buffers first, so that rank 0's JSON line is the LAST line of the job's output
     if dist is not None:
