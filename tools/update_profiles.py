@@ -163,7 +163,9 @@ for key, sub in (('mfma_pipe_busy_sum', 'mfma_sum'), ('mfma_pipe_busy_zscore', '
     c = counters(path)
     # the kernel that carries the permutations: the filtered form's own kernel ('sum'), the four-slice z form; before round 5
     # (or with SAFE_HIP_MFMA_FILTER=0) the six- / seven-slice general kernel
-    want = [s for s in (('k_permtest_mfma_f', 'k_permtest_mfma<false, 6') if sub == 'mfma_sum' else ('k_permtest_mfma<false, 4, true', 'k_permtest_mfma<false, 7'))
+    # (round 6: k_permtest_mfma_g<...> / k_permtest_mfma_gz<...>; the older names are kept for libraries run with SAFE_HIP_MFMA_FORM)
+    want = [s for s in (('k_permtest_mfma_g<', 'k_permtest_mfma_f', 'k_permtest_mfma<false, 6') if sub == 'mfma_sum'
+                        else ('k_permtest_mfma_gz<', 'k_permtest_mfma<false, 4, true', 'k_permtest_mfma<false, 7'))
             if get(c, s, 'SQ_VALU_MFMA_BUSY_CYCLES')]
     kern = want[0] if want else 'k_permtest_mfma'
     busy, gui, n_mfma = get(c, kern, 'SQ_VALU_MFMA_BUSY_CYCLES'), get(c, kern, 'GRBM_GUI_ACTIVE'), get(c, kern, 'SQ_INSTS_MFMA')
