@@ -2643,7 +2643,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // launches follow the stream's stages, one launch per stage (a launch over m stages after the start-up has fewer tails and
     // less per-task fixed cost -- kernel time per 1000 permutations 4.06 -> 3.94 / 3.89 ms at m = 2 / 3 in round 3 -- but the
     // step gets LONGER, 5.2 -> 5.5 / 5.8 ms: a merged launch waits for its last stage's draws)
-    const int merge = 1;
+    const int merge = 1;                               // (round 6, kernel-bound step: 2 / 3 stages per launch 3.13 -> 3.33-3.42 / 3.65 ms, kernels busy 2.54 -> 2.8)
     const std::vector<int64_t> starts = perm_launch_starts(perms, &span, merge);
     // Exchange overlap of the sharded step (safe_set_exchange_chunks): the LAST permutations -- the tail -- run as one launch per
     // COLUMN chunk over all of the tail instead of one launch per stage over all columns.  A chunk's counters are then final when

@@ -101,6 +101,14 @@ class _DeviceResult:
         self.buf.free()
 
 
+def _local_only_refcount():
+    probe = np.empty(1)
+    return sys.getrefcount(probe)
+
+
+_LOCAL_ONLY_REFCOUNT = _local_only_refcount()
+
+
 class _LazyArray:
     """Descriptor behind SAFE.ns / pvalues_neg / pvalues_pos / nes / nes_binary.  To the caller these
     are plain attributes holding host `float64 [N, M]` arrays (or None) exactly as in the reference
@@ -127,9 +135,10 @@ class _LazyArray:
         v = d.get(self.slot)
         if isinstance(v, _DeviceResult):
             into = d.pop(self.spare, None)
-            # (local name + getrefcount's argument = 2: no reference outside this function)
+            # (no reference outside this function: the count a fresh local array shows on THIS interpreter, measured once --
+            # 2 on CPython 3.10 (local name + getrefcount's argument), possibly 1 where references are borrowed)
             if not (isinstance(into, np.ndarray) and into.shape == tuple(v.shape) and into.dtype == np.float64
-                    and into.flags.c_contiguous and into.flags.owndata and sys.getrefcount(into) == 2):
+                    and into.flags.c_contiguous and into.flags.owndata and sys.getrefcount(into) == _LOCAL_ONLY_REFCOUNT):
                 into = None
             v = v.get(into)
             del into
