@@ -28,11 +28,15 @@ def test_library_exports_every_declared_symbol():
     assert _lib.lib.safe_abi_version() == _lib.ABI_VERSION
 
 
-def test_host_only_rng_stream_matches_numpy(golden_rng):
+@pytest.mark.parametrize('path', ['', 'scalar'])
+def test_host_only_rng_stream_matches_numpy(golden_rng, monkeypatch, path):
     """safe_rng_permutations_host needs no device: pin it to the reference's RNG known answers
     (tests/golden/rng_kat.npz, drawn through the reference's np.random calls) and to NumPy's
-    legacy stream at sizes that exercise both the vector and the scalar rejection paths."""
+    legacy stream at sizes that exercise both the vector and the scalar rejection paths.
+    path = 'scalar': SAFE_HIP_DRAW_PATH=scalar, the chain of a host without AVX-512 (read when a stream is created)."""
     from safepy_amd.backend import rng_permutations_host
+    if path:
+        monkeypatch.setenv('SAFE_HIP_DRAW_PATH', path)
     sizes = (1, 2, 10, 257, 3971)
     for seed in (0, 42, 12345, 4294967295):
         # the fixture's stream: for each size two consecutive draws, sizes in this order, ONE stream per seed
