@@ -284,7 +284,11 @@ std::vector<int64_t> perms_stage_plan(int64_t count) {
     // the tail: ... | <= 96 | 32.  (Round 6, on a box whose chain was slowed to 5 us per permutation so that the stages behind the last
     // draw are what is measured: ... | <= 112 | 32 | 16 made the step LONGER, 5.73-5.86 -> 5.91-5.94 ms -- a launch costs ~150 us
     // plus 2 us per permutation whatever its size (its heaviest slice group's tasks are its critical path), so more and
-    // shorter stages behind the last draw add more than they take away; a short tail joined to its predecessor was no better.)
+    // shorter stages behind the last draw add more than they take away; a short tail joined to its predecessor was no better.
+    // With the chain paced to 2.55 us per permutation -- the driver's box of round 5: step 3.55 ms = chain + 1.0, kernels busy 2.93 --
+    // tails of 64 | 64 | 40, 64 | 48 | 32 | 24 and 64-permutation stages over the last 300 permutations measured 3.60 / 3.76 / 3.67 ms
+    // (fast chain: 3.12 -> 3.19 / 3.40 / 3.32), and finer tasks (8 or 4 permutations at least) 3.57 / 3.76: at that chain rate the
+    // kernels' 2.5 ms of work and the chain's 2.55 ms are both critical, and only less kernel work would shorten the step.)
     if (count - last > 48 && count > kChunk) b.push_back(count - 32);
     b.push_back(count);
     // every per-stage buffer (pinned staging, ring slot, row maps, targets) holds kChunk permutations: whatever SAFE_HIP_STAGES
