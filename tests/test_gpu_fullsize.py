@@ -190,6 +190,57 @@ def test_config5_shape_quantitative_permutation_test_sampled_rows():
     nbr.close()
 
 
+def test_config5_shape_zscore_permutation_test_sampled_rows():
+    """The same shape with neighborhood_score_type='z-score' (safe_extras.py:19-31): the filtered z-score kernel of round 6
+    (k_permtest_mfma_gz: four of seven slices on the matrix cores, single-precision decision, the rest settled exactly by
+    k_mfma_resolve_z) at configs[4]'s network.  Sampled neighborhoods against the oracle's score function applied to the
+    matrices permuted with the device's own tables: observed z-scores to 1e-9, every <= / >= count identical wherever the
+    compare is not decided by the f64 rounding of a 600-term sum; NaN scores compare false on both sides."""
+    import safepy_amd
+    from safepy_amd import backend as be, workloads
+    ctx = safepy_amd.Context.default(0)
+    n, m, nperm, seed = 20000, 80, 30, 11
+    xy = workloads.uniform_layout(4, n)
+    b = workloads.quantitative_attributes(9, n, m)
+    nr = 0.1 * (xy[:, 0].max() - xy[:, 0].min())
+    nbr = be.Neighborhoods.euclidean(ctx, xy, nr)
+    attr = be.Attributes.from_host(ctx, b)
+    flags = attr.row_flags()
+    perms = be.Permutations(ctx, n, flags, nperm, seed)
+    ns, neg, pos = (ctx.alloc_f64(n, m) for _ in range(3))
+    be.permtest_counts(ctx, nbr, attr, perms, 'z-score', ns.ptr, neg.ptr, pos.ptr)
+    assert ctx.last_kernel()[0] == 'k_permtest_mfma'
+    core, undecided = be.last_mfma_filter(ctx)
+    assert core == 4 and undecided >= 0                          # the filtered form ran to the end
+    ns, neg, pos = ns.download((n, m)), neg.download((n, m)), pos.download((n, m))
+    table = perms.read()
+    rng = np.random.default_rng(1)
+    rows = rng.choice(n, 20, replace=False)
+    rp, col = nbr.csr()
+    a_rows = np.zeros((len(rows), n), dtype=np.int64)
+    for k, i in enumerate(rows):
+        a_rows[k, col[rp[i]:rp[i + 1]]] = 1
+    with np.errstate(invalid='ignore', divide='ignore'):
+        obs = orc.compute_neighborhood_score(a_rows, b, 'z-score')
+        np.testing.assert_allclose(ns[rows], obs, rtol=1e-9, atol=1e-9, equal_nan=True)
+        le = np.zeros_like(obs)
+        ge = np.zeros_like(obs)
+        unclear = np.zeros_like(obs)
+        for p_ in range(nperm):
+            z = orc.compute_neighborhood_score(a_rows, b[table[p_]], 'z-score')
+            clear = ~(np.abs(z - obs) <= 1e-9 * np.maximum(1.0, np.abs(obs)))        # (NaN on either side: clear, and false both ways)
+            le += (z <= obs) & clear
+            ge += (z >= obs) & clear
+            unclear += ~clear
+    assert unclear.mean() < 1e-3
+    assert np.all(np.abs(neg[rows] - le) <= unclear) and np.all(np.abs(pos[rows] - ge) <= unclear)
+    ok = unclear == 0
+    assert np.array_equal(neg[rows][ok], le[ok]) and np.array_equal(pos[rows][ok], ge[ok])
+    perms.close()
+    attr.close()
+    nbr.close()
+
+
 @pytest.mark.parametrize('n,expect', [(8300, 'k_permtest_bits'), (20000, 'k_permtest_mfma')])
 def test_binary_randomization_beyond_the_16_bit_address_range(n, expect):
     """0/1 attributes under how='randomization' on networks too large for the blocked bit-sliced kernel (member ids as
