@@ -1058,10 +1058,10 @@ def test_fdr_row_lengths_lds_equals_library_sort(amd, ctx, monkeypatch, m):
     assert np.array_equal(got['cub'], want, equal_nan=True)
 
 
-def test_numa_pinning_and_paired_draw_threads(amd, ctx, monkeypatch):
-    """Launcher helpers: pin_threads_to_device_numa keeps the process on CPUs it was allowed before (or changes
-    nothing), and the permutation stream is still NumPy's with the draw thread and its helper pinned to one
-    core's SMT pair (SAFE_HIP_DRAW_PAIR=1)."""
+def test_numa_pinning_keeps_the_permutation_stream(amd, ctx):
+    """Launcher helper: pin_threads_to_device_numa keeps the process on CPUs it was allowed before (or changes
+    nothing), and the permutation stream of a handle made afterwards (its draw thread inherits the mask) is
+    still NumPy's."""
     import os
     from safepy_amd import backend as be
     before = os.sched_getaffinity(0)
@@ -1069,7 +1069,6 @@ def test_numa_pinning_and_paired_draw_threads(amd, ctx, monkeypatch):
     after = os.sched_getaffinity(0)
     assert after <= before and len(after) >= 1
     assert node is None or (isinstance(node, int) and node >= 0 and after != set())
-    monkeypatch.setenv('SAFE_HIP_DRAW_PAIR', '1')
     n, nperm, seed = 777, 300, 12345
     flags = np.ones(n, dtype=np.uint8)
     flags[::7] = 0
