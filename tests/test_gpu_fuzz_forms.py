@@ -1,6 +1,8 @@
-"""A short run of tools/r6/fuzz_forms.py: random layouts, radii, data kinds, sizes, permutation counts and seeds; the counters
+"""Short runs of tools/r6/fuzz_forms.py and tools/r6/fuzz_binary.py.  fuzz_forms: random layouts, radii, data kinds, sizes, permutation counts and seeds; the counters
 of the default matrix-core kernels (filtered: high slices + exact resolve) must equal the general kernel's with ALL slices, and
-the f64 kernels' wherever the data is exact on both grids.  (The long run -- 4000 cases, 7 minutes -- is the tool itself.)"""
+the f64 kernels' wherever the data is exact on both grids.  fuzz_binary: 0/1 attributes, every kernel family (blocked / pre-permuted /
+LDS-row / stream-less bit-sliced, scatter, f64 gather) against the default.  (The long runs -- 4000 and 490 cases, 6-7 minutes each,
+0 failures at the end of round 6 -- are the tools themselves.)"""
 import importlib.util
 import os
 
@@ -11,15 +13,31 @@ pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
-def test_random_cases_every_form_leaves_the_same_counters(monkeypatch):
+def _tool(name):
+    import sys
     import safepy_amd
     assert safepy_amd.device_count() >= 1, 'no HIP device: the GPU tests must run on the MI355X box'
-    spec = importlib.util.spec_from_file_location('fuzz_forms', os.path.join(ROOT, 'tools', 'r6', 'fuzz_forms.py'))
-    fuzz = importlib.util.module_from_spec(spec)
-    spec.loader.exec_module(fuzz)
+    sys.path.insert(0, os.path.join(ROOT, 'tools', 'r6'))
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, 'tools', 'r6', name + '.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+def test_random_cases_every_form_leaves_the_same_counters(monkeypatch):
+    fuzz = _tool('fuzz_forms')
     monkeypatch.setenv('SAFE_HIP_NARROW_LDS', '0')          # run() sets it again; monkeypatch restores the caller's value afterwards
     cases, fails, _, used = fuzz.run(budget=120.0, first=20000, max_cases=250)
     assert cases >= 50 and fails == 0
     names = {k[0] for k in used}
     cores = {k[1] for k in used if k[0] == 'k_permtest_mfma'}
     assert 'k_permtest_mfma' in names and {3, 4} <= cores, used     # both filtered kernels were among the forms exercised
+
+
+def test_random_binary_cases_every_kernel_family_leaves_the_same_counters(monkeypatch):
+    fuzz = _tool('fuzz_binary')
+    monkeypatch.setenv('SAFE_HIP_NARROW_LDS', '0')
+    cases, fails, used = fuzz.run(budget=90.0, first=70000, max_cases=70)
+    assert cases >= 20 and fails == 0
+    ran = {k[1] for k in used}
+    assert {'k_permtest_bits_blk', 'k_permtest_bits_pre', 'k_permtest_bits', 'k_permtest_scatter'} <= ran, used
