@@ -7,7 +7,7 @@ into a neighborhood (tiny networks: 3 members of 20 nodes, 257 permutations) tie
 `<=` / `>=` is decided by the order its BLAS adds them -- a counter may differ from the oracle's by at most the
 number of such permutations of that neighborhood, which the test counts from the oracle's own index table.
 
-SAFE_FUZZ_SECONDS (default 60) bounds the run; SAFE_FUZZ_FIRST names the first case (cases are seeded by their number)."""
+SAFE_FUZZ_SECONDS (default 40) bounds the run; SAFE_FUZZ_FIRST names the first case (cases are seeded by their number)."""
 import os
 import time
 
@@ -94,7 +94,7 @@ def _counts_equal_up_to_ties(got, want, nperm, a, b, kw, seed, kind, tag):
 def test_random_whole_calls_against_the_oracle():
     import safepy_amd as amd
     assert amd.device_count() >= 1, 'no HIP device: the GPU tests must run on the MI355X box'
-    budget = float(os.environ.get('SAFE_FUZZ_SECONDS', '60'))
+    budget = float(os.environ.get('SAFE_FUZZ_SECONDS', '40'))
     first = int(os.environ.get('SAFE_FUZZ_FIRST', '0'))
     t0, case, seen, licensed = time.time(), first, set(), 0
     while time.time() - t0 < budget:

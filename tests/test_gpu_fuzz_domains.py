@@ -3,7 +3,7 @@ of the enriched nodes of every attribute (sizes against networkx through the ora
 its component) and condensed Jaccard distances between the attributes' enrichment columns (bit-identical to SciPy's pdist,
 NaN for two empty columns included).
 
-SAFE_FUZZ_SECONDS (default 30) bounds the run; SAFE_FUZZ_FIRST names the first case."""
+SAFE_FUZZ_SECONDS (default 15) bounds the run; SAFE_FUZZ_FIRST names the first case."""
 import os
 import time
 
@@ -21,7 +21,7 @@ def test_random_components_and_jaccard_against_the_oracle():
     from safepy_amd import backend as be
     assert amd.device_count() >= 1, 'no HIP device: the GPU tests must run on the MI355X box'
     ctx = amd.Context.default(0)
-    budget = float(os.environ.get('SAFE_FUZZ_SECONDS', '30'))
+    budget = float(os.environ.get('SAFE_FUZZ_SECONDS', '15'))
     first = int(os.environ.get('SAFE_FUZZ_FIRST', '0'))
     t0, case = time.time(), first
     while time.time() - t0 < budget:

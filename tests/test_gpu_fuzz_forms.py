@@ -37,7 +37,7 @@ def test_random_cases_every_form_leaves_the_same_counters(monkeypatch):
 def test_random_binary_cases_every_kernel_family_leaves_the_same_counters(monkeypatch):
     fuzz = _tool('fuzz_binary')
     monkeypatch.setenv('SAFE_HIP_NARROW_LDS', '0')
-    cases, fails, used = fuzz.run(budget=90.0, first=70000, max_cases=70)
+    cases, fails, used = fuzz.run(budget=60.0, first=70000, max_cases=40)
     assert cases >= 20 and fails == 0
     ran = {k[1] for k in used}
     assert {'k_permtest_bits_blk', 'k_permtest_bits_pre', 'k_permtest_bits', 'k_permtest_scatter'} <= ran, used

@@ -3,7 +3,7 @@ coincident points and pairs EXACTLY at the threshold, bounded shortest paths on 
 nodes, self loops, zero-length edges, integer / dyadic weights with many equal-length paths, random real weights), unweighted
 hop counts.  Memberships and path lengths are compared bit for bit.
 
-SAFE_FUZZ_SECONDS (default 40) bounds the run; SAFE_FUZZ_FIRST names the first case."""
+SAFE_FUZZ_SECONDS (default 20) bounds the run; SAFE_FUZZ_FIRST names the first case."""
 import os
 import time
 
@@ -55,7 +55,7 @@ def test_random_neighborhood_definitions_against_the_oracle():
     import safepy_amd as amd
     assert amd.device_count() >= 1, 'no HIP device: the GPU tests must run on the MI355X box'
     ctx = amd.Context.default(0)
-    budget = float(os.environ.get('SAFE_FUZZ_SECONDS', '40'))
+    budget = float(os.environ.get('SAFE_FUZZ_SECONDS', '20'))
     first = int(os.environ.get('SAFE_FUZZ_FIRST', '0'))
     t0, case, seen = time.time(), first, {}
     while time.time() - t0 < budget:
