@@ -573,13 +573,14 @@ def mfma_kernel(ctx, np, be):
 
 
 def off_fast_path(ctx, np, be, headline):
-    """Binary randomization on the shapes that fall off the blocked bit-sliced kernel (its word column must fit LDS: 8 (N + 1) <
-    65536, N <= 8190; neighborhoods below 1024 members) -- the reference has no such cliff (safe_extras.py:56-66 is one dgemm at
-    any N).  Outside the timed region; unseeded tables (generated on the device), so the figures are the kernels':
-      * N = 8300, the configs[1] surrogate's recipe at that size (k_permtest_bits, word column read from L2)
-      * configs[3]'s network: N = 20 000 uniform layout, euclidean r = 0.1, 577 members on average (matrix cores, 0/1 planes)
-    each x 1000 permutations; cost per member-word = time / (membership entries x 64-attribute words x permutations), beside the
-    headline kernel's (`headline`: kernel busy ms, nnz, words)."""
+    """Binary randomization on the shapes beyond the blocked bit-sliced kernel (its 16-bit LDS offsets: 8 (N + 1) < 65536,
+    N <= 8190) -- the reference has no such cliff (safe_extras.py:56-66 is one dgemm at any N).  Outside the timed region;
+    unseeded tables (generated on the device), so the figures are the kernels':
+      * N = 8300, the configs[1] surrogate's recipe at that size
+      * configs[3]'s network: N = 20 000 uniform layout, euclidean r = 0.1, 577 members on average
+    each x 1000 permutations (since round 6 both run k_permtest_bits_pre with sixteen-wave workgroups; round 5: k_permtest_bits
+    with one wave per SIMD and the two-slice matrix-core form); cost per member-word = time / (membership entries x 64-attribute
+    words x permutations), beside the headline kernel's (`headline`: kernel busy ms, nnz, words)."""
     import safepy_amd
     from safepy_amd import workloads
     out = {}

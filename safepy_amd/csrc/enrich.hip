@@ -599,18 +599,19 @@ __device__ __forceinline__ void vflush(uint32_t (&c)[CL], uint32_t &pend) {
 // A workgroup's copy of one word column into LDS: T[r] = src[r], r = 0 .. n.  Sixteen loads per thread are in flight before the
 // first LDS store (the plain loop compiled to load - wait - store per 256 rows: 16 L2 latencies in a row at N = 3971, 12-16 us
 // of every task, all four waves waiting at the barrier behind it).
+template <int NT = 256>
 __device__ __forceinline__ void load_word_column(uint2 *__restrict__ T, const uint2 *__restrict__ src, int64_t n) {
-    constexpr int UNL = 16;
-    for (int64_t r0 = threadIdx.x; r0 <= n; r0 += 256 * UNL) {
+    constexpr int UNL = NT > 256 ? 4 : 16;
+    for (int64_t r0 = threadIdx.x; r0 <= n; r0 += NT * UNL) {
         uint2 v[UNL];
 #pragma unroll
         for (int u = 0; u < UNL; ++u) {
-            const int64_t r = r0 + u * 256;
+            const int64_t r = r0 + u * NT;
             v[u] = src[r <= n ? r : n];
         }
 #pragma unroll
         for (int u = 0; u < UNL; ++u) {
-            const int64_t r = r0 + u * 256;
+            const int64_t r = r0 + u * NT;
             if (r <= n) T[r] = v[u];
         }
     }
@@ -642,8 +643,11 @@ __device__ __forceinline__ void transpose32(uint32_t (&a)[32]) {
     }
 }
 
-template <int CL, bool SCALED>
-__global__ __launch_bounds__(256) void k_permtest_bits(
+// WV = waves (= adjacent slices of a task) per workgroup.  4 is the form of the small networks; 16 (round 6) is for networks whose
+// word column + permutation rows leave room for ONE workgroup per CU (N > 8190: 12 bytes per node): the sixteen waves share that
+// one copy and the SIMDs keep four waves each, where four-wave workgroups ran one wave per SIMD.
+template <int CL, bool SCALED, int WV = 4>
+__global__ __launch_bounds__(64 * WV) void k_permtest_bits(
     int64_t n, int64_t n_perm, const uint16_t *__restrict__ cur16, int64_t stride16,
     const int32_t *__restrict__ sell_row, const int64_t *__restrict__ slice_off,
     const int32_t *__restrict__ slice_width, const uint16_t *__restrict__ sell_col2, int64_t n_slices,
@@ -662,6 +666,7 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
     const uint32_t t_addr2 = t_addr | (t_addr << 16);                    // both u16 halves
     const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
     const int vec_per_row = static_cast<int>(stride16 / 8);              // uint4 (8 x u16) per table row
+    constexpr int NT = 64 * WV;
 
     // a table row (8 x u16 per vector) scaled to T byte offsets
     auto scale_row = [=](uint4 v) {
@@ -687,13 +692,13 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
-        load_word_column(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
+        load_word_column<NT>(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
         if (p_end > p_begin)
-            for (int v = threadIdx.x; v < vec_per_row; v += 256)
+            for (int v = threadIdx.x; v < vec_per_row; v += NT)
                 reinterpret_cast<uint4_alias *>(CUR)[v] =
                     scale_row(reinterpret_cast<const uint4_alias *>(cur16 + p_begin * stride16)[v]);
 
-        const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
+        const int64_t s = static_cast<int64_t>(sg) * WV + wave;
         const bool active = s < n_slices;
         const int32_t row = active ? sell_row[s * 64 + lane] : -1;
         const uint16_t *cols2 = sell_col2 + (active ? slice_off[s] : 0) + lane;
@@ -745,8 +750,8 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
                 vflush<CL>(l1, lp1);
             }
 
-            if (vec_per_row > 256) {                                     // rows longer than 256 vectors: strided copy
-                for (int v = threadIdx.x + 256; v < vec_per_row; v += 256)
+            if (vec_per_row > NT) {                                      // rows longer than one vector per thread: strided copy
+                for (int v = threadIdx.x + NT; v < vec_per_row; v += NT)
                     if (p + 1 < p_end)
                         reinterpret_cast<uint4_alias *>(CUR + ((rel + 1) & 1) * stride16)[v] =
                             scale_row(reinterpret_cast<const uint4_alias *>(cur16 + (p + 1) * stride16)[v]);
@@ -805,7 +810,9 @@ __global__ __launch_bounds__(256) void k_permtest_bits(
 __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict__ cur16, int64_t stride16,
                                                       const uint16_t *__restrict__ sell_col2, int64_t entries,
                                                       int64_t entries_pad, int64_t p0, int64_t count, uint32_t pad_off,
-                                                      uint16_t *__restrict__ out, int diag_banks = 0) {
+                                                      uint16_t *__restrict__ out, int diag_banks = 0, int sh = 3) {
+    // sh: ids are written as id << sh -- 3: the LDS byte offset of the member's word pair (8 (N + 1) < 65536); 1: 2 * id for the
+    // larger networks of k_permtest_bits_pre<.., 16, 2>, whose byte offsets do not fit 16 bits (the kernel shifts once more)
     // one permutation row (<= 16 KB) staged in LDS per block, 4096 member entries per block: the
     // random 2-byte reads hit LDS instead of L2 sectors
     extern __shared__ uint16_t row[];
@@ -834,14 +841,14 @@ __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict
                 a0 = fix(a0), a1 = fix(a1), a2 = fix(a2), a3 = fix(a3);
                 a4 = fix(a4), a5 = fix(a5), a6 = fix(a6), a7 = fix(a7);
             }
-            o.x = (a0 << 3) | (a1 << 19);
-            o.y = (a2 << 3) | (a3 << 19);
-            o.z = (a4 << 3) | (a5 << 19);
-            o.w = (a6 << 3) | (a7 << 19);
+            o.x = (a0 << sh) | (a1 << (16 + sh));
+            o.y = (a2 << sh) | (a3 << (16 + sh));
+            o.z = (a4 << sh) | (a5 << (16 + sh));
+            o.w = (a6 << sh) | (a7 << (16 + sh));
         } else {
             uint32_t v[8];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) v[u] = e + u < entries ? static_cast<uint32_t>(row[sell_col2[e + u] >> 1]) << 3 : pad_off;
+            for (int u = 0; u < 8; ++u) v[u] = e + u < entries ? static_cast<uint32_t>(row[sell_col2[e + u] >> 1]) << sh : pad_off;
             o.x = (v[0] & 0xFFFFu) | (v[1] << 16);
             o.y = (v[2] & 0xFFFFu) | (v[3] << 16);
             o.z = (v[4] & 0xFFFFu) | (v[5] << 16);
@@ -884,8 +891,11 @@ __device__ __forceinline__ void bits_accumulate_ids(const uint16_t *__restrict__
     }
 }
 
-template <int CL>
-__global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
+// WV = 16, PSHIFT = 2 (round 6): networks of 8191 .. 20 470 nodes -- T alone (8 bytes per node) fills most of a CU's LDS, so ONE
+// workgroup of sixteen waves shares it (four waves per SIMD as in the small form), and the permuted lists hold 2 * id (the byte
+// offset 8 * id no longer fits 16 bits; the shift that is left costs one operation per member).
+template <int CL, int WV = 4, int PSHIFT = 0>
+__global__ __launch_bounds__(64 * WV, WV == 4 ? (CL <= 8 ? 4 : 3) : 1) void k_permtest_bits_pre(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
     const uint16_t *__restrict__ sell_col2, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
@@ -910,8 +920,8 @@ __global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
         const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
         if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
 
-        load_word_column(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
-        const int64_t s = static_cast<int64_t>(sg) * 4 + wave;
+        load_word_column<64 * WV>(T, bbits + static_cast<int64_t>(wg) * (n + 1), n);
+        const int64_t s = static_cast<int64_t>(sg) * WV + wave;
         const bool active = s < n_slices;
         const int32_t row = active ? sell_row[s * 64 + lane] : -1;
         const int64_t my_off = (active ? slice_off[s] : 0) + lane;
@@ -928,7 +938,7 @@ __global__ __launch_bounds__(256, CL <= 8 ? 4 : 3) void k_permtest_bits_pre(
 
         for (int64_t p = p_begin; p < p_end; ++p) {
             uint32_t s0[BT_LV], s1[BT_LV];
-            bits_accumulate_ids<0>(ids_p + (p - p_base) * entries_pad + my_off, wdt, t_addr, s0, s1);
+            bits_accumulate_ids<PSHIFT>(ids_p + (p - p_base) * entries_pad + my_off, wdt, t_addr, s0, s1);
             uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
 #pragma unroll
             for (int l = 0; l < BT_LV; ++l) {
@@ -2544,6 +2554,14 @@ static size_t bits_lds_bytes(int64_t n, int64_t stride16) {
     return (t_words + static_cast<size_t>(stride16) + 4) * sizeof(unsigned int);
 }
 
+// the pre-permuted form with sixteen-wave workgroups (k_permtest_bits_pre<8, 16, 2>): networks beyond the 16-bit LDS offsets whose
+// word column still fits a CU's LDS (8 bytes per node: N <= 20 470) and whose doubled ids fit 16 bits
+static size_t bits_pre_lds_bytes(int64_t n) { return (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int); }
+static bool bits_pre_wide_applicable(int64_t n) {
+    const char *pe = getenv("SAFE_HIP_BITS_PRE");
+    return (n + 1) * 8 >= 65536 && n < 32768 && bits_pre_lds_bytes(n) <= 160 * 1024 && !(pe && !strcmp(pe, "0"));
+}
+
 enum PermPath { PATH_GATHER = 0, PATH_SCATTER = 1, PATH_BITS = 2 };
 
 // Picks the kernel form.  The two integer forms need 'sum' scores of 0/1 data (exact in
@@ -2555,7 +2573,8 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
     if (z || n_perm < 1 || n_perm > 65535) return PATH_GATHER;
     if (safe_attr_prepare(attr) != SAFE_OK || attr->n_other != 0) return PATH_GATHER;
     if (nbr->n >= 65535) return PATH_GATHER;
-    const bool bits_ok = nbr->sell_col2 != nullptr && nbr->max_count < (1 << BT_LV) && bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024;
+    const bool bits_ok = nbr->sell_col2 != nullptr && nbr->max_count < (1 << BT_LV) &&
+                         (bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024 || bits_pre_wide_applicable(nbr->n));
     const bool scatter_ok = nbr->max_count < SC_EPOCH && scatter_lds_bytes(nbr->n) <= 160 * 1024;
     if (force && !strcmp(force, "bits") && bits_ok) return PATH_BITS;
     if (force && !strcmp(force, "scatter") && scatter_ok) return attr_build_support(attr) == SAFE_OK ? PATH_SCATTER : PATH_GATHER;
@@ -2688,10 +2707,13 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const size_t lds_bytes = bits_lds_bytes(n, perms->stride16);
     const int per_cu = static_cast<int>(std::max<size_t>(1, std::min<size_t>(8, (160 * 1024) / lds_bytes)));
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
-    const int64_t n_sg = ceil_div(nbr->n_slices, 4);
+    // waves (= adjacent slices of a task) per workgroup: 4; 16 when the word column and the permutation rows leave room for one
+    // workgroup per CU only (k_permtest_bits<.., 16>: N > 8190, where neither the pre-permuted nor the blocked lists apply)
+    const int wv = (n + 1) * 8 < 65536 ? 4 : 16;
+    const int64_t n_sg = ceil_div(nbr->n_slices, wv);
     std::vector<int64_t> sg_blocks(n_sg, 0);
     int64_t blocks_per_perm = 0;
-    for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / 4] = std::max<int64_t>(sg_blocks[s / 4], nbr->h_slice_width[s] / 8);
+    for (int64_t s = 0; s < nbr->n_slices; ++s) sg_blocks[s / wv] = std::max<int64_t>(sg_blocks[s / wv], nbr->h_slice_width[s] / 8);
     for (int64_t g = 0; g < n_sg; ++g) blocks_per_perm += std::max<int64_t>(sg_blocks[g], 1);
     // five waves per SIMD (k_permtest_bits_blk<.., 5>) when T fits five times into a CU's LDS; its wide classes count with five
     // levels, so their tasks hold at most 31 permutations
@@ -2769,7 +2791,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t n_launch = n_major + n_tail;           // stage launches over all columns, then the tail's column chunks
     // the lists only depend on the handle and on these numbers: the handle keeps the last plan
     std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch, max_ppt,
-                                     n_major, n_tail, xc_wpc};
+                                     n_major, n_tail, xc_wpc, wv};
     plan_key.insert(plan_key.end(), starts.begin(), starts.end());
     BitsTaskPlan &plan = nbr->bits_plan;
     if (plan.key != plan_key) {
@@ -2842,7 +2864,9 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const bool narrow = true;                         // a task counts at most 255 permutations (ppt above): 8 counter levels do
     const bool scaled = (n + 1) * 8 < 65536;
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
-    const bool pre = scaled && !(pre_env && !strcmp(pre_env, "0"));      // pre-permuted member lists
+    const bool pre_w = bits_pre_wide_applicable(n);                      // ... of the larger networks (k_permtest_bits_pre<8, 16, 2>)
+    const bool pre = (scaled && !(pre_env && !strcmp(pre_env, "0"))) || pre_w;      // pre-permuted member lists
+    const int id_shift = pre_w ? 1 : 3;                                   // the lists hold id << id_shift
     const int64_t entries_pad = (nbr->sell_entries + 1024 + 255) / 256 * 256;    // tail: the kernels fetch ids two blocks (2 x 512) ahead
     // consecutive launches run on NS = 2 streams: a launch is as long as its longest task, the next one fills the slots its short
     // tasks leave.  Three or four launches in flight measured WORSE (unseeded 1000-permutation step 3.01 -> 3.19 -> 3.43 ms,
@@ -2861,7 +2885,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
-    const bool blk = pre && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
+    const bool blk = pre && !pre_w && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     // SAFE_HIP_BITS_DBG: variants of the blocked kernel.  32 / 128 / 256 / 384 / 512 / 640 give correct results (A/B: one-stage carry
     // ripple, ..., 256 = no id stream = no hidden registers, 512 = no half-block gather pipeline); 1 / 2 / 4 / 8 / 16 / 64 skip work
     // (WRONG results) and exist only in a library built with `make DIAG=1`.  Anything else is refused.
@@ -2913,7 +2937,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            nbr->slice_off, nbr->slice_width, nbr->sell_col2b, nbr->n_slices, d_bits, mloc, d_obs, out.ns);
         SAFE_HIP_CHECK(hipGetLastError());
     }
-    if (pre)
+    if (pre_w)
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds_pre)));
+    else if (pre)
         SAFE_HIP_CHECK(hipFuncSetAttribute(narrow ? reinterpret_cast<const void *>(k_permtest_bits_pre<8>)
                                            : wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
                                                   : reinterpret_cast<const void *>(k_permtest_bits_pre<10>),
@@ -2922,7 +2949,12 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                      : reinterpret_cast<const void *>(k_permtest_bits<16, false>))
                            : (scaled ? reinterpret_cast<const void *>(k_permtest_bits<10, true>)
                                      : reinterpret_cast<const void *>(k_permtest_bits<10, false>));
-    SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    SAFE_REQUIRE(pre || lds_bytes <= 160 * 1024, "launch_bits: the word column and the permutation rows of %lld nodes do not fit a CU's LDS",
+                 static_cast<long long>(n));
+    if (!pre) SAFE_HIP_CHECK(hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_bytes)));
+    if (wv == 16 && !pre)         // (a task holds at most 255 permutations -- ppt_cap above --: eight counter levels, whatever P is)
+        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_bits<8, false, 16>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                                           static_cast<int>(lds_bytes)));
     ctx->last_kernel.name = blk ? "k_permtest_bits_blk" : pre ? "k_permtest_bits_pre" : "k_permtest_bits";
     ctx->last_kernel.total_ms = 0.0;
     ctx->last_kernel.busy_ms = 0.0;
@@ -2962,7 +2994,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                 hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), starts[t + 1] - starts[t]), dim3(256),
                                    static_cast<size_t>(perms->stride16) * sizeof(uint16_t), tail_ps, perms->table16, perms->stride16,
                                    nbr->sell_col2b, nbr->sell_entries, entries_pad, starts[t], starts[t + 1] - starts[t],
-                                   static_cast<uint32_t>(8 * n), d_ids_tail + (starts[t] - p_split) * entries_pad, diag_banks);
+                                   static_cast<uint32_t>(8 * n), d_ids_tail + (starts[t] - p_split) * entries_pad, diag_banks, 3);
                 SAFE_HIP_CHECK(hipGetLastError());
             }
             SAFE_HIP_CHECK(hipEventRecord(plain[8], tail_ps));
@@ -2980,7 +3012,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                 hipLaunchKernelGGL(k_permute_cols, dim3(ceil_div(entries_pad, 4096), p_limit - p_base), dim3(256),
                                    static_cast<size_t>(perms->stride16) * sizeof(uint16_t), ks, perms->table16,
                                    perms->stride16, blk ? nbr->sell_col2b : nbr->sell_col2, nbr->sell_entries, entries_pad, p_base,
-                                   p_limit - p_base, static_cast<uint32_t>(8 * n), d_ids[c % NS], diag_banks);
+                                   p_limit - p_base, static_cast<uint32_t>(static_cast<uint64_t>(n) << id_shift), d_ids[c % NS], diag_banks, id_shift);
             SAFE_HIP_CHECK(hipEventRecord(ev[2 * c], ks));
             // the kernel's workgroups are persistent and fill the register file (4 waves x 128 VGPRs per SIMD): on a CU they
             // hold, the table kernels of the next pipeline stage (aux stream: scan rounds, row emission) wait for a whole
@@ -3006,7 +3038,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                                           std::max<size_t>(1, std::min<size_t>(occ5 ? 5 : 4, (160 * 1024) / lds_pre)));   // 4 (5): the register file holds 16 (20) waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
                 if (tail) chunk_final(c, ks);
-            } else if (narrow)
+            } else if (pre_w)
+                hipLaunchKernelGGL((k_permtest_bits_pre<8, 16, 2>), dim3(std::min<int64_t>(n_tasks, std::max(1, ctx->num_cu - spare))), dim3(1024), lds_pre,
+                                   ks, n, d_ids[c % NS], entries_pad, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2,
+                                   nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
+            else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
@@ -3028,7 +3064,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            perms->table16, perms->stride16, nbr->sell_row, nbr->slice_off, nbr->slice_width,          \
                            nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, \
                            d_gl, n_pad, out.ns)
-        if (wide && scaled) LAUNCH_BITS(16, true);
+        if (wv == 16)
+            hipLaunchKernelGGL((k_permtest_bits<8, false, 16>), dim3(blocks), dim3(1024), lds_bytes, ks, n, P, perms->table16, perms->stride16,
+                               nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits, n_tasks, d_tasks,
+                               p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
+        else if (wide && scaled) LAUNCH_BITS(16, true);
         else if (wide) LAUNCH_BITS(16, false);
         else if (scaled) LAUNCH_BITS(10, true);
         else LAUNCH_BITS(10, false);

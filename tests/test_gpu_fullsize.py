@@ -241,12 +241,19 @@ def test_config5_shape_zscore_permutation_test_sampled_rows():
     nbr.close()
 
 
-@pytest.mark.parametrize('n,expect', [(8300, 'k_permtest_bits'), (20000, 'k_permtest_mfma')])
-def test_binary_randomization_beyond_the_16_bit_address_range(n, expect):
+@pytest.mark.parametrize('n,pre,expect', [(8300, '', 'k_permtest_bits_pre'), (8300, '0', 'k_permtest_bits'), (13000, '0', 'k_permtest_bits'),
+                                          (20000, '', 'k_permtest_bits_pre'), (20477, '', 'k_permtest_bits_pre'),
+                                          (20478, '', 'k_permtest_mfma'), (20000, '0', 'k_permtest_mfma')])
+def test_binary_randomization_beyond_the_16_bit_address_range(n, pre, expect, monkeypatch):
     """0/1 attributes under how='randomization' on networks too large for the blocked bit-sliced kernel (member ids as
-    16-bit LDS addresses need 8 (N + 1) < 65536): N = 8300 runs the bit-sliced kernel with the permutation row staged in
-    LDS and 32-bit ids, N = 20 000 the matrix-core kernel in its exact two-slice regime.  Sampled neighborhoods against a
-    direct NumPy evaluation over the device's own permutation tables: integer sums, every count identical."""
+    16-bit LDS addresses need 8 (N + 1) < 65536).  Up to N = 20 477 -- the word column of 8 bytes per node still fits a CU's
+    LDS -- the pre-permuted form runs with SIXTEEN-wave workgroups and doubled ids in its lists (k_permtest_bits_pre<8, 16, 2>,
+    round 6); SAFE_HIP_BITS_PRE=0 gives what ran before: the bit-sliced kernel with the permutation row staged in LDS (now also
+    sixteen waves per workgroup; up to N ~ 13 600) and beyond that the matrix-core kernel in its exact two-slice regime, which
+    also takes over at N = 20 478.  Sampled neighborhoods against a direct NumPy evaluation over the device's own permutation
+    tables: integer sums, every count identical."""
+    if pre:
+        monkeypatch.setenv('SAFE_HIP_BITS_PRE', pre)
     import safepy_amd
     from safepy_amd import backend as be, workloads
     ctx = safepy_amd.Context.default(0)
