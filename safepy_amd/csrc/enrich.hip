@@ -490,7 +490,8 @@ __device__ __forceinline__ uint32_t maj3(uint32_t a, uint32_t b, uint32_t c) { r
 
 // adds eight one-bit-per-attribute words into the low three levels of the vertical counter
 // and returns the carry into level 3 (the "eights")
-__device__ __forceinline__ uint32_t vadd8(uint32_t (&s)[BT_LV], const uint32_t (&x)[8]) {
+template <int LV>
+__device__ __forceinline__ uint32_t vadd8(uint32_t (&s)[LV], const uint32_t (&x)[8]) {
     uint32_t t2a = maj3(s[0], x[0], x[1]);
     s[0] = xor3(s[0], x[0], x[1]);
     uint32_t t2b = maj3(s[0], x[2], x[3]);
@@ -508,9 +509,10 @@ __device__ __forceinline__ uint32_t vadd8(uint32_t (&s)[BT_LV], const uint32_t (
     return t8;
 }
 
-__device__ __forceinline__ void vripple(uint32_t (&s)[BT_LV], uint32_t t8) {
+template <int LV>
+__device__ __forceinline__ void vripple(uint32_t (&s)[LV], uint32_t t8) {
 #pragma unroll
-    for (int l = 3; l < BT_LV; ++l) {
+    for (int l = 3; l < LV; ++l) {
         const uint32_t c = s[l] & t8;
         s[l] ^= t8;
         t8 = c;
@@ -860,11 +862,11 @@ __global__ __launch_bounds__(256) void k_permute_cols(const uint16_t *__restrict
 
 // ids: u16 LDS byte offsets (relative to T) of the members, SELL layout; SHIFT = 2 turns the
 // resident 2*id list into 8*id (observed pass), 0 takes pre-permuted offsets as they are
-template <int SHIFT>
+template <int SHIFT, int LV = BT_LV>
 __device__ __forceinline__ void bits_accumulate_ids(const uint16_t *__restrict__ ids, int wdt, uint32_t t_addr,
-                                                    uint32_t (&s0)[BT_LV], uint32_t (&s1)[BT_LV]) {
+                                                    uint32_t (&s0)[LV], uint32_t (&s1)[LV]) {
 #pragma unroll
-    for (int l = 0; l < BT_LV; ++l) s0[l] = s1[l] = 0;
+    for (int l = 0; l < LV; ++l) s0[l] = s1[l] = 0;
     uint32_t c[8];
 #pragma unroll
     for (int u = 0; u < 8; ++u) c[u] = ids[u * 64];
@@ -894,7 +896,9 @@ __device__ __forceinline__ void bits_accumulate_ids(const uint16_t *__restrict__
 // WV = 16, PSHIFT = 2 (round 6): networks of 8191 .. 20 470 nodes -- T alone (8 bytes per node) fills most of a CU's LDS, so ONE
 // workgroup of sixteen waves shares it (four waves per SIMD as in the small form), and the permuted lists hold 2 * id (the byte
 // offset 8 * id no longer fits 16 bits; the shift that is left costs one operation per member).
-template <int CL, int WV = 4, int PSHIFT = 0>
+// LVS = levels of the vertical sums: BT_LV (neighborhoods below 1024 members); the sixteen-wave form also exists with eleven (below
+// 2048: a few hub neighborhoods no longer send a whole call to the scatter or matrix-core kernels).
+template <int CL, int WV = 4, int PSHIFT = 0, int LVS = BT_LV>
 __global__ __launch_bounds__(64 * WV, WV == 4 ? (CL <= 8 ? 4 : 3) : 1) void k_permtest_bits_pre(
     int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
     const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
@@ -928,8 +932,8 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? (CL <= 8 ? 4 : 3) : 1) void k_pe
         const int wdt = active ? slice_width[s] : 0;
         __syncthreads();                                                  // T is complete; waves are independent from here
 
-        uint32_t o0[BT_LV], o1[BT_LV];                                   // observed sums (safe.py:496-499)
-        bits_accumulate_ids<2>(sell_col2 + my_off, wdt, t_addr, o0, o1);
+        uint32_t o0[LVS], o1[LVS];                                   // observed sums (safe.py:496-499)
+        bits_accumulate_ids<2, LVS>(sell_col2 + my_off, wdt, t_addr, o0, o1);
 
         uint32_t g0[CL], g1[CL], l0[CL], l1[CL];                          // #(S_p > S_obs), #(S_p < S_obs)
         uint32_t gp0 = 0, gp1 = 0, lp0 = 0, lp1 = 0;
@@ -937,11 +941,11 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? (CL <= 8 ? 4 : 3) : 1) void k_pe
         for (int l = 0; l < CL; ++l) g0[l] = g1[l] = l0[l] = l1[l] = 0;
 
         for (int64_t p = p_begin; p < p_end; ++p) {
-            uint32_t s0[BT_LV], s1[BT_LV];
-            bits_accumulate_ids<PSHIFT>(ids_p + (p - p_base) * entries_pad + my_off, wdt, t_addr, s0, s1);
+            uint32_t s0[LVS], s1[LVS];
+            bits_accumulate_ids<PSHIFT, LVS>(ids_p + (p - p_base) * entries_pad + my_off, wdt, t_addr, s0, s1);
             uint32_t gt0 = 0, gt1 = 0, lt0 = 0, lt1 = 0;
 #pragma unroll
-            for (int l = 0; l < BT_LV; ++l) {
+            for (int l = 0; l < LVS; ++l) {
                 // f(s, o, b) = (s != o) ? o : b  -> 0x8E ;  (s != o) ? s : b -> 0xB2
                 lt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], lt0, 0x8E);
                 gt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], gt0, 0xB2);
@@ -988,7 +992,7 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? (CL <= 8 ? 4 : 3) : 1) void k_pe
                 for (int bit = 0; bit < 32; ++bit) {
                     const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
                     if (jc >= mloc) break;
-                    ns_out[obase + jc] = static_cast<double>(half ? vextract<BT_LV>(o1, bit) : vextract<BT_LV>(o0, bit));
+                    ns_out[obase + jc] = static_cast<double>(half ? vextract<LVS>(o1, bit) : vextract<LVS>(o0, bit));
                 }
         }
         __syncthreads();                                                  // before T is overwritten by the next task
@@ -2557,9 +2561,11 @@ static size_t bits_lds_bytes(int64_t n, int64_t stride16) {
 // the pre-permuted form with sixteen-wave workgroups (k_permtest_bits_pre<8, 16, 2>): networks beyond the 16-bit LDS offsets whose
 // word column still fits a CU's LDS (8 bytes per node: N <= 20 470) and whose doubled ids fit 16 bits
 static size_t bits_pre_lds_bytes(int64_t n) { return (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int); }
-static bool bits_pre_wide_applicable(int64_t n) {
+// ... or with neighborhoods of 1024 .. 2047 members at any size (eleven levels of the vertical sums, which only this form has)
+static bool bits_pre_wide_applicable(int64_t n, int64_t max_count) {
     const char *pe = getenv("SAFE_HIP_BITS_PRE");
-    return (n + 1) * 8 >= 65536 && n < 32768 && bits_pre_lds_bytes(n) <= 160 * 1024 && !(pe && !strcmp(pe, "0"));
+    return ((n + 1) * 8 >= 65536 || max_count >= (1 << BT_LV)) && max_count < (2 << BT_LV) && n < 32768 &&
+           bits_pre_lds_bytes(n) <= 160 * 1024 && !(pe && !strcmp(pe, "0"));
 }
 
 enum PermPath { PATH_GATHER = 0, PATH_SCATTER = 1, PATH_BITS = 2 };
@@ -2573,8 +2579,9 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
     if (z || n_perm < 1 || n_perm > 65535) return PATH_GATHER;
     if (safe_attr_prepare(attr) != SAFE_OK || attr->n_other != 0) return PATH_GATHER;
     if (nbr->n >= 65535) return PATH_GATHER;
-    const bool bits_ok = nbr->sell_col2 != nullptr && nbr->max_count < (1 << BT_LV) &&
-                         (bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024 || bits_pre_wide_applicable(nbr->n));
+    const bool bits_ok = nbr->sell_col2 != nullptr &&
+                         ((nbr->max_count < (1 << BT_LV) && bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024) ||
+                          bits_pre_wide_applicable(nbr->n, nbr->max_count));
     const bool scatter_ok = nbr->max_count < SC_EPOCH && scatter_lds_bytes(nbr->n) <= 160 * 1024;
     if (force && !strcmp(force, "bits") && bits_ok) return PATH_BITS;
     if (force && !strcmp(force, "scatter") && scatter_ok) return attr_build_support(attr) == SAFE_OK ? PATH_SCATTER : PATH_GATHER;
@@ -2683,9 +2690,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // tail is OFF by default (SAFE_HIP_XCHG_TAIL=<fraction of the permutations> switches it on; 1e-9 = the last stage); the
     // chunked exchange itself (sharding.ChunkedExchange) then runs its collectives right after the kernels, chunk by chunk
     // beside the derivation of the previous chunk's matrices.
+    const bool pre_w = bits_pre_wide_applicable(n, nbr->max_count);     // the sixteen-wave pre-permuted form (k_permtest_bits_pre<8, 16, 2, ..>)
     const bool blk_expected = [&] {
         const char *pe = getenv("SAFE_HIP_BITS_PRE"), *ke = getenv("SAFE_HIP_BITS_KERNEL");
-        return (n + 1) * 8 < 65536 && !(pe && !strcmp(pe, "0")) && nbr->sell_col2b != nullptr && !(ke && !strcmp(ke, "pre"));
+        return !pre_w && (n + 1) * 8 < 65536 && !(pe && !strcmp(pe, "0")) && nbr->sell_col2b != nullptr && !(ke && !strcmp(ke, "pre"));
     }();
     int64_t n_major = static_cast<int64_t>(starts.size()) - 1, p_split = P, xc_wpc = 0;
     int xc_k = 0;
@@ -2709,7 +2717,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
     // waves (= adjacent slices of a task) per workgroup: 4; 16 when the word column and the permutation rows leave room for one
     // workgroup per CU only (k_permtest_bits<.., 16>: N > 8190, where neither the pre-permuted nor the blocked lists apply)
-    const int wv = (n + 1) * 8 < 65536 ? 4 : 16;
+    const int wv = (n + 1) * 8 < 65536 && !pre_w ? 4 : 16;
     const int64_t n_sg = ceil_div(nbr->n_slices, wv);
     std::vector<int64_t> sg_blocks(n_sg, 0);
     int64_t blocks_per_perm = 0;
@@ -2864,7 +2872,6 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const bool narrow = true;                         // a task counts at most 255 permutations (ppt above): 8 counter levels do
     const bool scaled = (n + 1) * 8 < 65536;
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
-    const bool pre_w = bits_pre_wide_applicable(n);                      // ... of the larger networks (k_permtest_bits_pre<8, 16, 2>)
     const bool pre = (scaled && !(pre_env && !strcmp(pre_env, "0"))) || pre_w;      // pre-permuted member lists
     const int id_shift = pre_w ? 1 : 3;                                   // the lists hold id << id_shift
     const int64_t entries_pad = (nbr->sell_entries + 1024 + 255) / 256 * 256;    // tail: the kernels fetch ids two blocks (2 x 512) ahead
@@ -2937,9 +2944,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            nbr->slice_off, nbr->slice_width, nbr->sell_col2b, nbr->n_slices, d_bits, mloc, d_obs, out.ns);
         SAFE_HIP_CHECK(hipGetLastError());
     }
+    const void *pre_w_fn = nbr->max_count < (1 << BT_LV) ? reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2>)
+                                                         : reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2, BT_LV + 1>);
     if (pre_w)
-        SAFE_HIP_CHECK(hipFuncSetAttribute(reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2>), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           static_cast<int>(lds_pre)));
+        SAFE_HIP_CHECK(hipFuncSetAttribute(pre_w_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
     else if (pre)
         SAFE_HIP_CHECK(hipFuncSetAttribute(narrow ? reinterpret_cast<const void *>(k_permtest_bits_pre<8>)
                                            : wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
@@ -3038,11 +3046,16 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                                           std::max<size_t>(1, std::min<size_t>(occ5 ? 5 : 4, (160 * 1024) / lds_pre)));   // 4 (5): the register file holds 16 (20) waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
                 if (tail) chunk_final(c, ks);
-            } else if (pre_w)
-                hipLaunchKernelGGL((k_permtest_bits_pre<8, 16, 2>), dim3(std::min<int64_t>(n_tasks, std::max(1, ctx->num_cu - spare))), dim3(1024), lds_pre,
-                                   ks, n, d_ids[c % NS], entries_pad, nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2,
-                                   nbr->n_slices, d_bits, n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);
-            else if (narrow)
+            } else if (pre_w) {
+                const uint16_t *ids_c = d_ids[c % NS];
+                unsigned int *queue_c = d_queue + 8 * c;
+                void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
+                                (void *)&nbr->slice_width, (void *)&nbr->sell_col2, (void *)&nbr->n_slices, (void *)&d_bits, (void *)&n_tasks,
+                                (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c, (void *)&mloc, (void *)&d_gl,
+                                (void *)&n_pad, (void *)&out.ns};
+                SAFE_HIP_CHECK(hipLaunchKernel(pre_w_fn, dim3(std::min<int64_t>(n_tasks, std::max(1, ctx->num_cu - spare))), dim3(1024), args,
+                                               lds_pre, ks));
+            } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,
                                    n_tasks, d_tasks, p_base, p_limit, d_queue + 8 * c, mloc, d_gl, n_pad, out.ns);

@@ -687,6 +687,33 @@ def test_bit_sliced_kernels_every_level_class(amd, monkeypatch, kernel, nperm):
     assert np.array_equal(ns, orc.compute_neighborhood_score(a, b, 'sum'))
 
 
+@pytest.mark.parametrize('biggest,expect', [(1023, 'k_permtest_bits_blk'), (1024, 'k_permtest_bits_pre'), (2047, 'k_permtest_bits_pre'),
+                                            (2048, None)])
+def test_hub_neighborhoods_of_1024_to_2047_members_stay_bit_sliced(amd, monkeypatch, biggest, expect):
+    """A few hub neighborhoods decide the kernel family of a whole call: below 1024 members the blocked kernel (ten levels of the
+    vertical sums), 1024 .. 2047 the sixteen-wave pre-permuted form with eleven levels (round 6), from 2048 the scatter / f64 /
+    matrix-core kernels.  Counts against the oracle in every case; sums that reach the top level (dense columns)."""
+    rng = np.random.default_rng(biggest)
+    n, m, nperm = 2600, 70, 40
+    sizes = np.r_[biggest, biggest - 1, rng.integers(900, biggest, 6), rng.integers(0, 300, n - 8)]
+    rng.shuffle(sizes)
+    a = np.zeros((n, n), dtype=np.int64)
+    for i, k in enumerate(sizes):
+        a[i, rng.choice(n, int(k), replace=False)] = 1
+    b = (rng.uniform(size=(n, m)) < np.linspace(0.005, 0.99, m)).astype(np.float32)
+    b[:, 3] = 1                                                  # every member carries it: the sums are the member counts
+    b[rng.choice(n, 30, replace=False)] = np.nan
+    cn_want, cp_want = orc.run_permutations(a, b, 'sum', nperm, 21)
+    cn, cp = amd.run_permutations((a, b, 'sum', nperm, 21), verbose=False)
+    name = amd.Context.default(0).last_kernel()[0]
+    if expect is None:
+        assert not name.startswith('k_permtest_bits'), name
+    else:
+        assert name == expect
+    assert np.array_equal(cn, cn_want) and np.array_equal(cp, cp_want)
+    assert np.array_equal(amd.compute_neighborhood_score(a, b, 'sum'), orc.compute_neighborhood_score(a, b, 'sum'))
+
+
 # ------------------------------------------------------------ attribute sharding ----------
 
 def test_sharded_columns_equal_unsharded(amd, ctx, golden_enr):

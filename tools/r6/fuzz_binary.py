@@ -50,7 +50,7 @@ def run(budget, first=0, max_cases=None):
         seed = int(rng.integers(0, 2 ** 32))
         if dense:                                       # rows of every width class of the bit-sliced kernels, asymmetric
             a = np.zeros((n, n), dtype=np.int64)
-            top = int(rng.choice([8, 56, 248, 504, 1000, 1500]))
+            top = int(rng.choice([8, 56, 248, 504, 1000, 1500, 2047, 2300]))
             sizes = np.minimum(rng.integers(0, top + 1, size=n), n)
             for i, k in enumerate(sizes):
                 a[i, rng.choice(n, int(k), replace=False)] = 1
