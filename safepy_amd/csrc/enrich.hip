@@ -1000,6 +1000,130 @@ __global__ __launch_bounds__(64 * WV, WV == 4 ? (CL <= 8 ? 4 : 3) : 1) void k_pe
 }
 
 // --------------------------------------------------------------------------------------
+// The pre-permuted form for networks of 20 478 .. 32 767 nodes (round 6): the 8-byte word column no longer fits a CU's LDS, a
+// column of 32-attribute HALF words (4 bytes per node) does.  A task is (word group, half, sixteen adjacent slices, permutation
+// range): task.x = 2 * word group + half; T holds .x or .y of the word pairs; the permuted lists hold the ids themselves
+// (k_permute_cols with shift 0: 4 * id does not fit 16 bits), the observed pass reads the resident 2 * id list.  Per 64 attributes
+// the id stream and the gathers run twice, the carry-save adds once: ~1.4 x the cost of the full-word form.
+// --------------------------------------------------------------------------------------
+typedef const __attribute__((address_space(3))) unsigned int *lds_u32_ptr;
+
+template <int SHIFT, int LV>
+__device__ __forceinline__ void bits_accumulate_ids32(const uint16_t *__restrict__ ids, int wdt, uint32_t t_addr, uint32_t (&s0)[LV]) {
+#pragma unroll
+    for (int l = 0; l < LV; ++l) s0[l] = 0;
+    uint32_t c[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) c[u] = ids[u * 64];
+    const uint16_t *pc = ids + 8 * 64;
+    for (int t0 = 0; t0 < wdt; t0 += 8, pc += 8 * 64) {
+        uint32_t r[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) r[u] = (c[u] << SHIFT) + t_addr;
+#pragma unroll
+        for (int u = 0; u < 8; ++u) c[u] = pc[u * 64];                                // next block (lists have a tail)
+        uint32_t x0[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) x0[u] = *(lds_u32_ptr)(uintptr_t)(r[u]);
+        const uint32_t e0 = vadd8(s0, x0);
+        if (__builtin_amdgcn_ballot_w64(e0 != 0)) vripple(s0, e0);
+    }
+}
+
+template <int CL, int WV, int LVS>
+__global__ __launch_bounds__(64 * WV, 1) void k_permtest_bits_pre32(
+    int64_t n, const uint16_t *__restrict__ ids_p, int64_t entries_pad, const int32_t *__restrict__ sell_row,
+    const int64_t *__restrict__ slice_off, const int32_t *__restrict__ slice_width,
+    const uint16_t *__restrict__ sell_col2, int64_t n_slices, const uint2 *__restrict__ bbits, int64_t n_tasks,
+    const int4 *__restrict__ tasks, int64_t p_base, int64_t p_limit, unsigned int *__restrict__ queue, int64_t mloc,
+    unsigned int *__restrict__ gl_counts, int64_t n_pad, double *__restrict__ ns_out) {
+    extern __shared__ unsigned int lds[];
+    const int64_t t_words = (n + 4) & ~int64_t(3);                      // T: (n+1) half words, 16-B padded
+    unsigned int *T = lds;
+    unsigned int *slot_box = lds + t_words;
+    const uint32_t t_addr = (uint32_t)(uintptr_t)((__attribute__((address_space(3))) unsigned int *)lds);
+    const int wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63;
+    constexpr int NT = 64 * WV;
+
+    for (;;) {
+        if (threadIdx.x == 0) *slot_box = atomicAdd(queue, 1u);
+        __syncthreads();
+        const int64_t slot = *slot_box;
+        __syncthreads();
+        if (slot >= n_tasks) break;
+        const int4 task = tasks[slot];
+        const int wg = task.x >> 1, half = task.x & 1, sg = task.y;
+        const int64_t p_begin = p_base + task.z;
+        const int64_t p_end = p_base + task.w < p_limit ? p_base + task.w : p_limit;
+        if (p_end <= p_begin) continue;                                   // a launch shorter than the task grid's span
+
+        {
+            const uint2 *src = bbits + static_cast<int64_t>(wg) * (n + 1);
+            for (int64_t r = threadIdx.x; r <= n; r += NT) T[r] = half ? src[r].y : src[r].x;
+        }
+        const int64_t s = static_cast<int64_t>(sg) * WV + wave;
+        const bool active = s < n_slices;
+        const int32_t row = active ? sell_row[s * 64 + lane] : -1;
+        const int64_t my_off = (active ? slice_off[s] : 0) + lane;
+        const int wdt = active ? slice_width[s] : 0;
+        __syncthreads();                                                  // T is complete; waves are independent from here
+
+        uint32_t o0[LVS];                                                // observed sums (safe.py:496-499)
+        bits_accumulate_ids32<1, LVS>(sell_col2 + my_off, wdt, t_addr, o0);           // 2 * id -> 4 * id
+
+        uint32_t g0[CL], l0[CL];                                         // #(S_p > S_obs), #(S_p < S_obs)
+        uint32_t gp0 = 0, lp0 = 0;
+#pragma unroll
+        for (int l = 0; l < CL; ++l) g0[l] = l0[l] = 0;
+
+        for (int64_t p = p_begin; p < p_end; ++p) {
+            uint32_t s0[LVS];
+            bits_accumulate_ids32<2, LVS>(ids_p + (p - p_base) * entries_pad + my_off, wdt, t_addr, s0);   // id -> 4 * id
+            uint32_t gt0 = 0, lt0 = 0;
+#pragma unroll
+            for (int l = 0; l < LVS; ++l) {
+                lt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], lt0, 0x8E);
+                gt0 = __builtin_amdgcn_bitop3_b32(s0[l], o0[l], gt0, 0xB2);
+            }
+            vcount<CL>(g0, gp0, gt0);
+            vcount<CL>(l0, lp0, lt0);
+            if (((p - p_begin) & 7) == 7) {
+                vflush<CL>(g0, gp0);
+                vflush<CL>(l0, lp0);
+            }
+        }
+        vflush<CL>(g0, gp0);
+        vflush<CL>(l0, lp0);
+
+        const bool live = row >= 0;
+        const int64_t spos = s * 64 + lane;
+        {
+            uint32_t m[32];
+#pragma unroll
+            for (int l = 0; l < 16; ++l) {
+                m[l] = l < CL ? g0[l < CL ? l : 0] : 0u;
+                m[16 + l] = l < CL ? l0[l < CL ? l : 0] : 0u;
+            }
+            transpose32(m);
+#pragma unroll
+            for (int bit = 0; bit < 32; ++bit) {
+                const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                if (jc < mloc && active && m[bit]) atomicAdd(&gl_counts[jc * n_pad + spos], m[bit]);
+            }
+        }
+        if (ns_out && p_begin == 0 && live) {
+            const int64_t obase = static_cast<int64_t>(row) * mloc;
+            for (int bit = 0; bit < 32; ++bit) {
+                const int64_t jc = static_cast<int64_t>(wg) * 64 + half * 32 + bit;
+                if (jc >= mloc) break;
+                ns_out[obase + jc] = static_cast<double>(vextract<LVS>(o0, bit));
+            }
+        }
+        __syncthreads();                                                  // before T is overwritten by the next task
+    }
+}
+
+// --------------------------------------------------------------------------------------
 // K5 bit-sliced form, BLOCKED member lists (the default when 8*(N+1) < 65536).  Same arithmetic as
 // k_permtest_bits_pre; what changed is how a lane gets at its members and how much it carries:
 //   * ids of 8 members are adjacent (k_sell_blocked16 / k_permute_cols on the blocked list): ONE 16-byte
@@ -2568,6 +2692,14 @@ static bool bits_pre_wide_applicable(int64_t n, int64_t max_count) {
            bits_pre_lds_bytes(n) <= 160 * 1024 && !(pe && !strcmp(pe, "0"));
 }
 
+// ... and the half-word form (k_permtest_bits_pre32): the networks whose full word column no longer fits, up to the 2 * id lists' 32 767
+static size_t bits_half_lds_bytes(int64_t n) { return (((static_cast<size_t>(n) + 4) & ~size_t(3)) + 4) * sizeof(unsigned int); }
+static bool bits_pre_half_applicable(int64_t n, int64_t max_count) {
+    const char *pe = getenv("SAFE_HIP_BITS_PRE");
+    return bits_pre_lds_bytes(n) > 160 * 1024 && bits_half_lds_bytes(n) <= 160 * 1024 && n < 32768 && max_count < (2 << BT_LV) &&
+           !(pe && !strcmp(pe, "0"));
+}
+
 enum PermPath { PATH_GATHER = 0, PATH_SCATTER = 1, PATH_BITS = 2 };
 
 // Picks the kernel form.  The two integer forms need 'sum' scores of 0/1 data (exact in
@@ -2581,7 +2713,7 @@ static PermPath choose_path(const safe_ctx *ctx, const safe_nbr *nbr, safe_attr 
     if (nbr->n >= 65535) return PATH_GATHER;
     const bool bits_ok = nbr->sell_col2 != nullptr &&
                          ((nbr->max_count < (1 << BT_LV) && bits_lds_bytes(nbr->n, (nbr->n + 8) / 8 * 8) <= 160 * 1024) ||
-                          bits_pre_wide_applicable(nbr->n, nbr->max_count));
+                          bits_pre_wide_applicable(nbr->n, nbr->max_count) || bits_pre_half_applicable(nbr->n, nbr->max_count));
     const bool scatter_ok = nbr->max_count < SC_EPOCH && scatter_lds_bytes(nbr->n) <= 160 * 1024;
     if (force && !strcmp(force, "bits") && bits_ok) return PATH_BITS;
     if (force && !strcmp(force, "scatter") && scatter_ok) return attr_build_support(attr) == SAFE_OK ? PATH_SCATTER : PATH_GATHER;
@@ -2691,9 +2823,11 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // chunked exchange itself (sharding.ChunkedExchange) then runs its collectives right after the kernels, chunk by chunk
     // beside the derivation of the previous chunk's matrices.
     const bool pre_w = bits_pre_wide_applicable(n, nbr->max_count);     // the sixteen-wave pre-permuted form (k_permtest_bits_pre<8, 16, 2, ..>)
+    const bool pre_h = bits_pre_half_applicable(n, nbr->max_count);     // ... with 32-attribute half words (k_permtest_bits_pre32): tasks per HALF word group
+    const int64_t n_wgt = pre_h ? 2 * n_wg : n_wg;
     const bool blk_expected = [&] {
         const char *pe = getenv("SAFE_HIP_BITS_PRE"), *ke = getenv("SAFE_HIP_BITS_KERNEL");
-        return !pre_w && (n + 1) * 8 < 65536 && !(pe && !strcmp(pe, "0")) && nbr->sell_col2b != nullptr && !(ke && !strcmp(ke, "pre"));
+        return !pre_w && !pre_h && (n + 1) * 8 < 65536 && !(pe && !strcmp(pe, "0")) && nbr->sell_col2b != nullptr && !(ke && !strcmp(ke, "pre"));
     }();
     int64_t n_major = static_cast<int64_t>(starts.size()) - 1, p_split = P, xc_wpc = 0;
     int xc_k = 0;
@@ -2717,7 +2851,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t slots = static_cast<int64_t>(ctx->num_cu) * per_cu;
     // waves (= adjacent slices of a task) per workgroup: 4; 16 when the word column and the permutation rows leave room for one
     // workgroup per CU only (k_permtest_bits<.., 16>: N > 8190, where neither the pre-permuted nor the blocked lists apply)
-    const int wv = (n + 1) * 8 < 65536 && !pre_w ? 4 : 16;
+    const int wv = (n + 1) * 8 < 65536 && !pre_w && !pre_h ? 4 : 16;
     const int64_t n_sg = ceil_div(nbr->n_slices, wv);
     std::vector<int64_t> sg_blocks(n_sg, 0);
     int64_t blocks_per_perm = 0;
@@ -2732,7 +2866,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                          // + two 32 x 32 bit transposes per wave: 11 % of the kernel at depth 2, tools/bits_ablate.py dbg=2), so
                                                          // as few tasks as fill the chip once -- depth 1 vs 2: seeded step 3.52 -> 3.41 ms, 10 000 unseeded
                                                          // permutations 25.8 -> 24.4 ms (tools/exp_ab.sh; round 3 had chosen 2 while the host stream bound the step)
-    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wg));
+    const int64_t tasks_per_wg = std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, n_wgt));
     // One task list per DISTINCT launch size: the stream's stages are 32, 96, 128 ... and short last ones, and a list cut for 128
     // permutations leaves a 32-permutation launch with half-empty and empty tasks (each still reloads T): a 32-permutation launch
     // took 207 us, 6.5 us per permutation against 3.2 in the long launches.
@@ -2746,10 +2880,10 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     // seeded step got LONGER (3.16-3.34 -> 3.30-3.38 ms: twice the wave-tasks, each with its fixed part) -- not kept.
     struct TaskCost { int4 t; int64_t cost; };
     auto build_tasks = [&](int64_t span_c, int64_t w_lo = 0, int64_t w_hi = -1) {
-        if (w_hi < 0) w_hi = n_wg;
+        if (w_hi < 0) w_hi = n_wgt;
         // (a column chunk of the tail has fewer word groups: its tasks are cut so that ITS launch fills the slots once too -- with
         // the stage launches' task size a chunk of the last stage had 288 tasks for 960 slots and lasted as long as a whole stage)
-        const int64_t tpw = w_hi - w_lo == n_wg ? tasks_per_wg : std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, std::max<int64_t>(1, w_hi - w_lo)));
+        const int64_t tpw = w_hi - w_lo == n_wgt ? tasks_per_wg : std::max<int64_t>(1, ceil_div(tasks_per_slot * slots, std::max<int64_t>(1, w_hi - w_lo)));
         const int64_t target = std::max<int64_t>(target_min, blocks_per_perm * span_c / tpw);    // block-permutations per task
         std::vector<TaskCost> tc;
         for (int64_t g = 0; g < n_sg; ++g) {
@@ -2762,6 +2896,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
             for (int64_t c = 0; c < chunks; ++c) {
                 const int64_t p0 = c * ppt, p1 = std::min<int64_t>(span_c, p0 + ppt);
                 for (int64_t w = w_lo; w < w_hi; ++w)
+                    if (!pre_h || (w >> 1) * 64 + (w & 1) * 32 < mloc)      // (a last half word without columns has no task)
                     tc.push_back({make_int4(static_cast<int>(w), static_cast<int>(g), static_cast<int>(p0), static_cast<int>(p1)),
                                   bl * (p1 - p0)});
             }
@@ -2799,7 +2934,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const int64_t n_launch = n_major + n_tail;           // stage launches over all columns, then the tail's column chunks
     // the lists only depend on the handle and on these numbers: the handle keeps the last plan
     std::vector<int64_t> plan_key = {n_wg, slots, tasks_per_slot, occ5 ? 1 : 0, xcd_queues ? 1 : 0, min_ppt, target_min, n_launch, max_ppt,
-                                     n_major, n_tail, xc_wpc, wv};
+                                     n_major, n_tail, xc_wpc, wv, pre_h ? 1 : 0, mloc};
     plan_key.insert(plan_key.end(), starts.begin(), starts.end());
     BitsTaskPlan &plan = nbr->bits_plan;
     if (plan.key != plan_key) {
@@ -2872,8 +3007,8 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const bool narrow = true;                         // a task counts at most 255 permutations (ppt above): 8 counter levels do
     const bool scaled = (n + 1) * 8 < 65536;
     const char *pre_env = getenv("SAFE_HIP_BITS_PRE");
-    const bool pre = (scaled && !(pre_env && !strcmp(pre_env, "0"))) || pre_w;      // pre-permuted member lists
-    const int id_shift = pre_w ? 1 : 3;                                   // the lists hold id << id_shift
+    const bool pre = (scaled && !(pre_env && !strcmp(pre_env, "0"))) || pre_w || pre_h;      // pre-permuted member lists
+    const int id_shift = pre_h ? 0 : pre_w ? 1 : 3;                       // the lists hold id << id_shift
     const int64_t entries_pad = (nbr->sell_entries + 1024 + 255) / 256 * 256;    // tail: the kernels fetch ids two blocks (2 x 512) ahead
     // consecutive launches run on NS = 2 streams: a launch is as long as its longest task, the next one fills the slots its short
     // tasks leave.  Three or four launches in flight measured WORSE (unseeded 1000-permutation step 3.01 -> 3.19 -> 3.43 ms,
@@ -2892,7 +3027,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
     const size_t lds_pre = (2 * ((static_cast<size_t>(n) + 2) & ~size_t(1)) + 4) * sizeof(unsigned int);
     // blocked member lists (k_permtest_bits_blk) unless SAFE_HIP_BITS_KERNEL=pre; SAFE_HIP_BITS_DBG=<mask>: diagnostic builds
     const char *kern_env = getenv("SAFE_HIP_BITS_KERNEL");
-    const bool blk = pre && !pre_w && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
+    const bool blk = pre && !pre_w && !pre_h && nbr->sell_col2b != nullptr && !(kern_env && !strcmp(kern_env, "pre"));
     // SAFE_HIP_BITS_DBG: variants of the blocked kernel.  32 / 128 / 256 / 384 / 512 / 640 give correct results (A/B: one-stage carry
     // ripple, ..., 256 = no id stream = no hidden registers, 512 = no half-block gather pipeline); 1 / 2 / 4 / 8 / 16 / 64 skip work
     // (WRONG results) and exist only in a library built with `make DIAG=1`.  Anything else is refused.
@@ -2944,10 +3079,14 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                            nbr->slice_off, nbr->slice_width, nbr->sell_col2b, nbr->n_slices, d_bits, mloc, d_obs, out.ns);
         SAFE_HIP_CHECK(hipGetLastError());
     }
-    const void *pre_w_fn = nbr->max_count < (1 << BT_LV) ? reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2>)
-                                                         : reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2, BT_LV + 1>);
-    if (pre_w)
-        SAFE_HIP_CHECK(hipFuncSetAttribute(pre_w_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre)));
+    const bool lv11 = nbr->max_count >= (1 << BT_LV);
+    const void *pre_w_fn = pre_h ? (lv11 ? reinterpret_cast<const void *>(k_permtest_bits_pre32<8, 16, BT_LV + 1>)
+                                         : reinterpret_cast<const void *>(k_permtest_bits_pre32<8, 16, BT_LV>))
+                                 : (lv11 ? reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2, BT_LV + 1>)
+                                         : reinterpret_cast<const void *>(k_permtest_bits_pre<8, 16, 2>));
+    const size_t lds_pre_w = pre_h ? bits_half_lds_bytes(n) : lds_pre;
+    if (pre_w || pre_h)
+        SAFE_HIP_CHECK(hipFuncSetAttribute(pre_w_fn, hipFuncAttributeMaxDynamicSharedMemorySize, static_cast<int>(lds_pre_w)));
     else if (pre)
         SAFE_HIP_CHECK(hipFuncSetAttribute(narrow ? reinterpret_cast<const void *>(k_permtest_bits_pre<8>)
                                            : wide ? reinterpret_cast<const void *>(k_permtest_bits_pre<16>)
@@ -3046,7 +3185,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                                                           std::max<size_t>(1, std::min<size_t>(occ5 ? 5 : 4, (160 * 1024) / lds_pre)));   // 4 (5): the register file holds 16 (20) waves per CU
                 SAFE_HIP_CHECK(hipLaunchKernel(blk_fn, dim3(blocks_blk), dim3(256), args, lds_pre, ks));
                 if (tail) chunk_final(c, ks);
-            } else if (pre_w) {
+            } else if (pre_w || pre_h) {
                 const uint16_t *ids_c = d_ids[c % NS];
                 unsigned int *queue_c = d_queue + 8 * c;
                 void *args[] = {(void *)&n, (void *)&ids_c, (void *)&entries_pad, (void *)&nbr->sell_row, (void *)&nbr->slice_off,
@@ -3054,7 +3193,7 @@ static int launch_bits(safe_ctx *ctx, safe_nbr *nbr, safe_attr *attr, safe_perms
                                 (void *)&d_tasks, (void *)&p_base, (void *)&p_limit, (void *)&queue_c, (void *)&mloc, (void *)&d_gl,
                                 (void *)&n_pad, (void *)&out.ns};
                 SAFE_HIP_CHECK(hipLaunchKernel(pre_w_fn, dim3(std::min<int64_t>(n_tasks, std::max(1, ctx->num_cu - spare))), dim3(1024), args,
-                                               lds_pre, ks));
+                                               lds_pre_w, ks));
             } else if (narrow)
                 hipLaunchKernelGGL(k_permtest_bits_pre<8>, dim3(blocks_pre), dim3(256), lds_pre, ks, n, d_ids[c % NS], entries_pad,
                                    nbr->sell_row, nbr->slice_off, nbr->slice_width, nbr->sell_col2, nbr->n_slices, d_bits,

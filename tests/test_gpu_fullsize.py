@@ -243,14 +243,16 @@ def test_config5_shape_zscore_permutation_test_sampled_rows():
 
 @pytest.mark.parametrize('n,pre,expect', [(8300, '', 'k_permtest_bits_pre'), (8300, '0', 'k_permtest_bits'), (13000, '0', 'k_permtest_bits'),
                                           (20000, '', 'k_permtest_bits_pre'), (20477, '', 'k_permtest_bits_pre'),
-                                          (20478, '', 'k_permtest_mfma'), (20000, '0', 'k_permtest_mfma')])
+                                          (20478, '', 'k_permtest_bits_pre'), (26001, '', 'k_permtest_bits_pre'), (32767, '', 'k_permtest_bits_pre'),
+                                          (32768, '', 'k_permtest_mfma'), (20000, '0', 'k_permtest_mfma')])
 def test_binary_randomization_beyond_the_16_bit_address_range(n, pre, expect, monkeypatch):
     """0/1 attributes under how='randomization' on networks too large for the blocked bit-sliced kernel (member ids as
     16-bit LDS addresses need 8 (N + 1) < 65536).  Up to N = 20 477 -- the word column of 8 bytes per node still fits a CU's
     LDS -- the pre-permuted form runs with SIXTEEN-wave workgroups and doubled ids in its lists (k_permtest_bits_pre<8, 16, 2>,
     round 6); SAFE_HIP_BITS_PRE=0 gives what ran before: the bit-sliced kernel with the permutation row staged in LDS (now also
-    sixteen waves per workgroup; up to N ~ 13 600) and beyond that the matrix-core kernel in its exact two-slice regime, which
-    also takes over at N = 20 478.  Sampled neighborhoods against a direct NumPy evaluation over the device's own permutation
+    sixteen waves per workgroup; up to N ~ 13 600) and beyond that the matrix-core kernel in its exact two-slice regime.  From
+    N = 20 478 to 32 767 (the resident lists hold 2 * id in 16 bits) the word column is kept as 32-attribute HALF words
+    (k_permtest_bits_pre32: every word group in two passes); at 32 768 the matrix cores take over.  Sampled neighborhoods against a direct NumPy evaluation over the device's own permutation
     tables: integer sums, every count identical."""
     if pre:
         monkeypatch.setenv('SAFE_HIP_BITS_PRE', pre)

@@ -5,7 +5,7 @@ Binary 'sum' scores are exact in integers, so every kernel family must leave the
   kernel, the pre-permuted, the LDS-row and the stream-less bit-sliced kernels (a forced form that does not apply to a shape
   falls through to what choose_path picks; the summary line says which kernel ran how often).
 The kernels themselves are pinned to the oracle by tests/test_gpu_parity.py; this tool walks shapes those tests do not: random
-sizes up to 20 470 nodes (past the blocked kernel's N <= 8190: the sixteen-wave forms), clustered layouts, dense random memberships with rows of every
+sizes up to 32 767 nodes (past the blocked kernel's N <= 8190: the sixteen-wave forms, full and half words), clustered layouts, dense random memberships with rows of every
 size class, NaN rows, empty and full columns, odd permutation counts.
 
     python tools/r6/fuzz_binary.py [seconds] [first_case]
@@ -44,7 +44,7 @@ def run(budget, first=0, max_cases=None):
         if dense:
             n = int(rng.integers(40, 2500))
         else:
-            n = int(rng.choice([rng.integers(20, 300), rng.integers(300, 3000), rng.integers(3000, 8191), rng.integers(8191, 20471)]))
+            n = int(rng.choice([rng.integers(20, 300), rng.integers(300, 3000), rng.integers(3000, 8191), rng.integers(8191, 32768)]))
         m = int(rng.choice([rng.integers(1, 8), rng.integers(8, 130), rng.integers(130, 700)]))
         nperm = int(rng.choice([rng.integers(1, 8), rng.integers(8, 120), rng.integers(120, 700)]))
         seed = int(rng.integers(0, 2 ** 32))
