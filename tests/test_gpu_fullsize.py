@@ -285,3 +285,44 @@ def test_binary_randomization_beyond_the_16_bit_address_range(n, pre, expect, mo
     perms.close()
     attr.close()
     nbr.close()
+
+
+@pytest.mark.parametrize('n', [9000, 21000])
+def test_fused_randomization_call_on_the_sixteen_wave_forms_against_the_oracle(n):
+    """The whole fused call (safe_randomization: scores, both empirical p-value matrices, NES, nes_binary, enriched counts) on
+    the networks of round 6's sixteen-wave bit-sliced forms -- N = 9000 full words, N = 21 000 half words -- against the oracle
+    (safe.py:496-554, 468-472) with the SEEDED stream, hub neighborhoods above 1023 members included.  The oracle's dot products
+    run in f32 on a dense 0/1 membership (sums of 0/1 below 2^24: exact), 12 permutations."""
+    import safepy_amd
+    from safepy_amd import backend as be, workloads
+    ctx = safepy_amd.Context.default(0)
+    m, nperm, seed = 70, 12, 17
+    xy = workloads.uniform_layout(3, n)
+    xy[:1200] = xy[0] + 0.004 * np.random.default_rng(2).normal(size=(1200, 2))             # a dense cluster: neighborhoods of 1024+ members
+    rng = np.random.default_rng(n)
+    b = (rng.uniform(size=(n, m)) < np.linspace(0.002, 0.5, m)).astype(np.float32)
+    b[rng.choice(n, n // 40, replace=False)] = np.nan
+    nr = 0.012 * (xy[:, 0].max() - xy[:, 0].min())
+    nbr = be.Neighborhoods.euclidean(ctx, xy, nr)
+    counts = nbr.row_counts()
+    assert 1024 <= counts.max() < 2048, counts.max()
+    attr = be.Attributes.from_host(ctx, b)
+    perms = be.Permutations(ctx, n, attr.row_flags(), nperm, seed)
+    outs = [ctx.alloc_f64(n, m) for _ in range(5)] + [ctx.alloc_f64(m)]
+    be.randomization(ctx, nbr, attr, perms, 'sum', 'both', 0.05, [o.ptr for o in outs])
+    assert ctx.last_kernel()[0] == 'k_permtest_bits_pre'
+    got = [o.download((n, m)) for o in outs[:5]] + [outs[5].download((m,))]
+    rp, col = nbr.csr()
+    a = np.zeros((n, n), dtype=np.float32)
+    a[np.repeat(np.arange(n), np.diff(rp)), col] = 1
+    want = orc.pvalues_by_randomization(a, b.copy(), 'sum', nperm, seed, 'both')
+    nes_binary, num_enriched = orc.binarize(want['nes'], 0.05)
+    for have, key in zip(got[:4], ('ns', 'pvalues_neg', 'pvalues_pos', 'nes')):
+        np.testing.assert_array_equal(have, want[key], err_msg=key)
+    np.testing.assert_array_equal(got[4], nes_binary)
+    np.testing.assert_array_equal(got[5], num_enriched)
+    for o in outs:
+        o.free()
+    perms.close()
+    attr.close()
+    nbr.close()
