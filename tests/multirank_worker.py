@@ -107,6 +107,27 @@ def main():
                 np.testing.assert_allclose(out['full_pvalues_pos'], want['pvalues_pos'], rtol=1e-6, atol=1e-300)
                 np.testing.assert_allclose(out['full_nes'], want['nes'], rtol=1e-6, atol=1e-9)
 
+        # ---- a network beyond the blocked kernel's 16-bit offsets (N = 9000: the sixteen-wave pre-permuted form leaves the packed
+        # counters the exchange carries): sharded == single process
+        n9 = 9000
+        xy9 = np.random.default_rng(5).uniform(size=(n9, 2))
+        sf9 = safepy_amd.SAFE(verbose=False, device=device)
+        sf9.graph = safepy_amd.LayoutGraph(xy9)
+        sf9.define_neighborhoods(node_distance_metric='euclidean', neighborhood_radius=0.02)
+        b9 = (np.random.default_rng(6).uniform(size=(n9, 131)) < 0.05).astype(np.float32)
+        b9[np.random.default_rng(7).choice(n9, 50, replace=False)] = np.nan
+        c0, c1 = sharding.column_shards(131, world)[rank]
+        out = sharding.sharded_compute_pvalues(sf9._ctx(), sf9._device_neighborhoods(), np.ascontiguousarray(b9[:, c0:c1]), 131,
+                                               enrichment_type='randomization', num_permutations=30, random_seed=4,
+                                               gather=('nes', 'nes_binary', 'pvalues_pos', 'pvalues_neg'))
+        assert sf9._ctx().last_kernel()[0] == 'k_permtest_bits_pre', sf9._ctx().last_kernel()
+        sf9.random_seed = 4
+        sf9.load_attributes(attribute_file=b9.copy())
+        sf9.compute_pvalues(how='randomization', num_permutations=30)
+        for key in ('nes', 'nes_binary', 'pvalues_pos', 'pvalues_neg'):
+            assert np.array_equal(out['full_' + key], getattr(sf9, key), equal_nan=True), ('N=9000', key, rank)
+        del sf9
+
         # ---- the chunked exchange (sharding.ChunkedExchange): settled in the head collective, one slab by default; a block wide
         # enough to be cut into column chunks; the column-chunked tail of the launches (SAFE_HIP_XCHG_TAIL) behind which they travel
         from safepy_amd import backend as be
