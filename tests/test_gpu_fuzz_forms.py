@@ -41,3 +41,27 @@ def test_random_binary_cases_every_kernel_family_leaves_the_same_counters(monkey
     assert cases >= 20 and fails == 0
     ran = {k[1] for k in used}
     assert {'k_permtest_bits_blk', 'k_permtest_bits_pre', 'k_permtest_bits', 'k_permtest_scatter'} <= ran, used
+
+
+@pytest.mark.parametrize('n,nperm', [(9000, 1100), (21000, 1030), (2600, 2000)])
+def test_more_than_1023_permutations_on_the_sixteen_wave_forms(n, nperm, monkeypatch):
+    """A task of the bit-sliced kernels counts at most 255 permutations in eight counter levels, whatever the call's count; the
+    sixteen-wave forms of round 6 (full words N = 9000, half words N = 21 000, eleven sum levels for a 1300-member hub at
+    N = 2600) against the f64 kernel over more than 1023 permutations (the exchange's narrow form ends there too)."""
+    import numpy as np
+    fuzz = _tool('fuzz_forms')
+    import safepy_amd
+    ctx = safepy_amd.Context.default(0)
+    rng = np.random.default_rng(n)
+    xy = rng.uniform(size=(n, 2))
+    if n == 2600:
+        xy[:1300] = xy[0] + 0.003 * rng.normal(size=(1300, 2))
+    nbr = safepy_amd.Neighborhoods.euclidean(ctx, xy, 0.02)
+    b = (rng.uniform(size=(n, 70)) < np.linspace(0.005, 0.6, 70)).astype(np.float32)
+    b[rng.choice(n, 40, replace=False)] = np.nan
+    d = fuzz.counts(ctx, nbr, b, nperm, 77, 'sum', {})
+    f = fuzz.counts(ctx, nbr, b, nperm, 77, 'sum', {'SAFE_HIP_FORCE_PATH': 'gather'})
+    assert d[3] == 'k_permtest_bits_pre' and f[3].startswith('k_permtest_gather')
+    assert np.array_equal(d[1], f[1]) and np.array_equal(d[2], f[2]) and np.array_equal(d[0], f[0], equal_nan=True)
+    assert d[1].max() == nperm
+    nbr.close()
